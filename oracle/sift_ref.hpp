@@ -1,0 +1,1309 @@
+// ========================================================================== //
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+//
+// Plain C++17 CPU restatement of Sara's default (non-Halide) CPU SIFT path.
+// It is the parity checker for the HIP product and the "port" CPU baseline of
+// bench.py.  Nothing under sara_amd/ may include, link or call this code: only
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+//
+// Every function cites the reference file:line it follows (paths relative to
+// /root/reference/cpp/src/DO/Sara).  No reference source is copied: the
+// reference is Eigen-based templates, this is flat loops over float buffers.
+//
+// PARITY PIN STATUS
+//   * pinned by the reference's own tests (restated in tests/test_oracle_*.py):
+//     convolve_array, row/column filter, Gaussian kernel (L2 1e-5), downscale,
+//     enlarge, gradient, 2-D hessian, scale-space extremum predicates, pyramid
+//     octave count, DoG blob test, histogram smoothing, hard binning, single
+//     peak recovery, descriptor API consistency.
+//   * "parity unpinned" (the reference holds no known-answer test, and the
+//     reference itself cannot be built here: Eigen >= 3.4 is neither vendored
+//     nor installed): refine_extremum / on_edge numerics, descriptor
+//     normalisation, and everything at the last-ulp level that depends on
+//     Eigen's packet exp and vectorised reductions (make_gaussian_kernel's
+//     exp()/sum(), normalize()'s squaredNorm()).  Those are restated with libm
+//     expf and left-to-right float sums.
+// ========================================================================== //
+#pragma once
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+#include <vector>
+
+#ifdef _OPENMP
+#  include <omp.h>
+#endif
+
+namespace sara_ref {
+
+  // ------------------------------------------------------------------------ //
+  // Containers.  Image.hpp:45-181: x-fastest storage, pixel (x,y) at y*w+x.
+  // ------------------------------------------------------------------------ //
+  struct Image
+  {
+    int w = 0, h = 0;
+    std::vector<float> d;
+    Image() = default;
+    Image(int w_, int h_) : w(w_), h(h_), d(size_t(w_) * h_) {}
+    float& operator()(int x, int y) { return d[size_t(y) * w + x]; }
+    const float& operator()(int x, int y) const { return d[size_t(y) * w + x]; }
+  };
+
+  //! Image<Vector2f>: (mag, ori) interleaved, 8 B per pixel.
+  struct Image2
+  {
+    int w = 0, h = 0;
+    std::vector<float> d;
+    Image2() = default;
+    Image2(int w_, int h_) : w(w_), h(h_), d(size_t(w_) * h_ * 2) {}
+    float* at(int x, int y) { return &d[(size_t(y) * w + x) * 2]; }
+    const float* at(int x, int y) const { return &d[(size_t(y) * w + x) * 2]; }
+  };
+
+  //! ImageProcessing/ImagePyramid.hpp:29-198.
+  struct PyramidParams
+  {
+    int first_octave_index = -1;
+    int scale_count_per_octave = 6;
+    float scale_geometric_factor = std::pow(2.f, 1.f / 3.f);
+    int image_padding_size = 1;
+    float scale_camera = 0.5f;
+    float scale_initial = 1.6f;
+    int num_octaves_max = std::numeric_limits<int>::max();
+  };
+
+  //! ImageProcessing/ImagePyramid.hpp:206-340.
+  template <typename Img>
+  struct Pyramid
+  {
+    std::vector<std::vector<Img>> octaves;
+    std::vector<float> oct_scaling_factors;
+    float scale_initial = 0.f;
+    float scale_geometric_factor = 0.f;
+
+    void reset(int num_octaves, int num_scales, float s0, float k)
+    {
+      octaves.assign(num_octaves, std::vector<Img>(num_scales));
+      oct_scaling_factors.assign(num_octaves, 0.f);
+      scale_initial = s0;
+      scale_geometric_factor = k;
+    }
+    int octave_count() const { return int(octaves.size()); }
+    int scale_count_per_octave() const { return int(octaves.front().size()); }
+    Img& operator()(int s, int o) { return octaves[o][s]; }
+    const Img& operator()(int s, int o) const { return octaves[o][s]; }
+    //! ImagePyramid.hpp:316-319 — std::pow(float, int) promotes to double.
+    double scale_relative_to_octave(int s) const
+    {
+      return std::pow(double(scale_geometric_factor), double(s)) *
+             double(scale_initial);
+    }
+  };
+
+  //! Features/Feature.hpp:40-179 — 48-byte layout (Matrix2f is 16-B aligned).
+  struct alignas(16) OERegion
+  {
+    float coords[2] = {0, 0};
+    float _pad0[2] = {0, 0};
+    float shape_matrix[4] = {0, 0, 0, 0};  // column-major 2x2
+    float orientation = 0;
+    float extremum_value = 0;
+    std::uint8_t type = 11;          // Type::Undefined
+    std::int8_t extremum_type = -2;  // ExtremumType::Undefined
+    std::uint8_t _pad1[6] = {0, 0, 0, 0, 0, 0};
+  };
+  static_assert(sizeof(OERegion) == 48, "OERegion must be 48 bytes");
+
+  //! Feature.hpp:79-83: shape = I * float(pow(double(scale), -2.0)).
+  inline OERegion make_oeregion(float x, float y, float scale)
+  {
+    OERegion f;
+    f.coords[0] = x;
+    f.coords[1] = y;
+    const float c = static_cast<float>(std::pow(double(scale), -2.0));
+    f.shape_matrix[0] = c;
+    f.shape_matrix[3] = c;
+    return f;
+  }
+
+  //! Features/Feature.cpp:28-39 for an isotropic shape matrix c*I: JacobiSVD
+  //! returns singular values (c, c), U = I; radius = 1/sqrt(c) (float ops).
+  //! General anisotropic matrices are not produced on this path.
+  inline float oeregion_scale(const OERegion& f)
+  {
+    const float c = f.shape_matrix[0];
+    const float r0 = 1.f / std::sqrt(c);
+    const float x = r0 * 1.f;
+    const float y = 0.f;
+    return std::sqrt(x * x + y * y);
+  }
+
+  // ------------------------------------------------------------------------ //
+  // Colour conversion (config 1 input only).
+  // Core/Pixel/SmartColorConversion.hpp:237-246,
+  // Core/Pixel/ChannelConversion.hpp:40-54, Core/Pixel/ColorConversion.hpp:26-34.
+  // ------------------------------------------------------------------------ //
+  inline float rgb8_to_gray32f(std::uint8_t r, std::uint8_t g, std::uint8_t b)
+  {
+    const double rd = (double(r) - 0.0) / 255.0;
+    const double gd = (double(g) - 0.0) / 255.0;
+    const double bd = (double(b) - 0.0) / 255.0;
+    const double gray = 0.2125 * rd + 0.7154 * gd + 0.0721 * bd;
+    return static_cast<float>(gray);
+  }
+
+  // ------------------------------------------------------------------------ //
+  // Linear filtering.
+  // ------------------------------------------------------------------------ //
+
+  //! ImageProcessing/LinearFiltering.hpp:43-63 — correlation, in place,
+  //! taps accumulated left to right from 0.f (mul then add, no FMA: the
+  //! reference is built -O3 for baseline x86-64).
+  inline void convolve_array(float* signal, const float* kernel,
+                             int signal_size, int kernel_size)
+  {
+    for (int i = 0; i < signal_size; ++i)
+    {
+      float sum = 0.f;
+      for (int j = 0; j < kernel_size; ++j)
+        sum += signal[i + j] * kernel[j];
+      signal[i] = sum;
+    }
+  }
+
+  //! ImageProcessing/LinearFiltering.hpp:76-107 (replicate borders; the omp
+  //! pragma is at :90).
+  inline void apply_row_based_filter(const Image& src, Image& dst,
+                                     const float* kernel, int kernel_size)
+  {
+    if (src.w != dst.w || src.h != dst.h)
+      throw std::domain_error{
+          "Source and destination image sizes are not equal!"};
+    const int w = src.w, h = src.h, half = kernel_size / 2;
+#pragma omp parallel for
+    for (int y = 0; y < h; ++y)
+    {
+      std::vector<float> buffer(w + half * 2);
+      for (int x = 0; x < half; ++x)
+        buffer[x] = src(0, y);
+      for (int x = 0; x < w; ++x)
+        buffer[half + x] = src(x, y);
+      for (int x = 0; x < half; ++x)
+        buffer[w + half + x] = src(w - 1, y);
+      convolve_array(buffer.data(), kernel, w, kernel_size);
+      for (int x = 0; x < w; ++x)
+        dst(x, y) = buffer[x];
+    }
+  }
+
+  //! ImageProcessing/LinearFiltering.hpp:118-149 (omp pragma at :132).
+  inline void apply_column_based_filter(const Image& src, Image& dst,
+                                        const float* kernel, int kernel_size)
+  {
+    if (src.w != dst.w || src.h != dst.h)
+      throw std::domain_error{
+          "Source and destination image sizes are not equal!"};
+    const int w = src.w, h = src.h, half = kernel_size / 2;
+#pragma omp parallel for
+    for (int x = 0; x < w; ++x)
+    {
+      std::vector<float> buffer(h + half * 2);
+      for (int y = 0; y < half; ++y)
+        buffer[y] = src(x, 0);
+      for (int y = 0; y < h; ++y)
+        buffer[half + y] = src(x, y);
+      for (int y = 0; y < half; ++y)
+        buffer[h + half + y] = src(x, h - 1);
+      convolve_array(buffer.data(), kernel, h, kernel_size);
+      for (int y = 0; y < h; ++y)
+        dst(x, y) = buffer[y];
+    }
+  }
+
+  //! ImageProcessing/LinearFiltering.hpp:171-203.  Eigen's packet exp() and
+  //! vectorised sum() are restated with expf and a left-to-right sum
+  //! (last-ulp "parity unpinned", see header).
+  inline std::vector<float> make_gaussian_kernel(float sigma,
+                                                 float gauss_truncate = 4.f)
+  {
+    int kernel_size = int(2 * gauss_truncate * sigma + 1);
+    kernel_size = std::max(3, kernel_size);
+    if (kernel_size % 2 == 0)
+      ++kernel_size;
+    const int c = kernel_size / 2;
+    std::vector<float> kernel(kernel_size);
+    const float denom = 2 * (sigma * sigma);
+    for (int i = 0; i < kernel_size; ++i)
+    {
+      const float d = float(i) - float(c);
+      kernel[i] = std::exp(-(d * d) / denom);
+    }
+    float sum = 0.f;
+    for (int i = 0; i < kernel_size; ++i)
+      sum += kernel[i];
+    for (int i = 0; i < kernel_size; ++i)
+      kernel[i] /= sum;
+    return kernel;
+  }
+
+  //! ImageProcessing/LinearFiltering.cpp:30-68 (#else branch): rows src->dst,
+  //! then columns dst->dst in place.
+  inline void apply_gaussian_filter(const Image& src, Image& dst, float sigma,
+                                    float gauss_truncate = 4.f)
+  {
+    if (src.w != dst.w || src.h != dst.h)
+      throw std::domain_error{
+          "Source and destination image sizes are not equal!"};
+    const auto kernel = make_gaussian_kernel(sigma, gauss_truncate);
+    apply_row_based_filter(src, dst, kernel.data(), int(kernel.size()));
+    apply_column_based_filter(dst, dst, kernel.data(), int(kernel.size()));
+  }
+
+  //! ImageProcessing/LinearFiltering.hpp:445-454.
+  inline Image gaussian(const Image& src, float sigma,
+                        float gauss_truncate = 4.f)
+  {
+    Image dst(src.w, src.h);
+    apply_gaussian_filter(src, dst, sigma, gauss_truncate);
+    return dst;
+  }
+
+  // ------------------------------------------------------------------------ //
+  // Resize.
+  // ------------------------------------------------------------------------ //
+
+  //! ImageProcessing/Resize.cpp:31-62 (#else branch): nearest neighbour with
+  //! float index arithmetic.
+  inline void scale(const Image& src, Image& dst)
+  {
+    const float sx = float(src.w) / float(dst.w);
+    const float sy = float(src.h) / float(dst.h);
+    const int w = dst.w;
+    const int wh = dst.w * dst.h;
+#pragma omp parallel for
+    for (int xy = 0; xy < wh; ++xy)
+    {
+      const int y = xy / w;
+      const int x = xy - y * w;
+      const int xi = int(float(x) * sx);
+      const int yi = int(float(y) * sy);
+      dst(x, y) = src(xi, yi);
+    }
+  }
+
+  //! ImageProcessing/Resize.cpp:64-84.
+  inline Image downscale(const Image& src, int fact)
+  {
+    Image dst(src.w / fact, src.h / fact);
+    scale(src, dst);
+    return dst;
+  }
+
+  //! ImageProcessing/Interpolation.hpp:33-78 specialised to 2-D float images:
+  //! bilinear in double, far border replicated, x-fastest accumulation.
+  inline double interpolate(const Image& image, double px, double py)
+  {
+    if (px < 0 || px >= image.w || py < 0 || py >= image.h)
+      throw std::out_of_range{
+          "Cannot interpolate: position is out of image domain"};
+    double ipx, ipy;
+    const double fx = std::modf(px, &ipx);
+    const double fy = std::modf(py, &ipy);
+    const int sx = int(ipx), sy = int(ipy);
+    double value = 0.;
+    for (int yy = sy; yy < sy + 2; ++yy)
+      for (int xx = sx; xx < sx + 2; ++xx)
+      {
+        double weight = 1.;
+        weight *= (xx == sx) ? (1. - fx) : fx;
+        weight *= (yy == sy) ? (1. - fy) : fy;
+        const int ox = xx < image.w ? 0 : -1;
+        const int oy = yy < image.h ? 0 : -1;
+        value += weight * double(image(xx + ox, yy + oy));
+      }
+    return value;
+  }
+
+  //! ImageProcessing/Resize.cpp:86-128 (#else branch).
+  inline void enlarge(const Image& src, Image& dst)
+  {
+    if (dst.w < src.w || dst.h < src.h)
+      throw std::range_error{"The destination image must have smaller sizes "
+                             "than the source image!"};
+    if (std::min(dst.w, dst.h) <= 0)
+      throw std::range_error{
+          "The sizes of the destination image must be positive!"};
+    const int wh = dst.w * dst.h;
+    const double sx = double(src.w) / double(dst.w);
+    const double sy = double(src.h) / double(dst.h);
+#pragma omp parallel for
+    for (int xy = 0; xy < wh; ++xy)
+    {
+      const int w = dst.w;
+      const int y = xy / w;
+      const int x = xy - y * w;
+      dst(x, y) =
+          static_cast<float>(interpolate(src, double(x) * sx, double(y) * sy));
+    }
+  }
+
+  //! ImageProcessing/Resize.hpp:190-216: enlarge(image, double fact).
+  inline Image enlarge(const Image& src, double fact)
+  {
+    Image dst(int(double(src.w) * fact), int(double(src.h) * fact));
+    enlarge(src, dst);
+    return dst;
+  }
+
+  // ------------------------------------------------------------------------ //
+  // Gaussian pyramid / DoG pyramid.
+  // ------------------------------------------------------------------------ //
+
+  //! ImageProcessing/GaussianPyramid.hpp:33-125, with quirks Q3-Q6 of
+  //! SURVEY.md: unqualified log()/sqrt() resolve to the double C functions.
+  inline Pyramid<Image> gaussian_pyramid(const Image& image,
+                                         const PyramidParams& params,
+                                         float gauss_truncate = 4.f)
+  {
+    const float resize_factor =
+        std::pow(2.f, -static_cast<float>(params.first_octave_index));
+    const float camera_sigma = params.scale_camera * resize_factor;
+    const float init_sigma = params.scale_initial;
+
+    Image I;
+    if (params.first_octave_index < 0)
+      I = enlarge(image, double(resize_factor));
+    else if (params.first_octave_index > 0)
+    {
+      if (camera_sigma < init_sigma)
+      {
+        const float sigma = std::sqrt(init_sigma * init_sigma -
+                                      camera_sigma * camera_sigma);
+        I = gaussian(image, sigma, gauss_truncate);
+      }
+      else
+        I = image;
+      I = downscale(I, int(std::round(1 / resize_factor)));
+    }
+    else
+    {
+      if (camera_sigma < init_sigma)
+      {
+        const float sigma = std::sqrt(init_sigma * init_sigma -
+                                      camera_sigma * camera_sigma);
+        I = gaussian(image, sigma);  // default truncate 4 (Q4)
+      }
+      else
+        I = image;
+    }
+
+    const int l = std::min(I.w, I.h);
+    const int b = params.image_padding_size;
+    const int num_octaves = std::min(
+        static_cast<int>(std::log(double(float(l) / (2.f * float(b)))) /
+                         std::log(double(2.f))),
+        params.num_octaves_max);
+
+    const float k = params.scale_geometric_factor;
+    const int num_scales = params.scale_count_per_octave;
+    const int downscale_index =
+        static_cast<int>(std::floor(std::log(double(2.f)) / std::log(double(k))));
+
+    Pyramid<Image> G;
+    G.reset(std::max(num_octaves, 0), num_scales, init_sigma, k);
+
+    for (int o = 0; o < num_octaves; ++o)
+    {
+      G.oct_scaling_factors[o] =
+          (o == 0) ? 1 / resize_factor : G.oct_scaling_factors[o - 1] * 2;
+
+      float sigma_s_1 = init_sigma;
+      if (o == 0)
+        G(0, o) = std::move(I);
+      else
+        G(0, o) = downscale(G(downscale_index, o - 1), 2);
+
+      for (int s = 1; s < num_scales; ++s)
+      {
+        const float ks = k * sigma_s_1;
+        const double sigma = std::sqrt(double(ks * ks - sigma_s_1 * sigma_s_1));
+        G(s, o) = gaussian(G(s - 1, o), static_cast<float>(sigma));
+        sigma_s_1 *= k;
+      }
+    }
+    return G;
+  }
+
+  //! ImageProcessing/GaussianPyramid.cpp:23-51 (#else branch).
+  inline Pyramid<Image> difference_of_gaussians_pyramid(const Pyramid<Image>& G)
+  {
+    Pyramid<Image> D;
+    D.reset(G.octave_count(), G.scale_count_per_octave() - 1, G.scale_initial,
+            G.scale_geometric_factor);
+    for (int o = 0; o < D.octave_count(); ++o)
+    {
+      D.oct_scaling_factors[o] = G.oct_scaling_factors[o];
+      for (int s = 0; s < D.scale_count_per_octave(); ++s)
+      {
+        const Image& a = G(s + 1, o);
+        const Image& b = G(s, o);
+        Image& d = D(s, o);
+        d = Image(b.w, b.h);
+        const size_t n = d.d.size();
+        for (size_t i = 0; i < n; ++i)
+          d.d[i] = a.d[i] - b.d[i];
+      }
+    }
+    return D;
+  }
+
+  // ------------------------------------------------------------------------ //
+  // Differential operators.
+  // ------------------------------------------------------------------------ //
+
+  //! ImageProcessing/Differential.hpp:46-61: central difference / 2, one-sided
+  //! (f1 - f0)/2 on the borders.
+  inline void gradient_at(const Image& f, int x, int y, float& gx, float& gy)
+  {
+    if (x == 0)
+      gx = (f(x + 1, y) - f(x, y)) / 2;
+    else if (x == f.w - 1)
+      gx = (f(x, y) - f(x - 1, y)) / 2;
+    else
+      gx = (f(x + 1, y) - f(x - 1, y)) / 2;
+    if (y == 0)
+      gy = (f(x, y + 1) - f(x, y)) / 2;
+    else if (y == f.h - 1)
+      gy = (f(x, y) - f(x, y - 1)) / 2;
+    else
+      gy = (f(x, y + 1) - f(x, y - 1)) / 2;
+  }
+
+  //! ImageProcessing/Differential.hpp:191-226: 2-D Hessian with clamped
+  //! neighbours.  H = [hxx hxy; hxy hyy].
+  inline void hessian_at(const Image& f, int x, int y, float& hxx, float& hxy,
+                         float& hyy)
+  {
+    const int nx = (x == f.w - 1) ? 0 : 1, px = (x == 0) ? 0 : -1;
+    const int ny = (y == f.h - 1) ? 0 : 1, py = (y == 0) ? 0 : -1;
+    hxx = f(x + nx, y) - 2.f * f(x, y) + f(x + px, y);
+    hyy = f(x, y + ny) - 2.f * f(x, y) + f(x, y + py);
+    hxy = (f(x + nx, y + ny) - f(x + px, y + ny) - f(x + nx, y + py) +
+           f(x + px, y + py)) /
+          4.f;
+  }
+
+  //! FeatureDescriptors/Orientation.cpp:24-56 (#else branch):
+  //! (2*||grad||, atan2f(gy, gx)) in float.
+  inline Image2 gradient_polar_coordinates(const Image& f)
+  {
+    Image2 out(f.w, f.h);
+    for (int y = 0; y < f.h; ++y)
+      for (int x = 0; x < f.w; ++x)
+      {
+        float gx, gy;
+        gradient_at(f, x, y, gx, gy);
+        const float r = 2 * std::sqrt(gx * gx + gy * gy);
+        const float theta = std::atan2(gy, gx);
+        float* p = out.at(x, y);
+        p[0] = r;
+        p[1] = theta;
+      }
+    return out;
+  }
+
+  //! FeatureDescriptors/Orientation.hpp:69-86.
+  inline Pyramid<Image2> gradient_polar_coordinates(const Pyramid<Image>& G)
+  {
+    Pyramid<Image2> P;
+    P.reset(G.octave_count(), G.scale_count_per_octave(), G.scale_initial,
+            G.scale_geometric_factor);
+    for (int o = 0; o < G.octave_count(); ++o)
+    {
+      P.oct_scaling_factors[o] = G.oct_scaling_factors[o];
+      for (int s = 0; s < G.scale_count_per_octave(); ++s)
+        P(s, o) = gradient_polar_coordinates(G(s, o));
+    }
+    return P;
+  }
+
+  // ------------------------------------------------------------------------ //
+  // Extrema.
+  // ------------------------------------------------------------------------ //
+
+  //! ImageProcessing/Extrema.hpp:28-46.
+  template <typename Compare>
+  inline bool compare_with_neighborhood3(float val, int x, int y,
+                                         const Image& I, bool with_center,
+                                         Compare cmp)
+  {
+    for (int v = -1; v <= 1; ++v)
+      for (int u = -1; u <= 1; ++u)
+      {
+        if (u == 0 && v == 0 && !with_center)
+          continue;
+        if (!cmp(val, I(x + u, y + v)))
+          return false;
+      }
+    return true;
+  }
+
+  //! ImageProcessing/Extrema.hpp:63-75.
+  template <typename Compare>
+  inline bool local_scale_space_extremum(int x, int y, int s, int o,
+                                         const Pyramid<Image>& I, Compare cmp)
+  {
+    const float val = I(s, o)(x, y);
+    return compare_with_neighborhood3(val, x, y, I(s - 1, o), true, cmp) &&
+           compare_with_neighborhood3(val, x, y, I(s, o), false, cmp) &&
+           compare_with_neighborhood3(val, x, y, I(s + 1, o), true, cmp);
+  }
+
+  //! FeatureDetectors/RefineExtremum.cpp:24-30.
+  inline bool on_edge(const Image& I, int x, int y, float edge_ratio)
+  {
+    float hxx, hxy, hyy;
+    hessian_at(I, x, y, hxx, hxy, hyy);
+    const float tr = hxx + hyy;
+    const float det = hxx * hyy - hxy * hxy;
+    return (tr * tr) * edge_ratio >=
+           ((edge_ratio + 1.f) * (edge_ratio + 1.f)) * std::abs(det);
+  }
+
+  //! ImageProcessing/GaussianPyramid.hpp:183-197.
+  inline void gradient3(const Pyramid<Image>& I, int x, int y, int s, int o,
+                        float d[3])
+  {
+    if (x < 1 || x >= I(s, o).w - 1 || y < 1 || y >= I(s, o).h - 1 || s < 1 ||
+        s >= int(I.octaves[o].size()) - 1)
+      throw std::out_of_range{"Computing gradient out of image range!"};
+    d[0] = (I(s, o)(x + 1, y) - I(s, o)(x - 1, y)) / 2.f;
+    d[1] = (I(s, o)(x, y + 1) - I(s, o)(x, y - 1)) / 2.f;
+    d[2] = (I(s + 1, o)(x, y) - I(s - 1, o)(x, y)) / 2.f;
+  }
+
+  //! ImageProcessing/GaussianPyramid.hpp:200-233.  H is symmetric 3x3,
+  //! order (x, y, s).
+  inline void hessian3(const Pyramid<Image>& I, int x, int y, int s, int o,
+                       float H[3][3])
+  {
+    if (x < 1 || x >= I(s, o).w - 1 || y < 1 || y >= I(s, o).h - 1 || s < 1 ||
+        s >= int(I.octaves[o].size()) - 1)
+      throw std::out_of_range{"Computing Hessian matrix out of image range!"};
+    const Image& c = I(s, o);
+    const Image& n = I(s + 1, o);
+    const Image& p = I(s - 1, o);
+    H[0][0] = c(x + 1, y) - 2.f * c(x, y) + c(x - 1, y);
+    H[1][1] = c(x, y + 1) - 2.f * c(x, y) + c(x, y - 1);
+    H[2][2] = n(x, y) - 2.f * c(x, y) + p(x, y);
+    H[0][1] = H[1][0] =
+        (c(x + 1, y + 1) - c(x - 1, y + 1) - c(x + 1, y - 1) + c(x - 1, y - 1)) /
+        4.f;
+    H[0][2] = H[2][0] =
+        (n(x + 1, y) - n(x - 1, y) - p(x + 1, y) + p(x - 1, y)) / 4.f;
+    H[1][2] = H[2][1] =
+        (n(x, y + 1) - n(x, y - 1) - p(x, y + 1) + p(x, y - 1)) / 4.f;
+  }
+
+  //! Eigenvalue signs of a symmetric 3x3 matrix, standing in for Eigen's
+  //! SelfAdjointEigenSolver<Matrix3f> at RefineExtremum.cpp:74-77.  The
+  //! reference only consumes max_i(lambda_i * type) >= 0, i.e. definiteness:
+  //!   returns +1 if all eigenvalues > 0, -1 if all < 0, 0 otherwise.
+  //! Decided in double by Sylvester's criterion on the float entries (the
+  //! float eigen-solver's own rounding near singular H is "parity unpinned").
+  inline int definiteness3(const float Hf[3][3])
+  {
+    double H[3][3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+        H[i][j] = double(Hf[i][j]);
+    const double m1 = H[0][0];
+    const double m2 = H[0][0] * H[1][1] - H[0][1] * H[1][0];
+    const double m3 = H[0][0] * (H[1][1] * H[2][2] - H[1][2] * H[2][1]) -
+                      H[0][1] * (H[1][0] * H[2][2] - H[1][2] * H[2][0]) +
+                      H[0][2] * (H[1][0] * H[2][1] - H[1][1] * H[2][0]);
+    if (m1 > 0 && m2 > 0 && m3 > 0)
+      return +1;
+    if (m1 < 0 && m2 > 0 && m3 < 0)
+      return -1;
+    return 0;
+  }
+
+  //! Cofactor (i,j) of a 3x3 matrix the way Eigen's 3x3 inverse forms it:
+  //! m(i1,j1)*m(i2,j2) - m(i1,j2)*m(i2,j1), i1=(i+1)%3, i2=(i+2)%3 (idem j).
+  inline float cofactor3(const float m[3][3], int i, int j)
+  {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+    const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1];
+  }
+
+  //! Eigen's fixed-size 3-term reduction is a binary split: a0 + (a1 + a2).
+  inline float sum3(float a0, float a1, float a2) { return a0 + (a1 + a2); }
+
+  //! h = -inverse(H) * g, standing in for Matrix3f::inverse() at
+  //! RefineExtremum.cpp:85: Eigen 3.4 forms the 3x3 inverse from cofactors
+  //! times 1/det in float (det = cofactor column 0 . matrix column 0), then a
+  //! coefficient-wise product.  "Parity unpinned" at the ulp level.
+  inline void newton_step3(const float H[3][3], const float g[3], float h[3])
+  {
+    const float c0 = cofactor3(H, 0, 0);
+    const float c1 = cofactor3(H, 1, 0);
+    const float c2 = cofactor3(H, 2, 0);
+    const float det = sum3(c0 * H[0][0], c1 * H[1][0], c2 * H[2][0]);
+    const float invdet = 1.f / det;
+    float inv[3][3];
+    inv[0][0] = c0 * invdet;
+    inv[0][1] = c1 * invdet;
+    inv[0][2] = c2 * invdet;
+    inv[1][0] = cofactor3(H, 0, 1) * invdet;
+    inv[1][1] = cofactor3(H, 1, 1) * invdet;
+    inv[1][2] = cofactor3(H, 2, 1) * invdet;
+    inv[2][0] = cofactor3(H, 0, 2) * invdet;
+    inv[2][1] = cofactor3(H, 1, 2) * invdet;
+    inv[2][2] = cofactor3(H, 2, 2) * invdet;
+    for (int i = 0; i < 3; ++i)
+      h[i] = sum3((-inv[i][0]) * g[0], (-inv[i][1]) * g[1], (-inv[i][2]) * g[2]);
+  }
+
+  //! FeatureDetectors/RefineExtremum.cpp:32-130.  `type` is the raw map value:
+  //! 1 for maxima, 255 for minima (quirk Q2: the uint8 map stores -1 as 255,
+  //! so minima are never refined and never take the `type == -1` branch).
+  inline bool refine_extremum(const Pyramid<Image>& I, int x, int y, int s,
+                              int o, int type, float pos[3], float& val,
+                              int border_sz, int num_iter)
+  {
+    float D_prime[3] = {0, 0, 0};
+    float D_second[3][3];
+    float h[3] = {0, 0, 0};
+
+    pos[0] = float(x);
+    pos[1] = float(y);
+    pos[2] = static_cast<float>(I.scale_relative_to_octave(s));
+
+    int i = 0;
+    for (; i < num_iter; ++i)
+    {
+      if (x < border_sz || x >= I(s, o).w - border_sz || y < border_sz ||
+          y >= I(s, o).h - border_sz || s < 1 ||
+          s >= int(I.octaves[o].size()) - 1)
+        break;
+
+      gradient3(I, x, y, s, o, D_prime);
+      hessian3(I, x, y, s, o, D_second);
+
+      // (lambda * float(type)).maxCoeff() >= 0
+      const int def = definiteness3(D_second);
+      bool not_definite_enough;
+      if (type > 0)  // lambda * positive: max >= 0 unless negative definite
+        not_definite_enough = (def != -1);
+      else  // lambda * negative: max >= 0 unless positive definite
+        not_definite_enough = (def != +1);
+      if (not_definite_enough)
+      {
+        h[0] = h[1] = h[2] = 0.f;
+        break;
+      }
+
+      newton_step3(D_second, D_prime, h);
+
+      if (std::max(std::abs(h[0]), std::abs(h[1])) > 1.5f)
+        return false;
+
+      if (std::min(std::abs(h[0]), std::abs(h[1])) > 0.6f)
+      {
+        x += h[0] > 0 ? 1 : -1;
+        y += h[1] > 0 ? 1 : -1;
+        continue;
+      }
+      break;
+    }
+
+    pos[0] = float(x);
+    pos[1] = float(y);
+    pos[2] = static_cast<float>(I.scale_relative_to_octave(s));
+    const float oldval = I(s, o)(x, y);
+    const float newval =
+        oldval +
+        0.5f * sum3(D_prime[0] * h[0], D_prime[1] * h[1], D_prime[2] * h[2]);
+
+    if ((type == 1 && oldval <= newval) || (type == -1 && oldval >= newval))
+    {
+      pos[0] += h[0];
+      pos[1] += h[1];
+      pos[2] *= std::pow(I.scale_geometric_factor, h[2]);
+      val = newval;
+    }
+    return true;
+  }
+
+  //! One entry of the intermediate extremum list (raster order per (s,o)).
+  struct ExtremumRecord
+  {
+    int x, y, s, o;
+    int type;  // +1 max, -1 min
+    OERegion region;
+  };
+
+  //! FeatureDetectors/RefineExtremum.cpp:363-521 (#else branch).
+  inline std::vector<OERegion>
+  local_scale_space_extrema(const Pyramid<Image>& I, int s, int o,
+                            float extremum_thres, float edge_ratio_thres,
+                            int img_padding_sz, int refine_iterations,
+                            std::vector<ExtremumRecord>* records = nullptr)
+  {
+    const int w = I(s, o).w;
+    const int h = I(s, o).h;
+    const int wh = w * h;
+
+    std::vector<std::uint8_t> map(size_t(wh), 0);
+
+#pragma omp parallel for
+    for (int xy = 0; xy < wh; ++xy)
+    {
+      const int y = xy / w;
+      const int x = xy - y * w;
+      const bool in_domain = img_padding_sz <= x && x < w - img_padding_sz &&
+                             img_padding_sz <= y && y < h - img_padding_sz;
+      if (!in_domain)
+        continue;
+
+      int type = 0;
+      if (local_scale_space_extremum(x, y, s, o, I, std::greater_equal<float>{}))
+        type = 1;
+      else if (local_scale_space_extremum(x, y, s, o, I,
+                                          std::less_equal<float>{}))
+        type = -1;
+      else
+        continue;
+
+      if (std::abs(I(s, o)(x, y)) < 0.8f * extremum_thres)
+        continue;
+      if (on_edge(I(s, o), x, y, edge_ratio_thres))
+        continue;
+
+      map[xy] = static_cast<std::uint8_t>(type);  // -1 -> 255 (Q2)
+    }
+
+    std::vector<float> location_refined(static_cast<size_t>(wh) * 3, 0.f);
+    std::vector<float> extremum_value(static_cast<size_t>(wh), 0.f);
+#pragma omp parallel for
+    for (int xy = 0; xy < wh; ++xy)
+    {
+      const int y = xy / w;
+      const int x = xy - y * w;
+      const std::uint8_t type = map[xy];
+      if (type == 0)
+        continue;
+      float* pos = &location_refined[size_t(xy) * 3];
+      float& val = extremum_value[xy];
+      val = I(s, o)(x, y);
+      refine_extremum(I, x, y, s, o, int(type), pos, val, img_padding_sz,
+                      refine_iterations);
+      if (std::abs(val) < extremum_thres)
+        map[xy] = 0;
+    }
+
+    std::vector<OERegion> extrema;
+    extrema.reserve(10000);
+    for (int xy = 0; xy < wh; ++xy)
+    {
+      const int y = xy / w;
+      const int x = xy - y * w;
+      const std::uint8_t type = map[xy];
+      if (type == 0)
+        continue;
+      const float* pos = &location_refined[size_t(xy) * 3];
+      OERegion dog = make_oeregion(pos[0], pos[1], pos[2]);
+      dog.extremum_value = extremum_value[xy];
+      dog.extremum_type = (type == 1) ? 1 : -1;
+      extrema.push_back(dog);
+      if (records)
+        records->push_back({x, y, s, o, type == 1 ? 1 : -1, dog});
+    }
+    return extrema;
+  }
+
+  // ------------------------------------------------------------------------ //
+  // Dominant orientations.
+  // ------------------------------------------------------------------------ //
+
+  inline int int_round(double x) { return static_cast<int>(std::round(x)); }
+  inline int int_round(float x) { return static_cast<int>(std::round(x)); }
+
+  //! FeatureDescriptors/Orientation.hpp:91-135 with T=float.  The unqualified
+  //! exp()/floor() bind to the double C functions, so the weight
+  //! and the accumulation are evaluated in double and rounded per pixel.
+  template <int N>
+  inline void compute_orientation_histogram(float* hist, const Image2& grad,
+                                            float x, float y, float s,
+                                            float patch_truncation_factor = 3.f,
+                                            float blur_factor = 1.5f)
+  {
+    for (int i = 0; i < N; ++i)
+      hist[i] = 0.f;
+    const int rounded_x = int_round(x);
+    const int rounded_y = int_round(y);
+    const float sigma = s * blur_factor;
+    const int patch_radius = int_round(sigma * patch_truncation_factor);
+
+    for (int v = -patch_radius; v <= patch_radius; ++v)
+      for (int u = -patch_radius; u <= patch_radius; ++u)
+      {
+        if (rounded_x + u < 0 || rounded_x + u >= grad.w ||
+            rounded_y + v < 0 || rounded_y + v >= grad.h)
+          continue;
+        const float* g = grad.at(rounded_x + u, rounded_y + v);
+        const float mag = g[0];
+        float ori = g[1];
+        ori = ori < 0 ? ori + float(2. * M_PI) : ori;
+        int bin_index = int(std::floor(double(ori / float(2 * M_PI) * N)));
+        bin_index %= N;
+        const double weight =
+            std::exp(double(-(u * u + v * v) / (2.f * sigma * sigma)));
+        hist[bin_index] =
+            static_cast<float>(double(hist[bin_index]) + weight * double(mag));
+      }
+  }
+
+  //! FeatureDescriptors/Orientation.hpp:143-163.
+  template <int N>
+  inline void lowe_smooth_histogram(float* hist, int num_iters = 6)
+  {
+    for (int iter = 0; iter < num_iters; ++iter)
+    {
+      const float first = hist[0];
+      float prev = hist[N - 1];
+      for (int i = 0; i < N - 1; ++i)
+      {
+        const float val = (prev + hist[i] + hist[i + 1]) / 3.f;
+        prev = hist[i];
+        hist[i] = val;
+      }
+      hist[N - 1] = (prev + hist[N - 1] + first) / 3.f;
+    }
+  }
+
+  //! FeatureDescriptors/Orientation.hpp:173-186.
+  template <int N>
+  inline std::vector<int> find_peaks(const float* hist,
+                                     float peak_ratio_thres = 0.8f)
+  {
+    float max = hist[0];
+    for (int i = 1; i < N; ++i)
+      max = std::max(max, hist[i]);
+    std::vector<int> peaks;
+    peaks.reserve(N);
+    for (int i = 0; i < N; ++i)
+      if (hist[i] >= peak_ratio_thres * max && hist[i] > hist[(i - 1 + N) % N] &&
+          hist[i] > hist[(i + 1) % N])
+        peaks.push_back(i);
+    return peaks;
+  }
+
+  //! FeatureDescriptors/Orientation.hpp:190-212.
+  template <int N>
+  inline float refine_peak(const float* hist, int i)
+  {
+    const float y0 = hist[(i - 1 + N) % N];
+    const float y1 = hist[i];
+    const float y2 = hist[(i + 1) % N];
+    const float fprime = (y2 - y0) / 2.f;
+    const float fsecond = y0 - 2.f * y1 + y2;
+    const float h = -fprime / fsecond;
+    return float(i) + 0.5f + h;
+  }
+
+  //! FeatureDescriptors/Orientation.cpp:90-118.
+  inline std::vector<float>
+  dominant_orientations(const Image2& grad, float x, float y, float sigma,
+                        float peak_ratio_thres = 0.8f,
+                        float patch_truncation_factor = 3.f,
+                        float blur_factor = 1.5f, float* hist_out = nullptr)
+  {
+    constexpr int O = 36;
+    float hist[O];
+    compute_orientation_histogram<O>(hist, grad, x, y, sigma,
+                                     patch_truncation_factor, blur_factor);
+    lowe_smooth_histogram<O>(hist);
+    if (hist_out)
+      std::memcpy(hist_out, hist, sizeof(hist));
+    const auto peak_indices = find_peaks<O>(hist, peak_ratio_thres);
+    std::vector<float> peaks(peak_indices.size());
+    for (size_t i = 0; i != peaks.size(); ++i)
+    {
+      peaks[i] = refine_peak<O>(hist, peak_indices[i]);
+      peaks[i] *= static_cast<float>(2 * M_PI) / O;
+      if (peaks[i] > float(M_PI))
+        peaks[i] -= 2.f * float(M_PI);
+    }
+    return peaks;
+  }
+
+  //! FeatureDescriptors/Orientation.cpp:120-166: expands the list, one copy of
+  //! the extremum per peak, serial loop.
+  inline void assign_dominant_orientations(const Pyramid<Image2>& pyramid,
+                                           std::vector<OERegion>& extrema,
+                                           std::vector<int>& so_pairs)
+  {
+    std::vector<OERegion> e2;
+    std::vector<int> so2;
+    e2.reserve(extrema.size() * 2);
+    so2.reserve(extrema.size() * 4);
+    for (size_t i = 0; i != extrema.size(); ++i)
+    {
+      const int s_index = so_pairs[2 * i], o_index = so_pairs[2 * i + 1];
+      const float s =
+          static_cast<float>(pyramid.scale_relative_to_octave(s_index));
+      const auto orientations = dominant_orientations(
+          pyramid(s_index, o_index), extrema[i].coords[0], extrema[i].coords[1],
+          s);
+      for (size_t k = 0; k != orientations.size(); ++k)
+      {
+        so2.push_back(s_index);
+        so2.push_back(o_index);
+        e2.push_back(extrema[i]);
+        e2.back().orientation = orientations[k];
+      }
+    }
+    e2.swap(extrema);
+    so2.swap(so_pairs);
+  }
+
+  // ------------------------------------------------------------------------ //
+  // SIFT descriptor, N=4, O=8.
+  // ------------------------------------------------------------------------ //
+
+  //! FeatureDescriptors/SIFT.hpp:204-238: std::modf truncates toward zero
+  //! (quirk Q13).
+  inline void sift_accumulate(float* h, float px, float py, float ori,
+                              float weight, float mag)
+  {
+    constexpr int N = 4, O = 8;
+    float xif, yif, oriif;
+    const float xfrac = std::modf(px, &xif);
+    const float yfrac = std::modf(py, &yif);
+    const float orifrac = std::modf(ori, &oriif);
+    const int xi = int(xif), yi = int(yif), orii = int(oriif);
+    for (int dy = 0; dy < 2; ++dy)
+    {
+      const int y = yi + dy;
+      if (y < 0 || y >= N)
+        continue;
+      const float wy = (dy == 0) ? 1 - yfrac : yfrac;
+      for (int dx = 0; dx < 2; ++dx)
+      {
+        const int x = xi + dx;
+        if (x < 0 || x >= N)
+          continue;
+        const float wx = (dx == 0) ? 1 - xfrac : xfrac;
+        for (int dori = 0; dori < 2; ++dori)
+        {
+          const int o = (orii + dori) % O;
+          const float wo = (dori == 0) ? 1 - orifrac : orifrac;
+          h[N * O * y + x * O + o] += wy * wx * wo * weight * mag;
+        }
+      }
+    }
+  }
+
+  //! Eigen's Matrix::normalize(): divide by the norm when squaredNorm() > 0.
+  //! Left-to-right float sum (Eigen's vectorised reduction order is "parity
+  //! unpinned").
+  inline void l2_normalize128(float* h)
+  {
+    float z = 0.f;
+    for (int i = 0; i < 128; ++i)
+      z += h[i] * h[i];
+    if (z > 0.f)
+    {
+      const float n = std::sqrt(z);
+      for (int i = 0; i < 128; ++i)
+        h[i] /= n;
+    }
+  }
+
+  //! FeatureDescriptors/SIFT.hpp:62-145 (+ normalize :241-252).  The
+  //! unqualified sqrt/cos/sin bind to the double C functions; T's entries are
+  //! rounded to float by Eigen's comma initialiser.
+  inline void compute_sift_descriptor(float* h, float x, float y, float s,
+                                      float theta, const Image2& grad,
+                                      bool do_normalization = true,
+                                      float bin_scale_unit_length = 3.f,
+                                      float max_bin_value = 0.2f)
+  {
+    constexpr int N = 4, O = 8, Dim = 128;
+    constexpr float pi = static_cast<float>(M_PI);
+    const float lambda = bin_scale_unit_length;
+    const float l = lambda * s;
+    const double r = std::sqrt(double(2.f)) * double(l) * (N + 1) / double(2.f);
+
+    float T00 = static_cast<float>(std::cos(double(theta)));
+    float T01 = static_cast<float>(std::sin(double(theta)));
+    float T10 = static_cast<float>(-std::sin(double(theta)));
+    float T11 = static_cast<float>(std::cos(double(theta)));
+    T00 /= l;
+    T01 /= l;
+    T10 /= l;
+    T11 /= l;
+
+    for (int i = 0; i < Dim; ++i)
+      h[i] = 0.f;
+
+    const int rounded_r = int_round(r);
+    const int rounded_x = int_round(x);
+    const int rounded_y = int_round(y);
+
+    for (int v = -rounded_r; v <= rounded_r; ++v)
+      for (int u = -rounded_r; u <= rounded_r; ++u)
+      {
+        float px = T00 * float(u) + T01 * float(v);
+        float py = T10 * float(u) + T11 * float(v);
+
+        if (rounded_x + u < 0 || rounded_x + u >= grad.w ||
+            rounded_y + v < 0 || rounded_y + v >= grad.h)
+          continue;
+
+        constexpr float sigma = N * N * 0.25f;
+        const float weight = std::exp(-(px * px + py * py) / (2.f * sigma));
+
+        const float* g = grad.at(rounded_x + u, rounded_y + v);
+        const float mag = g[0];
+        float ori = g[1] - theta;
+        ori = ori < 0.f ? ori + 2.f * pi : ori;
+        ori *= static_cast<float>(O) / (2.f * pi);
+
+        px += N / 2.f - 0.5f;
+        py += N / 2.f - 0.5f;
+
+        if (std::min(px, py) <= -1.f || std::max(px, py) >= static_cast<float>(N))
+          continue;
+
+        sift_accumulate(h, px, py, ori, weight, mag);
+      }
+
+    if (do_normalization)
+    {
+      l2_normalize128(h);
+      for (int i = 0; i < Dim; ++i)
+        h[i] = std::min(h[i], max_bin_value);
+      l2_normalize128(h);
+      for (int i = 0; i < Dim; ++i)
+        h[i] = std::min(h[i] * 512.f, 255.f);
+    }
+  }
+
+  // ------------------------------------------------------------------------ //
+  // Drivers.
+  // ------------------------------------------------------------------------ //
+
+  struct StageTimes
+  {
+    double gaussian_pyramid_ms = 0, dog_pyramid_ms = 0, dog_extrema_ms = 0;
+    double gradient_ms = 0, orientation_ms = 0, descriptors_ms = 0;
+    double total_ms = 0;
+  };
+
+  struct Timer
+  {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void restart() { t0 = std::chrono::steady_clock::now(); }
+    double elapsed_ms() const
+    {
+      return std::chrono::duration<double, std::milli>(
+                 std::chrono::steady_clock::now() - t0)
+          .count();
+    }
+  };
+
+  //! FeatureDetectors/DoG.hpp:72-90 + DoG.cpp:23-87.
+  struct ComputeDoGExtrema
+  {
+    PyramidParams pyramid_params;
+    float gauss_truncate = 4.f;
+    float extremum_thres = 0.01f;
+    float edge_ratio_thres = 10.f;
+    int img_padding_sz = 1;
+    int extremum_refinement_iter = 5;
+
+    Pyramid<Image> gaussians;
+    Pyramid<Image> diff_of_gaussians;
+    std::vector<ExtremumRecord> records;
+
+    ComputeDoGExtrema(const PyramidParams& p = PyramidParams(),
+                      float gauss_truncate_ = 4.f, float extremum_thres_ = 0.01f,
+                      float edge_ratio_thres_ = 10.f, int img_padding_sz_ = 1,
+                      int extremum_refinement_iter_ = 5)
+      : pyramid_params(p)
+      , gauss_truncate(gauss_truncate_)
+      , extremum_thres(extremum_thres_)
+      , edge_ratio_thres(edge_ratio_thres_)
+      , img_padding_sz(img_padding_sz_)
+      , extremum_refinement_iter(extremum_refinement_iter_)
+    {
+      if (pyramid_params.scale_count_per_octave < 4)
+        throw std::runtime_error{
+            "Error: The extraction of DoG extrema needs (1 + 3) = 4 scales per "
+            "octave at the very minimum!"};
+    }
+
+    //! so_pairs: flat (s, o) pairs.  stop_after: 0 = everything, 1 = stop
+    //! after the Gaussian pyramid, 2 = after the DoG pyramid.
+    std::vector<OERegion> operator()(const Image& image,
+                                     std::vector<int>* so_pairs,
+                                     StageTimes* times = nullptr,
+                                     int stop_after = 0)
+    {
+      Timer timer;
+      gaussians = gaussian_pyramid(image, pyramid_params, gauss_truncate);
+      if (times)
+        times->gaussian_pyramid_ms = timer.elapsed_ms();
+      std::vector<OERegion> extrema;
+      if (so_pairs)
+        so_pairs->clear();
+      records.clear();
+      if (stop_after == 1)
+        return extrema;
+
+      timer.restart();
+      diff_of_gaussians = difference_of_gaussians_pyramid(gaussians);
+      if (times)
+        times->dog_pyramid_ms = timer.elapsed_ms();
+      if (stop_after == 2)
+        return extrema;
+
+      timer.restart();
+      const auto& D = diff_of_gaussians;
+      extrema.reserve(10000);
+      for (int o = 0; o < D.octave_count(); ++o)
+        for (int s = 1; s < D.scale_count_per_octave() - 1; ++s)
+        {
+          const auto e = local_scale_space_extrema(
+              D, s, o, extremum_thres, edge_ratio_thres, img_padding_sz,
+              extremum_refinement_iter, &records);
+          extrema.insert(extrema.end(), e.begin(), e.end());
+          if (so_pairs)
+            for (size_t i = 0; i != e.size(); ++i)
+            {
+              so_pairs->push_back(s);
+              so_pairs->push_back(o);
+            }
+        }
+      if (times)
+        times->dog_extrema_ms = timer.elapsed_ms();
+      return extrema;
+    }
+  };
+
+  struct SiftResult
+  {
+    ComputeDoGExtrema dog;
+    Pyramid<Image2> nabla_G;
+    std::vector<OERegion> extrema;     // before orientation assignment
+    std::vector<int> extrema_so;       // flat (s,o)
+    std::vector<OERegion> features;    // final, rescaled
+    std::vector<int> so_pairs;         // flat (s,o) of the final list
+    std::vector<float> descriptors;    // N x 128 row-major
+    StageTimes times;
+  };
+
+  //! FeatureDetectors/SIFT.cpp:27-108, including the argument shift Q1:
+  //! extremum_refinement_iter lands in img_padding_sz.
+  //! stop_after: 0 full, 1 pyramid, 2 DoG, 3 extrema, 4 gradients,
+  //! 5 orientations.
+  inline void compute_sift_keypoints(SiftResult& R, const Image& image,
+                                     const PyramidParams& pyramid_params,
+                                     float gauss_truncate = 4.f,
+                                     float extremum_thres = 0.01f,
+                                     float edge_ratio_thres = 10.f,
+                                     int extremum_refinement_iter = 5,
+                                     bool parallel = false, int stop_after = 0)
+  {
+    Timer timer;
+    R.times = StageTimes{};
+    R.dog = ComputeDoGExtrema{pyramid_params, gauss_truncate, extremum_thres,
+                              edge_ratio_thres, extremum_refinement_iter};
+    R.features.clear();
+    R.so_pairs.clear();
+    R.descriptors.clear();
+    R.extrema = R.dog(image, &R.extrema_so, &R.times,
+                      (stop_after >= 1 && stop_after <= 2) ? stop_after : 0);
+    double elapsed = timer.elapsed_ms();
+    if (stop_after >= 1 && stop_after <= 3)
+    {
+      R.times.total_ms = elapsed;
+      return;
+    }
+
+    timer.restart();
+    R.nabla_G = gradient_polar_coordinates(R.dog.gaussians);
+    R.times.gradient_ms = timer.elapsed_ms();
+    elapsed += R.times.gradient_ms;
+    if (stop_after == 4)
+    {
+      R.times.total_ms = elapsed;
+      return;
+    }
+
+    timer.restart();
+    R.features = R.extrema;
+    R.so_pairs = R.extrema_so;
+    assign_dominant_orientations(R.nabla_G, R.features, R.so_pairs);
+    R.times.orientation_ms = timer.elapsed_ms();
+    elapsed += R.times.orientation_ms;
+    if (stop_after == 5)
+    {
+      R.times.total_ms = elapsed;
+      return;
+    }
+
+#ifdef _OPENMP
+    if (parallel)
+      omp_set_num_threads(omp_get_max_threads());
+#endif
+
+    timer.restart();
+    const int n = int(R.features.size());
+    R.descriptors.assign(size_t(n) * 128, 0.f);
+    if (parallel)
+    {
+#pragma omp parallel for
+      for (int i = 0; i < n; ++i)
+      {
+        const auto& f = R.features[i];
+        compute_sift_descriptor(&R.descriptors[size_t(i) * 128], f.coords[0],
+                                f.coords[1], oeregion_scale(f), f.orientation,
+                                R.nabla_G(R.so_pairs[2 * i], R.so_pairs[2 * i + 1]));
+      }
+    }
+    else
+    {
+      for (int i = 0; i < n; ++i)
+      {
+        const auto& f = R.features[i];
+        compute_sift_descriptor(&R.descriptors[size_t(i) * 128], f.coords[0],
+                                f.coords[1], oeregion_scale(f), f.orientation,
+                                R.nabla_G(R.so_pairs[2 * i], R.so_pairs[2 * i + 1]));
+      }
+    }
+    R.times.descriptors_ms = timer.elapsed_ms();
+
+    for (int i = 0; i < n; ++i)
+    {
+      const float factor = R.nabla_G.oct_scaling_factors[R.so_pairs[2 * i + 1]];
+      R.features[i].coords[0] *= factor;
+      R.features[i].coords[1] *= factor;
+      const float f2 = factor * factor;
+      for (int j = 0; j < 4; ++j)
+        R.features[i].shape_matrix[j] /= f2;
+    }
+    elapsed += R.times.descriptors_ms;
+    R.times.total_ms = elapsed;
+  }
+
+}  // namespace sara_ref

@@ -1,0 +1,403 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see sift_ref.hpp).
+// C-ABI over the CPU restatement so tests/ and bench.py's cpu_baseline leg can
+// drive it through ctypes.  Never linked into the product library.
+#include "sift_ref.hpp"
+
+#include <cstdio>
+#include <string>
+
+using namespace sara_ref;
+
+namespace {
+  thread_local std::string g_last_error;
+
+  PyramidParams to_params(const int* ip, const float* fp)
+  {
+    // ip = {first_octave_index, scale_count_per_octave, image_padding_size,
+    //       num_octaves_max}; fp = {scale_geometric_factor, scale_camera,
+    //       scale_initial}
+    PyramidParams p;
+    p.first_octave_index = ip[0];
+    p.scale_count_per_octave = ip[1];
+    p.image_padding_size = ip[2];
+    p.num_octaves_max = ip[3];
+    p.scale_geometric_factor = fp[0];
+    p.scale_camera = fp[1];
+    p.scale_initial = fp[2];
+    return p;
+  }
+
+  Image wrap(const float* data, int w, int h)
+  {
+    Image I(w, h);
+    std::memcpy(I.d.data(), data, sizeof(float) * size_t(w) * h);
+    return I;
+  }
+
+  Image2 wrap2(const float* data, int w, int h)
+  {
+    Image2 I(w, h);
+    std::memcpy(I.d.data(), data, sizeof(float) * size_t(w) * h * 2);
+    return I;
+  }
+}  // namespace
+
+extern "C" {
+
+const char* ref_last_error() { return g_last_error.c_str(); }
+
+int ref_omp_max_threads()
+{
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+void ref_omp_set_threads(int n)
+{
+#ifdef _OPENMP
+  omp_set_num_threads(n);
+#else
+  (void) n;
+#endif
+}
+
+// ---- unit-level entry points ------------------------------------------- //
+
+void ref_convolve_array(float* signal, const float* kernel, int signal_size,
+                        int kernel_size)
+{
+  convolve_array(signal, kernel, signal_size, kernel_size);
+}
+
+int ref_make_gaussian_kernel(float sigma, float gauss_truncate, float* out,
+                             int capacity)
+{
+  const auto k = make_gaussian_kernel(sigma, gauss_truncate);
+  if (int(k.size()) > capacity)
+    return -int(k.size());
+  std::memcpy(out, k.data(), sizeof(float) * k.size());
+  return int(k.size());
+}
+
+int ref_apply_row_based_filter(const float* src, float* dst, int w, int h,
+                               const float* kernel, int ksz)
+{
+  Image s = wrap(src, w, h), d(w, h);
+  apply_row_based_filter(s, d, kernel, ksz);
+  std::memcpy(dst, d.d.data(), sizeof(float) * size_t(w) * h);
+  return 0;
+}
+
+int ref_apply_column_based_filter(const float* src, float* dst, int w, int h,
+                                  const float* kernel, int ksz)
+{
+  Image s = wrap(src, w, h), d(w, h);
+  apply_column_based_filter(s, d, kernel, ksz);
+  std::memcpy(dst, d.d.data(), sizeof(float) * size_t(w) * h);
+  return 0;
+}
+
+int ref_apply_gaussian_filter(const float* src, float* dst, int w, int h,
+                              float sigma, float gauss_truncate)
+{
+  Image s = wrap(src, w, h), d(w, h);
+  apply_gaussian_filter(s, d, sigma, gauss_truncate);
+  std::memcpy(dst, d.d.data(), sizeof(float) * size_t(w) * h);
+  return 0;
+}
+
+void ref_downscale(const float* src, int w, int h, int fact, float* dst)
+{
+  const Image d = downscale(wrap(src, w, h), fact);
+  std::memcpy(dst, d.d.data(), sizeof(float) * d.d.size());
+}
+
+int ref_enlarge(const float* src, int w, int h, float* dst, int dw, int dh)
+{
+  try
+  {
+    Image s = wrap(src, w, h), d(dw, dh);
+    enlarge(s, d);
+    std::memcpy(dst, d.d.data(), sizeof(float) * d.d.size());
+    return 0;
+  }
+  catch (const std::exception& e)
+  {
+    g_last_error = e.what();
+    return 1;
+  }
+}
+
+void ref_gradient(const float* src, int w, int h, float* gxgy)
+{
+  const Image s = wrap(src, w, h);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x)
+      gradient_at(s, x, y, gxgy[(size_t(y) * w + x) * 2],
+                  gxgy[(size_t(y) * w + x) * 2 + 1]);
+}
+
+void ref_hessian(const float* src, int w, int h, float* hxx_hxy_hyy)
+{
+  const Image s = wrap(src, w, h);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x)
+    {
+      float* o = &hxx_hxy_hyy[(size_t(y) * w + x) * 3];
+      hessian_at(s, x, y, o[0], o[1], o[2]);
+    }
+}
+
+void ref_gradient_polar(const float* src, int w, int h, float* mag_ori)
+{
+  const Image2 g = gradient_polar_coordinates(wrap(src, w, h));
+  std::memcpy(mag_ori, g.d.data(), sizeof(float) * g.d.size());
+}
+
+//! layers = 3 images (s-1, s, s+1) of size w x h.  strict: 0 -> >=/<=,
+//! 1 -> >/<.  Returns +1 (max), -1 (min), 0.
+int ref_scale_space_extremum(const float* layers, int w, int h, int x, int y,
+                             int strict)
+{
+  Pyramid<Image> P;
+  P.reset(1, 3, 1.6f, std::pow(2.f, 1.f / 3.f));
+  for (int i = 0; i < 3; ++i)
+    P(i, 0) = wrap(layers + size_t(i) * w * h, w, h);
+  if (strict)
+  {
+    if (local_scale_space_extremum(x, y, 1, 0, P, std::greater<float>{}))
+      return 1;
+    if (local_scale_space_extremum(x, y, 1, 0, P, std::less<float>{}))
+      return -1;
+  }
+  else
+  {
+    if (local_scale_space_extremum(x, y, 1, 0, P, std::greater_equal<float>{}))
+      return 1;
+    if (local_scale_space_extremum(x, y, 1, 0, P, std::less_equal<float>{}))
+      return -1;
+  }
+  return 0;
+}
+
+int ref_on_edge(const float* img, int w, int h, int x, int y, float edge_ratio)
+{
+  return on_edge(wrap(img, w, h), x, y, edge_ratio) ? 1 : 0;
+}
+
+//! layers: n_layers images of one octave (a DoG octave).  Returns the bool of
+//! refine_extremum; pos[3], val in/out as in the reference.
+int ref_refine_extremum(const float* layers, int n_layers, int w, int h,
+                        float scale_initial, float k, int x, int y, int s,
+                        int type, float* pos, float* val, int border_sz,
+                        int num_iter)
+{
+  Pyramid<Image> P;
+  P.reset(1, n_layers, scale_initial, k);
+  for (int i = 0; i < n_layers; ++i)
+    P(i, 0) = wrap(layers + size_t(i) * w * h, w, h);
+  try
+  {
+    return refine_extremum(P, x, y, s, 0, type, pos, *val, border_sz, num_iter)
+               ? 1
+               : 0;
+  }
+  catch (const std::exception& e)
+  {
+    g_last_error = e.what();
+    return -1;
+  }
+}
+
+void ref_orientation_histogram36(const float* grad, int w, int h, float x,
+                                 float y, float s, float* hist36)
+{
+  compute_orientation_histogram<36>(hist36, wrap2(grad, w, h), x, y, s);
+}
+
+//! The reference's unit test instantiates N = 24 bins.
+void ref_orientation_histogram24(const float* grad, int w, int h, float x,
+                                 float y, float s, float* hist24)
+{
+  compute_orientation_histogram<24>(hist24, wrap2(grad, w, h), x, y, s);
+}
+
+void ref_lowe_smooth_histogram36(float* hist36, int iters)
+{
+  lowe_smooth_histogram<36>(hist36, iters);
+}
+
+int ref_dominant_orientations(const float* grad, int w, int h, float x, float y,
+                              float sigma, float* out, int capacity,
+                              float* hist36_out)
+{
+  const auto p = dominant_orientations(wrap2(grad, w, h), x, y, sigma, 0.8f,
+                                       3.f, 1.5f, hist36_out);
+  for (int i = 0; i < int(p.size()) && i < capacity; ++i)
+    out[i] = p[i];
+  return int(p.size());
+}
+
+void ref_sift_descriptor(const float* grad, int w, int h, float x, float y,
+                         float s, float theta, int normalize, float* out128)
+{
+  compute_sift_descriptor(out128, x, y, s, theta, wrap2(grad, w, h),
+                          normalize != 0);
+}
+
+float ref_oeregion_scale(float scale)
+{
+  return oeregion_scale(make_oeregion(0.f, 0.f, scale));
+}
+
+float ref_rgb8_to_gray32f(unsigned char r, unsigned char g, unsigned char b)
+{
+  return rgb8_to_gray32f(r, g, b);
+}
+
+// ---- whole-pipeline handle ---------------------------------------------- //
+
+struct ref_sift
+{
+  SiftResult R;
+};
+
+//! ip = {first_octave_index, scale_count_per_octave, image_padding_size,
+//!       num_octaves_max}; fp = {scale_geometric_factor, scale_camera,
+//!       scale_initial}.  Mirrors compute_sift_keypoints' argument order
+//!       (FeatureDetectors/SIFT.hpp:24-33).  stop_after: see sift_ref.hpp.
+ref_sift* ref_sift_run(const float* image, int w, int h, const int* ip,
+                       const float* fp, float gauss_truncate,
+                       float extremum_thres, float edge_ratio_thres,
+                       int extremum_refinement_iter, int parallel,
+                       int stop_after)
+{
+  try
+  {
+    auto* r = new ref_sift;
+    compute_sift_keypoints(r->R, wrap(image, w, h), to_params(ip, fp),
+                           gauss_truncate, extremum_thres, edge_ratio_thres,
+                           extremum_refinement_iter, parallel != 0, stop_after);
+    return r;
+  }
+  catch (const std::exception& e)
+  {
+    g_last_error = e.what();
+    return nullptr;
+  }
+}
+
+//! gaussian_pyramid() (+ difference_of_gaussians_pyramid() when with_dog)
+//! alone, without ComputeDoGExtrema's scale-count check
+//! (ImageProcessing/GaussianPyramid.hpp:33-125, GaussianPyramid.cpp:23-51).
+ref_sift* ref_pyramid_run(const float* image, int w, int h, const int* ip,
+                          const float* fp, float gauss_truncate, int with_dog)
+{
+  try
+  {
+    auto* r = new ref_sift;
+    r->R.dog.gaussians =
+        gaussian_pyramid(wrap(image, w, h), to_params(ip, fp), gauss_truncate);
+    if (with_dog && r->R.dog.gaussians.octave_count() > 0)
+      r->R.dog.diff_of_gaussians =
+          difference_of_gaussians_pyramid(r->R.dog.gaussians);
+    return r;
+  }
+  catch (const std::exception& e)
+  {
+    g_last_error = e.what();
+    return nullptr;
+  }
+}
+
+void ref_sift_free(ref_sift* r) { delete r; }
+
+int ref_sift_octave_count(const ref_sift* r)
+{
+  return r->R.dog.gaussians.octave_count();
+}
+
+void ref_sift_octave_info(const ref_sift* r, int o, int* w, int* h,
+                          float* factor)
+{
+  const auto& G = r->R.dog.gaussians;
+  *w = G(0, o).w;
+  *h = G(0, o).h;
+  *factor = G.oct_scaling_factors[o];
+}
+
+const float* ref_sift_gaussian(const ref_sift* r, int s, int o)
+{
+  return r->R.dog.gaussians(s, o).d.data();
+}
+
+const float* ref_sift_dog(const ref_sift* r, int s, int o)
+{
+  if (r->R.dog.diff_of_gaussians.octaves.empty())
+    return nullptr;
+  return r->R.dog.diff_of_gaussians(s, o).d.data();
+}
+
+const float* ref_sift_gradient(const ref_sift* r, int s, int o)
+{
+  if (r->R.nabla_G.octaves.empty())
+    return nullptr;
+  return r->R.nabla_G(s, o).d.data();
+}
+
+int ref_sift_extrema_count(const ref_sift* r) { return int(r->R.extrema.size()); }
+
+//! out_regions: N x 48 B; out_xyso_type: N x 5 ints (x, y, s, o, type).
+void ref_sift_extrema(const ref_sift* r, void* out_regions, int* out_xyso_type)
+{
+  const auto& rec = r->R.dog.records;
+  for (size_t i = 0; i < rec.size(); ++i)
+  {
+    std::memcpy(static_cast<char*>(out_regions) + 48 * i, &rec[i].region, 48);
+    out_xyso_type[5 * i + 0] = rec[i].x;
+    out_xyso_type[5 * i + 1] = rec[i].y;
+    out_xyso_type[5 * i + 2] = rec[i].s;
+    out_xyso_type[5 * i + 3] = rec[i].o;
+    out_xyso_type[5 * i + 4] = rec[i].type;
+  }
+}
+
+int ref_sift_keypoint_count(const ref_sift* r)
+{
+  return int(r->R.features.size());
+}
+
+//! out_regions: N x 48 B; out_so: N x 2 ints; out_desc: N x 128 floats (may be
+//! null when the run stopped before descriptors).
+void ref_sift_keypoints(const ref_sift* r, void* out_regions, int* out_so,
+                        float* out_desc)
+{
+  const auto& f = r->R.features;
+  if (out_regions && !f.empty())
+    std::memcpy(out_regions, f.data(), 48 * f.size());
+  if (out_so && !r->R.so_pairs.empty())
+    std::memcpy(out_so, r->R.so_pairs.data(), sizeof(int) * r->R.so_pairs.size());
+  if (out_desc && !r->R.descriptors.empty())
+    std::memcpy(out_desc, r->R.descriptors.data(),
+                sizeof(float) * r->R.descriptors.size());
+}
+
+//! times[7] = gaussian pyramid, DoG pyramid, DoG extrema, gradient,
+//! orientation, descriptors, total (ms) — the reference's stage names
+//! (FeatureDetectors/DoG.cpp:40-83, FeatureDetectors/SIFT.cpp:56-105).
+void ref_sift_times(const ref_sift* r, double* times)
+{
+  const auto& t = r->R.times;
+  times[0] = t.gaussian_pyramid_ms;
+  times[1] = t.dog_pyramid_ms;
+  times[2] = t.dog_extrema_ms;
+  times[3] = t.gradient_ms;
+  times[4] = t.orientation_ms;
+  times[5] = t.descriptors_ms;
+  times[6] = t.total_ms;
+}
+
+}  // extern "C"

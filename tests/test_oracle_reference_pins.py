@@ -1,0 +1,254 @@
+"""The reference's own hot-path unit tests, restated
+against the CPU oracle.  Each test cites the reference test it restates
+(paths relative to /root/reference/cpp/test/Sara).  These are the only result
+pins the reference offers; they run on CPU.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import refbind as rb
+
+
+# ImageProcessing/test_imageprocessing_linear_filtering.cpp:28-43
+def test_convolve_array(oracle):
+    out = oracle.convolve_array(np.ones(10), np.ones(3), 8)
+    assert np.array_equal(out, [3] * 8 + [1] * 2)
+
+
+SRC3 = np.array([[1, 2, 3]] * 3, dtype=np.float32)
+KDIFF = np.array([-0.5, 0.0, 0.5], dtype=np.float32)
+
+
+# ...linear_filtering.cpp:69-100
+def test_row_based_filter(oracle):
+    out = oracle.apply_row_based_filter(SRC3, KDIFF)
+    assert np.array_equal(out, np.array([[0.5, 1, 0.5]] * 3, dtype=np.float32))
+
+
+def test_column_based_filter(oracle):
+    out = oracle.apply_column_based_filter(SRC3, KDIFF)
+    assert np.array_equal(out, np.zeros((3, 3), dtype=np.float32))
+
+
+def _true_gaussian(n):
+    c = n // 2
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    m = np.exp(-((i - c) ** 2 + (j - c) ** 2).astype(np.float32) / np.float32(2))
+    return (m / m.sum()).astype(np.float32)
+
+
+# ...linear_filtering.cpp:136-187: Dirac responses, L2 distance 1e-5.
+@pytest.mark.parametrize("n,truncate", [(3, 1.0), (9, 4.0), (65, 4.0)])
+def test_gaussian_on_dirac(oracle, n, truncate):
+    src = np.zeros((n, n), dtype=np.float32)
+    src[n // 2, n // 2] = 1
+    out = oracle.apply_gaussian_filter(src, 1.0, truncate)
+    if n == 65:
+        # kernel is 9 taps; the rest of the 65x65 true matrix is < 1e-7.
+        true = np.zeros((65, 65), dtype=np.float64)
+        i, j = np.meshgrid(np.arange(65), np.arange(65), indexing="ij")
+        true = np.exp(-((i - 32.0) ** 2 + (j - 32.0) ** 2) / 2.0)
+        true /= true.sum()
+    else:
+        true = _true_gaussian(n)
+    assert np.linalg.norm(true - out) < 1e-5
+
+
+# kernel size rule of LinearFiltering.hpp:171-203.
+def test_gaussian_kernel_sizes(oracle):
+    k = np.float32(2.0) ** np.float32(1.0 / 3.0)
+    s = np.float32(1.6)
+    sizes = []
+    for _ in range(5):
+        sigma = np.float32(math.sqrt(float(np.float32(k * s) ** 2 - s * s)))
+        sizes.append(len(oracle.make_gaussian_kernel(float(sigma))))
+        s = np.float32(s * k)
+    assert sizes == [11, 13, 17, 21, 25]
+    init = np.float32(math.sqrt(1.6 ** 2 - 0.5 ** 2))
+    assert len(oracle.make_gaussian_kernel(float(init))) == 13
+    init1 = np.float32(np.sqrt(np.float32(1.6) ** 2 - np.float32(1.0)))
+    assert len(oracle.make_gaussian_kernel(float(init1))) == 11
+    for sig in (0.1, 1.0, 2.54):
+        kern = oracle.make_gaussian_kernel(sig)
+        assert len(kern) % 2 == 1 and len(kern) >= 3
+        assert abs(kern.sum() - 1) < 1e-6
+
+
+# ImageProcessing/test_imageprocessing_resize.cpp:48-69
+def test_downscale(oracle):
+    src = np.array([[0, 0, 1, 1], [0, 0, 1, 1], [2, 2, 3, 3], [2, 2, 3, 3]],
+                   dtype=np.float32)
+    assert np.array_equal(oracle.downscale(src, 2), [[0, 1], [2, 3]])
+
+
+# ...resize.cpp:71-131
+def test_enlarge(oracle):
+    src = np.array([[0, 1], [2, 3]], dtype=np.float32)
+    true = np.array([[0, 0.5, 1, 1], [1, 1.5, 2, 2], [2, 2.5, 3, 3],
+                     [2, 2.5, 3, 3]], dtype=np.float32)
+    assert np.array_equal(oracle.enlarge(src, 4, 4), true)
+    src = np.repeat(np.arange(5, dtype=np.float32)[:, None], 5, axis=1)
+    out = oracle.enlarge(src, 5, 10)
+    true = np.repeat(np.array([0, .5, 1, 1.5, 2, 2.5, 3, 3.5, 4, 4],
+                              dtype=np.float32)[:, None], 5, axis=1)
+    assert np.linalg.norm(true - out) <= 1e-9
+    with pytest.raises(ValueError):
+        oracle.enlarge(np.zeros((4, 4)), 2, 2)
+
+
+# ImageProcessing/test_imageprocessing_differential.cpp:47-72
+def test_gradient(oracle):
+    g = oracle.gradient(SRC3)
+    for y in range(3):
+        for x in range(3):
+            assert g[y, x, 0] == (1 if x == 1 else 0.5)
+            assert g[y, x, 1] == 0
+
+
+# ...differential.cpp:95-122
+def test_hessian_of_constant(oracle):
+    assert np.array_equal(oracle.hessian(np.ones((3, 3))), np.zeros((3, 3, 3)))
+
+
+# ImageProcessing/test_imageprocessing_local_extremum.cpp:92-127
+def test_local_scale_space_extremum(oracle):
+    I = np.ones((3, 10, 10), dtype=np.float32)
+    assert oracle.scale_space_extremum(I, 1, 1, strict=True) == 0
+    # non-strict on a plateau: max test fires first.
+    assert oracle.scale_space_extremum(I, 1, 1, strict=False) == 1
+    I[1, 1, 1] = 10
+    I[1, 7, 7] = 10
+    assert oracle.scale_space_extremum(I, 1, 1, strict=True) == 1
+    assert oracle.scale_space_extremum(I, 7, 7, strict=True) == 1
+    n_max = sum(oracle.scale_space_extremum(I, x, y, strict=True) == 1
+                for y in range(1, 9) for x in range(1, 9))
+    assert n_max == 2
+    I[1, 1, 1] *= -1
+    I[1, 7, 7] *= -1
+    assert oracle.scale_space_extremum(I, 1, 1, strict=False) == -1
+    assert oracle.scale_space_extremum(I, 1, 1, strict=True) == -1
+    n_min = sum(oracle.scale_space_extremum(I, x, y, strict=True) == -1
+                for y in range(1, 9) for x in range(1, 9))
+    assert n_min == 2
+
+
+# ImageProcessing/test_imageprocessing_gaussian_pyramid.cpp:30-49
+def test_gaussian_pyramid_with_fixed_octaves(oracle):
+    I = np.ones((16, 16), dtype=np.float32)
+    p = oracle.PyramidParams(-1, 2, 2.0, 1, 0.5, 1.6, 2)
+    r = oracle.RefSift(I, p, pyramid_only=True)
+    assert r.octave_count == 2
+    assert r.octave_info(0)[:2] == (32, 32)
+    assert r.octave_info(1)[:2] == (16, 16)
+
+
+# ...gaussian_pyramid.cpp:51-58 (builds for ImagePyramidParams(-1)).
+def test_gaussian_pyramid_default_params(oracle):
+    I = np.ones((16, 16), dtype=np.float32)
+    r = oracle.RefSift(I, oracle.PyramidParams(-1), pyramid_only=True)
+    # l = 32, b = 1 -> int(log(16)/log(2)) = 4 octaves: 32, 16, 8, 4.
+    assert r.octave_count == 4
+    assert [r.octave_info(o)[0] for o in range(4)] == [32, 16, 8, 4]
+    for o in range(4):
+        for s in range(5):
+            assert np.all(np.abs(r.dog(s, o)) < 1e-6)
+
+
+# FeatureDetectors/test_featuredetectors_dog.cpp:45-100
+def test_compute_dog_extrema_blob(oracle):
+    N = 11
+    I = np.zeros((N, N), dtype=np.float32)
+    I[3:8, 3:8] = 1
+    k = float(np.power(np.float32(2.0), np.float32(1.0) / np.float32(3)))
+    p = oracle.PyramidParams(0, 6, k, 1, 1.0, 1.6)
+    # ComputeDoGExtrema{pyramid_params, 1e-6f, 1e-6f}: truncate, threshold;
+    # edge ratio 10, padding 1, 5 iterations by default.  The driver
+    # compute_sift_keypoints shifts extremum_refinement_iter into the padding
+    # slot (Q1), so padding 1 is requested with extremum_refinement_iter=1.
+    r = oracle.RefSift(I, p, gauss_truncate=1e-6, extremum_thres=1e-6,
+                       edge_ratio_thres=10.0, extremum_refinement_iter=1,
+                       stop_after=3)
+    regions, xyso = r.extrema()
+    assert len(regions) > 0
+    f = regions[0]
+    z = r.octave_info(int(xyso[0, 3]))[2]
+    assert abs(f["coords"][0] * z - 5) < 1e-2
+    assert abs(f["coords"][1] * z - 5) < 1e-2
+
+
+# FeatureDescriptors/test_featuredescriptors_orientation.cpp:26-50
+def test_lowe_smooth_histogram(oracle):
+    h = np.zeros(36, dtype=np.float32)
+    h[0] = 1
+    h[14] = 1
+    h = oracle.lowe_smooth_histogram(h, 1)
+    for i in (35, 0, 1, 13, 14, 15):
+        assert abs(h[i] - 1 / 3) < 1e-5 / 3
+
+
+# ...orientation.cpp:52-99: hard binning into M = 24 bins.
+def test_orientation_histogram(oracle):
+    N, M = 5, 24
+    c = np.float32(2.5)
+    for gy in range(N):
+        for gx in range(N):
+            t = np.float32(math.atan2(float(np.float32(gy) - c),
+                                      float(np.float32(gx) - c)))
+            if t < 0:
+                t = np.float32(t + np.float32(2) * np.float32(math.pi))
+            theta_bin = int(math.floor(t / np.float32(2 * math.pi) * M)) % M
+            grad = np.zeros((N, N, 2), dtype=np.float32)
+            grad[gy, gx] = (1.0, t)
+            hist = oracle.orientation_histogram(grad, c, c, 1.0, bins=M)
+            hist = hist / hist.sum()
+            expected = np.zeros(M, dtype=np.float32)
+            expected[theta_bin] = 1
+            assert np.linalg.norm(expected - hist) < 1e-6
+
+
+# ...orientation.cpp:101-124
+def test_detect_single_peak(oracle):
+    N = 5
+    c = np.float32(2.5)
+    theta = np.float32(math.atan2(0 - 2.5, 0 - 2.5))
+    grad = np.zeros((N, N, 2), dtype=np.float32)
+    grad[0, 0] = (1.0, theta)
+    peaks, _ = oracle.dominant_orientations(grad, c, c, 1.0)
+    assert len(peaks) == 1
+    assert abs(theta - peaks[0]) < 1e-6
+
+
+# FeatureDescriptors/test_featuredescriptors_sift.cpp:25-55
+def test_sift_descriptor_nonzero(oracle):
+    N = 5
+    c = np.float32(2.5)
+    theta = np.float32(math.atan2(0 - 2.5, 0 - 2.5))
+    grad = np.zeros((N, N, 2), dtype=np.float32)
+    grad[0, 0] = (1.0, theta)
+    # OERegion{c, 1.f}.scale() == 1; orientation 0.
+    assert oracle.lib().ref_oeregion_scale(1.0) == 1.0
+    d = oracle.sift_descriptor(grad, c, c, 1.0, 0.0)
+    assert d.shape == (128,)
+    assert np.any(d != 0)
+    assert np.all(d <= 255) and np.all(d >= 0)
+
+
+# Core/Pixel colour conversion used for config 1 (SmartColorConversion.hpp:237-246).
+def test_rgb_to_gray(oracle):
+    rng = np.random.default_rng(0)
+    rgb = rng.integers(0, 256, size=(64, 3), dtype=np.uint8)
+    vec = oracle.rgb8_to_gray32f(rgb)
+    for i in range(64):
+        r, g, b = (int(v) for v in rgb[i])
+        assert vec[i] == np.float32(oracle.lib().ref_rgb8_to_gray32f(r, g, b))
+    assert oracle.rgb8_to_gray32f(np.array([255, 255, 255])) == np.float32(1.0)
+
+
+# Features/Feature.hpp:79-83 + Feature.cpp:28-39: scale() inverts the
+# constructor within float rounding.
+def test_oeregion_scale_roundtrip(oracle):
+    for s in (1.6, 2.0159, 3.2, 5.0797, 1.7342):
+        got = oracle.lib().ref_oeregion_scale(s)
+        assert abs(got - np.float32(s)) <= 2e-7 * s
