@@ -1,0 +1,322 @@
+/* ========================================================================== *
+ * sara_hip_sift.h — C-ABI of the MI355X-native SIFT front-end.
+ *
+ * Drop-in boundary for Sara's CPU SIFT path (reference paths are relative to
+ * /root/reference/cpp/src/DO/Sara):
+ *
+ *   compute_sift_keypoints()            FeatureDetectors/SIFT.hpp:24-33
+ *   ComputeDoGExtrema                   FeatureDetectors/DoG.hpp:72-165
+ *   ImagePyramidParams / ImagePyramid   ImageProcessing/ImagePyramid.hpp:29-340
+ *   OERegion / KeypointList             Features/Feature.hpp:40-179,
+ *                                       Features/KeypointList.hpp:35-96
+ *
+ * Plain C: pointers, sizes and PODs only.  No exceptions cross this boundary;
+ * every entry point returns a sara_hip_status and the message is available
+ * from sara_hip_last_error().  The C++ shim include/DO/Sara/HipSift.hpp maps
+ * the codes back onto the exception classes the reference throws.
+ *
+ * Threading: one context per (host thread, device).  A context is not
+ * thread-safe; distinct contexts are independent.
+ * ========================================================================== */
+#ifndef SARA_HIP_SIFT_H
+#define SARA_HIP_SIFT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#  define SARA_HIP_API __attribute__((visibility("default")))
+#else
+#  define SARA_HIP_API
+#endif
+
+/* -------------------------------------------------------------------------- */
+/* Status codes.  The shim re-throws: INVALID_PARAMS -> std::runtime_error     */
+/* (DoG.hpp:86-89), SIZE_MISMATCH -> std::domain_error                         */
+/* (LinearFiltering.cpp:33-35), OUT_OF_RANGE -> std::out_of_range              */
+/* (GaussianPyramid.hpp:187-190).                                              */
+/* -------------------------------------------------------------------------- */
+typedef enum sara_hip_status
+{
+  SARA_HIP_OK = 0,
+  SARA_HIP_INVALID_PARAMS = 1,
+  SARA_HIP_SIZE_MISMATCH = 2,
+  SARA_HIP_OUT_OF_RANGE = 3,
+  SARA_HIP_CAPACITY_EXCEEDED = 4, /* image/batch/keypoints above the ctx capacity */
+  SARA_HIP_RUNTIME_ERROR = 5,     /* a HIP call failed, message has the detail    */
+  SARA_HIP_NO_DEVICE = 6,
+  SARA_HIP_NOT_READY = 7          /* results requested before any detect()        */
+} sara_hip_status;
+
+/* ImagePyramidParams — ImageProcessing/ImagePyramid.hpp:29-52 (same member   */
+/* meaning and defaults; sara_hip_default_pyramid_params() fills them).        */
+typedef struct sara_pyramid_params
+{
+  int32_t first_octave_index;     /* default -1 */
+  int32_t scale_count_per_octave; /* default 6 = 3 + 3 */
+  float scale_geometric_factor;   /* default powf(2, 1/3) */
+  int32_t image_padding_size;     /* default 1 */
+  float scale_camera;             /* default 0.5 */
+  float scale_initial;            /* default 1.6 */
+  int32_t num_octaves_max;        /* default INT_MAX */
+} sara_pyramid_params;
+
+/* Arguments of compute_sift_keypoints — FeatureDetectors/SIFT.hpp:24-33.      */
+/* NB the reference forwards extremum_refinement_iter into                     */
+/* ComputeDoGExtrema's img_padding_sz slot (SIFT.cpp:45-51 vs DoG.hpp:72-78):  */
+/* the border padding becomes extremum_refinement_iter and the refinement      */
+/* always runs 5 iterations.  sara_hip_sift_create() reproduces that;          */
+/* sara_hip_sift_create_dog() takes the ComputeDoGExtrema constructor          */
+/* arguments unshifted.                                                        */
+typedef struct sara_sift_params
+{
+  sara_pyramid_params pyramid;
+  float gauss_truncate;             /* default 4 (only used when first octave > 0) */
+  float extremum_thres;             /* default 0.01 */
+  float edge_ratio_thres;           /* default 10 */
+  int32_t extremum_refinement_iter; /* default 5 */
+} sara_sift_params;
+
+/* OERegion — Features/Feature.hpp:155-177, byte-compatible with the reference */
+/* class (and with its HDF5 compound type, Features/IO.hpp:58-73): 48 bytes,   */
+/* shape_matrix column-major and 16-byte aligned.                              */
+typedef struct sara_oeregion
+{
+  float coords[2];       /* offset 0  */
+  float _pad0[2];
+  float shape_matrix[4]; /* offset 16, column-major 2x2 */
+  float orientation;     /* offset 32 */
+  float extremum_value;  /* offset 36 */
+  uint8_t type;          /* offset 40, OERegion::Type, 11 = Undefined */
+  int8_t extremum_type;  /* offset 41, -1 Min, 1 Max */
+  uint8_t _pad1[6];
+} sara_oeregion;
+
+/* Stages, in pipeline order; detect() runs every stage up to `last_stage`.    */
+typedef enum sara_hip_stage
+{
+  SARA_HIP_STAGE_PYRAMID = 1,     /* gaussian_pyramid + DoG pyramid           */
+  SARA_HIP_STAGE_EXTREMA = 2,     /* + local_scale_space_extrema (refined)    */
+  SARA_HIP_STAGE_GRADIENT = 3,    /* + gradient_polar_coordinates             */
+  SARA_HIP_STAGE_ORIENTATION = 4, /* + ComputeDominantOrientations            */
+  SARA_HIP_STAGE_DESCRIPTOR = 5   /* + ComputeSIFTDescriptor (full SIFT)      */
+} sara_hip_stage;
+
+/* Indices into the array filled by sara_hip_sift_stage_times().               */
+enum
+{
+  SARA_HIP_TIME_UPLOAD = 0,
+  SARA_HIP_TIME_PYRAMID = 1, /* Gaussian pyramid + fused DoG                  */
+  SARA_HIP_TIME_EXTREMA = 2,
+  SARA_HIP_TIME_GRADIENT = 3,
+  SARA_HIP_TIME_ORIENTATION = 4,
+  SARA_HIP_TIME_DESCRIPTOR = 5,
+  SARA_HIP_TIME_TOTAL = 6,
+  SARA_HIP_TIME_COUNT = 7
+};
+
+typedef struct sara_hip_sift sara_hip_sift; /* opaque context */
+
+/* Message of the last failing call on this thread (never NULL). */
+SARA_HIP_API const char* sara_hip_last_error(void);
+
+/* Library/ABI version: major*10000 + minor*100 + patch. */
+SARA_HIP_API int sara_hip_version(void);
+
+/* Number of visible HIP devices (0 when there is no GPU). */
+SARA_HIP_API int sara_hip_device_count(void);
+
+/* ImagePyramidParams() defaults (ImagePyramid.hpp:33-40) and the defaults of  */
+/* compute_sift_keypoints (SIFT.hpp:27-33).                                    */
+SARA_HIP_API void sara_hip_default_pyramid_params(sara_pyramid_params* p);
+SARA_HIP_API void sara_hip_default_sift_params(sara_sift_params* p);
+
+/* Number of octaves gaussian_pyramid() builds for a w x h image               */
+/* (GaussianPyramid.hpp:80-94) and the size/scaling factor of octave o.        */
+/* Host-only arithmetic: usable without a GPU.                                 */
+SARA_HIP_API int sara_hip_pyramid_octave_count(const sara_pyramid_params* p,
+                                              int width, int height);
+SARA_HIP_API sara_hip_status sara_hip_pyramid_octave_info(
+    const sara_pyramid_params* p, int width, int height, int octave,
+    int* octave_width, int* octave_height, float* octave_scaling_factor);
+
+/* make_gaussian_kernel (LinearFiltering.hpp:171-203): writes the taps, returns */
+/* the tap count (or -needed when capacity is too small).  Host-only.          */
+SARA_HIP_API int sara_hip_make_gaussian_kernel(float sigma, float gauss_truncate,
+                                              float* taps, int capacity);
+
+/* -------------------------------------------------------------------------- */
+/* Whole-pipeline context == compute_sift_keypoints over a batch of frames.    */
+/* All device buffers are owned by the context and sized at creation.          */
+/*   max_width/max_height : largest input frame                                */
+/*   max_batch            : frames per detect() call                           */
+/*   max_keypoints        : per-frame capacity of the extremum and keypoint    */
+/*                          lists (0 -> max_width*max_height/128)              */
+/*   device               : HIP device ordinal                                 */
+/* -------------------------------------------------------------------------- */
+SARA_HIP_API sara_hip_status sara_hip_sift_create(const sara_sift_params* params,
+                                                 int max_width, int max_height,
+                                                 int max_batch,
+                                                 int max_keypoints, int device,
+                                                 sara_hip_sift** out);
+
+/* Same, with ComputeDoGExtrema's constructor arguments (DoG.hpp:72-78):       */
+/* img_padding_sz and extremum_refinement_iter given separately.               */
+SARA_HIP_API sara_hip_status sara_hip_sift_create_dog(
+    const sara_pyramid_params* pyramid, float gauss_truncate,
+    float extremum_thres, float edge_ratio_thres, int img_padding_sz,
+    int extremum_refinement_iter, int max_width, int max_height, int max_batch,
+    int max_keypoints, int device, sara_hip_sift** out);
+
+SARA_HIP_API sara_hip_status sara_hip_sift_destroy(sara_hip_sift* ctx);
+
+/* Runs the pipeline on `batch` frames of width x height float32 gray pixels,  */
+/* row-major (pixel (x,y) at y*width+x, Core/Image/Image.hpp:99-108), frame b  */
+/* at images + b*frame_stride (in floats; 0 -> width*height).  `images` is a   */
+/* host pointer, or a device pointer when images_on_device != 0.  The input is */
+/* borrowed and never modified.  Work is enqueued on `hip_stream` (a           */
+/* hipStream_t, NULL = the context's own stream) and NOT waited for: results   */
+/* stay in HBM until fetched.  Keypoints of frame b come out in the            */
+/* reference's order: octave, scale, raster (y*w+x), ascending orientation bin */
+/* (DoG.cpp:70-82, RefineExtremum.cpp:497-515, Orientation.cpp:146-161).       */
+SARA_HIP_API sara_hip_status sara_hip_sift_detect(
+    sara_hip_sift* ctx, const float* images, size_t frame_stride, int batch,
+    int width, int height, int images_on_device, sara_hip_stage last_stage,
+    void* hip_stream);
+
+/* Waits for the last detect() on this context. */
+SARA_HIP_API sara_hip_status sara_hip_sift_synchronize(sara_hip_sift* ctx);
+
+/* Per-frame keypoint counts of the last detect() (host array of `batch`       */
+/* ints) and their sum.  Synchronises.  When a frame overflowed max_keypoints  */
+/* the call fails with SARA_HIP_CAPACITY_EXCEEDED.                             */
+SARA_HIP_API sara_hip_status sara_hip_sift_counts(sara_hip_sift* ctx,
+                                                 int* per_frame_counts,
+                                                 int* total);
+
+/* Copies the keypoints of the whole batch, frames concatenated in order:      */
+/*   features     : total x sara_oeregion (rescaled by the octave factor,      */
+/*                  SIFT.cpp:92-98)                                            */
+/*   descriptors  : total x 128 float, row-major (FeatureDescriptors/          */
+/*                  SIFT.hpp:166-200), NULL to skip                            */
+/*   scale_octave : total x 2 int32 (s, o) (DoG.cpp:75-81), NULL to skip       */
+/* Destinations are host pointers, or device pointers when dst_on_device != 0  */
+/* (device copies are enqueued on the detect stream and not waited for).       */
+SARA_HIP_API sara_hip_status sara_hip_sift_fetch(sara_hip_sift* ctx,
+                                                sara_oeregion* features,
+                                                float* descriptors,
+                                                int32_t* scale_octave,
+                                                int dst_on_device);
+
+/* Device-resident results of the last detect(): pointers into the context's   */
+/* own buffers (valid until the next detect()/destroy()), for zero-copy hand   */
+/* off to a collective.  Frame b occupies [frame_offsets[b], frame_offsets[b+1]) */
+/* rows; frame_offsets is a device array of batch+1 int32.                     */
+SARA_HIP_API sara_hip_status sara_hip_sift_device_results(
+    sara_hip_sift* ctx, const sara_oeregion** features,
+    const float** descriptors, const int32_t** scale_octave,
+    const int32_t** frame_offsets);
+
+/* ---- ComputeDoGExtrema accessors (DoG.hpp:115-165), device -> host -------- */
+
+/* Octaves built by the last detect(). */
+SARA_HIP_API int sara_hip_sift_octave_count(const sara_hip_sift* ctx);
+SARA_HIP_API sara_hip_status sara_hip_sift_octave_info(const sara_hip_sift* ctx,
+                                                      int octave, int* width,
+                                                      int* height,
+                                                      float* scaling_factor);
+
+/* gaussians()(s, o), diff_of_gaussians()(s, o) of frame `frame`: w_o*h_o      */
+/* floats.  gradient: (2*|grad|, atan2) interleaved, 2*w_o*h_o floats          */
+/* (Orientation.cpp:24-56); only scales 1..S-3 are materialised unless the     */
+/* context was told to keep all (sara_hip_sift_set_option).                    */
+SARA_HIP_API sara_hip_status sara_hip_sift_copy_gaussian(sara_hip_sift* ctx,
+                                                        int frame, int s, int o,
+                                                        float* dst);
+SARA_HIP_API sara_hip_status sara_hip_sift_copy_dog(sara_hip_sift* ctx, int frame,
+                                                   int s, int o, float* dst);
+SARA_HIP_API sara_hip_status sara_hip_sift_copy_gradient(sara_hip_sift* ctx,
+                                                        int frame, int s, int o,
+                                                        float* dst);
+
+/* Scale-space extrema before orientation assignment == the concatenation of   */
+/* ComputeDoGExtrema::extrema(s, o) in (o, s, raster) order                    */
+/* (DoG.cpp:62-82).  xyso_type: n x 5 int32 (x, y, s, o, type +1/-1), the      */
+/* integer detection site.  Either output may be NULL.                         */
+SARA_HIP_API sara_hip_status sara_hip_sift_extrema_counts(sara_hip_sift* ctx,
+                                                         int* per_frame_counts,
+                                                         int* total);
+SARA_HIP_API sara_hip_status sara_hip_sift_fetch_extrema(sara_hip_sift* ctx,
+                                                        sara_oeregion* regions,
+                                                        int32_t* xyso_type);
+
+/* Device time of each stage of the last detect() in milliseconds (hipEvent),  */
+/* indexed by SARA_HIP_TIME_*.  Synchronises.                                  */
+SARA_HIP_API sara_hip_status sara_hip_sift_stage_times(sara_hip_sift* ctx,
+                                                      float* ms);
+
+/* Options. */
+enum
+{
+  SARA_HIP_OPT_ALL_GRADIENT_SCALES = 1, /* 1: polar gradients of all S scales  */
+                                        /* as the reference does (default 0:   */
+                                        /* only the consumed ones)             */
+  SARA_HIP_OPT_STAGE_TIMERS = 2         /* 1: record per-stage hipEvents        */
+};
+SARA_HIP_API sara_hip_status sara_hip_sift_set_option(sara_hip_sift* ctx,
+                                                     int option, int value);
+
+/* -------------------------------------------------------------------------- */
+/* Operator-level seams: the five entry points where the reference swaps in    */
+/* its Halide AOT C functions under DO_SARA_USE_HALIDE.  Host pointers in and  */
+/* out, synchronous, one image; they exist for unit parity and for callers     */
+/* that use a single operator.  The pipeline context above is the fast path.   */
+/* -------------------------------------------------------------------------- */
+
+/* apply_gaussian_filter(src, dst, sigma, gauss_truncate)                      */
+/* LinearFiltering.cpp:30-68 (seam: shakti_separable_convolution_2d_cpu :50-54) */
+SARA_HIP_API sara_hip_status sara_hip_apply_gaussian_filter(
+    const float* src, float* dst, int width, int height, float sigma,
+    float gauss_truncate, int device);
+
+/* scale(src, dst): nearest-neighbour resize, Resize.cpp:31-62                 */
+/* (seam: shakti_scale_32f_cpu :42-43)                                         */
+SARA_HIP_API sara_hip_status sara_hip_scale(const float* src, int src_width,
+                                           int src_height, float* dst,
+                                           int dst_width, int dst_height,
+                                           int device);
+
+/* enlarge(src, dst): bilinear, Resize.cpp:86-128 (seam: shakti_enlarge_cpu)   */
+SARA_HIP_API sara_hip_status sara_hip_enlarge(const float* src, int src_width,
+                                             int src_height, float* dst,
+                                             int dst_width, int dst_height,
+                                             int device);
+
+/* out = a - b, GaussianPyramid.cpp:37-46 (seam: shakti_subtract_32f_cpu)      */
+SARA_HIP_API sara_hip_status sara_hip_subtract(const float* a, const float* b,
+                                              float* out, size_t count,
+                                              int device);
+
+/* gradient_polar_coordinates(f): (2*|grad f|, atan2(gy, gx)) interleaved,     */
+/* Orientation.cpp:24-56 (seam: shakti_polar_gradient_2d_32f_cpu,              */
+/* Differential.cpp:72-79)                                                     */
+SARA_HIP_API sara_hip_status sara_hip_gradient_polar_coordinates(
+    const float* src, int width, int height, float* mag_ori, int device);
+
+/* Extremum map of DoG layers (a = s-1, b = s, c = s+1): +1 max, -1 min, 0,    */
+/* including the 0.8*thres and edge tests, RefineExtremum.cpp:407-437          */
+/* (seam: shakti_scale_space_dog_extremum_32f_cpu, LocalExtremum.cpp:23-37).   */
+SARA_HIP_API sara_hip_status sara_hip_scale_space_dog_extremum_map(
+    const float* a, const float* b, const float* c, int width, int height,
+    float edge_ratio_thres, float extremum_thres, int img_padding_sz,
+    int8_t* out, int device);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* SARA_HIP_SIFT_H */

@@ -1,0 +1,428 @@
+"""sara_amd — MI355X-native SIFT front-end behind Sara's feature-detection API.
+
+Python-facing mirror of the reference's pybind11 surface
+(python/oddkiva/sara/pybind11/FeatureDetectors.cpp:29-125): the same names,
+argument meaning and defaults — ``ImagePyramidParams`` (whose *Python* default
+first octave is +1, :72-76), ``OERegion``, ``KeypointList``, ``features()``,
+``descriptors()``, ``compute_sift_keypoints()`` — over the C-ABI of
+include/sara_hip_sift.h.  ``SiftContext`` is the batched, HBM-resident entry
+point the benchmark and the multi-GPU path use.
+
+Everything computes on the GPU; there is no CPU path in this package.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import (OEREGION_DTYPE, STAGE_DESCRIPTOR, STAGE_EXTREMA,
+                   STAGE_GRADIENT, STAGE_ORIENTATION, STAGE_PYRAMID,
+                   SaraHipError)
+
+__all__ = [
+    "ImagePyramidParams", "OERegion", "KeypointList", "features", "descriptors",
+    "compute_sift_keypoints", "SiftContext", "ComputeDoGExtrema",
+    "apply_gaussian_filter", "gaussian", "scale", "downscale", "enlarge",
+    "gradient_polar_coordinates", "scale_space_dog_extremum_map",
+    "make_gaussian_kernel", "SaraHipError", "OEREGION_DTYPE",
+]
+
+_K_DEFAULT = float(np.power(np.float32(2.0), np.float32(1.0) / np.float32(3.0)))
+_INT_MAX = 2 ** 31 - 1
+
+
+class ImagePyramidParams:
+    """ImageProcessing/ImagePyramid.hpp:29-52 as exposed to Python
+    (pybind11/FeatureDetectors.cpp:70-87: default first_octave_index = 1).
+    ``num_octaves_max`` is the 7th C++ constructor argument."""
+
+    def __init__(self, first_octave_index=1, scale_count_per_octave=3 + 3,
+                 scale_geometric_factor=_K_DEFAULT, image_padding_size=1,
+                 scale_camera=0.5, scale_initial=1.6, num_octaves_max=_INT_MAX):
+        self._s = capi.PyramidParamsStruct(
+            int(first_octave_index), int(scale_count_per_octave),
+            float(scale_geometric_factor), int(image_padding_size),
+            float(scale_camera), float(scale_initial), int(num_octaves_max))
+
+    first_octave_index = property(lambda s: s._s.first_octave_index)
+    scale_count_per_octave = property(lambda s: s._s.scale_count_per_octave)
+    scale_geometric_factor = property(lambda s: s._s.scale_geometric_factor)
+    image_padding_size = property(lambda s: s._s.image_padding_size)
+    scale_camera = property(lambda s: s._s.scale_camera)
+    scale_initial = property(lambda s: s._s.scale_initial)
+    num_octaves_max = property(lambda s: s._s.num_octaves_max)
+
+    def octave_count(self, width, height):
+        """Octaves gaussian_pyramid() builds (GaussianPyramid.hpp:80-94)."""
+        return capi.load().sara_hip_pyramid_octave_count(C.byref(self._s),
+                                                         int(width), int(height))
+
+    def octave_info(self, width, height, octave):
+        w, h, f = C.c_int(), C.c_int(), C.c_float()
+        capi.check(capi.load().sara_hip_pyramid_octave_info(
+            C.byref(self._s), int(width), int(height), int(octave), C.byref(w),
+            C.byref(h), C.byref(f)))
+        return w.value, h.value, f.value
+
+
+class OERegion:
+    """Features/Feature.hpp:40-179 (fields of the pybind class :31-39)."""
+
+    __slots__ = ("coords", "shape_matrix", "orientation", "extremum_value",
+                 "type", "extremum_type")
+
+    def __init__(self, rec=None):
+        if rec is None:
+            self.coords = np.zeros(2, np.float32)
+            self.shape_matrix = np.zeros((2, 2), np.float32)
+            self.orientation = 0.0
+            self.extremum_value = 0.0
+            self.type = 11
+            self.extremum_type = -2
+        else:
+            self.coords = np.array(rec["coords"], np.float32)
+            # column-major 2x2
+            self.shape_matrix = np.array(rec["shape_matrix"],
+                                         np.float32).reshape(2, 2).T
+            self.orientation = float(rec["orientation"])
+            self.extremum_value = float(rec["extremum_value"])
+            self.type = int(rec["type"])
+            self.extremum_type = int(rec["extremum_type"])
+
+    def radius(self, radian=0.0):
+        """Features/Feature.cpp:28-39."""
+        u, s, _ = np.linalg.svd(self.shape_matrix.astype(np.float32))
+        radii = 1.0 / np.sqrt(s)
+        d = np.array([np.cos(radian), np.sin(radian)], np.float32)
+        x = radii[0] * u[:, 0].dot(d)
+        y = radii[1] * u[:, 1].dot(d)
+        return float(np.sqrt(x * x + y * y))
+
+    def __eq__(self, other):
+        return (np.array_equal(self.coords, other.coords)
+                and np.array_equal(self.shape_matrix, other.shape_matrix)
+                and self.orientation == other.orientation
+                and self.type == other.type)
+
+
+class KeypointList:
+    """Features/KeypointList.hpp:35-96: (features, N x 128 descriptors), plus
+    the (s, o) pairs the detector reports (DoG.cpp:75-81)."""
+
+    def __init__(self, regions=None, descriptor_matrix=None, scale_octave=None):
+        self.regions = (np.zeros(0, OEREGION_DTYPE) if regions is None
+                        else regions)
+        self.descriptor_matrix = (np.zeros((0, 128), np.float32)
+                                  if descriptor_matrix is None
+                                  else descriptor_matrix)
+        self.scale_octave = (np.zeros((0, 2), np.int32) if scale_octave is None
+                             else scale_octave)
+
+    def __len__(self):
+        return len(self.regions)
+
+
+def features(keys):
+    """List of OERegion (pybind11/FeatureDetectors.cpp:57-62)."""
+    return [OERegion(r) for r in keys.regions]
+
+
+def descriptors(keys):
+    """N x 128 float32 matrix (pybind11/FeatureDetectors.cpp:63-68)."""
+    return keys.descriptor_matrix
+
+
+class SiftContext:
+    """Batched compute_sift_keypoints with all stages resident in HBM.
+
+    ``dog_args=(img_padding_sz, extremum_refinement_iter)`` builds the context
+    with ComputeDoGExtrema's own constructor arguments (DoG.hpp:72-78) instead
+    of compute_sift_keypoints' shifted ones (SIFT.cpp:45-51).
+    """
+
+    def __init__(self, max_width, max_height, max_batch=1,
+                 pyramid_params=None, gauss_truncate=4.0, extremum_thres=0.01,
+                 edge_ratio_thres=10.0, extremum_refinement_iter=5,
+                 max_keypoints=0, device=0, dog_args=None):
+        lib = capi.load()
+        capi.require_gpu()
+        self.params = pyramid_params or ImagePyramidParams()
+        self._h = C.c_void_p()
+        if dog_args is None:
+            sp = capi.SiftParamsStruct(self.params._s, gauss_truncate,
+                                       extremum_thres, edge_ratio_thres,
+                                       int(extremum_refinement_iter))
+            st = lib.sara_hip_sift_create(C.byref(sp), max_width, max_height,
+                                          max_batch, max_keypoints, device,
+                                          C.byref(self._h))
+        else:
+            st = lib.sara_hip_sift_create_dog(
+                C.byref(self.params._s), gauss_truncate, extremum_thres,
+                edge_ratio_thres, int(dog_args[0]), int(dog_args[1]), max_width,
+                max_height, max_batch, max_keypoints, device, C.byref(self._h))
+        capi.check(st)
+        self.device = device
+        self.max_batch = max_batch
+        self.batch = 0
+        self._keepalive = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            capi.load().sara_hip_sift_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_option(self, option, value):
+        capi.check(capi.load().sara_hip_sift_set_option(self._h, option, value))
+
+    # -- detection ---------------------------------------------------------- #
+    def detect(self, images, last_stage=STAGE_DESCRIPTOR, stream=None):
+        """images: H x W or B x H x W float32 (host numpy array)."""
+        a = np.ascontiguousarray(images, dtype=np.float32)
+        if a.ndim == 2:
+            a = a[None]
+        if a.ndim != 3:
+            raise ValueError("images must be H x W or B x H x W")
+        b, h, w = a.shape
+        self._keepalive = a
+        self.batch = b
+        capi.check(capi.load().sara_hip_sift_detect(
+            self._h, a.ctypes.data, 0, b, w, h, 0, int(last_stage), stream))
+        return self
+
+    def detect_device(self, ptr, batch, width, height, frame_stride=0,
+                      last_stage=STAGE_DESCRIPTOR, stream=None):
+        """Frames already resident in HBM at raw device pointer ``ptr``."""
+        self.batch = batch
+        capi.check(capi.load().sara_hip_sift_detect(
+            self._h, ptr, frame_stride, batch, width, height, 1,
+            int(last_stage), stream))
+        return self
+
+    def synchronize(self):
+        capi.check(capi.load().sara_hip_sift_synchronize(self._h))
+
+    def counts(self):
+        c = np.zeros(self.batch, np.int32)
+        tot = C.c_int32()
+        capi.check(capi.load().sara_hip_sift_counts(
+            self._h, c.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(tot)))
+        return c, tot.value
+
+    def fetch(self, with_descriptors=True):
+        """-> (per-frame counts, regions[N], descriptors[N,128] or None,
+        scale_octave[N,2]) for the whole batch, frames concatenated."""
+        c, total = self.counts()
+        regions = np.zeros(total, OEREGION_DTYPE)
+        so = np.zeros((total, 2), np.int32)
+        desc = np.zeros((total, 128), np.float32) if with_descriptors else None
+        capi.check(capi.load().sara_hip_sift_fetch(
+            self._h, regions.ctypes.data,
+            desc.ctypes.data if with_descriptors else None, so.ctypes.data, 0))
+        return c, regions, desc, so
+
+    def device_results(self):
+        f, d, s, o = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        capi.check(capi.load().sara_hip_sift_device_results(
+            self._h, C.byref(f), C.byref(d), C.byref(s), C.byref(o)))
+        return f.value, d.value, s.value, o.value
+
+    def keypoint_lists(self, with_descriptors=True):
+        c, regions, desc, so = self.fetch(with_descriptors)
+        out, at = [], 0
+        for n in c:
+            n = int(n)
+            out.append(KeypointList(regions[at:at + n],
+                                    desc[at:at + n] if desc is not None else None,
+                                    so[at:at + n]))
+            at += n
+        return out
+
+    # -- ComputeDoGExtrema accessors ------------------------------------------ #
+    @property
+    def octave_count(self):
+        return capi.load().sara_hip_sift_octave_count(self._h)
+
+    def octave_info(self, o):
+        w, h, f = C.c_int(), C.c_int(), C.c_float()
+        capi.check(capi.load().sara_hip_sift_octave_info(
+            self._h, o, C.byref(w), C.byref(h), C.byref(f)))
+        return w.value, h.value, f.value
+
+    def _plane(self, fn, frame, s, o, ch):
+        w, h, _ = self.octave_info(o)
+        out = np.zeros((h, w) if ch == 1 else (h, w, ch), np.float32)
+        capi.check(fn(self._h, frame, s, o,
+                      out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def gaussian(self, s, o, frame=0):
+        return self._plane(capi.load().sara_hip_sift_copy_gaussian, frame, s, o, 1)
+
+    def dog(self, s, o, frame=0):
+        return self._plane(capi.load().sara_hip_sift_copy_dog, frame, s, o, 1)
+
+    def gradient(self, s, o, frame=0):
+        return self._plane(capi.load().sara_hip_sift_copy_gradient, frame, s, o, 2)
+
+    def extrema(self):
+        """-> (per-frame counts, regions[N], xyso_type[N,5]) in (o, s, raster)
+        order, before orientation assignment."""
+        lib = capi.load()
+        c = np.zeros(self.batch, np.int32)
+        tot = C.c_int32()
+        capi.check(lib.sara_hip_sift_extrema_counts(
+            self._h, c.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(tot)))
+        regions = np.zeros(tot.value, OEREGION_DTYPE)
+        xyso = np.zeros((tot.value, 5), np.int32)
+        capi.check(lib.sara_hip_sift_fetch_extrema(
+            self._h, regions.ctypes.data,
+            xyso.ctypes.data_as(C.POINTER(C.c_int32))))
+        return c, regions, xyso
+
+    def stage_times(self):
+        ms = (C.c_float * 7)()
+        capi.check(capi.load().sara_hip_sift_stage_times(self._h, ms))
+        return dict(zip(capi.TIME_NAMES, list(ms)))
+
+
+def compute_sift_keypoints(image, pyramid_params=None, gauss_truncate=4.0,
+                           extremum_thres=0.01, edge_ratio_thres=10.0,
+                           extremum_refinement_iter=5, parallel=True, device=0):
+    """FeatureDetectors/SIFT.hpp:24-33 / pybind11/FeatureDetectors.cpp:116-124.
+
+    ``image``: H x W float32.  ``parallel`` is accepted for signature
+    compatibility (the GPU path is always parallel)."""
+    del parallel
+    img = np.ascontiguousarray(image, dtype=np.float32)
+    if img.ndim != 2:
+        raise ValueError("image must be a 2-D float32 array")
+    h, w = img.shape
+    params = pyramid_params or ImagePyramidParams()
+    with SiftContext(w, h, 1, params, gauss_truncate, extremum_thres,
+                     edge_ratio_thres, extremum_refinement_iter,
+                     device=device) as ctx:
+        ctx.detect(img)
+        return ctx.keypoint_lists()[0]
+
+
+class ComputeDoGExtrema:
+    """FeatureDetectors/DoG.hpp:72-165: functor keeping the pyramids."""
+
+    def __init__(self, pyramid_params=None, gauss_truncate=4.0,
+                 extremum_thres=0.01, edge_ratio_thres=10.0, img_padding_sz=1,
+                 extremum_refinement_iter=5, device=0):
+        self.params = pyramid_params or ImagePyramidParams()
+        if self.params.scale_count_per_octave < 4:
+            raise RuntimeError("Error: The extraction of DoG extrema needs "
+                               "(1 + 3) = 4 scales per octave at the very "
+                               "minimum!")
+        self._args = (gauss_truncate, extremum_thres, edge_ratio_thres,
+                      img_padding_sz, extremum_refinement_iter, device)
+        self._ctx = None
+
+    def __call__(self, image):
+        """-> (regions, scale_octave pairs [N,2])."""
+        img = np.ascontiguousarray(image, dtype=np.float32)
+        h, w = img.shape
+        gt, et, er, pad, it, dev = self._args
+        if self._ctx is not None:
+            self._ctx.close()
+        self._ctx = SiftContext(w, h, 1, self.params, gt, et, er,
+                                dog_args=(pad, it), device=dev)
+        self._ctx.detect(img, last_stage=STAGE_EXTREMA)
+        _, regions, xyso = self._ctx.extrema()
+        return regions, xyso[:, 2:4].copy()
+
+    def gaussians(self, s, o):
+        return self._ctx.gaussian(s, o)
+
+    def diff_of_gaussians(self, s, o):
+        return self._ctx.dog(s, o)
+
+
+# ---- operator-level seams --------------------------------------------------- #
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def make_gaussian_kernel(sigma, gauss_truncate=4.0):
+    """LinearFiltering.hpp:171-203 (host arithmetic, no GPU needed)."""
+    out = np.zeros(1024, np.float32)
+    n = capi.load().sara_hip_make_gaussian_kernel(
+        sigma, gauss_truncate, out.ctypes.data_as(C.POINTER(C.c_float)), 1024)
+    if n <= 0:
+        raise ValueError("kernel too large")
+    return out[:n].copy()
+
+
+def apply_gaussian_filter(src, sigma, gauss_truncate=4.0, device=0):
+    """LinearFiltering.cpp:30-68."""
+    s, sp = _f32(src)
+    d = np.zeros_like(s)
+    capi.check(capi.load().sara_hip_apply_gaussian_filter(
+        sp, d.ctypes.data_as(C.POINTER(C.c_float)), s.shape[1], s.shape[0],
+        sigma, gauss_truncate, device))
+    return d
+
+
+gaussian = apply_gaussian_filter
+
+
+def scale(src, dst_width, dst_height, device=0):
+    """Resize.cpp:31-62 (nearest neighbour)."""
+    s, sp = _f32(src)
+    d = np.zeros((dst_height, dst_width), np.float32)
+    capi.check(capi.load().sara_hip_scale(
+        sp, s.shape[1], s.shape[0], d.ctypes.data_as(C.POINTER(C.c_float)),
+        dst_width, dst_height, device))
+    return d
+
+
+def downscale(src, fact, device=0):
+    """Resize.cpp:64-84."""
+    h, w = np.asarray(src).shape
+    return scale(src, w // fact, h // fact, device)
+
+
+def enlarge(src, dst_width, dst_height, device=0):
+    """Resize.cpp:86-128 (bilinear)."""
+    s, sp = _f32(src)
+    d = np.zeros((dst_height, dst_width), np.float32)
+    capi.check(capi.load().sara_hip_enlarge(
+        sp, s.shape[1], s.shape[0], d.ctypes.data_as(C.POINTER(C.c_float)),
+        dst_width, dst_height, device))
+    return d
+
+
+def gradient_polar_coordinates(src, device=0):
+    """Orientation.cpp:24-56 -> H x W x 2 (2*|grad|, atan2)."""
+    s, sp = _f32(src)
+    d = np.zeros(s.shape + (2,), np.float32)
+    capi.check(capi.load().sara_hip_gradient_polar_coordinates(
+        sp, s.shape[1], s.shape[0], d.ctypes.data_as(C.POINTER(C.c_float)),
+        device))
+    return d
+
+
+def scale_space_dog_extremum_map(a, b, c, edge_ratio_thres=10.0,
+                                 extremum_thres=0.01, img_padding_sz=1,
+                                 device=0):
+    """RefineExtremum.cpp:407-437 -> int8 map (+1 max, -1 min, 0)."""
+    a, ap = _f32(a)
+    b, bp = _f32(b)
+    c, cp = _f32(c)
+    out = np.zeros(a.shape, np.int8)
+    capi.check(capi.load().sara_hip_scale_space_dog_extremum_map(
+        ap, bp, cp, a.shape[1], a.shape[0], edge_ratio_thres, extremum_thres,
+        img_padding_sz, out.ctypes.data_as(C.POINTER(C.c_int8)), device))
+    return out

@@ -1,0 +1,178 @@
+"""ctypes binding of the C-ABI in include/sara_hip_sift.h.
+
+Loads sara_amd/lib/libsara_hip_sift.so (built in-tree by
+``__graft_entry__.build()`` / ``make -C sara_amd/csrc``).  There is no CPU
+fallback: a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsara_hip_sift.so")
+
+# status codes (sara_hip_status)
+OK, INVALID_PARAMS, SIZE_MISMATCH, OUT_OF_RANGE, CAPACITY_EXCEEDED, \
+    RUNTIME_ERROR, NO_DEVICE, NOT_READY = range(8)
+
+# stages (sara_hip_stage)
+STAGE_PYRAMID, STAGE_EXTREMA, STAGE_GRADIENT, STAGE_ORIENTATION, \
+    STAGE_DESCRIPTOR = 1, 2, 3, 4, 5
+
+TIME_NAMES = ["upload", "pyramid", "extrema", "gradient", "orientation",
+              "descriptor", "total"]
+
+OPT_ALL_GRADIENT_SCALES = 1
+OPT_STAGE_TIMERS = 2
+
+#: numpy view of sara_oeregion (48 bytes, Features/Feature.hpp:155-177).
+OEREGION_DTYPE = np.dtype(
+    {
+        "names": ["coords", "shape_matrix", "orientation", "extremum_value",
+                  "type", "extremum_type"],
+        "formats": [("<f4", 2), ("<f4", 4), "<f4", "<f4", "u1", "i1"],
+        "offsets": [0, 16, 32, 36, 40, 41],
+        "itemsize": 48,
+    }
+)
+
+
+class PyramidParamsStruct(C.Structure):
+    _fields_ = [
+        ("first_octave_index", C.c_int32),
+        ("scale_count_per_octave", C.c_int32),
+        ("scale_geometric_factor", C.c_float),
+        ("image_padding_size", C.c_int32),
+        ("scale_camera", C.c_float),
+        ("scale_initial", C.c_float),
+        ("num_octaves_max", C.c_int32),
+    ]
+
+
+class SiftParamsStruct(C.Structure):
+    _fields_ = [
+        ("pyramid", PyramidParamsStruct),
+        ("gauss_truncate", C.c_float),
+        ("extremum_thres", C.c_float),
+        ("edge_ratio_thres", C.c_float),
+        ("extremum_refinement_iter", C.c_int32),
+    ]
+
+
+#: every entry point include/sara_hip_sift.h declares.
+EXPORTS = [
+    "sara_hip_last_error", "sara_hip_version", "sara_hip_device_count",
+    "sara_hip_default_pyramid_params", "sara_hip_default_sift_params",
+    "sara_hip_pyramid_octave_count", "sara_hip_pyramid_octave_info",
+    "sara_hip_make_gaussian_kernel", "sara_hip_sift_create",
+    "sara_hip_sift_create_dog", "sara_hip_sift_destroy", "sara_hip_sift_detect",
+    "sara_hip_sift_synchronize", "sara_hip_sift_counts", "sara_hip_sift_fetch",
+    "sara_hip_sift_device_results", "sara_hip_sift_octave_count",
+    "sara_hip_sift_octave_info", "sara_hip_sift_copy_gaussian",
+    "sara_hip_sift_copy_dog", "sara_hip_sift_copy_gradient",
+    "sara_hip_sift_extrema_counts", "sara_hip_sift_fetch_extrema",
+    "sara_hip_sift_stage_times", "sara_hip_sift_set_option",
+    "sara_hip_apply_gaussian_filter", "sara_hip_scale", "sara_hip_enlarge",
+    "sara_hip_subtract", "sara_hip_gradient_polar_coordinates",
+    "sara_hip_scale_space_dog_extremum_map",
+]
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+
+
+class SaraHipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("sara_hip status %d: %s" % (status, message))
+        self.status = status
+
+
+def _declare(lib):
+    lib.sara_hip_last_error.restype = C.c_char_p
+    lib.sara_hip_version.restype = C.c_int
+    lib.sara_hip_device_count.restype = C.c_int
+    lib.sara_hip_default_pyramid_params.argtypes = [C.POINTER(PyramidParamsStruct)]
+    lib.sara_hip_default_pyramid_params.restype = None
+    lib.sara_hip_default_sift_params.argtypes = [C.POINTER(SiftParamsStruct)]
+    lib.sara_hip_default_sift_params.restype = None
+    lib.sara_hip_pyramid_octave_count.argtypes = [C.POINTER(PyramidParamsStruct),
+                                                  C.c_int, C.c_int]
+    lib.sara_hip_pyramid_octave_info.argtypes = [C.POINTER(PyramidParamsStruct),
+                                                 C.c_int, C.c_int, C.c_int,
+                                                 C.POINTER(C.c_int),
+                                                 C.POINTER(C.c_int), _f32p]
+    lib.sara_hip_make_gaussian_kernel.argtypes = [C.c_float, C.c_float, _f32p,
+                                                  C.c_int]
+    lib.sara_hip_sift_create.argtypes = [C.POINTER(SiftParamsStruct), C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(_vp)]
+    lib.sara_hip_sift_create_dog.argtypes = [C.POINTER(PyramidParamsStruct),
+                                             C.c_float, C.c_float, C.c_float,
+                                             C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, C.c_int,
+                                             C.POINTER(_vp)]
+    lib.sara_hip_sift_destroy.argtypes = [_vp]
+    lib.sara_hip_sift_detect.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, _vp]
+    lib.sara_hip_sift_synchronize.argtypes = [_vp]
+    lib.sara_hip_sift_counts.argtypes = [_vp, _i32p, _i32p]
+    lib.sara_hip_sift_fetch.argtypes = [_vp, _vp, _vp, _vp, C.c_int]
+    lib.sara_hip_sift_device_results.argtypes = [_vp, C.POINTER(_vp),
+                                                 C.POINTER(_vp), C.POINTER(_vp),
+                                                 C.POINTER(_vp)]
+    lib.sara_hip_sift_octave_count.argtypes = [_vp]
+    lib.sara_hip_sift_octave_info.argtypes = [_vp, C.c_int, C.POINTER(C.c_int),
+                                              C.POINTER(C.c_int), _f32p]
+    for name in ("sara_hip_sift_copy_gaussian", "sara_hip_sift_copy_dog",
+                 "sara_hip_sift_copy_gradient"):
+        getattr(lib, name).argtypes = [_vp, C.c_int, C.c_int, C.c_int, _f32p]
+    lib.sara_hip_sift_extrema_counts.argtypes = [_vp, _i32p, _i32p]
+    lib.sara_hip_sift_fetch_extrema.argtypes = [_vp, _vp, _i32p]
+    lib.sara_hip_sift_stage_times.argtypes = [_vp, _f32p]
+    lib.sara_hip_sift_set_option.argtypes = [_vp, C.c_int, C.c_int]
+    lib.sara_hip_apply_gaussian_filter.argtypes = [_f32p, _f32p, C.c_int,
+                                                   C.c_int, C.c_float,
+                                                   C.c_float, C.c_int]
+    lib.sara_hip_scale.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int,
+                                   C.c_int, C.c_int]
+    lib.sara_hip_enlarge.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int,
+                                     C.c_int, C.c_int]
+    lib.sara_hip_subtract.argtypes = [_f32p, _f32p, _f32p, C.c_size_t, C.c_int]
+    lib.sara_hip_gradient_polar_coordinates.argtypes = [_f32p, C.c_int, C.c_int,
+                                                        _f32p, C.c_int]
+    lib.sara_hip_scale_space_dog_extremum_map.argtypes = [
+        _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+        C.POINTER(C.c_int8), C.c_int]
+    return lib
+
+
+_lib = None
+
+
+def load():
+    """Loads the native library; raises when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `python -c 'import "
+                "__graft_entry__ as g; g.build()'` or `make -C sara_amd/csrc`. "
+                "There is no CPU fallback." % LIB_PATH)
+        _lib = _declare(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def check(status):
+    if status != OK:
+        raise SaraHipError(status, load().sara_hip_last_error().decode())
+
+
+def require_gpu():
+    n = load().sara_hip_device_count()
+    if n <= 0:
+        raise SaraHipError(NO_DEVICE,
+                           "no HIP device visible: the MI355X SIFT front-end "
+                           "has no CPU fallback")
+    return n

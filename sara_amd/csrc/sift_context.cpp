@@ -1,0 +1,1189 @@
+// Host side of the C-ABI (include/sara_hip_sift.h): parameter schedule,
+// HBM buffer ownership, stage sequencing.  Mirrors the control flow of
+//   compute_sift_keypoints     FeatureDetectors/SIFT.cpp:27-108
+//   ComputeDoGExtrema::op()    FeatureDetectors/DoG.cpp:23-87
+//   gaussian_pyramid           ImageProcessing/GaussianPyramid.hpp:33-125
+// but batched over frames and with every stage resident in HBM.
+#include "sift_kernels.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace sara_hip;
+
+namespace {
+
+  thread_local std::string g_error = "";
+
+  sara_hip_status fail(sara_hip_status code, const std::string& msg)
+  {
+    g_error = msg;
+    return code;
+  }
+
+#define HIP_TRY(expr)                                                          \
+  do                                                                           \
+  {                                                                            \
+    const hipError_t e_ = (expr);                                              \
+    if (e_ != hipSuccess)                                                      \
+      return fail(SARA_HIP_RUNTIME_ERROR, std::string(#expr) + ": " +          \
+                                              hipGetErrorString(e_));          \
+  } while (0)
+
+  // ---- host restatement of the parameter schedule --------------------------
+
+  //! make_gaussian_kernel, ImageProcessing/LinearFiltering.hpp:171-203.
+  std::vector<float> gaussian_taps(float sigma, float gauss_truncate)
+  {
+    int size = int(2 * gauss_truncate * sigma + 1);
+    size = std::max(3, size);
+    if (size % 2 == 0)
+      ++size;
+    const int c = size / 2;
+    std::vector<float> k(size);
+    const float denom = 2 * (sigma * sigma);
+    for (int i = 0; i < size; ++i)
+    {
+      const float d = float(i) - float(c);
+      k[i] = std::exp(-(d * d) / denom);
+    }
+    float sum = 0.f;
+    for (int i = 0; i < size; ++i)
+      sum += k[i];
+    for (int i = 0; i < size; ++i)
+      k[i] /= sum;
+    return k;
+  }
+
+  bool to_taps(const std::vector<float>& k, Taps& t)
+  {
+    if (int(k.size()) > kMaxTaps)
+      return false;
+    t.size = int(k.size());
+    std::memset(t.k, 0, sizeof(t.k));
+    std::memcpy(t.k, k.data(), sizeof(float) * k.size());
+    return true;
+  }
+
+  struct OctaveGeom
+  {
+    int w = 0, h = 0;
+    float factor = 0.f;
+  };
+
+  struct Schedule
+  {
+    int base_w = 0, base_h = 0;  // octave 0 size
+    float resize_factor = 1.f;
+    int num_octaves = 0;
+    int downscale_index = 0;
+    bool init_blur = false;
+    float init_sigma = 0.f;
+    std::vector<OctaveGeom> oct;
+  };
+
+  //! Geometry part of gaussian_pyramid(), GaussianPyramid.hpp:43-122.
+  Schedule make_schedule(const sara_pyramid_params& p, int w, int h)
+  {
+    Schedule s;
+    s.resize_factor = std::pow(2.f, -static_cast<float>(p.first_octave_index));
+    const float camera_sigma = p.scale_camera * s.resize_factor;
+    const float init_sigma = p.scale_initial;
+    if (p.first_octave_index < 0)
+    {
+      s.base_w = int(double(w) * double(s.resize_factor));
+      s.base_h = int(double(h) * double(s.resize_factor));
+    }
+    else
+    {
+      if (camera_sigma < init_sigma)
+      {
+        s.init_blur = true;
+        s.init_sigma =
+            std::sqrt(init_sigma * init_sigma - camera_sigma * camera_sigma);
+      }
+      if (p.first_octave_index > 0)
+      {
+        const int f = int(std::round(1 / s.resize_factor));
+        s.base_w = f > 0 ? w / f : 0;
+        s.base_h = f > 0 ? h / f : 0;
+      }
+      else
+      {
+        s.base_w = w;
+        s.base_h = h;
+      }
+    }
+    const int l = std::min(s.base_w, s.base_h);
+    const int b = p.image_padding_size;
+    int n = 0;
+    if (l > 0 && b > 0)
+      n = std::min(static_cast<int>(std::log(double(float(l) / (2.f * float(b)))) /
+                                    std::log(double(2.f))),
+                   p.num_octaves_max);
+    s.num_octaves = std::max(n, 0);
+    s.downscale_index = static_cast<int>(std::floor(
+        std::log(double(2.f)) / std::log(double(p.scale_geometric_factor))));
+    s.oct.resize(s.num_octaves);
+    for (int o = 0; o < s.num_octaves; ++o)
+    {
+      s.oct[o].factor = (o == 0) ? 1 / s.resize_factor : s.oct[o - 1].factor * 2;
+      s.oct[o].w = (o == 0) ? s.base_w : s.oct[o - 1].w / 2;
+      s.oct[o].h = (o == 0) ? s.base_h : s.oct[o - 1].h / 2;
+    }
+    return s;
+  }
+
+  sara_hip_status validate(const sara_pyramid_params& p, int padding)
+  {
+    if (p.scale_count_per_octave < 4)
+      return fail(SARA_HIP_INVALID_PARAMS,
+                  "Error: The extraction of DoG extrema needs (1 + 3) = 4 "
+                  "scales per octave at the very minimum!");
+    if (p.scale_count_per_octave > kMaxScales)
+      return fail(SARA_HIP_INVALID_PARAMS, "scale_count_per_octave > 16");
+    if (!(p.scale_geometric_factor > 1.f))
+      return fail(SARA_HIP_INVALID_PARAMS, "scale_geometric_factor must be > 1");
+    if (p.image_padding_size < 1)
+      return fail(SARA_HIP_INVALID_PARAMS, "image_padding_size must be >= 1");
+    if (padding < 1)
+      return fail(SARA_HIP_INVALID_PARAMS,
+                  "the extremum border padding must be >= 1 (the reference "
+                  "reads out of bounds below that)");
+    if (!(p.scale_initial > 0.f) || !(p.scale_camera >= 0.f))
+      return fail(SARA_HIP_INVALID_PARAMS, "scales must be positive");
+    return SARA_HIP_OK;
+  }
+
+}  // namespace
+
+struct sara_hip_sift
+{
+  int device = 0;
+  sara_pyramid_params pyr{};
+  float gauss_truncate = 4.f, extremum_thres = 0.01f, edge_ratio = 10.f;
+  int img_padding = 1, refine_iters = 5;
+  int max_w = 0, max_h = 0, max_batch = 0, cap = 0;
+  int S = 6;
+
+  hipStream_t own_stream = nullptr;
+  hipStream_t last_stream = nullptr;
+
+  Schedule max_sched;
+  Schedule cur;
+  int cur_w = -1, cur_h = -1, cur_batch = 0;
+  sara_hip_stage last_stage = SARA_HIP_STAGE_PYRAMID;
+  bool has_result = false;
+  bool all_gradient_scales = false;
+  bool timers = true;
+
+  // pyramids, one allocation per octave (sized for max dims / max batch)
+  std::vector<float*> G, D, GR;
+  float* d_input = nullptr;  // staged host frames, or enlarge/blur scratch
+  float* d_full = nullptr;   // first_octave > 0: blurred full-size frames
+
+  // schedule constants
+  bool have_init_taps = false;
+  Taps init_taps{};
+  std::vector<Taps> taps;  // per scale s = 1..S-1
+  ScaleTable h_tab{};
+  ScaleTable* d_tab = nullptr;
+  double* d_oriw = nullptr;
+  GradPyramidView* h_grad = nullptr;  // pinned
+  GradPyramidView* d_grad = nullptr;
+
+  CandidateLists cand{};
+  OrientationLists ori{};
+  int* d_ex_offset = nullptr;
+  sara_oeregion* d_feat = nullptr;
+  int32_t* d_so = nullptr;
+  float* d_desc = nullptr;
+  sara_oeregion* d_ex_regions = nullptr;
+  int32_t* d_ex_xyso = nullptr;
+
+  int* h_counts = nullptr;  // pinned, 2*(max_batch+1)
+  hipEvent_t ev[SARA_HIP_TIME_COUNT + 1] = {};
+  bool ev_recorded[SARA_HIP_TIME_COUNT + 1] = {};
+
+  std::vector<void*> allocations;
+
+  template <typename T>
+  sara_hip_status alloc(T*& p, size_t count)
+  {
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+    allocations.push_back(q);
+    p = static_cast<T*>(q);
+    return SARA_HIP_OK;
+  }
+
+  float* plane(std::vector<float*>& pyr_, int o, int frame, int s, int chans,
+               int scales) const
+  {
+    const size_t pl = size_t(cur.oct[o].w) * cur.oct[o].h * chans;
+    return pyr_[o] + (size_t(frame) * scales + s) * pl;
+  }
+};
+
+namespace {
+
+  sara_hip_status create_impl(const sara_pyramid_params& pyr, float gauss_truncate,
+                              float extremum_thres, float edge_ratio_thres,
+                              int img_padding_sz, int refine_iters, int max_w,
+                              int max_h, int max_batch, int max_keypoints,
+                              int device, sara_hip_sift** out)
+  {
+    if (!out)
+      return fail(SARA_HIP_INVALID_PARAMS, "out is null");
+    *out = nullptr;
+    const sara_hip_status v = validate(pyr, img_padding_sz);
+    if (v != SARA_HIP_OK)
+      return v;
+    if (max_w < 2 || max_h < 2 || max_batch < 1)
+      return fail(SARA_HIP_INVALID_PARAMS, "max_width/max_height/max_batch");
+    if (max_w >= (1 << 20) || max_h >= (1 << 20))
+      return fail(SARA_HIP_INVALID_PARAMS, "image side must be < 2^20");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      return fail(SARA_HIP_NO_DEVICE,
+                  "no HIP device: the SIFT front-end has no CPU fallback");
+    if (device < 0 || device >= ndev)
+      return fail(SARA_HIP_INVALID_PARAMS, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    auto* c = new sara_hip_sift;
+    c->device = device;
+    c->pyr = pyr;
+    c->gauss_truncate = gauss_truncate;
+    c->extremum_thres = extremum_thres;
+    c->edge_ratio = edge_ratio_thres;
+    c->img_padding = img_padding_sz;
+    c->refine_iters = refine_iters;
+    c->max_w = max_w;
+    c->max_h = max_h;
+    c->max_batch = max_batch;
+    c->S = pyr.scale_count_per_octave;
+    c->max_sched = make_schedule(pyr, max_w, max_h);
+    if (c->max_sched.num_octaves > 16)
+    {
+      delete c;
+      return fail(SARA_HIP_INVALID_PARAMS, "more than 16 octaves");
+    }
+    if (c->max_sched.downscale_index >= c->S)
+    {
+      delete c;
+      return fail(SARA_HIP_INVALID_PARAMS,
+                  "downscale index floor(log 2 / log k) >= scale count");
+    }
+    c->cap = max_keypoints > 0
+                 ? max_keypoints
+                 : std::max(1024, int((size_t(c->max_sched.base_w) *
+                                       size_t(c->max_sched.base_h)) /
+                                      128));
+
+    auto cleanup = [&](sara_hip_status st) {
+      sara_hip_sift_destroy(c);
+      return st;
+    };
+#define TRY_ST(expr)                                                           \
+  do                                                                           \
+  {                                                                            \
+    const sara_hip_status st_ = (expr);                                        \
+    if (st_ != SARA_HIP_OK)                                                    \
+      return cleanup(st_);                                                     \
+  } while (0)
+#define TRY_HIP(expr)                                                          \
+  do                                                                           \
+  {                                                                            \
+    const hipError_t e_ = (expr);                                              \
+    if (e_ != hipSuccess)                                                      \
+      return cleanup(fail(SARA_HIP_RUNTIME_ERROR,                              \
+                          std::string(#expr) + ": " + hipGetErrorString(e_))); \
+  } while (0)
+
+    TRY_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    for (auto& e : c->ev)
+      TRY_HIP(hipEventCreate(&e));
+
+    // ---- taps and tables (host arithmetic as in GaussianPyramid.hpp:106-121)
+    const float k = pyr.scale_geometric_factor;
+    if (c->max_sched.init_blur)
+    {
+      const float trunc = pyr.first_octave_index > 0 ? gauss_truncate : 4.f;
+      if (!to_taps(gaussian_taps(c->max_sched.init_sigma, trunc), c->init_taps))
+        return cleanup(fail(SARA_HIP_INVALID_PARAMS,
+                            "initial Gaussian needs more than 65 taps"));
+      c->have_init_taps = true;
+    }
+    c->taps.resize(c->S);
+    {
+      float sigma_s_1 = pyr.scale_initial;
+      for (int s = 1; s < c->S; ++s)
+      {
+        const float ks = k * sigma_s_1;
+        const double sigma = std::sqrt(double(ks * ks - sigma_s_1 * sigma_s_1));
+        if (!to_taps(gaussian_taps(static_cast<float>(sigma), 4.f), c->taps[s]))
+          return cleanup(fail(SARA_HIP_INVALID_PARAMS,
+                              "a pyramid Gaussian needs more than 65 taps"));
+        sigma_s_1 *= k;
+      }
+    }
+    std::vector<double> oriw;
+    for (int s = 0; s < c->S; ++s)
+    {
+      // ImagePyramid.hpp:316-319 / Orientation.hpp:105-108,127.
+      const float sigma = static_cast<float>(std::pow(double(k), double(s)) *
+                                             double(pyr.scale_initial));
+      c->h_tab.sigma[s] = sigma;
+      const float sw = sigma * 1.5f;
+      c->h_tab.ori_sigma[s] = sw;
+      const int R = static_cast<int>(std::round(sw * 3.f));
+      c->h_tab.ori_radius[s] = R;
+      c->h_tab.ori_woff[s] = int(oriw.size());
+      const bool used = s >= 1 && s <= c->S - 3;
+      if (used)
+        for (int d2 = 0; d2 <= 2 * R * R; ++d2)
+          oriw.push_back(std::exp(double(float(-d2) / (2.f * sw * sw))));
+    }
+    TRY_ST(c->alloc(c->d_tab, 1));
+    TRY_HIP(hipMemcpy(c->d_tab, &c->h_tab, sizeof(ScaleTable),
+                      hipMemcpyHostToDevice));
+    TRY_ST(c->alloc(c->d_oriw, oriw.size()));
+    if (!oriw.empty())
+      TRY_HIP(hipMemcpy(c->d_oriw, oriw.data(), sizeof(double) * oriw.size(),
+                        hipMemcpyHostToDevice));
+    TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_grad),
+                          sizeof(GradPyramidView)));
+    std::memset(c->h_grad, 0, sizeof(GradPyramidView));
+    TRY_ST(c->alloc(c->d_grad, 1));
+    TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_counts),
+                          sizeof(int) * 2 * (size_t(max_batch) + 1)));
+
+    // ---- HBM: pyramids [frame][scale][h][w] per octave
+    const int no = c->max_sched.num_octaves;
+    c->G.assign(no, nullptr);
+    c->D.assign(no, nullptr);
+    c->GR.assign(no, nullptr);
+    for (int o = 0; o < no; ++o)
+    {
+      const size_t pl = size_t(c->max_sched.oct[o].w) * c->max_sched.oct[o].h;
+      TRY_ST(c->alloc(c->G[o], pl * c->S * max_batch));
+      TRY_ST(c->alloc(c->D[o], pl * (c->S - 1) * max_batch));
+      TRY_ST(c->alloc(c->GR[o], pl * c->S * max_batch * 2));
+    }
+    TRY_ST(c->alloc(c->d_input, size_t(max_w) * max_h * max_batch));
+    if (pyr.first_octave_index > 0)
+      TRY_ST(c->alloc(c->d_full, size_t(max_w) * max_h * max_batch));
+
+    // ---- candidate / keypoint lists
+    const size_t rows = size_t(max_batch) * c->cap;
+    c->cand.cap = c->cap;
+    TRY_ST(c->alloc(c->cand.key, rows));
+    TRY_ST(c->alloc(c->cand.data, rows));
+    TRY_ST(c->alloc(c->cand.count, max_batch));
+    TRY_ST(c->alloc(c->cand.order, rows));
+    TRY_ST(c->alloc(c->ori.peak_count, rows));
+    TRY_ST(c->alloc(c->ori.peak_theta, rows * kMaxPeaks));
+    TRY_ST(c->alloc(c->ori.offset, rows));
+    TRY_ST(c->alloc(c->ori.kp_count, max_batch));
+    TRY_ST(c->alloc(c->ori.frame_offset, size_t(max_batch) + 1));
+    TRY_ST(c->alloc(c->d_ex_offset, size_t(max_batch) + 1));
+    TRY_ST(c->alloc(c->d_feat, rows));
+    TRY_ST(c->alloc(c->d_so, rows * 2));
+    TRY_ST(c->alloc(c->d_desc, rows * 128));
+    TRY_ST(c->alloc(c->d_ex_regions, rows));
+    TRY_ST(c->alloc(c->d_ex_xyso, rows * 5));
+#undef TRY_ST
+#undef TRY_HIP
+    *out = c;
+    return SARA_HIP_OK;
+  }
+
+  sara_hip_status require_result(const sara_hip_sift* ctx, sara_hip_stage need)
+  {
+    if (!ctx)
+      return fail(SARA_HIP_INVALID_PARAMS, "null context");
+    if (!ctx->has_result)
+      return fail(SARA_HIP_NOT_READY, "no detect() has run on this context");
+    if (ctx->last_stage < need)
+      return fail(SARA_HIP_NOT_READY,
+                  "the last detect() stopped before the requested stage");
+    return SARA_HIP_OK;
+  }
+
+}  // namespace
+
+namespace {
+  struct DeviceScratch
+  {
+    std::vector<void*> ptrs;
+    ~DeviceScratch()
+    {
+      for (void* p : ptrs)
+        (void) hipFree(p);
+    }
+    template <typename T>
+    hipError_t get(T*& p, size_t count)
+    {
+      void* q = nullptr;
+      const hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+      if (e == hipSuccess)
+      {
+        ptrs.push_back(q);
+        p = static_cast<T*>(q);
+      }
+      return e;
+    }
+  };
+
+  sara_hip_status select_device(int device)
+  {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      return fail(SARA_HIP_NO_DEVICE,
+                  "no HIP device: the SIFT front-end has no CPU fallback");
+    if (device < 0 || device >= ndev)
+      return fail(SARA_HIP_INVALID_PARAMS, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    return SARA_HIP_OK;
+  }
+}  // namespace
+
+extern "C" {
+
+const char* sara_hip_last_error(void) { return g_error.c_str(); }
+
+int sara_hip_version(void) { return 100; }
+
+int sara_hip_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+void sara_hip_default_pyramid_params(sara_pyramid_params* p)
+{
+  p->first_octave_index = -1;
+  p->scale_count_per_octave = 3 + 3;
+  p->scale_geometric_factor = std::pow(2.f, 1.f / 3.f);
+  p->image_padding_size = 1;
+  p->scale_camera = 0.5f;
+  p->scale_initial = 1.6f;
+  p->num_octaves_max = INT_MAX;
+}
+
+void sara_hip_default_sift_params(sara_sift_params* p)
+{
+  sara_hip_default_pyramid_params(&p->pyramid);
+  p->gauss_truncate = 4.f;
+  p->extremum_thres = 0.01f;
+  p->edge_ratio_thres = 10.f;
+  p->extremum_refinement_iter = 5;
+}
+
+int sara_hip_pyramid_octave_count(const sara_pyramid_params* p, int width,
+                                  int height)
+{
+  if (!p)
+    return 0;
+  return make_schedule(*p, width, height).num_octaves;
+}
+
+sara_hip_status sara_hip_pyramid_octave_info(const sara_pyramid_params* p,
+                                             int width, int height, int octave,
+                                             int* ow, int* oh, float* factor)
+{
+  if (!p)
+    return fail(SARA_HIP_INVALID_PARAMS, "null params");
+  const Schedule s = make_schedule(*p, width, height);
+  if (octave < 0 || octave >= s.num_octaves)
+    return fail(SARA_HIP_OUT_OF_RANGE, "octave index out of range");
+  if (ow)
+    *ow = s.oct[octave].w;
+  if (oh)
+    *oh = s.oct[octave].h;
+  if (factor)
+    *factor = s.oct[octave].factor;
+  return SARA_HIP_OK;
+}
+
+int sara_hip_make_gaussian_kernel(float sigma, float gauss_truncate, float* taps,
+                                  int capacity)
+{
+  const auto k = gaussian_taps(sigma, gauss_truncate);
+  if (int(k.size()) > capacity || !taps)
+    return -int(k.size());
+  std::memcpy(taps, k.data(), sizeof(float) * k.size());
+  return int(k.size());
+}
+
+sara_hip_status sara_hip_sift_create(const sara_sift_params* params, int max_width,
+                                     int max_height, int max_batch,
+                                     int max_keypoints, int device,
+                                     sara_hip_sift** out)
+{
+  if (!params)
+    return fail(SARA_HIP_INVALID_PARAMS, "null params");
+  // FeatureDetectors/SIFT.cpp:45-51: the 5th constructor argument of
+  // ComputeDoGExtrema is img_padding_sz, so extremum_refinement_iter becomes
+  // the border padding and the iteration count keeps its default of 5.
+  return create_impl(params->pyramid, params->gauss_truncate,
+                     params->extremum_thres, params->edge_ratio_thres,
+                     params->extremum_refinement_iter, 5, max_width, max_height,
+                     max_batch, max_keypoints, device, out);
+}
+
+sara_hip_status sara_hip_sift_create_dog(const sara_pyramid_params* pyramid,
+                                         float gauss_truncate,
+                                         float extremum_thres,
+                                         float edge_ratio_thres,
+                                         int img_padding_sz,
+                                         int extremum_refinement_iter,
+                                         int max_width, int max_height,
+                                         int max_batch, int max_keypoints,
+                                         int device, sara_hip_sift** out)
+{
+  if (!pyramid)
+    return fail(SARA_HIP_INVALID_PARAMS, "null params");
+  return create_impl(*pyramid, gauss_truncate, extremum_thres, edge_ratio_thres,
+                     img_padding_sz, extremum_refinement_iter, max_width,
+                     max_height, max_batch, max_keypoints, device, out);
+}
+
+sara_hip_status sara_hip_sift_destroy(sara_hip_sift* c)
+{
+  if (!c)
+    return SARA_HIP_OK;
+  (void) hipSetDevice(c->device);
+  if (c->last_stream)
+    (void) hipStreamSynchronize(c->last_stream);
+  if (c->own_stream)
+    (void) hipStreamSynchronize(c->own_stream);
+  for (void* p : c->allocations)
+    (void) hipFree(p);
+  if (c->h_grad)
+    (void) hipHostFree(c->h_grad);
+  if (c->h_counts)
+    (void) hipHostFree(c->h_counts);
+  for (auto& e : c->ev)
+    if (e)
+      (void) hipEventDestroy(e);
+  if (c->own_stream)
+    (void) hipStreamDestroy(c->own_stream);
+  delete c;
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_sift_set_option(sara_hip_sift* c, int option, int value)
+{
+  if (!c)
+    return fail(SARA_HIP_INVALID_PARAMS, "null context");
+  switch (option)
+  {
+  case SARA_HIP_OPT_ALL_GRADIENT_SCALES:
+    c->all_gradient_scales = value != 0;
+    return SARA_HIP_OK;
+  case SARA_HIP_OPT_STAGE_TIMERS:
+    c->timers = value != 0;
+    return SARA_HIP_OK;
+  default:
+    return fail(SARA_HIP_INVALID_PARAMS, "unknown option");
+  }
+}
+
+sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
+                                     size_t frame_stride, int batch, int width,
+                                     int height, int images_on_device,
+                                     sara_hip_stage last_stage, void* hip_stream)
+{
+  if (!c || !images)
+    return fail(SARA_HIP_INVALID_PARAMS, "null context or images");
+  if (batch < 1 || batch > c->max_batch)
+    return fail(SARA_HIP_CAPACITY_EXCEEDED, "batch exceeds max_batch");
+  if (width < 2 || height < 2)
+    return fail(SARA_HIP_INVALID_PARAMS, "image smaller than 2x2");
+  if (width > c->max_w || height > c->max_h)
+    return fail(SARA_HIP_CAPACITY_EXCEEDED,
+                "image larger than the context's max_width/max_height");
+  if (last_stage < SARA_HIP_STAGE_PYRAMID || last_stage > SARA_HIP_STAGE_DESCRIPTOR)
+    return fail(SARA_HIP_INVALID_PARAMS, "last_stage");
+  if (frame_stride == 0)
+    frame_stride = size_t(width) * height;
+  if (frame_stride < size_t(width) * height)
+    return fail(SARA_HIP_SIZE_MISMATCH, "frame_stride < width*height");
+
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t stream =
+      hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  if (c->last_stream && c->last_stream != stream)
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+
+  const bool dims_changed = (width != c->cur_w || height != c->cur_h);
+  if (dims_changed)
+  {
+    if (c->last_stream)
+      HIP_TRY(hipStreamSynchronize(c->last_stream));
+    c->cur = make_schedule(c->pyr, width, height);
+    c->cur_w = width;
+    c->cur_h = height;
+    GradPyramidView& gv = *c->h_grad;
+    std::memset(&gv, 0, sizeof(gv));
+    gv.octaves = c->cur.num_octaves;
+    for (int o = 0; o < c->cur.num_octaves; ++o)
+    {
+      gv.base[o] = c->GR[o];
+      gv.w[o] = c->cur.oct[o].w;
+      gv.h[o] = c->cur.oct[o].h;
+      gv.plane[o] = size_t(gv.w[o]) * gv.h[o];
+      gv.frame_stride[o] = gv.plane[o] * 2 * c->S;
+      gv.factor[o] = c->cur.oct[o].factor;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_grad, c->h_grad, sizeof(GradPyramidView),
+                           hipMemcpyHostToDevice, stream));
+  }
+  c->last_stream = stream;
+  c->cur_batch = batch;
+  c->last_stage = last_stage;
+  c->has_result = false;
+  std::fill(std::begin(c->ev_recorded), std::end(c->ev_recorded), false);
+  auto mark = [&](int i) -> hipError_t {
+    if (!c->timers)
+      return hipSuccess;
+    c->ev_recorded[i] = true;
+    return hipEventRecord(c->ev[i], stream);
+  };
+
+  const Schedule& sc = c->cur;
+  const int S = c->S;
+  const size_t in_plane = size_t(width) * height;
+
+  HIP_TRY(mark(0));
+  // ---- upload -------------------------------------------------------------
+  const float* src = images;
+  size_t src_stride = frame_stride;
+  if (!images_on_device)
+  {
+    HIP_TRY(hipMemcpy2DAsync(c->d_input, in_plane * sizeof(float), images,
+                             frame_stride * sizeof(float),
+                             in_plane * sizeof(float), batch,
+                             hipMemcpyHostToDevice, stream));
+    src = c->d_input;
+    src_stride = in_plane;
+  }
+  HIP_TRY(mark(1));
+
+  // ---- Gaussian pyramid + fused DoG ---------------------------------------
+  if (sc.num_octaves > 0)
+  {
+    const size_t pl0 = size_t(sc.oct[0].w) * sc.oct[0].h;
+    float* G00 = c->G[0];
+    const size_t g_stride0 = pl0 * S;
+    if (c->pyr.first_octave_index < 0)
+    {
+      launch_enlarge(src, src_stride, width, height, G00, g_stride0, sc.oct[0].w,
+                     sc.oct[0].h, batch, stream);
+    }
+    else if (c->pyr.first_octave_index > 0)
+    {
+      const float* blurred = src;
+      size_t bstride = src_stride;
+      if (sc.init_blur)
+      {
+        launch_gaussian_blur(src, src_stride, c->d_full, in_plane, nullptr, 0,
+                             width, height, batch, c->init_taps, stream);
+        blurred = c->d_full;
+        bstride = in_plane;
+      }
+      launch_scale(blurred, bstride, width, height, G00, g_stride0, sc.oct[0].w,
+                   sc.oct[0].h, batch, stream);
+    }
+    else if (sc.init_blur)
+    {
+      launch_gaussian_blur(src, src_stride, G00, g_stride0, nullptr, 0, width,
+                           height, batch, c->init_taps, stream);
+    }
+    else
+    {
+      launch_copy_planes(src, src_stride, G00, g_stride0, pl0, batch, stream);
+    }
+
+    for (int o = 0; o < sc.num_octaves; ++o)
+    {
+      const int w = sc.oct[o].w, h = sc.oct[o].h;
+      const size_t pl = size_t(w) * h;
+      const size_t gs = pl * S, ds = pl * (S - 1);
+      if (o > 0)
+      {
+        const int pw = sc.oct[o - 1].w, ph = sc.oct[o - 1].h;
+        const size_t ppl = size_t(pw) * ph;
+        launch_scale(c->G[o - 1] + ppl * sc.downscale_index, ppl * S, pw, ph,
+                     c->G[o], gs, w, h, batch, stream);
+      }
+      for (int s = 1; s < S; ++s)
+        launch_gaussian_blur(c->G[o] + pl * (s - 1), gs, c->G[o] + pl * s, gs,
+                             c->D[o] + pl * (s - 1), ds, w, h, batch, c->taps[s],
+                             stream);
+    }
+  }
+  HIP_TRY(mark(2));
+
+  // ---- extrema ------------------------------------------------------------
+  HIP_TRY(hipMemsetAsync(c->cand.count, 0, sizeof(int) * batch, stream));
+  HIP_TRY(hipMemsetAsync(c->ori.kp_count, 0, sizeof(int) * batch, stream));
+  HIP_TRY(hipMemsetAsync(c->ori.frame_offset, 0, sizeof(int) * (batch + 1),
+                         stream));
+  if (last_stage >= SARA_HIP_STAGE_EXTREMA)
+  {
+    ExtremaParams ep;
+    ep.extremum_thres = c->extremum_thres;
+    ep.edge_ratio_thres = c->edge_ratio;
+    ep.img_padding_sz = c->img_padding;
+    ep.refine_iters = c->refine_iters;
+    ep.scale_geometric_factor = c->pyr.scale_geometric_factor;
+    for (int o = 0; o < sc.num_octaves; ++o)
+    {
+      OctaveView dv;
+      dv.base = c->D[o];
+      dv.w = sc.oct[o].w;
+      dv.h = sc.oct[o].h;
+      dv.scales = S - 1;
+      dv.plane = size_t(dv.w) * dv.h;
+      dv.frame_stride = dv.plane * (S - 1);
+      if (dv.w > 2 * c->img_padding && dv.h > 2 * c->img_padding)
+        launch_extrema_scan(dv, o, batch, ep, c->d_tab, c->cand, stream);
+    }
+    launch_rank_candidates(c->cand, batch, stream);
+    launch_extrema_offsets(c->cand, c->d_ex_offset, batch, stream);
+  }
+  HIP_TRY(mark(3));
+
+  // ---- polar gradients ----------------------------------------------------
+  if (last_stage >= SARA_HIP_STAGE_GRADIENT)
+  {
+    const int s_lo = c->all_gradient_scales ? 0 : 1;
+    const int s_n = c->all_gradient_scales ? S : S - 3;
+    for (int o = 0; o < sc.num_octaves; ++o)
+    {
+      const int w = sc.oct[o].w, h = sc.oct[o].h;
+      const size_t pl = size_t(w) * h;
+      launch_gradient_polar(c->G[o] + pl * s_lo, pl * S, c->GR[o] + pl * 2 * s_lo,
+                            pl * 2 * S, w, h, s_n, batch, stream);
+    }
+  }
+  HIP_TRY(mark(4));
+
+  // ---- orientations -------------------------------------------------------
+  if (last_stage >= SARA_HIP_STAGE_ORIENTATION)
+  {
+    launch_orientations(c->d_grad, c->d_tab, c->d_oriw, c->cand, c->ori, batch,
+                        stream);
+    launch_scan_peaks(c->cand, c->ori, batch, stream);
+  }
+  HIP_TRY(mark(5));
+
+  // ---- descriptors --------------------------------------------------------
+  if (last_stage >= SARA_HIP_STAGE_ORIENTATION)
+    launch_descriptors(c->d_grad, c->cand, c->ori, batch, c->d_feat, c->d_so,
+                       c->d_desc, last_stage >= SARA_HIP_STAGE_DESCRIPTOR ? 1 : 0,
+                       stream);
+  HIP_TRY(mark(6));
+  HIP_TRY(hipGetLastError());
+  c->has_result = true;
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_sift_synchronize(sara_hip_sift* c)
+{
+  if (!c)
+    return fail(SARA_HIP_INVALID_PARAMS, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->last_stream)
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_sift_counts(sara_hip_sift* c, int* per_frame, int* total)
+{
+  const sara_hip_status st = require_result(c, SARA_HIP_STAGE_ORIENTATION);
+  if (st != SARA_HIP_OK)
+    return st;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(c->h_counts, c->ori.kp_count, sizeof(int) * c->cur_batch,
+                         hipMemcpyDeviceToHost, c->last_stream));
+  HIP_TRY(hipStreamSynchronize(c->last_stream));
+  int sum = 0;
+  bool overflow = false;
+  for (int b = 0; b < c->cur_batch; ++b)
+  {
+    const int n = c->h_counts[b];
+    overflow = overflow || n > c->cap;
+    if (per_frame)
+      per_frame[b] = std::min(n, c->cap);
+    sum += std::min(n, c->cap);
+  }
+  if (total)
+    *total = sum;
+  if (overflow)
+    return fail(SARA_HIP_CAPACITY_EXCEEDED,
+                "a frame produced more keypoints than max_keypoints");
+  // the extremum list can also overflow without the keypoint list doing so
+  HIP_TRY(hipMemcpy(c->h_counts, c->cand.count, sizeof(int) * c->cur_batch,
+                    hipMemcpyDeviceToHost));
+  for (int b = 0; b < c->cur_batch; ++b)
+    if (c->h_counts[b] > c->cap)
+      return fail(SARA_HIP_CAPACITY_EXCEEDED,
+                  "a frame produced more extrema than max_keypoints");
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_sift_fetch(sara_hip_sift* c, sara_oeregion* features,
+                                    float* descriptors, int32_t* scale_octave,
+                                    int dst_on_device)
+{
+  const sara_hip_status st = require_result(c, SARA_HIP_STAGE_ORIENTATION);
+  if (st != SARA_HIP_OK)
+    return st;
+  if (descriptors && c->last_stage < SARA_HIP_STAGE_DESCRIPTOR)
+    return fail(SARA_HIP_NOT_READY, "descriptors were not computed");
+  HIP_TRY(hipSetDevice(c->device));
+  int total = 0;
+  HIP_TRY(hipMemcpyAsync(&c->h_counts[0], c->ori.frame_offset + c->cur_batch,
+                         sizeof(int), hipMemcpyDeviceToHost, c->last_stream));
+  HIP_TRY(hipStreamSynchronize(c->last_stream));
+  total = c->h_counts[0];
+  if (total == 0)
+    return SARA_HIP_OK;
+  const hipMemcpyKind kind =
+      dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (features)
+    HIP_TRY(hipMemcpyAsync(features, c->d_feat, sizeof(sara_oeregion) * total,
+                           kind, c->last_stream));
+  if (descriptors)
+    HIP_TRY(hipMemcpyAsync(descriptors, c->d_desc,
+                           sizeof(float) * 128 * size_t(total), kind,
+                           c->last_stream));
+  if (scale_octave)
+    HIP_TRY(hipMemcpyAsync(scale_octave, c->d_so, sizeof(int32_t) * 2 * total,
+                           kind, c->last_stream));
+  if (!dst_on_device)
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_sift_device_results(sara_hip_sift* c,
+                                             const sara_oeregion** features,
+                                             const float** descriptors,
+                                             const int32_t** scale_octave,
+                                             const int32_t** frame_offsets)
+{
+  const sara_hip_status st = require_result(c, SARA_HIP_STAGE_ORIENTATION);
+  if (st != SARA_HIP_OK)
+    return st;
+  if (features)
+    *features = c->d_feat;
+  if (descriptors)
+    *descriptors = c->d_desc;
+  if (scale_octave)
+    *scale_octave = c->d_so;
+  if (frame_offsets)
+    *frame_offsets = c->ori.frame_offset;
+  return SARA_HIP_OK;
+}
+
+int sara_hip_sift_octave_count(const sara_hip_sift* c)
+{
+  return (c && c->cur_w > 0) ? c->cur.num_octaves : 0;
+}
+
+sara_hip_status sara_hip_sift_octave_info(const sara_hip_sift* c, int octave,
+                                          int* w, int* h, float* factor)
+{
+  if (!c || c->cur_w <= 0)
+    return fail(SARA_HIP_NOT_READY, "no detect() has run on this context");
+  if (octave < 0 || octave >= c->cur.num_octaves)
+    return fail(SARA_HIP_OUT_OF_RANGE, "octave index out of range");
+  if (w)
+    *w = c->cur.oct[octave].w;
+  if (h)
+    *h = c->cur.oct[octave].h;
+  if (factor)
+    *factor = c->cur.oct[octave].factor;
+  return SARA_HIP_OK;
+}
+
+static sara_hip_status copy_plane(sara_hip_sift* c, std::vector<float*>& pyr,
+                                  int frame, int s, int o, int scales, int chans,
+                                  float* dst, sara_hip_stage need)
+{
+  const sara_hip_status st = require_result(c, need);
+  if (st != SARA_HIP_OK)
+    return st;
+  if (!dst)
+    return fail(SARA_HIP_INVALID_PARAMS, "null destination");
+  if (frame < 0 || frame >= c->cur_batch || o < 0 || o >= c->cur.num_octaves ||
+      s < 0 || s >= scales)
+    return fail(SARA_HIP_OUT_OF_RANGE, "frame/scale/octave index out of range");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->last_stream));
+  const size_t pl = size_t(c->cur.oct[o].w) * c->cur.oct[o].h * chans;
+  HIP_TRY(hipMemcpy(dst, c->plane(pyr, o, frame, s, chans, scales),
+                    pl * sizeof(float), hipMemcpyDeviceToHost));
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_sift_copy_gaussian(sara_hip_sift* c, int frame, int s,
+                                            int o, float* dst)
+{
+  return copy_plane(c, c->G, frame, s, o, c ? c->S : 0, 1, dst,
+                    SARA_HIP_STAGE_PYRAMID);
+}
+
+sara_hip_status sara_hip_sift_copy_dog(sara_hip_sift* c, int frame, int s, int o,
+                                       float* dst)
+{
+  return copy_plane(c, c->D, frame, s, o, c ? c->S - 1 : 0, 1, dst,
+                    SARA_HIP_STAGE_PYRAMID);
+}
+
+sara_hip_status sara_hip_sift_copy_gradient(sara_hip_sift* c, int frame, int s,
+                                            int o, float* dst)
+{
+  if (c && !c->all_gradient_scales && (s < 1 || s > c->S - 3))
+    return fail(SARA_HIP_OUT_OF_RANGE,
+                "only scales 1..S-3 are materialised; set "
+                "SARA_HIP_OPT_ALL_GRADIENT_SCALES for the others");
+  return copy_plane(c, c->GR, frame, s, o, c ? c->S : 0, 2, dst,
+                    SARA_HIP_STAGE_GRADIENT);
+}
+
+sara_hip_status sara_hip_sift_extrema_counts(sara_hip_sift* c, int* per_frame,
+                                             int* total)
+{
+  const sara_hip_status st = require_result(c, SARA_HIP_STAGE_EXTREMA);
+  if (st != SARA_HIP_OK)
+    return st;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(c->h_counts, c->cand.count, sizeof(int) * c->cur_batch,
+                         hipMemcpyDeviceToHost, c->last_stream));
+  HIP_TRY(hipStreamSynchronize(c->last_stream));
+  int sum = 0;
+  bool overflow = false;
+  for (int b = 0; b < c->cur_batch; ++b)
+  {
+    const int n = c->h_counts[b];
+    overflow = overflow || n > c->cap;
+    if (per_frame)
+      per_frame[b] = std::min(n, c->cap);
+    sum += std::min(n, c->cap);
+  }
+  if (total)
+    *total = sum;
+  if (overflow)
+    return fail(SARA_HIP_CAPACITY_EXCEEDED,
+                "a frame produced more extrema than max_keypoints");
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_sift_fetch_extrema(sara_hip_sift* c,
+                                            sara_oeregion* regions,
+                                            int32_t* xyso_type)
+{
+  int total = 0;
+  sara_hip_status st = sara_hip_sift_extrema_counts(c, nullptr, &total);
+  if (st != SARA_HIP_OK && st != SARA_HIP_CAPACITY_EXCEEDED)
+    return st;
+  if (total == 0)
+    return st;
+  launch_gather_extrema(c->cand, c->d_ex_offset, c->cur_batch, c->d_ex_regions,
+                        c->d_ex_xyso, c->last_stream);
+  if (regions)
+    HIP_TRY(hipMemcpyAsync(regions, c->d_ex_regions,
+                           sizeof(sara_oeregion) * total, hipMemcpyDeviceToHost,
+                           c->last_stream));
+  if (xyso_type)
+    HIP_TRY(hipMemcpyAsync(xyso_type, c->d_ex_xyso, sizeof(int32_t) * 5 * total,
+                           hipMemcpyDeviceToHost, c->last_stream));
+  HIP_TRY(hipStreamSynchronize(c->last_stream));
+  return st;
+}
+
+sara_hip_status sara_hip_sift_stage_times(sara_hip_sift* c, float* ms)
+{
+  const sara_hip_status st = require_result(c, SARA_HIP_STAGE_PYRAMID);
+  if (st != SARA_HIP_OK)
+    return st;
+  if (!ms)
+    return fail(SARA_HIP_INVALID_PARAMS, "null destination");
+  if (!c->timers)
+    return fail(SARA_HIP_NOT_READY, "stage timers are disabled");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->last_stream));
+  for (int i = 0; i < SARA_HIP_TIME_TOTAL; ++i)
+  {
+    ms[i] = 0.f;
+    if (c->ev_recorded[i] && c->ev_recorded[i + 1])
+      HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+  }
+  ms[SARA_HIP_TIME_TOTAL] = 0.f;
+  if (c->ev_recorded[0] && c->ev_recorded[SARA_HIP_TIME_TOTAL])
+    HIP_TRY(hipEventElapsedTime(&ms[SARA_HIP_TIME_TOTAL], c->ev[0],
+                                c->ev[SARA_HIP_TIME_TOTAL]));
+  return SARA_HIP_OK;
+}
+
+// ---- operator-level seams --------------------------------------------------
+
+sara_hip_status sara_hip_apply_gaussian_filter(const float* src, float* dst,
+                                               int w, int h, float sigma,
+                                               float gauss_truncate, int device)
+{
+  if (!src || !dst || w < 1 || h < 1)
+    return fail(SARA_HIP_SIZE_MISMATCH,
+                "Source and destination image sizes are not equal!");
+  Taps taps;
+  if (!to_taps(gaussian_taps(sigma, gauss_truncate), taps))
+    return fail(SARA_HIP_INVALID_PARAMS, "Gaussian needs more than 65 taps");
+  const sara_hip_status st = select_device(device);
+  if (st != SARA_HIP_OK)
+    return st;
+  DeviceScratch sc;
+  float *ds = nullptr, *dd = nullptr;
+  const size_t n = size_t(w) * h;
+  HIP_TRY(sc.get(ds, n));
+  HIP_TRY(sc.get(dd, n));
+  HIP_TRY(hipMemcpy(ds, src, n * sizeof(float), hipMemcpyHostToDevice));
+  launch_gaussian_blur(ds, n, dd, n, nullptr, 0, w, h, 1, taps, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(dst, dd, n * sizeof(float), hipMemcpyDeviceToHost));
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_scale(const float* src, int sw, int sh, float* dst,
+                               int dw, int dh, int device)
+{
+  if (!src || !dst || sw < 1 || sh < 1 || dw < 1 || dh < 1)
+    return fail(SARA_HIP_INVALID_PARAMS, "bad image sizes");
+  const sara_hip_status st = select_device(device);
+  if (st != SARA_HIP_OK)
+    return st;
+  DeviceScratch sc;
+  float *ds = nullptr, *dd = nullptr;
+  HIP_TRY(sc.get(ds, size_t(sw) * sh));
+  HIP_TRY(sc.get(dd, size_t(dw) * dh));
+  HIP_TRY(hipMemcpy(ds, src, size_t(sw) * sh * sizeof(float),
+                    hipMemcpyHostToDevice));
+  launch_scale(ds, 0, sw, sh, dd, 0, dw, dh, 1, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(dst, dd, size_t(dw) * dh * sizeof(float),
+                    hipMemcpyDeviceToHost));
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_enlarge(const float* src, int sw, int sh, float* dst,
+                                 int dw, int dh, int device)
+{
+  if (!src || !dst)
+    return fail(SARA_HIP_INVALID_PARAMS, "null image");
+  if (dw < sw || dh < sh)
+    return fail(SARA_HIP_OUT_OF_RANGE,
+                "The destination image must have smaller sizes than the source "
+                "image!");
+  if (std::min(dw, dh) <= 0 || sw < 1 || sh < 1)
+    return fail(SARA_HIP_OUT_OF_RANGE,
+                "The sizes of the destination image must be positive!");
+  const sara_hip_status st = select_device(device);
+  if (st != SARA_HIP_OK)
+    return st;
+  DeviceScratch sc;
+  float *ds = nullptr, *dd = nullptr;
+  HIP_TRY(sc.get(ds, size_t(sw) * sh));
+  HIP_TRY(sc.get(dd, size_t(dw) * dh));
+  HIP_TRY(hipMemcpy(ds, src, size_t(sw) * sh * sizeof(float),
+                    hipMemcpyHostToDevice));
+  launch_enlarge(ds, 0, sw, sh, dd, 0, dw, dh, 1, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(dst, dd, size_t(dw) * dh * sizeof(float),
+                    hipMemcpyDeviceToHost));
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_subtract(const float* a, const float* b, float* out,
+                                  size_t count, int device)
+{
+  if (!a || !b || !out)
+    return fail(SARA_HIP_INVALID_PARAMS, "null operand");
+  const sara_hip_status st = select_device(device);
+  if (st != SARA_HIP_OK)
+    return st;
+  DeviceScratch sc;
+  float *da = nullptr, *db = nullptr, *dout = nullptr;
+  HIP_TRY(sc.get(da, count));
+  HIP_TRY(sc.get(db, count));
+  HIP_TRY(sc.get(dout, count));
+  HIP_TRY(hipMemcpy(da, a, count * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, b, count * sizeof(float), hipMemcpyHostToDevice));
+  launch_subtract(da, db, dout, count, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, dout, count * sizeof(float), hipMemcpyDeviceToHost));
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_gradient_polar_coordinates(const float* src, int w,
+                                                    int h, float* mag_ori,
+                                                    int device)
+{
+  if (!src || !mag_ori || w < 2 || h < 2)
+    return fail(SARA_HIP_INVALID_PARAMS, "image must be at least 2x2");
+  const sara_hip_status st = select_device(device);
+  if (st != SARA_HIP_OK)
+    return st;
+  DeviceScratch sc;
+  float *ds = nullptr, *dd = nullptr;
+  const size_t n = size_t(w) * h;
+  HIP_TRY(sc.get(ds, n));
+  HIP_TRY(sc.get(dd, 2 * n));
+  HIP_TRY(hipMemcpy(ds, src, n * sizeof(float), hipMemcpyHostToDevice));
+  launch_gradient_polar(ds, n, dd, 2 * n, w, h, 1, 1, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(mag_ori, dd, 2 * n * sizeof(float), hipMemcpyDeviceToHost));
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_scale_space_dog_extremum_map(
+    const float* a, const float* b, const float* c, int w, int h,
+    float edge_ratio_thres, float extremum_thres, int img_padding_sz,
+    int8_t* out, int device)
+{
+  if (!a || !b || !c || !out || w < 3 || h < 3)
+    return fail(SARA_HIP_INVALID_PARAMS, "layers must be at least 3x3");
+  if (img_padding_sz < 1)
+    return fail(SARA_HIP_INVALID_PARAMS, "img_padding_sz must be >= 1");
+  const sara_hip_status st = select_device(device);
+  if (st != SARA_HIP_OK)
+    return st;
+  DeviceScratch sc;
+  float *da = nullptr, *db = nullptr, *dc = nullptr;
+  int8_t* dout = nullptr;
+  const size_t n = size_t(w) * h;
+  HIP_TRY(sc.get(da, n));
+  HIP_TRY(sc.get(db, n));
+  HIP_TRY(sc.get(dc, n));
+  HIP_TRY(sc.get(dout, n));
+  HIP_TRY(hipMemcpy(da, a, n * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, b, n * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dc, c, n * sizeof(float), hipMemcpyHostToDevice));
+  launch_extremum_map(da, db, dc, w, h, edge_ratio_thres, extremum_thres,
+                      img_padding_sz, dout, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, dout, n, hipMemcpyDeviceToHost));
+  return SARA_HIP_OK;
+}
+
+}  // extern "C"

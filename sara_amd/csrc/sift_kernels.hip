@@ -1,0 +1,1222 @@
+// gfx950 (MI355X / CDNA4) kernels of the SIFT front-end.
+//
+// Built with -ffp-contract=off: the CPU reference is compiled for baseline
+// x86-64 (no FMA), and every kernel below evaluates its float expressions in
+// the reference's operation order so that pyramids, DoG layers, extremum
+// classification, refinement and polar gradients come out bit-identical.
+//
+// Wave = 64 lanes everywhere; workgroups are 256 threads = 4 waves.
+#include "sift_kernels.hpp"
+
+#include "device_math.hpp"
+
+#include <cmath>
+
+namespace sara_hip {
+
+  // ======================================================================== //
+  // Gaussian blur: rows then columns through LDS, replicate borders.
+  // Reference: apply_gaussian_filter, ImageProcessing/LinearFiltering.cpp:30-68
+  //            apply_row_based_filter / apply_column_based_filter / convolve_array,
+  //            ImageProcessing/LinearFiltering.hpp:43-149.
+  // Optional fused epilogue: dog = dst - src (GaussianPyramid.cpp:44-46).
+  //
+  // One workgroup produces a TX x TY tile.  The (TY+2R) x (TX+2R) source
+  // window is staged in LDS once, row-filtered into a (TY+2R) x TX LDS tile
+  // (each lane: 4 adjacent outputs from ds_read_b128 windows), then
+  // column-filtered (each lane: 8 outputs of one column from a register
+  // window).  Taps sit in SGPRs.  Accumulation is `sum += v * k` from 0.f in
+  // ascending tap order, mul and add unfused, as in convolve_array.
+  // ======================================================================== //
+  constexpr int TX = 64;
+  constexpr int TY = 32;
+  constexpr int NT = 256;
+
+  template <int R>
+  __global__ __launch_bounds__(NT) void gaussian_blur_kernel(
+      const float* __restrict__ src, size_t src_stride,
+      float* __restrict__ dst, size_t dst_stride, float* __restrict__ dog,
+      size_t dog_stride, int w, int h, Taps taps)
+  {
+    constexpr int K = 2 * R + 1;
+    constexpr int IW = TX + 2 * R;
+    constexpr int IH = TY + 2 * R;
+    constexpr int NQ = (4 + 2 * R + 3) / 4;       // b128 reads per 4 outputs
+    constexpr int IP = ((IW + 3) / 4) * 4 + 4;    // row pitch, over-read safe
+    __shared__ __attribute__((aligned(16))) float s_in[IH * IP];
+    __shared__ __attribute__((aligned(16))) float s_tmp[IH * TX];
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TX;
+    const int y0 = blockIdx.y * TY;
+    const size_t b = blockIdx.z;
+    src += b * src_stride;
+    dst += b * dst_stride;
+
+    // Stage the clamped source window.
+    for (int idx = tid; idx < IH * IW; idx += NT)
+    {
+      const int r = idx / IW;
+      const int c = idx - r * IW;
+      int gy = y0 - R + r;
+      int gx = x0 - R + c;
+      gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
+      gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
+      s_in[r * IP + c] = src[size_t(gy) * w + gx];
+    }
+    __syncthreads();
+
+    // Row pass.
+    for (int it = tid; it < IH * (TX / 4); it += NT)
+    {
+      const int r = it / (TX / 4);
+      const int q = it - r * (TX / 4);
+      float v[NQ * 4];
+      const float4* p = reinterpret_cast<const float4*>(&s_in[r * IP + 4 * q]);
+#pragma unroll
+      for (int m = 0; m < NQ; ++m)
+      {
+        const float4 t = p[m];
+        v[4 * m + 0] = t.x;
+        v[4 * m + 1] = t.y;
+        v[4 * m + 2] = t.z;
+        v[4 * m + 3] = t.w;
+      }
+      float acc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+      {
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+          sum += v[i + j] * taps.k[j];
+        acc[i] = sum;
+      }
+      *reinterpret_cast<float4*>(&s_tmp[r * TX + 4 * q]) =
+          make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    __syncthreads();
+
+    // Column pass: lane -> column tx, 8 consecutive rows.
+    const int tx = tid & 63;
+    const int yq = tid >> 6;
+    constexpr int NV = 8 + 2 * R;
+    float v[NV];
+#pragma unroll
+    for (int m = 0; m < NV; ++m)
+      v[m] = s_tmp[(yq * 8 + m) * TX + tx];
+
+    const int gx = x0 + tx;
+    if (gx >= w)
+      return;
+    if (dog)
+      dog += b * dog_stride;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+    {
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+        sum += v[i + j] * taps.k[j];
+      const int gy = y0 + yq * 8 + i;
+      if (gy < h)
+      {
+        dst[size_t(gy) * w + gx] = sum;
+        if (dog)
+          dog[size_t(gy) * w + gx] = sum - s_in[(yq * 8 + i + R) * IP + tx + R];
+      }
+    }
+  }
+
+  //! Any radius up to kMaxRadius: same structure, runtime loops, dynamic LDS.
+  __global__ __launch_bounds__(NT) void gaussian_blur_generic_kernel(
+      const float* __restrict__ src, size_t src_stride,
+      float* __restrict__ dst, size_t dst_stride, float* __restrict__ dog,
+      size_t dog_stride, int w, int h, Taps taps)
+  {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    const int R = taps.size / 2;
+    const int K = taps.size;
+    const int IW = TX + 2 * R;
+    const int IH = TY + 2 * R;
+    float* s_in = s_dyn;
+    float* s_tmp = s_dyn + IH * IW;
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TX;
+    const int y0 = blockIdx.y * TY;
+    const size_t b = blockIdx.z;
+    src += b * src_stride;
+    dst += b * dst_stride;
+    if (dog)
+      dog += b * dog_stride;
+
+    for (int idx = tid; idx < IH * IW; idx += NT)
+    {
+      const int r = idx / IW;
+      const int c = idx - r * IW;
+      int gy = y0 - R + r;
+      int gx = x0 - R + c;
+      gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
+      gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
+      s_in[idx] = src[size_t(gy) * w + gx];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < IH * TX; idx += NT)
+    {
+      const int r = idx / TX;
+      const int c = idx - r * TX;
+      float sum = 0.f;
+      for (int j = 0; j < K; ++j)
+        sum += s_in[r * IW + c + j] * taps.k[j];
+      s_tmp[idx] = sum;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < TY * TX; idx += NT)
+    {
+      const int r = idx / TX;
+      const int c = idx - r * TX;
+      float sum = 0.f;
+      for (int j = 0; j < K; ++j)
+        sum += s_tmp[(r + j) * TX + c] * taps.k[j];
+      const int gx = x0 + c, gy = y0 + r;
+      if (gx < w && gy < h)
+      {
+        dst[size_t(gy) * w + gx] = sum;
+        if (dog)
+          dog[size_t(gy) * w + gx] = sum - s_in[(r + R) * IW + c + R];
+      }
+    }
+  }
+
+  template <int R>
+  static void launch_blur_r(const float* src, size_t src_stride, float* dst,
+                            size_t dst_stride, float* dog, size_t dog_stride,
+                            int w, int h, int batch, const Taps& taps,
+                            hipStream_t stream)
+  {
+    const dim3 grid((w + TX - 1) / TX, (h + TY - 1) / TY, batch);
+    hipLaunchKernelGGL(gaussian_blur_kernel<R>, grid, dim3(NT), 0, stream, src,
+                       src_stride, dst, dst_stride, dog, dog_stride, w, h, taps);
+  }
+
+  void launch_gaussian_blur(const float* src, size_t src_stride, float* dst,
+                            size_t dst_stride, float* dog, size_t dog_stride,
+                            int w, int h, int batch, const Taps& taps,
+                            hipStream_t stream)
+  {
+    const int R = taps.size / 2;
+#define SARA_BLUR_CASE(r)                                                      \
+  case r:                                                                      \
+    launch_blur_r<r>(src, src_stride, dst, dst_stride, dog, dog_stride, w, h,  \
+                     batch, taps, stream);                                     \
+    return;
+    switch (R)
+    {
+      SARA_BLUR_CASE(1)
+      SARA_BLUR_CASE(2)
+      SARA_BLUR_CASE(3)
+      SARA_BLUR_CASE(4)
+      SARA_BLUR_CASE(5)
+      SARA_BLUR_CASE(6)
+      SARA_BLUR_CASE(7)
+      SARA_BLUR_CASE(8)
+      SARA_BLUR_CASE(9)
+      SARA_BLUR_CASE(10)
+      SARA_BLUR_CASE(11)
+      SARA_BLUR_CASE(12)
+      SARA_BLUR_CASE(13)
+      SARA_BLUR_CASE(14)
+      SARA_BLUR_CASE(15)
+      SARA_BLUR_CASE(16)
+    default:
+      break;
+    }
+#undef SARA_BLUR_CASE
+    const dim3 grid((w + TX - 1) / TX, (h + TY - 1) / TY, batch);
+    const size_t lds =
+        sizeof(float) * size_t(TY + 2 * R) * (size_t(TX + 2 * R) + TX);
+    hipLaunchKernelGGL(gaussian_blur_generic_kernel, grid, dim3(NT), lds, stream,
+                       src, src_stride, dst, dst_stride, dog, dog_stride, w, h,
+                       taps);
+  }
+
+  // ======================================================================== //
+  // Resize / copy / subtract.
+  // ======================================================================== //
+
+  //! scale(): ImageProcessing/Resize.cpp:45-60.
+  __global__ void scale_kernel(const float* __restrict__ src, size_t src_stride,
+                               int sw, int sh, float* __restrict__ dst,
+                               size_t dst_stride, int dw, int dh)
+  {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= dw || y >= dh)
+      return;
+    const size_t b = blockIdx.z;
+    const float sx = float(sw) / float(dw);
+    const float sy = float(sh) / float(dh);
+    const int xi = int(float(x) * sx);
+    const int yi = int(float(y) * sy);
+    dst[b * dst_stride + size_t(y) * dw + x] =
+        src[b * src_stride + size_t(yi) * sw + xi];
+  }
+
+  void launch_scale(const float* src, size_t src_stride, int sw, int sh,
+                    float* dst, size_t dst_stride, int dw, int dh, int batch,
+                    hipStream_t stream)
+  {
+    const dim3 block(64, 4);
+    const dim3 grid((dw + 63) / 64, (dh + 3) / 4, batch);
+    hipLaunchKernelGGL(scale_kernel, grid, block, 0, stream, src, src_stride, sw,
+                       sh, dst, dst_stride, dw, dh);
+  }
+
+  //! enlarge(): ImageProcessing/Resize.cpp:110-126 + interpolate(),
+  //! ImageProcessing/Interpolation.hpp:33-78 (bilinear in double, far border
+  //! replicated, x-fastest accumulation).
+  __global__ void enlarge_kernel(const float* __restrict__ src,
+                                 size_t src_stride, int sw, int sh,
+                                 float* __restrict__ dst, size_t dst_stride,
+                                 int dw, int dh)
+  {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= dw || y >= dh)
+      return;
+    const size_t b = blockIdx.z;
+    const float* s = src + b * src_stride;
+    const double scx = double(sw) / double(dw);
+    const double scy = double(sh) / double(dh);
+    const double px = double(x) * scx;
+    const double py = double(y) * scy;
+    const double ipx = trunc(px), ipy = trunc(py);
+    const double fx = px - ipx, fy = py - ipy;
+    const int x0 = int(ipx), y0 = int(ipy);
+    double value = 0.;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx)
+      {
+        double weight = 1.;
+        weight *= (dx == 0) ? (1. - fx) : fx;
+        weight *= (dy == 0) ? (1. - fy) : fy;
+        const int xx = (x0 + dx < sw) ? x0 + dx : x0 + dx - 1;
+        const int yy = (y0 + dy < sh) ? y0 + dy : y0 + dy - 1;
+        value += weight * double(s[size_t(yy) * sw + xx]);
+      }
+    dst[b * dst_stride + size_t(y) * dw + x] = float(value);
+  }
+
+  void launch_enlarge(const float* src, size_t src_stride, int sw, int sh,
+                      float* dst, size_t dst_stride, int dw, int dh, int batch,
+                      hipStream_t stream)
+  {
+    const dim3 block(64, 4);
+    const dim3 grid((dw + 63) / 64, (dh + 3) / 4, batch);
+    hipLaunchKernelGGL(enlarge_kernel, grid, block, 0, stream, src, src_stride,
+                       sw, sh, dst, dst_stride, dw, dh);
+  }
+
+  __global__ void copy_planes_kernel(const float* __restrict__ src,
+                                     size_t src_stride, float* __restrict__ dst,
+                                     size_t dst_stride, size_t count)
+  {
+    const size_t b = blockIdx.y;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count;
+         i += size_t(gridDim.x) * blockDim.x)
+      dst[b * dst_stride + i] = src[b * src_stride + i];
+  }
+
+  void launch_copy_planes(const float* src, size_t src_stride, float* dst,
+                          size_t dst_stride, size_t count, int batch,
+                          hipStream_t stream)
+  {
+    const int blocks = int(std::min<size_t>((count + 255) / 256, 2048));
+    hipLaunchKernelGGL(copy_planes_kernel, dim3(blocks, batch), dim3(256), 0,
+                       stream, src, src_stride, dst, dst_stride, count);
+  }
+
+  __global__ void subtract_kernel(const float* __restrict__ a,
+                                  const float* __restrict__ b,
+                                  float* __restrict__ out, size_t count)
+  {
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count;
+         i += size_t(gridDim.x) * blockDim.x)
+      out[i] = a[i] - b[i];
+  }
+
+  void launch_subtract(const float* a, const float* b, float* out, size_t count,
+                       hipStream_t stream)
+  {
+    const int blocks = int(std::min<size_t>((count + 255) / 256, 2048));
+    hipLaunchKernelGGL(subtract_kernel, dim3(blocks), dim3(256), 0, stream, a, b,
+                       out, count);
+  }
+
+  // ======================================================================== //
+  // Polar gradients.  Reference: gradient_polar_coordinates,
+  // FeatureDescriptors/Orientation.cpp:24-56; Gradient functor,
+  // ImageProcessing/Differential.hpp:46-61 (central difference / 2, one-sided
+  // (f1 - f0) / 2 on the borders).  Output (2*|g|, atan2f(gy, gx)).
+  // ======================================================================== //
+  __global__ void gradient_polar_kernel(const float* __restrict__ src,
+                                        size_t src_stride,
+                                        float2* __restrict__ dst,
+                                        size_t dst_stride2, int w, int h,
+                                        int nscales)
+  {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h)
+      return;
+    const int z = blockIdx.z;
+    const size_t b = z / nscales;
+    const size_t s = z - b * nscales;
+    const size_t plane = size_t(w) * h;
+    const float* f = src + b * src_stride + s * plane;
+    float2* o = dst + b * dst_stride2 + s * plane;
+
+    const size_t c = size_t(y) * w + x;
+    float gx, gy;
+    if (x == 0)
+      gx = (f[c + 1] - f[c]) / 2;
+    else if (x == w - 1)
+      gx = (f[c] - f[c - 1]) / 2;
+    else
+      gx = (f[c + 1] - f[c - 1]) / 2;
+    if (y == 0)
+      gy = (f[c + w] - f[c]) / 2;
+    else if (y == h - 1)
+      gy = (f[c] - f[c - w]) / 2;
+    else
+      gy = (f[c + w] - f[c - w]) / 2;
+    const float r = 2 * sqrtf(gx * gx + gy * gy);
+    const float theta = fdlibm_atan2f(gy, gx);
+    o[c] = make_float2(r, theta);
+  }
+
+  void launch_gradient_polar(const float* src, size_t src_stride, float* dst,
+                             size_t dst_stride, int w, int h, int nscales,
+                             int batch, hipStream_t stream)
+  {
+    const dim3 block(64, 4);
+    const dim3 grid((w + 63) / 64, (h + 3) / 4, batch * nscales);
+    hipLaunchKernelGGL(gradient_polar_kernel, grid, block, 0, stream, src,
+                       src_stride, reinterpret_cast<float2*>(dst),
+                       dst_stride / 2, w, h, nscales);
+  }
+
+  // ======================================================================== //
+  // Scale-space extrema.  Reference: local_scale_space_extrema (non-Halide
+  // branch), FeatureDetectors/RefineExtremum.cpp:363-521; predicates
+  // ImageProcessing/Extrema.hpp:28-75; on_edge RefineExtremum.cpp:24-30;
+  // refine_extremum RefineExtremum.cpp:32-130 with the 3-D gradient/hessian of
+  // ImageProcessing/GaussianPyramid.hpp:183-233.
+  // ======================================================================== //
+
+  //! One frame's DoG octave: layer s at base + s*plane.
+  struct DogOctave
+  {
+    const float* base;
+    int w, h;
+    size_t plane;
+    int layers;
+    __device__ float at(int x, int y, int s) const
+    {
+      return base[size_t(s) * plane + size_t(y) * w + x];
+    }
+  };
+
+  __device__ inline float sum3(float a0, float a1, float a2)
+  {
+    return a0 + (a1 + a2);
+  }
+
+  __device__ inline float cofactor3(const float m[3][3], int i, int j)
+  {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+    const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1];
+  }
+
+  //! +1 positive definite, -1 negative definite, 0 otherwise (Sylvester in
+  //! double on the float entries; stands in for SelfAdjointEigenSolver).
+  __device__ inline int definiteness3(const float Hf[3][3])
+  {
+    double H[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        H[i][j] = double(Hf[i][j]);
+    const double m1 = H[0][0];
+    const double m2 = H[0][0] * H[1][1] - H[0][1] * H[1][0];
+    const double m3 = H[0][0] * (H[1][1] * H[2][2] - H[1][2] * H[2][1]) -
+                      H[0][1] * (H[1][0] * H[2][2] - H[1][2] * H[2][0]) +
+                      H[0][2] * (H[1][0] * H[2][1] - H[1][1] * H[2][0]);
+    if (m1 > 0 && m2 > 0 && m3 > 0)
+      return +1;
+    if (m1 < 0 && m2 > 0 && m3 < 0)
+      return -1;
+    return 0;
+  }
+
+  //! refine_extremum.  type: 1 maximum, 255 minimum (the reference's uint8
+  //! map stores -1 as 255, so minima are never refined).  pos = (x, y, sigma).
+  __device__ inline void refine_extremum(const DogOctave& I, int x, int y, int s,
+                                         int type, float pos[3], float& val,
+                                         int border_sz, int num_iter,
+                                         const ScaleTable& tab, float kfactor)
+  {
+    float D_prime[3] = {0.f, 0.f, 0.f};
+    float H[3][3];
+    float hh[3] = {0.f, 0.f, 0.f};
+
+    pos[0] = float(x);
+    pos[1] = float(y);
+    pos[2] = tab.sigma[s];
+
+    for (int i = 0; i < num_iter; ++i)
+    {
+      if (x < border_sz || x >= I.w - border_sz || y < border_sz ||
+          y >= I.h - border_sz || s < 1 || s >= I.layers - 1)
+        break;
+
+      const float c = I.at(x, y, s);
+      D_prime[0] = (I.at(x + 1, y, s) - I.at(x - 1, y, s)) / 2.f;
+      D_prime[1] = (I.at(x, y + 1, s) - I.at(x, y - 1, s)) / 2.f;
+      D_prime[2] = (I.at(x, y, s + 1) - I.at(x, y, s - 1)) / 2.f;
+
+      H[0][0] = I.at(x + 1, y, s) - 2.f * c + I.at(x - 1, y, s);
+      H[1][1] = I.at(x, y + 1, s) - 2.f * c + I.at(x, y - 1, s);
+      H[2][2] = I.at(x, y, s + 1) - 2.f * c + I.at(x, y, s - 1);
+      H[0][1] = H[1][0] = (I.at(x + 1, y + 1, s) - I.at(x - 1, y + 1, s) -
+                           I.at(x + 1, y - 1, s) + I.at(x - 1, y - 1, s)) /
+                          4.f;
+      H[0][2] = H[2][0] = (I.at(x + 1, y, s + 1) - I.at(x - 1, y, s + 1) -
+                           I.at(x + 1, y, s - 1) + I.at(x - 1, y, s - 1)) /
+                          4.f;
+      H[1][2] = H[2][1] = (I.at(x, y + 1, s + 1) - I.at(x, y - 1, s + 1) -
+                           I.at(x, y + 1, s - 1) + I.at(x, y - 1, s - 1)) /
+                          4.f;
+
+      // (lambda * float(type)).maxCoeff() >= 0: with type in {1, 255} the
+      // Newton step is taken only when H is negative definite.
+      if (definiteness3(H) != -1)
+      {
+        hh[0] = hh[1] = hh[2] = 0.f;
+        break;
+      }
+
+      // h = -inverse(H) * D' (cofactor inverse, Eigen's evaluation order).
+      const float c0 = cofactor3(H, 0, 0);
+      const float c1 = cofactor3(H, 1, 0);
+      const float c2 = cofactor3(H, 2, 0);
+      const float det = sum3(c0 * H[0][0], c1 * H[1][0], c2 * H[2][0]);
+      const float invdet = 1.f / det;
+      float inv[3][3];
+      inv[0][0] = c0 * invdet;
+      inv[0][1] = c1 * invdet;
+      inv[0][2] = c2 * invdet;
+      inv[1][0] = cofactor3(H, 0, 1) * invdet;
+      inv[1][1] = cofactor3(H, 1, 1) * invdet;
+      inv[1][2] = cofactor3(H, 2, 1) * invdet;
+      inv[2][0] = cofactor3(H, 0, 2) * invdet;
+      inv[2][1] = cofactor3(H, 1, 2) * invdet;
+      inv[2][2] = cofactor3(H, 2, 2) * invdet;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        hh[r] = sum3((-inv[r][0]) * D_prime[0], (-inv[r][1]) * D_prime[1],
+                     (-inv[r][2]) * D_prime[2]);
+
+      if (fmaxf(fabsf(hh[0]), fabsf(hh[1])) > 1.5f)
+        return;  // pos keeps the start site, val the unrefined value
+
+      if (fminf(fabsf(hh[0]), fabsf(hh[1])) > 0.6f)
+      {
+        x += hh[0] > 0 ? 1 : -1;
+        y += hh[1] > 0 ? 1 : -1;
+        continue;
+      }
+      break;
+    }
+
+    pos[0] = float(x);
+    pos[1] = float(y);
+    pos[2] = tab.sigma[s];
+    const float oldval = I.at(x, y, s);
+    const float newval = oldval + 0.5f * sum3(D_prime[0] * hh[0],
+                                              D_prime[1] * hh[1],
+                                              D_prime[2] * hh[2]);
+    if ((type == 1 && oldval <= newval) || (type == -1 && oldval >= newval))
+    {
+      pos[0] += hh[0];
+      pos[1] += hh[1];
+      // powf(k, h_s) of the CPU path, evaluated in double and rounded.
+      pos[2] *= float(exp(double(hh[2]) * log(double(kfactor))));
+      val = newval;
+    }
+  }
+
+  //! Classification of one site: +1 max, -1 min, 0 none (incl. the 0.8*thres
+  //! and on_edge rejections).  a/b/c = layers s-1, s, s+1; p points at (x,y).
+  __device__ inline int classify_site(const float* __restrict__ a,
+                                      const float* __restrict__ b,
+                                      const float* __restrict__ c, int w,
+                                      float thres, float edge_ratio)
+  {
+    const float v = b[0];
+    if (fabsf(v) < 0.8f * thres)
+      return 0;
+    bool is_max = true, is_min = true;
+#pragma unroll
+    for (int dv = -1; dv <= 1; ++dv)
+#pragma unroll
+      for (int du = -1; du <= 1; ++du)
+      {
+        const int off = dv * w + du;
+        const float na = a[off], nc = c[off];
+        is_max = is_max && (v >= na) && (v >= nc);
+        is_min = is_min && (v <= na) && (v <= nc);
+        if (du != 0 || dv != 0)
+        {
+          const float nb = b[off];
+          is_max = is_max && (v >= nb);
+          is_min = is_min && (v <= nb);
+        }
+      }
+    if (!is_max && !is_min)
+      return 0;
+    const float hxx = b[1] - 2.f * v + b[-1];
+    const float hyy = b[w] - 2.f * v + b[-w];
+    const float hxy = (b[w + 1] - b[w - 1] - b[-w + 1] + b[-w - 1]) / 4.f;
+    const float tr = hxx + hyy;
+    const float det = hxx * hyy - hxy * hxy;
+    if ((tr * tr) * edge_ratio >=
+        ((edge_ratio + 1.f) * (edge_ratio + 1.f)) * fabsf(det))
+      return 0;
+    return is_max ? 1 : -1;
+  }
+
+  __global__ void extrema_scan_kernel(OctaveView dog, int octave, int nscan,
+                                      ExtremaParams p,
+                                      const ScaleTable* __restrict__ tabp,
+                                      CandidateLists cand)
+  {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = blockIdx.z;
+    const int b = z / nscan;
+    const int s = 1 + (z - b * nscan);
+    const int w = dog.w, h = dog.h;
+    const int pad = p.img_padding_sz;
+    if (!(pad <= x && x < w - pad && pad <= y && y < h - pad))
+      return;
+
+    const float* base = dog.base + size_t(b) * dog.frame_stride;
+    const size_t c = size_t(y) * w + x;
+    const float* pb = base + size_t(s) * dog.plane + c;
+    const int type = classify_site(pb - dog.plane, pb, pb + dog.plane, w,
+                                   p.extremum_thres, p.edge_ratio_thres);
+    if (type == 0)
+      return;
+
+    DogOctave I{base, w, h, dog.plane, dog.scales};
+    float pos[3];
+    float val = pb[0];
+    refine_extremum(I, x, y, s, type == 1 ? 1 : 255, pos, val, pad,
+                    p.refine_iters, *tabp, p.scale_geometric_factor);
+    if (fabsf(val) < p.extremum_thres)
+      return;
+
+    const int slot = atomicAdd(&cand.count[b], 1);
+    if (slot < cand.cap)
+    {
+      const size_t i = size_t(b) * cand.cap + slot;
+      cand.key[i] =
+          ((((unsigned long long) (octave * kMaxScales + s) << 20 | (unsigned) y)
+            << 20 | (unsigned) x)
+           << 1) |
+          (unsigned) (type == 1);
+      cand.data[i] = make_float4(pos[0], pos[1], pos[2], val);
+    }
+  }
+
+  void launch_extrema_scan(const OctaveView& dog, int octave, int batch,
+                           const ExtremaParams& p, const ScaleTable* tab,
+                           const CandidateLists& cand, hipStream_t stream)
+  {
+    const int nscan = dog.scales - 2;
+    if (nscan <= 0)
+      return;
+    const dim3 block(64, 4);
+    const dim3 grid((dog.w + 63) / 64, (dog.h + 3) / 4, batch * nscan);
+    hipLaunchKernelGGL(extrema_scan_kernel, grid, block, 0, stream, dog, octave,
+                       nscan, p, tab, cand);
+  }
+
+  __global__ void extremum_map_kernel(const float* __restrict__ a,
+                                      const float* __restrict__ b,
+                                      const float* __restrict__ c, int w, int h,
+                                      float edge_ratio, float thres, int pad,
+                                      int8_t* __restrict__ out)
+  {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h)
+      return;
+    const size_t i = size_t(y) * w + x;
+    int type = 0;
+    if (pad <= x && x < w - pad && pad <= y && y < h - pad)
+      type = classify_site(a + i, b + i, c + i, w, thres, edge_ratio);
+    out[i] = int8_t(type);
+  }
+
+  void launch_extremum_map(const float* a, const float* b, const float* c,
+                           int w, int h, float edge_ratio, float thres, int pad,
+                           int8_t* out, hipStream_t stream)
+  {
+    const dim3 block(64, 4);
+    const dim3 grid((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(extremum_map_kernel, grid, block, 0, stream, a, b, c, w,
+                       h, edge_ratio, thres, pad, out);
+  }
+
+  // ------------------------------------------------------------------------ //
+  // Ordering: the reference emits extrema in (octave, scale, raster) order
+  // (DoG.cpp:62-82, RefineExtremum.cpp:497-515).  Keys are unique per frame,
+  // so rank = number of smaller keys.
+  // ------------------------------------------------------------------------ //
+  __global__ __launch_bounds__(256) void rank_candidates_kernel(
+      CandidateLists cand)
+  {
+    __shared__ unsigned long long s_keys[256];
+    const int b = blockIdx.y;
+    const int n = min(cand.count[b], cand.cap);
+    if (int(blockIdx.x) * 256 >= n)
+      return;
+    const unsigned long long* keys = cand.key + size_t(b) * cand.cap;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long mine = i < n ? keys[i] : ~0ull;
+    int rank = 0;
+    for (int base = 0; base < n; base += 256)
+    {
+      const int j = base + threadIdx.x;
+      s_keys[threadIdx.x] = j < n ? keys[j] : ~0ull;
+      __syncthreads();
+      const int m = min(256, n - base);
+      for (int t = 0; t < m; ++t)
+        rank += (s_keys[t] < mine);
+      __syncthreads();
+    }
+    if (i < n)
+      cand.order[size_t(b) * cand.cap + rank] = i;
+  }
+
+  void launch_rank_candidates(const CandidateLists& cand, int batch,
+                              hipStream_t stream)
+  {
+    const dim3 grid((cand.cap + 255) / 256, batch);
+    hipLaunchKernelGGL(rank_candidates_kernel, grid, dim3(256), 0, stream, cand);
+  }
+
+  // ======================================================================== //
+  // Dominant orientations.  Reference: ComputeDominantOrientations,
+  // FeatureDescriptors/Orientation.cpp:82-166; compute_orientation_histogram,
+  // lowe_smooth_histogram, find_peaks, refine_peak,
+  // FeatureDescriptors/Orientation.hpp:91-212.
+  //
+  // One wave per extremum.  The CPU path adds the window's pixels to the
+  // 36-bin histogram one by one in raster order, rounding to float after every
+  // addition (the weight is a double).  To reproduce that exactly, lanes
+  // evaluate 64 pixels at a time (bin, double contribution) and lanes 0..35
+  // each own one bin and replay the 64 contributions in raster order through
+  // v_readlane broadcasts.  Smoothing / peak search are exact lane-parallel
+  // restatements.
+  // ======================================================================== //
+  __device__ inline int key_octave(unsigned long long key)
+  {
+    return int(key >> 41) / kMaxScales;
+  }
+  __device__ inline int key_scale(unsigned long long key)
+  {
+    return int(key >> 41) % kMaxScales;
+  }
+  __device__ inline int key_y(unsigned long long key)
+  {
+    return int((key >> 21) & 0xfffff);
+  }
+  __device__ inline int key_x(unsigned long long key)
+  {
+    return int((key >> 1) & 0xfffff);
+  }
+
+  __device__ inline double readlane_f64(double v, int lane)
+  {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane(unsigned(u), lane);
+    const unsigned hi = __builtin_amdgcn_readlane(unsigned(u >> 32), lane);
+    return __longlong_as_double(((unsigned long long) hi << 32) | lo);
+  }
+
+  __global__ __launch_bounds__(256) void orientation_kernel(
+      const GradPyramidView* __restrict__ gradp,
+      const ScaleTable* __restrict__ tabp, const double* __restrict__ weights,
+      CandidateLists cand, OrientationLists ori)
+  {
+    const GradPyramidView& grad = *gradp;
+    const ScaleTable& tab = *tabp;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int idx = blockIdx.x * 4 + wave;
+    const int n = min(cand.count[b], cand.cap);
+    if (idx >= n)
+      return;
+
+    const size_t row = size_t(b) * cand.cap;
+    const int slot = cand.order[row + idx];
+    const unsigned long long key = cand.key[row + slot];
+    const float4 d = cand.data[row + slot];
+    const int o = key_octave(key);
+    const int s = key_scale(key);
+
+    const int rx = int(roundf(d.x));
+    const int ry = int(roundf(d.y));
+    const int R = tab.ori_radius[s];
+    const double* wt = weights + tab.ori_woff[s];
+    const int w = grad.w[o], h = grad.h[o];
+    const float2* g = reinterpret_cast<const float2*>(
+                          grad.base[o] + size_t(b) * grad.frame_stride[o]) +
+                      size_t(s) * grad.plane[o];
+
+    const int D = 2 * R + 1;
+    const int npx = D * D;
+    float hist = 0.f;
+
+    // (u, v) of this lane's pixel, advanced by 64 pixels per chunk.
+    int v = lane / D - R;
+    int u = lane % D - R;
+    const int dv64 = 64 / D, du64 = 64 % D;
+
+    for (int base = 0; base < npx; base += 64)
+    {
+      int bin = -1;
+      double c = 0.;
+      if (base + lane < npx)
+      {
+        const int xx = rx + u, yy = ry + v;
+        if (xx >= 0 && xx < w && yy >= 0 && yy < h)
+        {
+          const float2 mo = g[size_t(yy) * w + xx];
+          float a = mo.y;
+          a = a < 0 ? a + float(2. * M_PI) : a;
+          bin = int(floor(double(a / float(2 * M_PI) * kOriBins)));
+          bin %= kOriBins;
+          c = wt[u * u + v * v] * double(mo.x);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 64; ++k)
+      {
+        const int bk = __builtin_amdgcn_readlane(bin, k);
+        if (bk >= 0)  // wave-uniform
+        {
+          const double ck = readlane_f64(c, k);
+          if (lane == bk)
+            hist = float(double(hist) + ck);
+        }
+      }
+      u += du64;
+      v += dv64;
+      if (u > R)
+      {
+        u -= D;
+        v += 1;
+      }
+    }
+
+    // lowe_smooth_histogram: 6 circular box-blur iterations.
+    const int lp = lane < kOriBins ? (lane + kOriBins - 1) % kOriBins : lane;
+    const int ln = lane < kOriBins ? (lane + 1) % kOriBins : lane;
+    for (int iter = 0; iter < 6; ++iter)
+    {
+      const float prev = __shfl(hist, lp);
+      const float next = __shfl(hist, ln);
+      hist = (prev + hist + next) / 3.f;
+    }
+
+    // find_peaks + refine_peak.
+    float mx = lane < kOriBins ? hist : -INFINITY;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+      mx = fmaxf(mx, __shfl_xor(mx, off));
+    const float y0 = __shfl(hist, lp);
+    const float y2 = __shfl(hist, ln);
+    const bool is_peak =
+        lane < kOriBins && hist >= 0.8f * mx && hist > y0 && hist > y2;
+    const unsigned long long mask = __ballot(is_peak);
+    if (is_peak)
+    {
+      const float fprime = (y2 - y0) / 2.f;
+      const float fsecond = y0 - 2.f * hist + y2;
+      const float hh = -fprime / fsecond;
+      float theta = float(lane) + 0.5f + hh;
+      theta *= float(2 * M_PI) / kOriBins;
+      if (theta > float(M_PI))
+        theta -= 2.f * float(M_PI);
+      const int r = __popcll(mask & ((1ull << lane) - 1ull));
+      ori.peak_theta[(row + idx) * kMaxPeaks + r] = theta;
+    }
+    if (lane == 0)
+      ori.peak_count[row + idx] = __popcll(mask);
+  }
+
+  void launch_orientations(const GradPyramidView* grad, const ScaleTable* tab,
+                           const double* ori_weights,
+                           const CandidateLists& cand,
+                           const OrientationLists& ori, int batch,
+                           hipStream_t stream)
+  {
+    const dim3 grid((cand.cap + 3) / 4, batch);
+    hipLaunchKernelGGL(orientation_kernel, grid, dim3(256), 0, stream, grad, tab,
+                       ori_weights, cand, ori);
+  }
+
+  // ------------------------------------------------------------------------ //
+  // Output offsets: exclusive scan of the per-extremum peak counts in sorted
+  // order (Orientation.cpp:146-161 expands the list in input order).
+  // ------------------------------------------------------------------------ //
+  __global__ __launch_bounds__(256) void scan_peaks_kernel(CandidateLists cand,
+                                                           OrientationLists ori)
+  {
+    __shared__ int s_scan[256];
+    const int b = blockIdx.x;
+    const int n = min(cand.count[b], cand.cap);
+    const size_t row = size_t(b) * cand.cap;
+    int running = 0;
+    for (int base = 0; base < n; base += 256)
+    {
+      const int i = base + threadIdx.x;
+      const int v = i < n ? ori.peak_count[row + i] : 0;
+      s_scan[threadIdx.x] = v;
+      __syncthreads();
+      for (int off = 1; off < 256; off <<= 1)
+      {
+        const int t = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
+        __syncthreads();
+        s_scan[threadIdx.x] += t;
+        __syncthreads();
+      }
+      if (i < n)
+        ori.offset[row + i] = running + s_scan[threadIdx.x] - v;
+      running += s_scan[255];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0)
+      ori.kp_count[b] = running;
+  }
+
+  __global__ void frame_offsets_kernel(const int* __restrict__ counts, int cap,
+                                       int* __restrict__ offsets, int batch)
+  {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+    {
+      int acc = 0;
+      for (int b = 0; b < batch; ++b)
+      {
+        offsets[b] = acc;
+        acc += min(counts[b], cap);
+      }
+      offsets[batch] = acc;
+    }
+  }
+
+  void launch_scan_peaks(const CandidateLists& cand, const OrientationLists& ori,
+                         int batch, hipStream_t stream)
+  {
+    hipLaunchKernelGGL(scan_peaks_kernel, dim3(batch), dim3(256), 0, stream, cand,
+                       ori);
+    hipLaunchKernelGGL(frame_offsets_kernel, dim3(1), dim3(64), 0, stream,
+                       ori.kp_count, cand.cap, ori.frame_offset, batch);
+  }
+
+  void launch_extrema_offsets(const CandidateLists& cand, int* ex_offset,
+                              int batch, hipStream_t stream)
+  {
+    hipLaunchKernelGGL(frame_offsets_kernel, dim3(1), dim3(64), 0, stream,
+                       cand.count, cand.cap, ex_offset, batch);
+  }
+
+  // ======================================================================== //
+  // SIFT descriptors (N = 4, O = 8).  Reference: ComputeSIFTDescriptor,
+  // FeatureDescriptors/SIFT.hpp:62-145 (patch loop), :204-238 (trilinear
+  // accumulate with std::modf truncation), :241-252 (normalisation);
+  // OERegion::scale(), Features/Feature.cpp:28-39; final rescale,
+  // FeatureDetectors/SIFT.cpp:92-98.
+  //
+  // One wave per extremum, looping over its orientations; lanes stride the
+  // patch pixels and accumulate into a 128-bin LDS histogram (one histogram
+  // per wave, ds_add_f32).  Float tolerance vs the CPU path: summation order
+  // and expf/cos/sin last-ulp differences only.
+  // ======================================================================== //
+  __device__ inline float wave_sum(float v)
+  {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+      v += __shfl_xor(v, off);
+    return v;
+  }
+
+  __global__ __launch_bounds__(256) void descriptor_kernel(
+      const GradPyramidView* __restrict__ gradp, CandidateLists cand,
+      OrientationLists ori, sara_oeregion* __restrict__ features,
+      int32_t* __restrict__ scale_octave, float* __restrict__ descriptors,
+      int with_descriptors)
+  {
+    const GradPyramidView& grad = *gradp;
+    __shared__ float s_hist[4][128];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int idx = blockIdx.x * 4 + wave;
+    const int n = min(cand.count[b], cand.cap);
+    if (idx >= n)
+      return;
+
+    const size_t row = size_t(b) * cand.cap;
+    const int npeaks = ori.peak_count[row + idx];
+    if (npeaks == 0)
+      return;
+    const int slot = cand.order[row + idx];
+    const unsigned long long key = cand.key[row + slot];
+    const float4 d = cand.data[row + slot];
+    const int o = key_octave(key);
+    const int s = key_scale(key);
+    const int is_max = int(key & 1ull);
+    const int frame_base = ori.frame_offset[b];
+    const int local0 = ori.offset[row + idx];
+
+    // OERegion(pos, sigma): shape = I * float(pow(double(sigma), -2)).
+    const float shape = float(1.0 / (double(d.z) * double(d.z)));
+    // OERegion::scale() for an isotropic shape matrix.
+    const float scale = 1.f / sqrtf(shape);
+
+    constexpr float pi = float(M_PI);
+    const float l = 3.f * scale;
+    const double r = sqrt(double(2.f)) * double(l) * 5 / double(2.f);
+    const int rr = int(round(r));
+    const int rx = int(roundf(d.x));
+    const int ry = int(roundf(d.y));
+    const int w = grad.w[o], h = grad.h[o];
+    const float2* g = reinterpret_cast<const float2*>(
+                          grad.base[o] + size_t(b) * grad.frame_stride[o]) +
+                      size_t(s) * grad.plane[o];
+    const float factor = grad.factor[o];
+    float* hist = s_hist[wave];
+
+    const int D = 2 * rr + 1;
+    const int npx = D * D;
+    const int dv64 = 64 / D, du64 = 64 % D;
+
+    for (int k = 0; k < npeaks; ++k)
+    {
+      const int local = local0 + k;
+      if (local >= cand.cap)
+        break;
+      const size_t out = size_t(frame_base) + local;
+      const float theta = ori.peak_theta[(row + idx) * kMaxPeaks + k];
+
+      if (lane == 0)
+      {
+        sara_oeregion f;
+        f.coords[0] = d.x * factor;
+        f.coords[1] = d.y * factor;
+        f._pad0[0] = f._pad0[1] = 0.f;
+        const float f2 = factor * factor;
+        f.shape_matrix[0] = shape / f2;
+        f.shape_matrix[1] = 0.f / f2;
+        f.shape_matrix[2] = 0.f / f2;
+        f.shape_matrix[3] = shape / f2;
+        f.orientation = theta;
+        f.extremum_value = d.w;
+        f.type = 11;
+        f.extremum_type = is_max ? 1 : -1;
+        for (int q = 0; q < 6; ++q)
+          f._pad1[q] = 0;
+        features[out] = f;
+        scale_octave[2 * out + 0] = s;
+        scale_octave[2 * out + 1] = o;
+      }
+      if (!with_descriptors)
+        continue;
+
+      hist[lane] = 0.f;
+      hist[lane + 64] = 0.f;
+      __builtin_amdgcn_wave_barrier();
+
+      const float ct = float(cos(double(theta)));
+      const float st = float(sin(double(theta)));
+      const float T00 = ct / l, T01 = st / l, T10 = (-st) / l, T11 = ct / l;
+
+      int v = lane / D - rr;
+      int u = lane % D - rr;
+      for (int base = 0; base < npx; base += 64)
+      {
+        if (base + lane < npx)
+        {
+          const int xx = rx + u, yy = ry + v;
+          float px = T00 * float(u) + T01 * float(v);
+          float py = T10 * float(u) + T11 * float(v);
+          if (xx >= 0 && xx < w && yy >= 0 && yy < h)
+          {
+            const float weight = expf(-(px * px + py * py) / (2.f * 4.f));
+            const float2 mo = g[size_t(yy) * w + xx];
+            const float mag = mo.x;
+            float a = mo.y - theta;
+            a = a < 0.f ? a + 2.f * pi : a;
+            a *= 8.f / (2.f * pi);
+            px += 1.5f;
+            py += 1.5f;
+            if (!(fminf(px, py) <= -1.f || fmaxf(px, py) >= 4.f))
+            {
+              const float xif = truncf(px), yif = truncf(py), oif = truncf(a);
+              const float xfrac = px - xif, yfrac = py - yif, ofrac = a - oif;
+              const int xi = int(xif), yi = int(yif), oi = int(oif);
+#pragma unroll
+              for (int dy = 0; dy < 2; ++dy)
+              {
+                const int y_ = yi + dy;
+                if (y_ < 0 || y_ >= 4)
+                  continue;
+                const float wy = (dy == 0) ? 1 - yfrac : yfrac;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx)
+                {
+                  const int x_ = xi + dx;
+                  if (x_ < 0 || x_ >= 4)
+                    continue;
+                  const float wx = (dx == 0) ? 1 - xfrac : xfrac;
+#pragma unroll
+                  for (int dori = 0; dori < 2; ++dori)
+                  {
+                    const int o_ = (oi + dori) % 8;
+                    const float wo = (dori == 0) ? 1 - ofrac : ofrac;
+                    atomicAdd(&hist[32 * y_ + 8 * x_ + o_],
+                              wy * wx * wo * weight * mag);
+                  }
+                }
+              }
+            }
+          }
+        }
+        u += du64;
+        v += dv64;
+        if (u > rr)
+        {
+          u -= D;
+          v += 1;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+
+      float h0 = hist[lane], h1 = hist[lane + 64];
+      // normalize(): L2, clamp at 0.2, L2; then x512, clamp at 255.
+      float z = wave_sum(h0 * h0 + h1 * h1);
+      if (z > 0.f)
+      {
+        const float nrm = sqrtf(z);
+        h0 /= nrm;
+        h1 /= nrm;
+      }
+      h0 = fminf(h0, 0.2f);
+      h1 = fminf(h1, 0.2f);
+      z = wave_sum(h0 * h0 + h1 * h1);
+      if (z > 0.f)
+      {
+        const float nrm = sqrtf(z);
+        h0 /= nrm;
+        h1 /= nrm;
+      }
+      h0 = fminf(h0 * 512.f, 255.f);
+      h1 = fminf(h1 * 512.f, 255.f);
+      descriptors[out * 128 + lane] = h0;
+      descriptors[out * 128 + 64 + lane] = h1;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
+  void launch_descriptors(const GradPyramidView* grad,
+                          const CandidateLists& cand,
+                          const OrientationLists& ori, int batch,
+                          sara_oeregion* features, int32_t* scale_octave,
+                          float* descriptors, int with_descriptors,
+                          hipStream_t stream)
+  {
+    const dim3 grid((cand.cap + 3) / 4, batch);
+    hipLaunchKernelGGL(descriptor_kernel, grid, dim3(256), 0, stream, grad, cand,
+                       ori, features, scale_octave, descriptors,
+                       with_descriptors);
+  }
+
+  // ------------------------------------------------------------------------ //
+  // Extrema before orientation assignment, in reference order.
+  // ------------------------------------------------------------------------ //
+  __global__ void gather_extrema_kernel(CandidateLists cand,
+                                        const int* __restrict__ ex_offset,
+                                        sara_oeregion* __restrict__ regions,
+                                        int32_t* __restrict__ xyso_type)
+  {
+    const int b = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = min(cand.count[b], cand.cap);
+    if (idx >= n)
+      return;
+    const size_t row = size_t(b) * cand.cap;
+    const int slot = cand.order[row + idx];
+    const unsigned long long key = cand.key[row + slot];
+    const float4 d = cand.data[row + slot];
+    const size_t out = size_t(ex_offset[b]) + idx;
+    if (regions)
+    {
+      sara_oeregion f;
+      f.coords[0] = d.x;
+      f.coords[1] = d.y;
+      f._pad0[0] = f._pad0[1] = 0.f;
+      const float shape = float(1.0 / (double(d.z) * double(d.z)));
+      f.shape_matrix[0] = shape;
+      f.shape_matrix[1] = 0.f;
+      f.shape_matrix[2] = 0.f;
+      f.shape_matrix[3] = shape;
+      f.orientation = 0.f;
+      f.extremum_value = d.w;
+      f.type = 11;
+      f.extremum_type = (key & 1ull) ? 1 : -1;
+      for (int q = 0; q < 6; ++q)
+        f._pad1[q] = 0;
+      regions[out] = f;
+    }
+    if (xyso_type)
+    {
+      xyso_type[5 * out + 0] = key_x(key);
+      xyso_type[5 * out + 1] = key_y(key);
+      xyso_type[5 * out + 2] = key_scale(key);
+      xyso_type[5 * out + 3] = key_octave(key);
+      xyso_type[5 * out + 4] = (key & 1ull) ? 1 : -1;
+    }
+  }
+
+  void launch_gather_extrema(const CandidateLists& cand, const int* ex_offset,
+                             int batch, sara_oeregion* regions,
+                             int32_t* xyso_type, hipStream_t stream)
+  {
+    const dim3 grid((cand.cap + 255) / 256, batch);
+    hipLaunchKernelGGL(gather_extrema_kernel, grid, dim3(256), 0, stream, cand,
+                       ex_offset, regions, xyso_type);
+  }
+
+}  // namespace sara_hip

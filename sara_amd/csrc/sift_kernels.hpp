@@ -1,0 +1,166 @@
+// Launch interface between the context (sift_context.cpp) and the gfx950
+// kernels (sift_kernels.hip).  Internal header, not part of the C-ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/sara_hip_sift.h"
+
+namespace sara_hip {
+
+  constexpr int kMaxRadius = 32;          // Gaussian taps <= 65
+  constexpr int kMaxTaps = 2 * kMaxRadius + 1;
+  constexpr int kMaxScales = 16;          // scale_count_per_octave upper bound
+  constexpr int kMaxPeaks = 18;           // a 36-bin histogram has <= 18 peaks
+  constexpr int kOriBins = 36;
+
+  struct Taps
+  {
+    int size;  // odd
+    float k[kMaxTaps];
+  };
+
+  //! One octave of one pyramid kind in HBM: planes [frame][scale][h][w].
+  struct OctaveView
+  {
+    float* base;
+    int w, h;
+    int scales;          // planes per frame
+    size_t plane;        // w*h
+    size_t frame_stride; // scales*plane (x2 floats for the gradient pyramid)
+  };
+
+  //! Per-octave constants of the extremum / descriptor stages.
+  struct ScaleTable
+  {
+    float sigma[kMaxScales];     // float(pow(k, s) * sigma0), ImagePyramid.hpp:316-319
+    int ori_radius[kMaxScales];  // int_round(sigma*1.5f*3.f), Orientation.hpp:105-108
+    float ori_sigma[kMaxScales]; // sigma * 1.5f
+    int ori_woff[kMaxScales];    // offset of the weight table of scale s
+  };
+
+  struct ExtremaParams
+  {
+    float extremum_thres;
+    float edge_ratio_thres;
+    int img_padding_sz;
+    int refine_iters;
+    float scale_geometric_factor;
+  };
+
+  //! Unordered candidate lists of the extremum scan, per frame.
+  struct CandidateLists
+  {
+    unsigned long long* key; // [frame][cap]  (o,s,y,x | type)
+    float4* data;            // [frame][cap]  (x, y, sigma, value) refined
+    int* count;              // [frame]       number appended (may exceed cap)
+    int* order;              // [frame][cap]  slot of the rank-th candidate
+    int cap;
+  };
+
+  struct OrientationLists
+  {
+    int* peak_count;   // [frame][cap]
+    float* peak_theta; // [frame][cap][kMaxPeaks]
+    int* offset;       // [frame][cap] exclusive prefix of peak_count
+    int* kp_count;     // [frame] keypoints of the frame (may exceed cap)
+    int* frame_offset; // [batch+1] exclusive prefix of min(kp_count, cap)
+  };
+
+  inline unsigned long long make_key(int o, int s, int y, int x, int is_max)
+  {
+    return ((((unsigned long long) (o * kMaxScales + s) << 20 | (unsigned) y)
+             << 20 | (unsigned) x)
+            << 1) |
+           (unsigned) is_max;
+  }
+
+  // ---- pyramid -------------------------------------------------------------
+  //! dst = gaussian(src) [rows then columns, replicate borders]; when dog is
+  //! not null also dog = dst - src.  Planes are w x h; frame b of each
+  //! operand lives at base + b*stride.
+  void launch_gaussian_blur(const float* src, size_t src_stride, float* dst,
+                            size_t dst_stride, float* dog, size_t dog_stride,
+                            int w, int h, int batch, const Taps& taps,
+                            hipStream_t stream);
+
+  //! Nearest-neighbour resize (Resize.cpp:31-62).
+  void launch_scale(const float* src, size_t src_stride, int sw, int sh,
+                    float* dst, size_t dst_stride, int dw, int dh, int batch,
+                    hipStream_t stream);
+
+  //! Bilinear enlarge in double (Resize.cpp:86-128).
+  void launch_enlarge(const float* src, size_t src_stride, int sw, int sh,
+                      float* dst, size_t dst_stride, int dw, int dh, int batch,
+                      hipStream_t stream);
+
+  void launch_copy_planes(const float* src, size_t src_stride, float* dst,
+                          size_t dst_stride, size_t count, int batch,
+                          hipStream_t stream);
+
+  void launch_subtract(const float* a, const float* b, float* out, size_t count,
+                       hipStream_t stream);
+
+  // ---- gradients -----------------------------------------------------------
+  //! (2*|grad|, atan2(gy,gx)) of `nscales` consecutive planes per frame.
+  void launch_gradient_polar(const float* src, size_t src_stride, float* dst,
+                             size_t dst_stride, int w, int h, int nscales,
+                             int batch, hipStream_t stream);
+
+  // ---- extrema -------------------------------------------------------------
+  //! Scans DoG scales 1..S-2 of one octave, refines and appends candidates.
+  void launch_extrema_scan(const OctaveView& dog, int octave, int batch,
+                           const ExtremaParams& p, const ScaleTable* tab,
+                           const CandidateLists& cand, hipStream_t stream);
+
+  void launch_extremum_map(const float* a, const float* b, const float* c,
+                           int w, int h, float edge_ratio, float thres, int pad,
+                           int8_t* out, hipStream_t stream);
+
+  //! order[b][rank] = slot, rank = number of smaller keys in the frame.
+  void launch_rank_candidates(const CandidateLists& cand, int batch,
+                              hipStream_t stream);
+
+  // ---- orientation / descriptors ----------------------------------------------
+  struct GradPyramidView
+  {
+    const float* base[16]; // per octave, planes [frame][scale][h][w][2]
+    int w[16], h[16];
+    size_t plane[16];        // w*h (in pixels)
+    size_t frame_stride[16]; // in floats
+    float factor[16];        // octave scaling factor
+    int octaves;
+  };
+
+  //! grad / tab are device pointers (indexed per wave, so they live in HBM
+  //! rather than in the kernel argument segment).
+  void launch_orientations(const GradPyramidView* grad, const ScaleTable* tab,
+                           const double* ori_weights,
+                           const CandidateLists& cand,
+                           const OrientationLists& ori, int batch,
+                           hipStream_t stream);
+
+  //! Per-frame exclusive scan of peak counts + frame offsets.
+  void launch_scan_peaks(const CandidateLists& cand, const OrientationLists& ori,
+                         int batch, hipStream_t stream);
+
+  void launch_descriptors(const GradPyramidView* grad,
+                          const CandidateLists& cand,
+                          const OrientationLists& ori, int batch,
+                          sara_oeregion* features, int32_t* scale_octave,
+                          float* descriptors, int with_descriptors,
+                          hipStream_t stream);
+
+  //! Sorted extrema (before orientation assignment) as OERegion + site.
+  void launch_gather_extrema(const CandidateLists& cand, const int* ex_offset,
+                             int batch, sara_oeregion* regions,
+                             int32_t* xyso_type, hipStream_t stream);
+
+  //! ex_offset[b] = exclusive prefix of min(count[b], cap), b in [0, batch].
+  void launch_extrema_offsets(const CandidateLists& cand, int* ex_offset,
+                              int batch, hipStream_t stream);
+
+}  // namespace sara_hip
