@@ -1,0 +1,310 @@
+#!/usr/bin/env python
+"""Benchmark of the MI355X SIFT front-end (BASELINE.json's metric).
+
+  python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the full SIFT hot path (Gaussian pyramid + DoG,
+extrema + refinement, polar gradients, dominant orientations, 128-D
+descriptors) over one batch of synthetic 1920x1080 frames per GPU, 4 octaves x
+3 scales/octave, with the frames already resident in HBM when the timed region
+starts.  Frames are independent, so ranks shard them with no data-path
+collective; the only exchange is the gather of the variable-length keypoint
+arrays to rank 0 over RCCL at the end of every step (N > 1).
+
+Rank 0 prints ONE JSON line (see the driver's contract) that also carries
+  "roofline"     : the Gaussian-pyramid kernels against the HBM roofline
+  "cpu_baseline" : the CPU oracle timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames-per-gpu", type=int, default=64)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--octaves", type=int, default=4)
+    ap.add_argument("--unique-frames", type=int, default=4,
+                    help="distinct synthetic frames generated per rank (the "
+                         "rest are their flips)")
+    ap.add_argument("--cpu-frames", type=int, default=3,
+                    help="frames of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--stage", type=int, default=5,
+                    help="last pipeline stage (5 = full SIFT)")
+    return ap.parse_args()
+
+
+def pyramid_bytes_per_frame(width, height, octaves, scales=6):
+    """Algorithmic HBM bytes of the Gaussian-pyramid stage per frame as THIS
+    design moves them: every blurred plane is one 4-byte
+    read + one 4-byte write per pixel (48*P for 6 planes/octave),
+    the fused DoG epilogue adds its 4-byte write (the reference's separate DoG
+    pass would be 12), and each octave hand-over reads/writes the quarter-size
+    plane once."""
+    total = 0
+    w, h = width, height
+    launches = 0
+    for o in range(octaves):
+        px = w * h
+        if o == 0:
+            total += 8 * px          # initial blur: read frame, write G(0,0)
+            launches += 1
+        else:
+            total += 8 * px          # nearest-neighbour half of G(2, o-1)
+        total += (scales - 1) * 12 * px  # blur: read G(s-1), write G(s), D(s-1)
+        launches += scales - 1
+        w //= 2
+        h //= 2
+    return total, launches
+
+
+def host_cores():
+    """CPUs this process may actually use: affinity mask capped by the cgroup
+    CPU quota (the GPU boxes expose 256 logical CPUs under a 16-CPU quota;
+    running OpenMP on all of them is 100x slower than on the quota)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(args, frames):
+    """The CPU oracle (a port of Sara's CPU SIFT with the reference's loop
+    structure and OpenMP pragmas, see oracle/sift_ref.hpp) on a bounded
+    sample of the same workload, on this host's cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import refbind as rb
+    rb.build()
+    cores = host_cores()
+    rb.lib().ref_omp_set_threads(cores)
+    params = rb.PyramidParams(0, 6, None, 1, 0.5, 1.6, args.octaves)
+    n = min(args.cpu_frames, len(frames))
+    kp = 0
+    stage = {}
+    t0 = time.perf_counter()
+    for i in range(n):
+        r = rb.RefSift(frames[i], params, parallel=True)
+        kp += len(r.keypoints()[0])
+        for k, v in r.times().items():
+            stage[k] = stage.get(k, 0.0) + v / n
+    dt = time.perf_counter() - t0
+    return {
+        "value": kp / dt, "unit": "keypoints/s", "cores": cores, "kind": "port",
+        "sample": "%d synthetic %dx%d frames, full SIFT, %d octaves; %.2f s "
+                  "wall; OpenMP on the reference's pragmas" %
+                  (n, args.width, args.height, args.octaves, dt),
+        "ms_per_frame": 1e3 * dt / n,
+        "stage_ms_per_frame": {k: round(v, 2) for k, v in stage.items()},
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run "
+                             "--nproc-per-node %d bench.py ...`" %
+                             (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    import sara_amd
+    from sara_amd import capi
+    from sara_amd.synth import synth_batch
+
+    capi.require_gpu()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=dev)
+
+    B, W, H = args.frames_per_gpu, args.width, args.height
+    frames_host = synth_batch(W, H, B, first_index=rank * B,
+                              unique=args.unique_frames)
+    frames = torch.from_numpy(frames_host).to(dev)  # resident in HBM
+    torch.cuda.synchronize()
+
+    params = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=args.octaves)
+    ctx = sara_amd.SiftContext(W, H, B, params, device=local_rank)
+    stream = torch.cuda.current_stream(dev)
+
+    # gather buffers (variable-length arrays, padded to the context capacity)
+    feat_buf = desc_buf = so_buf = None
+
+    def step():
+        """One pass over the batch; returns this rank's keypoint count."""
+        ctx.detect_device(frames.data_ptr(), B, W, H, last_stage=args.stage,
+                          stream=stream.cuda_stream)
+        if args.stage < 4:
+            c, _, _ = ctx.extrema() if args.stage >= 2 else (np.zeros(B), 0, 0)
+            return int(np.sum(c))
+        counts, total = ctx.counts()
+        if world > 1:
+            gather_to_root(total)
+        return total
+
+    def gather_to_root(total):
+        """gatherv of OERegion[ ] (48 B), descriptors (512 B) and (s,o) pairs
+        to rank 0: counts first, then one grouped send/recv per peer."""
+        nonlocal feat_buf, desc_buf, so_buf
+        n_t = torch.tensor([total], device=dev, dtype=torch.int64)
+        all_n = [torch.zeros_like(n_t) for _ in range(world)]
+        dist.all_gather(all_n, n_t)
+        all_n = [int(t.item()) for t in all_n]
+        mine_f = torch.empty((total, 48), dtype=torch.uint8, device=dev)
+        mine_d = torch.empty((total, 128), dtype=torch.float32, device=dev)
+        mine_s = torch.empty((total, 2), dtype=torch.int32, device=dev)
+        capi.check(capi.load().sara_hip_sift_fetch(
+            ctx._h, mine_f.data_ptr(), mine_d.data_ptr(), mine_s.data_ptr(), 1))
+        ctx.synchronize()  # the copies run on the detect stream
+        if rank == 0:
+            tot = sum(all_n)
+            feat_buf = torch.empty((tot, 48), dtype=torch.uint8, device=dev)
+            desc_buf = torch.empty((tot, 128), dtype=torch.float32, device=dev)
+            so_buf = torch.empty((tot, 2), dtype=torch.int32, device=dev)
+            feat_buf[:total] = mine_f
+            desc_buf[:total] = mine_d
+            so_buf[:total] = mine_s
+            ops, at = [], total
+            for r in range(1, world):
+                n = all_n[r]
+                if n:
+                    ops += [dist.P2POp(dist.irecv, feat_buf[at:at + n], r),
+                            dist.P2POp(dist.irecv, desc_buf[at:at + n], r),
+                            dist.P2POp(dist.irecv, so_buf[at:at + n], r)]
+                at += n
+        else:
+            ops = []
+            if total:
+                ops = [dist.P2POp(dist.isend, mine_f, 0),
+                       dist.P2POp(dist.isend, mine_d, 0),
+                       dist.P2POp(dist.isend, mine_s, 0)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+    def sync():
+        torch.cuda.synchronize()
+        ctx.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    stage_ms = {}
+    kp_local = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kp_local += step()
+        if ctx is not None and args.stage >= 1:
+            for k, v in ctx.stage_times().items():
+                stage_ms[k] = stage_ms.get(k, 0.0) + v
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    kp = torch.tensor([kp_local], device=dev, dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kp, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    kp_total = int(kp.item())
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        stage_ms = {k: v / steps for k, v in stage_ms.items()}
+        bytes_frame, launches = pyramid_bytes_per_frame(W, H, args.octaves)
+        pyr_ms = stage_ms.get("pyramid", 0.0)
+        achieved = (bytes_frame * B / 1e9) / (pyr_ms / 1e3) if pyr_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pyramid_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "SIFT keypoints/sec @1080p (4 octaves, 3 scales/oct)",
+            "value": kp_total / elapsed,
+            "unit": "keypoints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "full SIFT (pyramid+DoG, extrema+refine, polar "
+                            "gradients, orientations, 128-D descriptors) on "
+                            "%d synthetic %dx%d frames per GPU, %d octaves x 3 "
+                            "scales/octave, frames resident in HBM" %
+                            (B, W, H, args.octaves),
+                "frames_per_gpu": B,
+                "global_frames": B * world,
+                "keypoints_per_frame": kp_total / (steps * B * world),
+                "frames_per_s": steps * B * world / elapsed,
+                "parallelism": "frames sharded %d/GPU, RCCL gatherv of "
+                               "keypoints to rank 0" % B if world > 1
+                               else "single GPU",
+                "last_stage": args.stage,
+            },
+            "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+            "roofline": {
+                "kernel": "gaussian_blur_kernel<R> (Gaussian pyramid + fused "
+                          "DoG; %d launches/step incl. octave hand-overs "
+                          "timed with them)" % launches,
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_step": bytes_frame * B,
+                "us_per_frame": 1e3 * pyr_ms / B,
+            },
+        }
+        if world == 1 and args.cpu_frames > 0:
+            out["cpu_baseline"] = cpu_baseline(args, frames_host)
+            out["config"]["gpu_over_cpu"] = out["value"] / max(
+                out["cpu_baseline"]["value"], 1e-9)
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

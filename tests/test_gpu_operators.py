@@ -1,0 +1,180 @@
+"""-m gpu: operator-level parity.  The reference's own unit tests (SURVEY.md
+section 4) restated against the HIP kernels through the C-ABI, plus
+kernel-vs-oracle comparisons on seeded inputs.  Bit-exact unless stated.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import sara_amd
+
+pytestmark = pytest.mark.gpu
+
+RNG = np.random.default_rng(7)
+
+
+# test_imageprocessing_linear_filtering.cpp:136-187 on the HIP blur.
+@pytest.mark.parametrize("n,truncate", [(3, 1.0), (9, 4.0), (65, 4.0)])
+def test_gaussian_on_dirac(n, truncate):
+    src = np.zeros((n, n), np.float32)
+    src[n // 2, n // 2] = 1
+    out = sara_amd.apply_gaussian_filter(src, 1.0, truncate)
+    c = n // 2
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    true = np.exp(-((i - c) ** 2.0 + (j - c) ** 2.0) / 2.0)
+    if n == 3:
+        true = np.exp(-((i - c) ** 2.0 + (j - c) ** 2.0) / 2.0)
+    true /= true.sum()
+    assert np.linalg.norm(true - out) < 1e-5
+
+
+def test_blur_of_constant_is_constant():
+    src = np.full((37, 53), 0.3125, np.float32)
+    out = sara_amd.apply_gaussian_filter(src, 2.0)
+    assert np.allclose(out, 0.3125, rtol=0, atol=3e-7)
+
+
+@pytest.mark.parametrize("shape", [(3, 3), (5, 64), (64, 5), (33, 65), (97, 131),
+                                   (270, 480), (135, 240), (67, 119)])
+@pytest.mark.parametrize("sigma", [0.5, 1.2262735, 1.5198685, 1.946588, 3.0900156,
+                                   4.1])
+def test_gaussian_filter_matches_oracle_bit_exact(oracle, shape, sigma):
+    src = RNG.random(shape, dtype=np.float32)
+    got = sara_amd.apply_gaussian_filter(src, sigma)
+    want = oracle.apply_gaussian_filter(src, sigma)
+    assert np.array_equal(got, want)
+
+
+def test_gaussian_filter_generic_radius_path(oracle):
+    # sigma = 5 -> 41 taps (radius 20 > 16): the runtime-radius kernel.
+    src = RNG.random((150, 210), dtype=np.float32)
+    assert len(sara_amd.make_gaussian_kernel(5.0)) == 41
+    assert np.array_equal(sara_amd.apply_gaussian_filter(src, 5.0),
+                          oracle.apply_gaussian_filter(src, 5.0))
+    assert np.array_equal(sara_amd.apply_gaussian_filter(src, 7.9),
+                          oracle.apply_gaussian_filter(src, 7.9))
+    with pytest.raises(sara_amd.SaraHipError):
+        sara_amd.apply_gaussian_filter(src, 9.0)  # 73 taps > 65
+
+
+def test_gaussian_filter_truncate_argument(oracle):
+    src = RNG.random((40, 40), dtype=np.float32)
+    for t in (1.0, 2.0, 1e-6):
+        assert np.array_equal(sara_amd.apply_gaussian_filter(src, 1.6, t),
+                              oracle.apply_gaussian_filter(src, 1.6, t))
+
+
+# test_imageprocessing_resize.cpp:48-69
+def test_downscale_table():
+    src = np.array([[0, 0, 1, 1], [0, 0, 1, 1], [2, 2, 3, 3], [2, 2, 3, 3]],
+                   np.float32)
+    assert np.array_equal(sara_amd.downscale(src, 2), [[0, 1], [2, 3]])
+
+
+@pytest.mark.parametrize("shape", [(135, 240), (67, 119), (9, 9), (270, 481)])
+def test_downscale_matches_oracle(oracle, shape):
+    src = RNG.random(shape, dtype=np.float32)
+    assert np.array_equal(sara_amd.downscale(src, 2), oracle.downscale(src, 2))
+
+
+# test_imageprocessing_resize.cpp:71-131
+def test_enlarge_tables(oracle):
+    src = np.array([[0, 1], [2, 3]], np.float32)
+    true = np.array([[0, .5, 1, 1], [1, 1.5, 2, 2], [2, 2.5, 3, 3],
+                     [2, 2.5, 3, 3]], np.float32)
+    assert np.array_equal(sara_amd.enlarge(src, 4, 4), true)
+    src = np.repeat(np.arange(5, dtype=np.float32)[:, None], 5, axis=1)
+    true = np.repeat(np.array([0, .5, 1, 1.5, 2, 2.5, 3, 3.5, 4, 4],
+                              np.float32)[:, None], 5, axis=1)
+    assert np.linalg.norm(true - sara_amd.enlarge(src, 5, 10)) <= 1e-9
+    with pytest.raises(sara_amd.SaraHipError) as e:
+        sara_amd.enlarge(np.zeros((4, 4), np.float32), 2, 2)
+    assert e.value.status == sara_amd.capi.OUT_OF_RANGE
+    src = RNG.random((33, 47), dtype=np.float32)
+    assert np.array_equal(sara_amd.enlarge(src, 94, 66), oracle.enlarge(src, 94, 66))
+    assert np.array_equal(sara_amd.enlarge(src, 70, 50), oracle.enlarge(src, 70, 50))
+
+
+# test_imageprocessing_differential.cpp:47-72 through the polar seam.
+def test_polar_gradient_of_ramp():
+    src = np.array([[1, 2, 3]] * 3, np.float32)
+    g = sara_amd.gradient_polar_coordinates(src)
+    for y in range(3):
+        for x in range(3):
+            assert g[y, x, 0] == 2 * (1.0 if x == 1 else 0.5)
+            assert g[y, x, 1] == 0.0
+
+
+@pytest.mark.parametrize("shape", [(2, 2), (3, 7), (64, 64), (135, 240), (101, 67)])
+def test_polar_gradient_matches_oracle_bit_exact(oracle, shape):
+    src = RNG.random(shape, dtype=np.float32)
+    got = sara_amd.gradient_polar_coordinates(src)
+    want = oracle.gradient_polar(src)
+    assert np.array_equal(got, want)  # glibc atan2f restated bit for bit
+
+
+def test_polar_gradient_special_directions(oracle):
+    # axis-aligned / diagonal / zero gradients exercise atan2f's branches.
+    src = np.zeros((9, 9), np.float32)
+    src[4, 4] = 1
+    src[2, 6] = -3
+    src[7, 1] = 2.5
+    assert np.array_equal(sara_amd.gradient_polar_coordinates(src),
+                          oracle.gradient_polar(src))
+
+
+# test_imageprocessing_local_extremum.cpp:92-127 through the extremum map.
+def test_extremum_map_predicates():
+    I = np.ones((3, 10, 10), np.float32)
+    m = sara_amd.scale_space_dog_extremum_map(I[0], I[1], I[2], 10.0, 0.01, 1)
+    # plateau: non-strict max everywhere, but zero Hessian => on_edge rejects
+    # (0 >= 0), so nothing survives.
+    assert not m.any()
+    I[1, 1, 1] = 10
+    I[1, 7, 7] = 10
+    m = sara_amd.scale_space_dog_extremum_map(I[0], I[1], I[2], 10.0, 0.01, 1)
+    # the two spikes are the only maxima; their plateau neighbours qualify as
+    # NON-strict minima (<= everything around them), as in the reference.
+    assert m[1, 1] == 1 and m[7, 7] == 1 and np.count_nonzero(m == 1) == 2
+    I[1, 1, 1] = -10
+    I[1, 7, 7] = -10
+    m = sara_amd.scale_space_dog_extremum_map(I[0], I[1], I[2], 10.0, 0.01, 1)
+    assert m[1, 1] == -1 and m[7, 7] == -1 and np.count_nonzero(m == -1) == 2
+
+
+@pytest.mark.parametrize("pad", [1, 3, 5])
+def test_extremum_map_matches_oracle(oracle, pad):
+    h, w = 60, 83
+    layers = (RNG.random((3, h, w), dtype=np.float32) - 0.5) * 0.2
+    # a few exact ties to exercise the non-strict comparisons
+    layers[0, 20, 20:24] = layers[1, 20, 21]
+    layers[2, 30, 40] = layers[1, 30, 40]
+    got = sara_amd.scale_space_dog_extremum_map(layers[0], layers[1], layers[2],
+                                                10.0, 0.01, pad)
+    want = np.zeros((h, w), np.int8)
+    for y in range(pad, h - pad):
+        for x in range(pad, w - pad):
+            t = oracle.scale_space_extremum(layers, x, y, strict=False)
+            if t == 0:
+                continue
+            if abs(layers[1, y, x]) < np.float32(0.8) * np.float32(0.01):
+                continue
+            if oracle.on_edge(layers[1], x, y, 10.0):
+                continue
+            want[y, x] = t
+    assert np.count_nonzero(want) > 20
+    assert np.array_equal(got, want)
+
+
+def test_subtract():
+    lib = sara_amd.capi.load()
+    import ctypes as C
+    a = RNG.random(1000, dtype=np.float32)
+    b = RNG.random(1000, dtype=np.float32)
+    out = np.zeros(1000, np.float32)
+    fp = C.POINTER(C.c_float)
+    sara_amd.capi.check(lib.sara_hip_subtract(
+        a.ctypes.data_as(fp), b.ctypes.data_as(fp), out.ctypes.data_as(fp),
+        1000, 0))
+    assert np.array_equal(out, a - b)

@@ -1,0 +1,335 @@
+"""-m gpu: whole-pipeline parity of the HIP path (through the C-ABI) against
+the CPU oracle and the committed golden vectors.
+
+Tolerances (stated once, used everywhere below):
+  * Gaussian / DoG pyramids, polar gradients: bit-exact.
+  * extremum sites, types, order, refined (x, y), value: bit-exact; refined
+    sigma / shape matrix: relative 1e-6 (pow/exp evaluated in double on the
+    GPU, rounded once).
+  * keypoint count, order, (s, o) pairs: exact; orientation: 1e-6 rad.
+  * descriptors (range 0..255): max-abs 2e-3 (summation order + expf/cos/sin
+    last-ulp differences; the reference itself accepts 2e-1 CPU<->Halide,
+    test_halide_sift_descriptor.cpp:210,303).
+"""
+import numpy as np
+import pytest
+
+import common
+import sara_amd
+from sara_amd.synth import synth, synth_batch
+
+pytestmark = pytest.mark.gpu
+
+DESC_ATOL = 2e-3
+SHAPE_RTOL = 1e-6
+THETA_ATOL = 1e-6
+
+
+def hip_params(first=0, noct=4, cam=0.5, scales=6, k=None):
+    kw = {} if k is None else {"scale_geometric_factor": k}
+    return sara_amd.ImagePyramidParams(first, scales, image_padding_size=1,
+                                       scale_camera=cam, scale_initial=1.6,
+                                       num_octaves_max=noct, **kw)
+
+
+def ref_params(rb, first=0, noct=4, cam=0.5, scales=6, k=None):
+    return rb.PyramidParams(first, scales, k, 1, cam, 1.6, noct)
+
+
+def compare_full(ctx, ref, frame=0, check_planes=True):
+    S = ref.params.scale_count_per_octave
+    assert ctx.octave_count == ref.octave_count
+    for o in range(ref.octave_count):
+        assert ctx.octave_info(o) == ref.octave_info(o)
+        if not check_planes:
+            continue
+        for s in range(S):
+            assert np.array_equal(ctx.gaussian(s, o, frame), ref.gaussian(s, o)), \
+                ("G", s, o)
+        for s in range(S - 1):
+            assert np.array_equal(ctx.dog(s, o, frame), ref.dog(s, o)), ("D", s, o)
+        for s in range(1, S - 2):
+            assert np.array_equal(ctx.gradient(s, o, frame), ref.gradient(s, o)), \
+                ("grad", s, o)
+
+
+def compare_lists(ctx_lists, ref, frame):
+    ecounts, eregions, exyso, kcounts, kregions, kdesc, kso = ctx_lists
+    e0 = int(ecounts[:frame].sum())
+    k0 = int(kcounts[:frame].sum())
+    rreg, rxyso = ref.extrema()
+    assert int(ecounts[frame]) == len(rreg)
+    sl = slice(e0, e0 + len(rreg))
+    assert np.array_equal(exyso[sl], rxyso)
+    common.assert_regions_equal(eregions[sl], rreg, rtol_shape=SHAPE_RTOL)
+    rk, rso, rdesc = ref.keypoints()
+    assert int(kcounts[frame]) == len(rk)
+    sl = slice(k0, k0 + len(rk))
+    assert np.array_equal(kso[sl], rso)
+    common.assert_regions_equal(kregions[sl], rk, rtol_shape=SHAPE_RTOL,
+                                atol_theta=THETA_ATOL)
+    if len(rk):
+        assert np.max(np.abs(kdesc[sl] - rdesc)) <= DESC_ATOL
+    return len(rreg), len(rk)
+
+
+def run_lists(ctx):
+    ec, ereg, exyso = ctx.extrema()
+    kc, kreg, kdesc, kso = ctx.fetch()
+    return ec, ereg, exyso, kc, kreg, kdesc, kso
+
+
+@pytest.mark.parametrize("w,h,noct", [(640, 480, 4), (501, 377, 4), (320, 200, 3),
+                                      (96, 64, 9)])
+def test_full_parity_synthetic(oracle, w, h, noct):
+    img = synth(w, h, 1234)
+    ref = oracle.RefSift(img, ref_params(oracle, 0, noct))
+    with sara_amd.SiftContext(w, h, 1, hip_params(0, noct)) as ctx:
+        ctx.detect(img)
+        compare_full(ctx, ref)
+        ne, nk = compare_lists(run_lists(ctx), ref, 0)
+    assert ne > 0 and nk >= ne * 0.8
+
+
+def test_sift_example_camera_scale_1(oracle):
+    """sift_example.cpp:51-58 uses scale_camera = 1.0 (11-tap initial blur)."""
+    img = synth(400, 300, 99)
+    ref = oracle.RefSift(img, ref_params(oracle, 0, 4, cam=1.0))
+    with sara_amd.SiftContext(400, 300, 1, hip_params(0, 4, cam=1.0)) as ctx:
+        ctx.detect(img)
+        compare_full(ctx, ref)
+        compare_lists(run_lists(ctx), ref, 0)
+
+
+def test_camera_scale_not_below_initial(oracle):
+    """camera_sigma >= init_sigma: no initial blur (GaussianPyramid.hpp:72-75)."""
+    img = synth(200, 160, 5)
+    ref = oracle.RefSift(img, ref_params(oracle, 0, 3, cam=1.6))
+    with sara_amd.SiftContext(200, 160, 1, hip_params(0, 3, cam=1.6)) as ctx:
+        ctx.detect(img)
+        assert np.array_equal(ctx.gaussian(0, 0), img)
+        compare_full(ctx, ref)
+        compare_lists(run_lists(ctx), ref, 0)
+
+
+@pytest.mark.parametrize("first", [-1, 1])
+def test_other_first_octaves(oracle, first):
+    """first octave -1 (bilinear enlarge, no blur: Q5) and +1 (blur with
+    gauss_truncate, then downscale)."""
+    img = synth(240, 180, 77)
+    ref = oracle.RefSift(img, ref_params(oracle, first, 3), gauss_truncate=3.0)
+    with sara_amd.SiftContext(240, 180, 1, hip_params(first, 3),
+                              gauss_truncate=3.0) as ctx:
+        ctx.detect(img)
+        compare_full(ctx, ref)
+        compare_lists(run_lists(ctx), ref, 0)
+
+
+def test_other_scale_counts(oracle):
+    """5 scales per octave with k = 2^(1/2): downscale index 2 == S_D - 2."""
+    k = float(np.float32(2.0) ** np.float32(0.5))
+    img = synth(256, 192, 3)
+    ref = oracle.RefSift(img, ref_params(oracle, 0, 3, scales=5, k=k))
+    with sara_amd.SiftContext(256, 192, 1, hip_params(0, 3, scales=5, k=k)) as ctx:
+        ctx.detect(img)
+        compare_full(ctx, ref)
+        compare_lists(run_lists(ctx), ref, 0)
+
+
+def test_argument_shift_q1(oracle):
+    """extremum_refinement_iter lands in the padding slot (SIFT.cpp:45-51)."""
+    img = synth(320, 240, 11)
+    for it in (1, 3, 8):
+        ref = oracle.RefSift(img, ref_params(oracle, 0, 3),
+                             extremum_refinement_iter=it)
+        with sara_amd.SiftContext(320, 240, 1, hip_params(0, 3),
+                                  extremum_refinement_iter=it) as ctx:
+            ctx.detect(img)
+            compare_lists(run_lists(ctx), ref, 0)
+            _, _, xyso = ctx.extrema()
+            assert xyso[:, 0].min() >= it and xyso[:, 1].min() >= it
+
+
+def test_thresholds(oracle):
+    img = synth(320, 240, 12)
+    for thres, edge in ((0.02, 10.0), (0.004, 5.0), (1e-6, 20.0)):
+        ref = oracle.RefSift(img, ref_params(oracle, 0, 3), extremum_thres=thres,
+                             edge_ratio_thres=edge)
+        with sara_amd.SiftContext(320, 240, 1, hip_params(0, 3),
+                                  extremum_thres=thres, edge_ratio_thres=edge,
+                                  max_keypoints=60000) as ctx:
+            ctx.detect(img)
+            compare_lists(run_lists(ctx), ref, 0)
+
+
+def test_batch_of_distinct_frames(oracle):
+    """Each frame of a batch equals the single-frame oracle result; frames are
+    concatenated in order."""
+    w, h, b = 320, 240, 5
+    frames = synth_batch(w, h, b)
+    with sara_amd.SiftContext(w, h, b, hip_params(0, 3)) as ctx:
+        ctx.detect(frames)
+        lists = run_lists(ctx)
+        for i in range(b):
+            ref = oracle.RefSift(frames[i], ref_params(oracle, 0, 3))
+            compare_full(ctx, ref, frame=i, check_planes=(i in (0, b - 1)))
+            compare_lists(lists, ref, i)
+        # per-frame KeypointList view
+        kl = ctx.keypoint_lists()
+        assert [len(k) for k in kl] == list(lists[3])
+
+
+def test_context_reuse_and_smaller_frames(oracle):
+    with sara_amd.SiftContext(400, 300, 2, hip_params(0, 4)) as ctx:
+        for (w, h, seed) in ((400, 300, 1), (200, 150, 2), (333, 222, 3),
+                             (400, 300, 1)):
+            img = synth(w, h, seed)
+            ref = oracle.RefSift(img, ref_params(oracle, 0, 4))
+            ctx.detect(img)
+            compare_lists(run_lists(ctx), ref, 0)
+
+
+def test_reference_dog_blob_test():
+    """test_featuredetectors_dog.cpp:45-100 on the GPU functor."""
+    N = 11
+    I = np.zeros((N, N), np.float32)
+    I[3:8, 3:8] = 1
+    k = float(np.power(np.float32(2.0), np.float32(1.0) / np.float32(3)))
+    p = sara_amd.ImagePyramidParams(0, 6, k, 1, 1.0, 1.6)
+    dog = sara_amd.ComputeDoGExtrema(p, 1e-6, 1e-6)
+    regions, so = dog(I)
+    assert len(regions) > 0
+    z = p.octave_info(N, N, int(so[0, 1]))[2]
+    assert abs(regions[0]["coords"][0] * z - 5) < 1e-2
+    assert abs(regions[0]["coords"][1] * z - 5) < 1e-2
+
+
+def test_python_api_zero_image():
+    """python/oddkiva/sara/pybind11/test/test_sfm.py:16-21: SIFT on zeros."""
+    keys = sara_amd.compute_sift_keypoints(np.zeros((24, 32), np.float32),
+                                           sara_amd.ImagePyramidParams(0))
+    assert len(sara_amd.features(keys)) == 0
+    assert sara_amd.descriptors(keys).shape == (0, 128)
+
+
+def test_python_api_matches_oracle(oracle):
+    img = synth(256, 192, 21)
+    keys = sara_amd.compute_sift_keypoints(img, hip_params(0, 3))
+    ref = oracle.RefSift(img, ref_params(oracle, 0, 3))
+    rk, rso, rdesc = ref.keypoints()
+    feats = sara_amd.features(keys)
+    assert len(feats) == len(rk) > 0
+    f = feats[len(feats) // 2]
+    r = rk[len(feats) // 2]
+    assert np.array_equal(f.coords, r["coords"])
+    assert f.type == 11 and f.extremum_type in (-1, 1)
+    assert abs(f.radius() - 1 / np.sqrt(r["shape_matrix"][0])) < 1e-4
+    assert np.max(np.abs(sara_amd.descriptors(keys) - rdesc)) <= DESC_ATOL
+
+
+def test_golden_sunflower_crop():
+    """HIP path vs the committed golden vectors (no oracle involved)."""
+    g = np.load(common.GOLDEN + "/sunflower_crop.npz")
+    gray = common.load_sunflower_gray()
+    x0, y0, w, h = (int(v) for v in g["crop"])
+    crop = np.ascontiguousarray(gray[y0:y0 + h, x0:x0 + w])
+    with sara_amd.SiftContext(w, h, 1, hip_params(0, 4)) as ctx:
+        ctx.set_option(sara_amd.capi.OPT_ALL_GRADIENT_SCALES, 1)
+        ctx.detect(crop)
+        names = [str(n) for n in g["plane_names"]]
+        shas = [str(s) for s in g["plane_sha256"]]
+        for name, want in zip(names, shas):
+            kind, s, o = name.split("_")
+            fn = {"G": ctx.gaussian, "D": ctx.dog, "grad": ctx.gradient}[kind]
+            assert common.sha(fn(int(s), int(o))) == want, name
+        ec, ereg, exyso = ctx.extrema()
+        kc, kreg, kdesc, kso = ctx.fetch()
+    assert np.array_equal(exyso, g["extrema_xyso_type"])
+    common.assert_regions_equal(ereg, common.regions_from_bytes(g["extrema"]),
+                                rtol_shape=SHAPE_RTOL)
+    assert np.array_equal(kso, g["scale_octave"])
+    common.assert_regions_equal(kreg, common.regions_from_bytes(g["regions"]),
+                                rtol_shape=SHAPE_RTOL, atol_theta=THETA_ATOL)
+    assert np.max(np.abs(kdesc - g["descriptors"])) <= DESC_ATOL
+
+
+def test_golden_sunflower_full_frame():
+    """Config 1 of BASELINE.json: sunflowerField 1600x1200, 4 octaves."""
+    g = np.load(common.GOLDEN + "/sunflower_full.npz")
+    gray = common.load_sunflower_gray()
+    with sara_amd.SiftContext(1600, 1200, 1, hip_params(0, 4)) as ctx:
+        ctx.detect(gray)
+        ec, ereg, exyso = ctx.extrema()
+        kc, kreg, kdesc, kso = ctx.fetch()
+    assert int(ec[0]) == int(g["n_extrema"]) == 5592
+    assert int(kc[0]) == int(g["n_keypoints"]) == 6832
+    assert np.array_equal(exyso, g["extrema_xyso_type"])
+    assert np.array_equal(kso, g["scale_octave"])
+    common.assert_regions_equal(kreg, common.regions_from_bytes(g["regions"]),
+                                rtol_shape=SHAPE_RTOL, atol_theta=THETA_ATOL)
+    assert np.max(np.abs(kdesc[::8] - g["desc_every8"])) <= DESC_ATOL
+    assert np.allclose(kdesc.sum(axis=1), g["desc_row_sums"], rtol=0, atol=0.05)
+
+
+def test_edge_cases(oracle):
+    # constant image: DoG is ~0 everywhere -> nothing.
+    with sara_amd.SiftContext(64, 48, 1, hip_params(0, 3)) as ctx:
+        ctx.detect(np.full((48, 64), 0.5, np.float32))
+        kc, kreg, kdesc, kso = ctx.fetch()
+        assert kc[0] == 0 and len(kreg) == 0
+        ec, ereg, exyso = ctx.extrema()
+        assert ec[0] == 0
+    # the smallest frames the octave rule admits
+    for (w, h) in ((8, 8), (12, 9), (5, 40)):
+        img = synth(w, h, 4)
+        ref = oracle.RefSift(img, ref_params(oracle, 0, 9),
+                             extremum_refinement_iter=1)
+        with sara_amd.SiftContext(w, h, 1, hip_params(0, 9),
+                                  extremum_refinement_iter=1) as ctx:
+            ctx.detect(img)
+            compare_full(ctx, ref)
+            compare_lists(run_lists(ctx), ref, 0)
+
+
+def test_error_behaviour():
+    with sara_amd.SiftContext(64, 64, 2, hip_params(0, 3)) as ctx:
+        with pytest.raises(sara_amd.SaraHipError) as e:
+            ctx.detect(np.zeros((65, 64), np.float32))
+        assert e.value.status == sara_amd.capi.CAPACITY_EXCEEDED
+        with pytest.raises(sara_amd.SaraHipError) as e:
+            ctx.detect(np.zeros((3, 64, 64), np.float32))
+        assert e.value.status == sara_amd.capi.CAPACITY_EXCEEDED
+        with pytest.raises(sara_amd.SaraHipError) as e:
+            ctx.counts()
+        assert e.value.status == sara_amd.capi.NOT_READY
+        ctx.detect(np.zeros((64, 64), np.float32),
+                   last_stage=sara_amd.STAGE_PYRAMID)
+        with pytest.raises(sara_amd.SaraHipError) as e:
+            ctx.extrema()
+        assert e.value.status == sara_amd.capi.NOT_READY
+        with pytest.raises(sara_amd.SaraHipError) as e:
+            ctx.gaussian(0, 7)
+        assert e.value.status == sara_amd.capi.OUT_OF_RANGE
+    # keypoint capacity overflow is reported, never silent
+    img = synth(320, 240, 12)
+    with sara_amd.SiftContext(320, 240, 1, hip_params(0, 3),
+                              max_keypoints=50) as ctx:
+        ctx.detect(img)
+        with pytest.raises(sara_amd.SaraHipError) as e:
+            ctx.counts()
+        assert e.value.status == sara_amd.capi.CAPACITY_EXCEEDED
+
+
+def test_stage_stops(oracle):
+    img = synth(200, 150, 8)
+    ref = oracle.RefSift(img, ref_params(oracle, 0, 3))
+    with sara_amd.SiftContext(200, 150, 1, hip_params(0, 3)) as ctx:
+        ctx.detect(img, last_stage=sara_amd.STAGE_EXTREMA)
+        ec, ereg, exyso = ctx.extrema()
+        assert np.array_equal(exyso, ref.extrema()[1])
+        ctx.detect(img, last_stage=sara_amd.STAGE_ORIENTATION)
+        kc, kreg, kdesc, kso = ctx.fetch(with_descriptors=False)
+        common.assert_regions_equal(kreg, ref.keypoints()[0],
+                                    rtol_shape=SHAPE_RTOL, atol_theta=THETA_ATOL)
+        t = ctx.stage_times()
+        assert t["total"] > 0 and t["pyramid"] > 0
