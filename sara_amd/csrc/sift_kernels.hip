@@ -754,6 +754,20 @@ namespace sara_hip {
     return int((key >> 1) & 0xfffff);
   }
 
+  //! Workgroup -> work item remap that keeps a contiguous slice of a frame's
+  //! (octave, scale, y, x)-sorted list on one XCD (workgroup b runs on XCD
+  //! b % 8), so that neighbouring keypoints share their image rows in that
+  //! XCD's L2.  Returns the logical block index or -1.
+  __device__ inline int xcd_local_block(int bx, int nblk)
+  {
+    const int chunk = (nblk + 7) >> 3;
+    const int j = bx >> 3;
+    if (j >= chunk)
+      return -1;
+    const int lb = (bx & 7) * chunk + j;
+    return lb < nblk ? lb : -1;
+  }
+
   __device__ inline double readlane_f64(double v, int lane)
   {
     const unsigned long long u = __double_as_longlong(v);
@@ -772,8 +786,11 @@ namespace sara_hip {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
-    const int idx = blockIdx.x * 4 + wave;
     const int n = min(cand.count[b], cand.cap);
+    const int lb = xcd_local_block(blockIdx.x, (n + 3) >> 2);
+    if (lb < 0)
+      return;
+    const int idx = lb * 4 + wave;
     if (idx >= n)
       return;
 
@@ -971,6 +988,13 @@ namespace sara_hip {
     return v;
   }
 
+  // LDS accumulation of the 128 bins.  ds_add_f32 costs ~192 clk per wave
+  // instruction on gfx950 whatever the address pattern (tools/ubench/
+  // lds_atomic.hip), ds_add_u32 ~6-16, so contributions are accumulated as a
+  // (hi, lo) pair of 32-bit fixed-point integers: value = hi*2^-14 + lo*2^-34,
+  // exact to 2^-34 per sample and order-independent (deterministic).
+  constexpr int kDescCopies = 4;  // histogram replicas per wave
+
   __global__ __launch_bounds__(256) void descriptor_kernel(
       const GradPyramidView* __restrict__ gradp, CandidateLists cand,
       OrientationLists ori, sara_oeregion* __restrict__ features,
@@ -978,12 +1002,16 @@ namespace sara_hip {
       int with_descriptors)
   {
     const GradPyramidView& grad = *gradp;
-    __shared__ float s_hist[4][128];
+    __shared__ int s_hi[4][128 * kDescCopies];
+    __shared__ unsigned s_lo[4][128 * kDescCopies];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
-    const int idx = blockIdx.x * 4 + wave;
     const int n = min(cand.count[b], cand.cap);
+    const int lb = xcd_local_block(blockIdx.x, (n + 3) >> 2);
+    if (lb < 0)
+      return;
+    const int idx = lb * 4 + wave;
     if (idx >= n)
       return;
 
@@ -1016,11 +1044,13 @@ namespace sara_hip {
                           grad.base[o] + size_t(b) * grad.frame_stride[o]) +
                       size_t(s) * grad.plane[o];
     const float factor = grad.factor[o];
-    float* hist = s_hist[wave];
+    int* hist_hi = s_hi[wave];
+    unsigned* hist_lo = s_lo[wave];
+    const int copy = lane & (kDescCopies - 1);
 
-    const int D = 2 * rr + 1;
-    const int npx = D * D;
-    const int dv64 = 64 / D, du64 = 64 % D;
+    // rows / columns of the patch that fall inside the image
+    const int v_lo = max(-rr, -ry), v_hi = min(rr, h - 1 - ry);
+    const int u_min = max(-rr, -rx), u_max = min(rr, w - 1 - rx);
 
     for (int k = 0; k < npeaks; ++k)
     {
@@ -1054,77 +1084,106 @@ namespace sara_hip {
       if (!with_descriptors)
         continue;
 
-      hist[lane] = 0.f;
-      hist[lane + 64] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 2 * kDescCopies; ++q)
+      {
+        hist_hi[q * 64 + lane] = 0;
+        hist_lo[q * 64 + lane] = 0u;
+      }
       __builtin_amdgcn_wave_barrier();
 
       const float ct = float(cos(double(theta)));
       const float st = float(sin(double(theta)));
       const float T00 = ct / l, T01 = st / l, T10 = (-st) / l, T11 = ct / l;
 
-      int v = lane / D - rr;
-      int u = lane % D - rr;
-      for (int base = 0; base < npx; base += 64)
+      for (int v = v_lo; v <= v_hi; ++v)
       {
-        if (base + lane < npx)
+        // Conservative u-interval of the samples with |p.x|, |p.y| < 2.5 in
+        // this patch row (the exact float test below decides).
+        const float fv = float(v);
+        float lo = float(u_min), hi = float(u_max);
         {
-          const int xx = rx + u, yy = ry + v;
-          float px = T00 * float(u) + T01 * float(v);
-          float py = T10 * float(u) + T11 * float(v);
-          if (xx >= 0 && xx < w && yy >= 0 && yy < h)
+          const float bx_ = T01 * fv, by_ = T11 * fv;
+          if (fabsf(T00) > 1e-12f)
           {
-            const float weight = expf(-(px * px + py * py) / (2.f * 4.f));
-            const float2 mo = g[size_t(yy) * w + xx];
-            const float mag = mo.x;
-            float a = mo.y - theta;
-            a = a < 0.f ? a + 2.f * pi : a;
-            a *= 8.f / (2.f * pi);
-            px += 1.5f;
-            py += 1.5f;
-            if (!(fminf(px, py) <= -1.f || fmaxf(px, py) >= 4.f))
+            const float a = (-2.5f - bx_) / T00, c = (2.5f - bx_) / T00;
+            lo = fmaxf(lo, fminf(a, c) - 1.f);
+            hi = fminf(hi, fmaxf(a, c) + 1.f);
+          }
+          else if (fabsf(bx_) > 2.6f)
+            hi = lo - 1.f;
+          if (fabsf(T10) > 1e-12f)
+          {
+            const float a = (-2.5f - by_) / T10, c = (2.5f - by_) / T10;
+            lo = fmaxf(lo, fminf(a, c) - 1.f);
+            hi = fminf(hi, fmaxf(a, c) + 1.f);
+          }
+          else if (fabsf(by_) > 2.6f)
+            hi = lo - 1.f;
+        }
+        const int u_lo = int(floorf(lo)), u_hi = int(ceilf(hi));
+        const float2* grow = g + size_t(ry + v) * w + rx;
+        for (int u = max(u_lo, u_min) + lane; u <= min(u_hi, u_max); u += 64)
+        {
+          float px = T00 * float(u) + T01 * fv;
+          float py = T10 * float(u) + T11 * fv;
+          const float nrm2 = px * px + py * py;
+          px += 1.5f;
+          py += 1.5f;
+          if (fminf(px, py) <= -1.f || fmaxf(px, py) >= 4.f)
+            continue;
+          const float weight = expf(-nrm2 / (2.f * 4.f));
+          const float2 mo = grow[u];
+          const float mag = mo.x;
+          float a = mo.y - theta;
+          a = a < 0.f ? a + 2.f * pi : a;
+          a *= 8.f / (2.f * pi);
+          const float xif = truncf(px), yif = truncf(py), oif = truncf(a);
+          const float xfrac = px - xif, yfrac = py - yif, ofrac = a - oif;
+          const int xi = int(xif), yi = int(yif), oi = int(oif);
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy)
+          {
+            const int y_ = yi + dy;
+            if (y_ < 0 || y_ >= 4)
+              continue;
+            const float wy = (dy == 0) ? 1 - yfrac : yfrac;
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
             {
-              const float xif = truncf(px), yif = truncf(py), oif = truncf(a);
-              const float xfrac = px - xif, yfrac = py - yif, ofrac = a - oif;
-              const int xi = int(xif), yi = int(yif), oi = int(oif);
+              const int x_ = xi + dx;
+              if (x_ < 0 || x_ >= 4)
+                continue;
+              const float wx = (dx == 0) ? 1 - xfrac : xfrac;
 #pragma unroll
-              for (int dy = 0; dy < 2; ++dy)
+              for (int dori = 0; dori < 2; ++dori)
               {
-                const int y_ = yi + dy;
-                if (y_ < 0 || y_ >= 4)
-                  continue;
-                const float wy = (dy == 0) ? 1 - yfrac : yfrac;
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx)
-                {
-                  const int x_ = xi + dx;
-                  if (x_ < 0 || x_ >= 4)
-                    continue;
-                  const float wx = (dx == 0) ? 1 - xfrac : xfrac;
-#pragma unroll
-                  for (int dori = 0; dori < 2; ++dori)
-                  {
-                    const int o_ = (oi + dori) % 8;
-                    const float wo = (dori == 0) ? 1 - ofrac : ofrac;
-                    atomicAdd(&hist[32 * y_ + 8 * x_ + o_],
-                              wy * wx * wo * weight * mag);
-                  }
-                }
+                const int o_ = (oi + dori) % 8;
+                const float wo = (dori == 0) ? 1 - ofrac : ofrac;
+                const float c = wy * wx * wo * weight * mag;
+                const float x14 = c * 16384.f;
+                const float hif = floorf(x14);
+                const int bin = (32 * y_ + 8 * x_ + o_) * kDescCopies + copy;
+                atomicAdd(&hist_hi[bin], int(hif));
+                atomicAdd(&hist_lo[bin], unsigned((x14 - hif) * 1048576.f));
               }
             }
           }
-        }
-        u += du64;
-        v += dv64;
-        if (u > rr)
-        {
-          u -= D;
-          v += 1;
         }
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
 
-      float h0 = hist[lane], h1 = hist[lane + 64];
+      double a0 = 0., a1 = 0.;
+#pragma unroll
+      for (int c = 0; c < kDescCopies; ++c)
+      {
+        a0 += double(hist_hi[lane * kDescCopies + c]) * 0x1p-14 +
+              double(hist_lo[lane * kDescCopies + c]) * 0x1p-34;
+        a1 += double(hist_hi[(lane + 64) * kDescCopies + c]) * 0x1p-14 +
+              double(hist_lo[(lane + 64) * kDescCopies + c]) * 0x1p-34;
+      }
+      float h0 = float(a0), h1 = float(a1);
       // normalize(): L2, clamp at 0.2, L2; then x512, clamp at 255.
       float z = wave_sum(h0 * h0 + h1 * h1);
       if (z > 0.f)
