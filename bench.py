@@ -49,24 +49,18 @@ def parse():
 
 
 def pyramid_bytes_per_frame(width, height, octaves, scales=6):
-    """Algorithmic HBM bytes of the Gaussian-pyramid stage per frame as THIS
-    design moves them: every blurred plane is one 4-byte
-    read + one 4-byte write per pixel (48*P for 6 planes/octave),
-    the fused DoG epilogue adds its 4-byte write (the reference's separate DoG
-    pass would be 12), and each octave hand-over reads/writes the quarter-size
-    plane once."""
+    """Algorithmic HBM bytes of the Gaussian-pyramid stage per frame
+    (SURVEY.md 8d): every one of the `scales` planes of an octave is produced
+    by one 4-byte read + one 4-byte write per pixel => 48*P for 6 planes per
+    octave (the initial blur and the octave hand-overs are the s = 0 planes).
+    The DoG pyramid is not materialised by this design, so it contributes no
+    bytes here (the reference's separate DoG pass would add 60*P)."""
     total = 0
     w, h = width, height
     launches = 0
-    for o in range(octaves):
-        px = w * h
-        if o == 0:
-            total += 8 * px          # initial blur: read frame, write G(0,0)
-            launches += 1
-        else:
-            total += 8 * px          # nearest-neighbour half of G(2, o-1)
-        total += (scales - 1) * 12 * px  # blur: read G(s-1), write G(s), D(s-1)
-        launches += scales - 1
+    for _ in range(octaves):
+        total += 8 * w * h * scales
+        launches += scales
         w //= 2
         h //= 2
     return total, launches
@@ -282,9 +276,9 @@ def main():
             },
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {
-                "kernel": "gaussian_blur_kernel<R> (Gaussian pyramid + fused "
-                          "DoG; %d launches/step incl. octave hand-overs "
-                          "timed with them)" % launches,
+                "kernel": "gaussian_blur_march_kernel<R> (Gaussian pyramid "
+                          "stage: %d launches/step, the 3 nearest-neighbour "
+                          "octave hand-overs timed with the blurs)" % launches,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

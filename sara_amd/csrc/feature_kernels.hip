@@ -11,350 +11,10 @@
 #include "device_math.hpp"
 
 #include <cmath>
+#include <cstdlib>
+#include <string>
 
 namespace sara_hip {
-
-  // ======================================================================== //
-  // Gaussian blur: rows then columns through LDS, replicate borders.
-  // Reference: apply_gaussian_filter, ImageProcessing/LinearFiltering.cpp:30-68
-  //            apply_row_based_filter / apply_column_based_filter / convolve_array,
-  //            ImageProcessing/LinearFiltering.hpp:43-149.
-  // Optional fused epilogue: dog = dst - src (GaussianPyramid.cpp:44-46).
-  //
-  // One workgroup produces a TX x TY tile.  The (TY+2R) x (TX+2R) source
-  // window is staged in LDS once, row-filtered into a (TY+2R) x TX LDS tile
-  // (each lane: 4 adjacent outputs from ds_read_b128 windows), then
-  // column-filtered (each lane: 8 outputs of one column from a register
-  // window).  Taps sit in SGPRs.  Accumulation is `sum += v * k` from 0.f in
-  // ascending tap order, mul and add unfused, as in convolve_array.
-  // ======================================================================== //
-  constexpr int TX = 64;
-  constexpr int TY = 32;
-  constexpr int NT = 256;
-
-  template <int R>
-  __global__ __launch_bounds__(NT) void gaussian_blur_kernel(
-      const float* __restrict__ src, size_t src_stride,
-      float* __restrict__ dst, size_t dst_stride, float* __restrict__ dog,
-      size_t dog_stride, int w, int h, Taps taps)
-  {
-    constexpr int K = 2 * R + 1;
-    constexpr int IW = TX + 2 * R;
-    constexpr int IH = TY + 2 * R;
-    constexpr int NQ = (4 + 2 * R + 3) / 4;       // b128 reads per 4 outputs
-    constexpr int IP = ((IW + 3) / 4) * 4 + 4;    // row pitch, over-read safe
-    __shared__ __attribute__((aligned(16))) float s_in[IH * IP];
-    __shared__ __attribute__((aligned(16))) float s_tmp[IH * TX];
-
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * TX;
-    const int y0 = blockIdx.y * TY;
-    const size_t b = blockIdx.z;
-    src += b * src_stride;
-    dst += b * dst_stride;
-
-    // Stage the clamped source window.
-    for (int idx = tid; idx < IH * IW; idx += NT)
-    {
-      const int r = idx / IW;
-      const int c = idx - r * IW;
-      int gy = y0 - R + r;
-      int gx = x0 - R + c;
-      gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
-      gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
-      s_in[r * IP + c] = src[size_t(gy) * w + gx];
-    }
-    __syncthreads();
-
-    // Row pass.
-    for (int it = tid; it < IH * (TX / 4); it += NT)
-    {
-      const int r = it / (TX / 4);
-      const int q = it - r * (TX / 4);
-      float v[NQ * 4];
-      const float4* p = reinterpret_cast<const float4*>(&s_in[r * IP + 4 * q]);
-#pragma unroll
-      for (int m = 0; m < NQ; ++m)
-      {
-        const float4 t = p[m];
-        v[4 * m + 0] = t.x;
-        v[4 * m + 1] = t.y;
-        v[4 * m + 2] = t.z;
-        v[4 * m + 3] = t.w;
-      }
-      float acc[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-      {
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < K; ++j)
-          sum += v[i + j] * taps.k[j];
-        acc[i] = sum;
-      }
-      *reinterpret_cast<float4*>(&s_tmp[r * TX + 4 * q]) =
-          make_float4(acc[0], acc[1], acc[2], acc[3]);
-    }
-    __syncthreads();
-
-    // Column pass: lane -> column tx, 8 consecutive rows.
-    const int tx = tid & 63;
-    const int yq = tid >> 6;
-    constexpr int NV = 8 + 2 * R;
-    float v[NV];
-#pragma unroll
-    for (int m = 0; m < NV; ++m)
-      v[m] = s_tmp[(yq * 8 + m) * TX + tx];
-
-    const int gx = x0 + tx;
-    if (gx >= w)
-      return;
-    if (dog)
-      dog += b * dog_stride;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-    {
-      float sum = 0.f;
-#pragma unroll
-      for (int j = 0; j < K; ++j)
-        sum += v[i + j] * taps.k[j];
-      const int gy = y0 + yq * 8 + i;
-      if (gy < h)
-      {
-        dst[size_t(gy) * w + gx] = sum;
-        if (dog)
-          dog[size_t(gy) * w + gx] = sum - s_in[(yq * 8 + i + R) * IP + tx + R];
-      }
-    }
-  }
-
-  //! Any radius up to kMaxRadius: same structure, runtime loops, dynamic LDS.
-  __global__ __launch_bounds__(NT) void gaussian_blur_generic_kernel(
-      const float* __restrict__ src, size_t src_stride,
-      float* __restrict__ dst, size_t dst_stride, float* __restrict__ dog,
-      size_t dog_stride, int w, int h, Taps taps)
-  {
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-    const int R = taps.size / 2;
-    const int K = taps.size;
-    const int IW = TX + 2 * R;
-    const int IH = TY + 2 * R;
-    float* s_in = s_dyn;
-    float* s_tmp = s_dyn + IH * IW;
-
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * TX;
-    const int y0 = blockIdx.y * TY;
-    const size_t b = blockIdx.z;
-    src += b * src_stride;
-    dst += b * dst_stride;
-    if (dog)
-      dog += b * dog_stride;
-
-    for (int idx = tid; idx < IH * IW; idx += NT)
-    {
-      const int r = idx / IW;
-      const int c = idx - r * IW;
-      int gy = y0 - R + r;
-      int gx = x0 - R + c;
-      gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
-      gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
-      s_in[idx] = src[size_t(gy) * w + gx];
-    }
-    __syncthreads();
-    for (int idx = tid; idx < IH * TX; idx += NT)
-    {
-      const int r = idx / TX;
-      const int c = idx - r * TX;
-      float sum = 0.f;
-      for (int j = 0; j < K; ++j)
-        sum += s_in[r * IW + c + j] * taps.k[j];
-      s_tmp[idx] = sum;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < TY * TX; idx += NT)
-    {
-      const int r = idx / TX;
-      const int c = idx - r * TX;
-      float sum = 0.f;
-      for (int j = 0; j < K; ++j)
-        sum += s_tmp[(r + j) * TX + c] * taps.k[j];
-      const int gx = x0 + c, gy = y0 + r;
-      if (gx < w && gy < h)
-      {
-        dst[size_t(gy) * w + gx] = sum;
-        if (dog)
-          dog[size_t(gy) * w + gx] = sum - s_in[(r + R) * IW + c + R];
-      }
-    }
-  }
-
-  template <int R>
-  static void launch_blur_r(const float* src, size_t src_stride, float* dst,
-                            size_t dst_stride, float* dog, size_t dog_stride,
-                            int w, int h, int batch, const Taps& taps,
-                            hipStream_t stream)
-  {
-    const dim3 grid((w + TX - 1) / TX, (h + TY - 1) / TY, batch);
-    hipLaunchKernelGGL(gaussian_blur_kernel<R>, grid, dim3(NT), 0, stream, src,
-                       src_stride, dst, dst_stride, dog, dog_stride, w, h, taps);
-  }
-
-  void launch_gaussian_blur(const float* src, size_t src_stride, float* dst,
-                            size_t dst_stride, float* dog, size_t dog_stride,
-                            int w, int h, int batch, const Taps& taps,
-                            hipStream_t stream)
-  {
-    const int R = taps.size / 2;
-#define SARA_BLUR_CASE(r)                                                      \
-  case r:                                                                      \
-    launch_blur_r<r>(src, src_stride, dst, dst_stride, dog, dog_stride, w, h,  \
-                     batch, taps, stream);                                     \
-    return;
-    switch (R)
-    {
-      SARA_BLUR_CASE(1)
-      SARA_BLUR_CASE(2)
-      SARA_BLUR_CASE(3)
-      SARA_BLUR_CASE(4)
-      SARA_BLUR_CASE(5)
-      SARA_BLUR_CASE(6)
-      SARA_BLUR_CASE(7)
-      SARA_BLUR_CASE(8)
-      SARA_BLUR_CASE(9)
-      SARA_BLUR_CASE(10)
-      SARA_BLUR_CASE(11)
-      SARA_BLUR_CASE(12)
-      SARA_BLUR_CASE(13)
-      SARA_BLUR_CASE(14)
-      SARA_BLUR_CASE(15)
-      SARA_BLUR_CASE(16)
-    default:
-      break;
-    }
-#undef SARA_BLUR_CASE
-    const dim3 grid((w + TX - 1) / TX, (h + TY - 1) / TY, batch);
-    const size_t lds =
-        sizeof(float) * size_t(TY + 2 * R) * (size_t(TX + 2 * R) + TX);
-    hipLaunchKernelGGL(gaussian_blur_generic_kernel, grid, dim3(NT), lds, stream,
-                       src, src_stride, dst, dst_stride, dog, dog_stride, w, h,
-                       taps);
-  }
-
-  // ======================================================================== //
-  // Resize / copy / subtract.
-  // ======================================================================== //
-
-  //! scale(): ImageProcessing/Resize.cpp:45-60.
-  __global__ void scale_kernel(const float* __restrict__ src, size_t src_stride,
-                               int sw, int sh, float* __restrict__ dst,
-                               size_t dst_stride, int dw, int dh)
-  {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= dw || y >= dh)
-      return;
-    const size_t b = blockIdx.z;
-    const float sx = float(sw) / float(dw);
-    const float sy = float(sh) / float(dh);
-    const int xi = int(float(x) * sx);
-    const int yi = int(float(y) * sy);
-    dst[b * dst_stride + size_t(y) * dw + x] =
-        src[b * src_stride + size_t(yi) * sw + xi];
-  }
-
-  void launch_scale(const float* src, size_t src_stride, int sw, int sh,
-                    float* dst, size_t dst_stride, int dw, int dh, int batch,
-                    hipStream_t stream)
-  {
-    const dim3 block(64, 4);
-    const dim3 grid((dw + 63) / 64, (dh + 3) / 4, batch);
-    hipLaunchKernelGGL(scale_kernel, grid, block, 0, stream, src, src_stride, sw,
-                       sh, dst, dst_stride, dw, dh);
-  }
-
-  //! enlarge(): ImageProcessing/Resize.cpp:110-126 + interpolate(),
-  //! ImageProcessing/Interpolation.hpp:33-78 (bilinear in double, far border
-  //! replicated, x-fastest accumulation).
-  __global__ void enlarge_kernel(const float* __restrict__ src,
-                                 size_t src_stride, int sw, int sh,
-                                 float* __restrict__ dst, size_t dst_stride,
-                                 int dw, int dh)
-  {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= dw || y >= dh)
-      return;
-    const size_t b = blockIdx.z;
-    const float* s = src + b * src_stride;
-    const double scx = double(sw) / double(dw);
-    const double scy = double(sh) / double(dh);
-    const double px = double(x) * scx;
-    const double py = double(y) * scy;
-    const double ipx = trunc(px), ipy = trunc(py);
-    const double fx = px - ipx, fy = py - ipy;
-    const int x0 = int(ipx), y0 = int(ipy);
-    double value = 0.;
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 2; ++dx)
-      {
-        double weight = 1.;
-        weight *= (dx == 0) ? (1. - fx) : fx;
-        weight *= (dy == 0) ? (1. - fy) : fy;
-        const int xx = (x0 + dx < sw) ? x0 + dx : x0 + dx - 1;
-        const int yy = (y0 + dy < sh) ? y0 + dy : y0 + dy - 1;
-        value += weight * double(s[size_t(yy) * sw + xx]);
-      }
-    dst[b * dst_stride + size_t(y) * dw + x] = float(value);
-  }
-
-  void launch_enlarge(const float* src, size_t src_stride, int sw, int sh,
-                      float* dst, size_t dst_stride, int dw, int dh, int batch,
-                      hipStream_t stream)
-  {
-    const dim3 block(64, 4);
-    const dim3 grid((dw + 63) / 64, (dh + 3) / 4, batch);
-    hipLaunchKernelGGL(enlarge_kernel, grid, block, 0, stream, src, src_stride,
-                       sw, sh, dst, dst_stride, dw, dh);
-  }
-
-  __global__ void copy_planes_kernel(const float* __restrict__ src,
-                                     size_t src_stride, float* __restrict__ dst,
-                                     size_t dst_stride, size_t count)
-  {
-    const size_t b = blockIdx.y;
-    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count;
-         i += size_t(gridDim.x) * blockDim.x)
-      dst[b * dst_stride + i] = src[b * src_stride + i];
-  }
-
-  void launch_copy_planes(const float* src, size_t src_stride, float* dst,
-                          size_t dst_stride, size_t count, int batch,
-                          hipStream_t stream)
-  {
-    const int blocks = int(std::min<size_t>((count + 255) / 256, 2048));
-    hipLaunchKernelGGL(copy_planes_kernel, dim3(blocks, batch), dim3(256), 0,
-                       stream, src, src_stride, dst, dst_stride, count);
-  }
-
-  __global__ void subtract_kernel(const float* __restrict__ a,
-                                  const float* __restrict__ b,
-                                  float* __restrict__ out, size_t count)
-  {
-    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count;
-         i += size_t(gridDim.x) * blockDim.x)
-      out[i] = a[i] - b[i];
-  }
-
-  void launch_subtract(const float* a, const float* b, float* out, size_t count,
-                       hipStream_t stream)
-  {
-    const int blocks = int(std::min<size_t>((count + 255) / 256, 2048));
-    hipLaunchKernelGGL(subtract_kernel, dim3(blocks), dim3(256), 0, stream, a, b,
-                       out, count);
-  }
 
   // ======================================================================== //
   // Polar gradients.  Reference: gradient_polar_coordinates,
@@ -398,10 +58,147 @@ namespace sara_hip {
     o[c] = make_float2(r, theta);
   }
 
+  //! Fast path (w % 4 == 0): one wave marches down a strip of 256 columns
+  //! (4 per lane, float4 loads, 32-byte stores).  Rows y-1, y, y+1 live in a
+  //! register ring (loop unrolled 3x), horizontal neighbours come from the
+  //! adjacent lane through ds_bpermute and, at the strip edges, from one extra
+  //! scalar load.  HBM traffic: 4 B read + 8 B written per pixel.
+  template <int PF>
+  __global__ __launch_bounds__(64) void gradient_polar_march_kernel(
+      const float* __restrict__ src, size_t src_stride,
+      float* __restrict__ dst, size_t dst_stride, int w, int h, int nscales,
+      int seg_rows, int nstrips)
+  {
+    constexpr int W = 256;
+    const int lane = threadIdx.x;
+    const int strip = blockIdx.x % nstrips;
+    const int seg = blockIdx.x / nstrips;
+    const int z = blockIdx.y;
+    const size_t b = z / nscales;
+    const size_t s = z - b * nscales;
+    const size_t plane = size_t(w) * h;
+    const float* f = src + b * src_stride + s * plane;
+    float* o = dst + b * dst_stride + s * plane * 2;
+
+    const int x0 = strip * W;
+    const int col = x0 + 4 * lane;
+    const bool col_ok = col < w;
+    const int mcol = col_ok ? col : w - 4;
+    const int y0 = seg * seg_rows;
+    const int y1 = min(h, y0 + seg_rows);
+    // strip-edge neighbours: lane 0 needs column x0-1, lane 63 column x0+256
+    const int ecol = lane == 0 ? max(x0 - 1, 0) : min(x0 + W, w - 1);
+    const bool edge_lane = (lane == 0) || (lane == 63);
+
+    auto load_row = [&](int yy, float4& m, float& e) {
+      const int gy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+      const float* rowp = f + size_t(gy) * w;
+      m = *reinterpret_cast<const float4*>(rowp + mcol);
+      e = 0.f;
+      if (edge_lane)
+        e = rowp[ecol];
+    };
+
+    float4 ring[3];   // source rows (n-2, n-1, n) by n % 3
+    float ering[3];
+    float4 pm[PF];
+    float pe[PF];
+    const int T = (y1 - y0) + 2;  // source rows y0-1 .. y1
+#pragma unroll
+    for (int q = 0; q < PF; ++q)
+      load_row(y0 - 1 + q, pm[q], pe[q]);
+
+    for (int n0 = 0; n0 < T; n0 += 3 * PF)
+    {
+#pragma unroll
+      for (int i = 0; i < 3 * PF; ++i)
+      {
+        const int n = n0 + i;
+        const int yy = y0 - 1 + n;  // source row arriving now
+        ring[i % 3] = pm[i % PF];
+        ering[i % 3] = pe[i % PF];
+        load_row(yy + PF, pm[i % PF], pe[i % PF]);
+
+        const int y = yy - 1;  // output row: needs rows y-1, y, y+1
+        if (n >= 2 && y < y1)
+        {
+          const float4 up = ring[(i + 1) % 3];   // row y-1
+          const float4 mid = ring[(i + 2) % 3];  // row y
+          const float4 dn = ring[i % 3];         // row y+1
+          const float emid = ering[(i + 2) % 3];
+          // horizontal neighbours of the 4 columns
+          float left = __shfl_up(mid.w, 1);
+          float right = __shfl_down(mid.x, 1);
+          if (lane == 0)
+            left = emid;
+          if (lane == 63)
+            right = emid;
+          const float cx[6] = {left, mid.x, mid.y, mid.z, mid.w, right};
+          const float cu[4] = {up.x, up.y, up.z, up.w};
+          const float cd[4] = {dn.x, dn.y, dn.z, dn.w};
+          float res[8];
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+          {
+            const int x = col + c;
+            float gx, gy;
+            if (x == 0)
+              gx = (cx[c + 2] - cx[c + 1]) / 2;
+            else if (x == w - 1)
+              gx = (cx[c + 1] - cx[c]) / 2;
+            else
+              gx = (cx[c + 2] - cx[c]) / 2;
+            if (y == 0)
+              gy = (cd[c] - cx[c + 1]) / 2;
+            else if (y == h - 1)
+              gy = (cx[c + 1] - cu[c]) / 2;
+            else
+              gy = (cd[c] - cu[c]) / 2;
+            res[2 * c] = 2 * sqrtf(gx * gx + gy * gy);
+            res[2 * c + 1] = fdlibm_atan2f(gy, gx);
+          }
+          if (col_ok)
+          {
+            float4* op = reinterpret_cast<float4*>(o + (size_t(y) * w + col) * 2);
+            op[0] = make_float4(res[0], res[1], res[2], res[3]);
+            op[1] = make_float4(res[4], res[5], res[6], res[7]);
+          }
+        }
+      }
+    }
+  }
+
+  static const bool g_use_march = [] {
+    const char* e = getenv("SARA_HIP_FEATURES");
+    return !(e && std::string(e) == "tile");
+  }();
+  static const int g_march_waves = [] {
+    const char* e = getenv("SARA_HIP_MARCH_WAVES");
+    return e ? std::max(64, atoi(e)) : 4096;
+  }();
+
   void launch_gradient_polar(const float* src, size_t src_stride, float* dst,
                              size_t dst_stride, int w, int h, int nscales,
                              int batch, hipStream_t stream)
   {
+    const bool aligned4 = (w % 4 == 0) && w >= 4 && h >= 2 &&
+                          (src_stride % 4 == 0) && (dst_stride % 4 == 0) &&
+                          (reinterpret_cast<uintptr_t>(src) % 16 == 0) &&
+                          (reinterpret_cast<uintptr_t>(dst) % 16 == 0);
+    if (aligned4 && g_use_march)
+    {
+      const int nstrips = (w + 255) / 256;
+      const int planes = batch * nscales;
+      int nseg = (g_march_waves + nstrips * planes - 1) / (nstrips * planes);
+      nseg = std::max(1, std::min(nseg, (h + 15) / 16));
+      const int seg_rows = (h + nseg - 1) / nseg;
+      nseg = (h + seg_rows - 1) / seg_rows;
+      hipLaunchKernelGGL((gradient_polar_march_kernel<4>),
+                         dim3(nstrips * nseg, planes), dim3(64), 0, stream, src,
+                         src_stride, dst, dst_stride, w, h, nscales, seg_rows,
+                         nstrips);
+      return;
+    }
     const dim3 block(64, 4);
     const dim3 grid((w + 63) / 64, (h + 3) / 4, batch * nscales);
     hipLaunchKernelGGL(gradient_polar_kernel, grid, block, 0, stream, src,
@@ -417,16 +214,19 @@ namespace sara_hip {
   // ImageProcessing/GaussianPyramid.hpp:183-233.
   // ======================================================================== //
 
-  //! One frame's DoG octave: layer s at base + s*plane.
+  //! One frame's DoG octave, never materialised: layer s is the difference of
+  //! the Gaussian planes s+1 and s (GaussianPyramid.cpp:44-46), evaluated where
+  //! it is needed.  `layers` = number of DoG layers = Gaussian scales - 1.
   struct DogOctave
   {
-    const float* base;
+    const float* base;  // Gaussian planes [scale][h][w] of one frame
     int w, h;
     size_t plane;
     int layers;
     __device__ float at(int x, int y, int s) const
     {
-      return base[size_t(s) * plane + size_t(y) * w + x];
+      const size_t i = size_t(s) * plane + size_t(y) * w + x;
+      return base[i + plane] - base[i];
     }
   };
 
@@ -601,41 +401,37 @@ namespace sara_hip {
     return is_max ? 1 : -1;
   }
 
-  __global__ void extrema_scan_kernel(OctaveView dog, int octave, int nscan,
-                                      ExtremaParams p,
-                                      const ScaleTable* __restrict__ tabp,
-                                      CandidateLists cand)
+  //! Edge test, refinement, contrast test and append of one classified site
+  //! (RefineExtremum.cpp:429-434, :454-484, :497-515).  type: +1 / -1.
+  __device__ inline void finish_candidate(const DogOctave& I, int x, int y, int s,
+                                          int type, int octave, int frame,
+                                          const ExtremaParams& p,
+                                          const ScaleTable& tab,
+                                          const CandidateLists& cand)
   {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    const int z = blockIdx.z;
-    const int b = z / nscan;
-    const int s = 1 + (z - b * nscan);
-    const int w = dog.w, h = dog.h;
-    const int pad = p.img_padding_sz;
-    if (!(pad <= x && x < w - pad && pad <= y && y < h - pad))
+    const float v = I.at(x, y, s);
+    const float hxx = I.at(x + 1, y, s) - 2.f * v + I.at(x - 1, y, s);
+    const float hyy = I.at(x, y + 1, s) - 2.f * v + I.at(x, y - 1, s);
+    const float hxy = (I.at(x + 1, y + 1, s) - I.at(x - 1, y + 1, s) -
+                       I.at(x + 1, y - 1, s) + I.at(x - 1, y - 1, s)) /
+                      4.f;
+    const float tr = hxx + hyy;
+    const float det = hxx * hyy - hxy * hxy;
+    const float er = p.edge_ratio_thres;
+    if ((tr * tr) * er >= ((er + 1.f) * (er + 1.f)) * fabsf(det))
       return;
 
-    const float* base = dog.base + size_t(b) * dog.frame_stride;
-    const size_t c = size_t(y) * w + x;
-    const float* pb = base + size_t(s) * dog.plane + c;
-    const int type = classify_site(pb - dog.plane, pb, pb + dog.plane, w,
-                                   p.extremum_thres, p.edge_ratio_thres);
-    if (type == 0)
-      return;
-
-    DogOctave I{base, w, h, dog.plane, dog.scales};
     float pos[3];
-    float val = pb[0];
-    refine_extremum(I, x, y, s, type == 1 ? 1 : 255, pos, val, pad,
-                    p.refine_iters, *tabp, p.scale_geometric_factor);
+    float val = v;
+    refine_extremum(I, x, y, s, type == 1 ? 1 : 255, pos, val, p.img_padding_sz,
+                    p.refine_iters, tab, p.scale_geometric_factor);
     if (fabsf(val) < p.extremum_thres)
       return;
 
-    const int slot = atomicAdd(&cand.count[b], 1);
+    const int slot = atomicAdd(&cand.count[frame], 1);
     if (slot < cand.cap)
     {
-      const size_t i = size_t(b) * cand.cap + slot;
+      const size_t i = size_t(frame) * cand.cap + slot;
       cand.key[i] =
           ((((unsigned long long) (octave * kMaxScales + s) << 20 | (unsigned) y)
             << 20 | (unsigned) x)
@@ -645,16 +441,181 @@ namespace sara_hip {
     }
   }
 
-  void launch_extrema_scan(const OctaveView& dog, int octave, int batch,
+  //! General path (any width): one thread per site, 26 neighbours read
+  //! through the on-the-fly DoG accessor.
+  __global__ void extrema_scan_kernel(OctaveView gauss, int octave, int nscan,
+                                      ExtremaParams p,
+                                      const ScaleTable* __restrict__ tabp,
+                                      CandidateLists cand)
+  {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = blockIdx.z;
+    const int b = z / nscan;
+    const int s = 1 + (z - b * nscan);
+    const int w = gauss.w, h = gauss.h;
+    const int pad = p.img_padding_sz;
+    if (!(pad <= x && x < w - pad && pad <= y && y < h - pad))
+      return;
+
+    const DogOctave I{gauss.base + size_t(b) * gauss.frame_stride, w, h,
+                      gauss.plane, gauss.scales - 1};
+    const float v = I.at(x, y, s);
+    if (fabsf(v) < 0.8f * p.extremum_thres)
+      return;
+    bool is_max = true, is_min = true;
+#pragma unroll
+    for (int ds = -1; ds <= 1; ++ds)
+#pragma unroll
+      for (int dv = -1; dv <= 1; ++dv)
+#pragma unroll
+        for (int du = -1; du <= 1; ++du)
+        {
+          if (ds == 0 && dv == 0 && du == 0)
+            continue;
+          const float nb = I.at(x + du, y + dv, s + ds);
+          is_max = is_max && (v >= nb);
+          is_min = is_min && (v <= nb);
+        }
+    if (!is_max && !is_min)
+      return;
+    finish_candidate(I, x, y, s, is_max ? 1 : -1, octave, b, p, *tabp, cand);
+  }
+
+  //! Fast path (even widths, ND = scales-1 DoG layers known at compile time).
+  //! One wave marches down a strip of 128 columns (2 per lane, 8-byte loads of
+  //! the ND+1 Gaussian planes, strips overlap by 2 columns).  The DoG rows
+  //! y-1, y, y+1 of all ND layers live in a register ring.  A site is a
+  //! non-strict maximum of its 26 neighbours iff it equals the maximum of the
+  //! whole 3x3x3 block, and that maximum is separable: 3-row max per layer
+  //! (v_max3), 3-column max through the neighbouring lane, 3-layer max - and
+  //! the per-layer 3x3 maxima are shared by the ND-2 scales scanned.  The rare
+  //! classified sites go through finish_candidate().
+  //! HBM traffic: 4*(ND+1) B read per pixel, nothing written but candidates.
+  template <int ND, int PF>
+  __global__ __launch_bounds__(64) void extrema_march_kernel(
+      OctaveView gauss, int octave, ExtremaParams p,
+      const ScaleTable* __restrict__ tabp, CandidateLists cand, int seg_rows,
+      int nstrips)
+  {
+    static_assert(PF == 3, "the row loop is unrolled 3x");
+    constexpr int NG = ND + 1;
+    constexpr int STRIDE = 126;
+    const int lane = threadIdx.x;
+    const int strip = blockIdx.x % nstrips;
+    const int seg = blockIdx.x / nstrips;
+    const int b = blockIdx.y;
+    const int w = gauss.w, h = gauss.h;
+    const int pad = p.img_padding_sz;
+    const float* g = gauss.base + size_t(b) * gauss.frame_stride;
+    const size_t plane = gauss.plane;
+
+    const int x0 = strip * STRIDE;
+    const int col = x0 + 2 * lane;
+    const int mcol = min(col, w - 2);
+    const int y0 = seg * seg_rows;
+    const int y1 = min(h, y0 + seg_rows);
+    const float thr8 = 0.8f * p.extremum_thres;
+
+    auto load_row = [&](int yy, float2 (&r)[NG]) {
+      const int gy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+      const float* rowp = g + size_t(gy) * w + mcol;
+#pragma unroll
+      for (int l = 0; l < NG; ++l)
+        r[l] = *reinterpret_cast<const float2*>(rowp + size_t(l) * plane);
+    };
+
+    float2 pg[PF][NG];
+    float2 ring[3][ND];
+#pragma unroll
+    for (int q = 0; q < PF; ++q)
+      load_row(y0 - 1 + q, pg[q]);
+    const int T = (y1 - y0) + 2;  // source rows y0-1 .. y1
+
+    for (int n0 = 0; n0 < T; n0 += 3)
+    {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+      {
+        const int n = n0 + i;
+        const int yy = y0 - 1 + n;
+#pragma unroll
+        for (int l = 0; l < ND; ++l)
+          ring[i][l] = make_float2(pg[i][l + 1].x - pg[i][l].x,
+                                   pg[i][l + 1].y - pg[i][l].y);
+        load_row(yy + PF, pg[i]);
+
+        const int y = yy - 1;
+        if (n < 2 || y >= y1 || y < pad || y >= h - pad)
+          continue;  // wave-uniform
+        const int ia = (i + 1) % 3, ib = (i + 2) % 3, ic = i;  // y-1, y, y+1
+
+        float2 m[ND], mn[ND];
+#pragma unroll
+        for (int l = 0; l < ND; ++l)
+        {
+          const float vx = fmaxf(fmaxf(ring[ia][l].x, ring[ib][l].x), ring[ic][l].x);
+          const float vy = fmaxf(fmaxf(ring[ia][l].y, ring[ib][l].y), ring[ic][l].y);
+          const float ux = fminf(fminf(ring[ia][l].x, ring[ib][l].x), ring[ic][l].x);
+          const float uy = fminf(fminf(ring[ia][l].y, ring[ib][l].y), ring[ic][l].y);
+          const float vl = __shfl_up(vy, 1), vr = __shfl_down(vx, 1);
+          const float ul = __shfl_up(uy, 1), ur = __shfl_down(ux, 1);
+          m[l] = make_float2(fmaxf(fmaxf(vl, vx), vy), fmaxf(fmaxf(vx, vy), vr));
+          mn[l] = make_float2(fminf(fminf(ul, ux), uy), fminf(fminf(ux, uy), ur));
+        }
+#pragma unroll
+        for (int s = 1; s <= ND - 2; ++s)
+        {
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+          {
+            const float v = c == 0 ? ring[ib][s].x : ring[ib][s].y;
+            const float M = c == 0 ? fmaxf(fmaxf(m[s - 1].x, m[s].x), m[s + 1].x)
+                                   : fmaxf(fmaxf(m[s - 1].y, m[s].y), m[s + 1].y);
+            const float N = c == 0 ? fminf(fminf(mn[s - 1].x, mn[s].x), mn[s + 1].x)
+                                   : fminf(fminf(mn[s - 1].y, mn[s].y), mn[s + 1].y);
+            const int x = col + c;
+            // interior columns of the strip only (the outer two are halo)
+            const bool mine = (c == 0 ? lane > 0 : lane < 63) && x >= pad &&
+                              x < w - pad;
+            const bool is_max = (v == M), is_min = (v == N);
+            if (mine && !(fabsf(v) < thr8) && (is_max || is_min))
+            {
+              const DogOctave I{g, w, h, plane, ND};
+              finish_candidate(I, x, y, s, is_max ? 1 : -1, octave, b, p, *tabp,
+                               cand);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  void launch_extrema_scan(const OctaveView& gauss, int octave, int batch,
                            const ExtremaParams& p, const ScaleTable* tab,
                            const CandidateLists& cand, hipStream_t stream)
   {
-    const int nscan = dog.scales - 2;
+    const int nscan = gauss.scales - 3;  // DoG layers 1 .. (scales-1)-2
     if (nscan <= 0)
       return;
+    const bool aligned2 = (gauss.w % 2 == 0) && gauss.w >= 4 &&
+                          (gauss.plane % 2 == 0) &&
+                          (reinterpret_cast<uintptr_t>(gauss.base) % 8 == 0);
+    if (aligned2 && g_use_march && gauss.scales == 6)
+    {
+      const int nstrips = (gauss.w - 2 + 125) / 126;
+      int nseg = (g_march_waves + nstrips * batch - 1) / (nstrips * batch);
+      nseg = std::max(1, std::min(nseg, (gauss.h + 15) / 16));
+      const int seg_rows = (gauss.h + nseg - 1) / nseg;
+      nseg = (gauss.h + seg_rows - 1) / seg_rows;
+      hipLaunchKernelGGL((extrema_march_kernel<5, 3>), dim3(nstrips * nseg, batch),
+                         dim3(64), 0, stream, gauss, octave, p, tab, cand,
+                         seg_rows, nstrips);
+      return;
+    }
     const dim3 block(64, 4);
-    const dim3 grid((dog.w + 63) / 64, (dog.h + 3) / 4, batch * nscan);
-    hipLaunchKernelGGL(extrema_scan_kernel, grid, block, 0, stream, dog, octave,
+    const dim3 grid((gauss.w + 63) / 64, (gauss.h + 3) / 4, batch * nscan);
+    hipLaunchKernelGGL(extrema_scan_kernel, grid, block, 0, stream, gauss, octave,
                        nscan, p, tab, cand);
   }
 

@@ -1,0 +1,578 @@
+// gfx950 (MI355X / CDNA4) kernels of the SIFT front-end.
+//
+// Built with -ffp-contract=off: the CPU reference is compiled for baseline
+// x86-64 (no FMA), and every kernel below evaluates its float expressions in
+// the reference's operation order so that pyramids, DoG layers, extremum
+// classification, refinement and polar gradients come out bit-identical.
+//
+// Wave = 64 lanes everywhere; workgroups are 256 threads = 4 waves.
+#include "sift_kernels.hpp"
+
+#include "device_math.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <string>
+
+namespace sara_hip {
+
+  // ======================================================================== //
+  // Gaussian blur: rows then columns through LDS, replicate borders.
+  // Reference: apply_gaussian_filter, ImageProcessing/LinearFiltering.cpp:30-68
+  //            apply_row_based_filter / apply_column_based_filter / convolve_array,
+  //            ImageProcessing/LinearFiltering.hpp:43-149.
+  // Optional fused epilogue: dog = dst - src (GaussianPyramid.cpp:44-46).
+  //
+  // One workgroup produces a TX x TY tile.  The (TY+2R) x (TX+2R) source
+  // window is staged in LDS once, row-filtered into a (TY+2R) x TX LDS tile
+  // (each lane: 4 adjacent outputs from ds_read_b128 windows), then
+  // column-filtered (each lane: 8 outputs of one column from a register
+  // window).  Taps sit in SGPRs.  Accumulation is `sum += v * k` from 0.f in
+  // ascending tap order, mul and add unfused, as in convolve_array.
+  // ======================================================================== //
+  constexpr int TX = 64;
+  constexpr int TY = 32;
+  constexpr int NT = 256;
+
+  //! Debug/A-B switch (SARA_HIP_BLUR=tile forces the tiled kernel).
+  static const bool g_use_march = [] {
+    const char* e = getenv("SARA_HIP_BLUR");
+    return !(e && std::string(e) == "tile");
+  }();
+  //! Target number of waves per marching launch (tuning knob).
+  static const int g_march_waves = [] {
+    const char* e = getenv("SARA_HIP_MARCH_WAVES");
+    return e ? std::max(64, atoi(e)) : 4096;
+  }();
+
+  template <int R>
+  __global__ __launch_bounds__(NT) void gaussian_blur_kernel(
+      const float* __restrict__ src, size_t src_stride,
+      float* __restrict__ dst, size_t dst_stride, float* __restrict__ dog,
+      size_t dog_stride, int w, int h, Taps taps)
+  {
+    constexpr int K = 2 * R + 1;
+    constexpr int IW = TX + 2 * R;
+    constexpr int IH = TY + 2 * R;
+    constexpr int NQ = (4 + 2 * R + 3) / 4;       // b128 reads per 4 outputs
+    constexpr int IP = ((IW + 3) / 4) * 4 + 4;    // row pitch, over-read safe
+    __shared__ __attribute__((aligned(16))) float s_in[IH * IP];
+    __shared__ __attribute__((aligned(16))) float s_tmp[IH * TX];
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TX;
+    const int y0 = blockIdx.y * TY;
+    const size_t b = blockIdx.z;
+    src += b * src_stride;
+    dst += b * dst_stride;
+
+    // Stage the clamped source window.
+    for (int idx = tid; idx < IH * IW; idx += NT)
+    {
+      const int r = idx / IW;
+      const int c = idx - r * IW;
+      int gy = y0 - R + r;
+      int gx = x0 - R + c;
+      gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
+      gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
+      s_in[r * IP + c] = src[size_t(gy) * w + gx];
+    }
+    __syncthreads();
+
+    // Row pass.
+    for (int it = tid; it < IH * (TX / 4); it += NT)
+    {
+      const int r = it / (TX / 4);
+      const int q = it - r * (TX / 4);
+      float v[NQ * 4];
+      const float4* p = reinterpret_cast<const float4*>(&s_in[r * IP + 4 * q]);
+#pragma unroll
+      for (int m = 0; m < NQ; ++m)
+      {
+        const float4 t = p[m];
+        v[4 * m + 0] = t.x;
+        v[4 * m + 1] = t.y;
+        v[4 * m + 2] = t.z;
+        v[4 * m + 3] = t.w;
+      }
+      float acc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+      {
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+          sum += v[i + j] * taps.k[j];
+        acc[i] = sum;
+      }
+      *reinterpret_cast<float4*>(&s_tmp[r * TX + 4 * q]) =
+          make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    __syncthreads();
+
+    // Column pass: lane -> column tx, 8 consecutive rows.
+    const int tx = tid & 63;
+    const int yq = tid >> 6;
+    constexpr int NV = 8 + 2 * R;
+    float v[NV];
+#pragma unroll
+    for (int m = 0; m < NV; ++m)
+      v[m] = s_tmp[(yq * 8 + m) * TX + tx];
+
+    const int gx = x0 + tx;
+    if (gx >= w)
+      return;
+    if (dog)
+      dog += b * dog_stride;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+    {
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+        sum += v[i + j] * taps.k[j];
+      const int gy = y0 + yq * 8 + i;
+      if (gy < h)
+      {
+        dst[size_t(gy) * w + gx] = sum;
+        if (dog)
+          dog[size_t(gy) * w + gx] = sum - s_in[(yq * 8 + i + R) * IP + tx + R];
+      }
+    }
+  }
+
+  //! Any radius up to kMaxRadius: same structure, runtime loops, dynamic LDS.
+  __global__ __launch_bounds__(NT) void gaussian_blur_generic_kernel(
+      const float* __restrict__ src, size_t src_stride,
+      float* __restrict__ dst, size_t dst_stride, float* __restrict__ dog,
+      size_t dog_stride, int w, int h, Taps taps)
+  {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    const int R = taps.size / 2;
+    const int K = taps.size;
+    const int IW = TX + 2 * R;
+    const int IH = TY + 2 * R;
+    float* s_in = s_dyn;
+    float* s_tmp = s_dyn + IH * IW;
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TX;
+    const int y0 = blockIdx.y * TY;
+    const size_t b = blockIdx.z;
+    src += b * src_stride;
+    dst += b * dst_stride;
+    if (dog)
+      dog += b * dog_stride;
+
+    for (int idx = tid; idx < IH * IW; idx += NT)
+    {
+      const int r = idx / IW;
+      const int c = idx - r * IW;
+      int gy = y0 - R + r;
+      int gx = x0 - R + c;
+      gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
+      gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
+      s_in[idx] = src[size_t(gy) * w + gx];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < IH * TX; idx += NT)
+    {
+      const int r = idx / TX;
+      const int c = idx - r * TX;
+      float sum = 0.f;
+      for (int j = 0; j < K; ++j)
+        sum += s_in[r * IW + c + j] * taps.k[j];
+      s_tmp[idx] = sum;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < TY * TX; idx += NT)
+    {
+      const int r = idx / TX;
+      const int c = idx - r * TX;
+      float sum = 0.f;
+      for (int j = 0; j < K; ++j)
+        sum += s_tmp[(r + j) * TX + c] * taps.k[j];
+      const int gx = x0 + c, gy = y0 + r;
+      if (gx < w && gy < h)
+      {
+        dst[size_t(gy) * w + gx] = sum;
+        if (dog)
+          dog[size_t(gy) * w + gx] = sum - s_in[(r + R) * IW + c + R];
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------------ //
+  // Marching Gaussian blur (the fast path; widths that are multiples of 4).
+  //
+  // One wave owns a strip of 256 columns (4 per lane) and marches down
+  // `seg_rows` output rows.  Per source row: the (strip + 2R halo) segment is
+  // loaded PF rows ahead into registers, staged in a small LDS ring, every
+  // lane row-filters its 4 adjacent columns from ds_read_b128 windows, and the
+  // column filter is a ring of K = 2R+1 partial sums per column held in
+  // registers: the row arriving at step n adds tap j to the output row that is
+  // j steps old.  Taps therefore accumulate in ascending order from 0.f
+  // exactly like convolve_array (LinearFiltering.hpp:43-63), and each source
+  // row is row-filtered once per segment instead of once per 32-row tile.
+  // Ring positions are compile-time constants because the row loop is
+  // unrolled K times; the prefetch registers are re-aligned once per K rows.
+  //
+  // gfx950 counts loads and stores on one in-order counter (vmcnt), so a wave
+  // that consumes a load issued one step ago also waits for that step's
+  // stores to be acknowledged; the PF-deep prefetch keeps ~PF rows of loads
+  // and stores in flight per wave (measured: 1.9-3.2 TB/s at depth 2).
+  //
+  // HBM traffic per output pixel: 4 B read (x (1 + 2R/seg_rows) halo rows),
+  // 4 B write.  The DoG layers are NOT materialised: their consumers (extremum
+  // scan, refinement) subtract on the fly, see feature_kernels.hip.
+  // ------------------------------------------------------------------------ //
+  template <int R, int PF>
+  __global__ __launch_bounds__(64) void gaussian_blur_march_kernel(
+      const float* __restrict__ src, size_t src_stride,
+      float* __restrict__ dst, size_t dst_stride, int w, int h, int seg_rows,
+      int nstrips, Taps taps)
+  {
+    constexpr int CPL = 4;
+    constexpr int K = 2 * R + 1;
+    constexpr int W = 64 * CPL;
+    constexpr int RP = ((R + 3) / 4) * 4;  // left halo padded for alignment
+    constexpr int D = RP - R;
+    constexpr int ROWF = RP + W + RP;      // floats per LDS row slot
+    constexpr int NQ = (D + CPL + 2 * R + 3) / 4;  // b128 reads per window
+    __shared__ __attribute__((aligned(16))) float s_row[2 * ROWF];
+
+    const int lane = threadIdx.x;
+    const int strip = blockIdx.x % nstrips;
+    const int seg = blockIdx.x / nstrips;
+    const size_t b = blockIdx.y;
+    src += b * src_stride;
+    dst += b * dst_stride;
+
+    const int x0 = strip * W;
+    const int y0 = seg * seg_rows;
+    const int y1 = min(h, y0 + seg_rows);
+    const int col = x0 + CPL * lane;
+    const bool col_ok = col < w;  // w % 4 == 0: a float4 is all in or all out
+    // halo column of this lane (lanes < 2R)
+    int hcol = lane < R ? x0 - R + lane : x0 + W + (lane - R);
+    hcol = hcol < 0 ? 0 : (hcol > w - 1 ? w - 1 : hcol);
+    const int hslot = lane < R ? RP - R + lane : RP + W + (lane - R);
+    const int mcol = col_ok ? col : w - 4;
+
+    auto load_row = [&](int yy, float4& m, float& hv) {
+      const int gy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+      const float* rowp = src + size_t(gy) * w;
+      m = *reinterpret_cast<const float4*>(rowp + mcol);
+      if (!col_ok)
+        m = make_float4(m.w, m.w, m.w, m.w);  // replicate src(w-1, y)
+      hv = 0.f;
+      if (lane < 2 * R)
+        hv = rowp[hcol];
+    };
+
+    float A[K][CPL];
+    float4 pm[PF];
+    float phv[PF];
+    const int T = (y1 - y0) + 2 * R;  // source rows y0-R .. y1+R-1
+
+#pragma unroll
+    for (int q = 0; q < PF; ++q)
+      load_row(y0 - R + q, pm[q], phv[q]);
+
+    for (int n0 = 0; n0 < T; n0 += K)
+    {
+#pragma unroll
+      for (int i = 0; i < K; ++i)
+      {
+        const int n = n0 + i;
+        const int yy = y0 - R + n;
+        constexpr int dummy = 0;
+        (void) dummy;
+        // stage source row n (loaded PF steps ago) and refill its slot
+        float* rowbuf = s_row + (n & 1) * ROWF;
+        *reinterpret_cast<float4*>(rowbuf + RP + CPL * lane) = pm[i % PF];
+        if (lane < 2 * R)
+          rowbuf[hslot] = phv[i % PF];
+        load_row(yy + PF, pm[i % PF], phv[i % PF]);
+
+        // row pass on source row n
+        float t[CPL];
+        {
+          const float4* p =
+              reinterpret_cast<const float4*>(rowbuf + CPL * lane);
+          float v[NQ * 4];
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+          {
+            const float4 x = p[q];
+            v[4 * q + 0] = x.x;
+            v[4 * q + 1] = x.y;
+            v[4 * q + 2] = x.z;
+            v[4 * q + 3] = x.w;
+          }
+#pragma unroll
+          for (int c = 0; c < CPL; ++c)
+          {
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+              sum += v[D + c + j] * taps.k[j];
+            t[c] = sum;
+          }
+        }
+
+        // column pass: tap j goes to the output that is j steps old
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+        {
+          const int sl = (i + K - 1 - j) % K;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c)
+          {
+            if (j == 0)
+              A[sl][c] = 0.f + t[c] * taps.k[0];
+            else
+              A[sl][c] += t[c] * taps.k[j];
+          }
+        }
+
+        const int o = yy - R;
+        if ((o >= y0) && (o < y1) && col_ok)
+          *reinterpret_cast<float4*>(dst + size_t(o) * w + col) =
+              make_float4(A[i][0], A[i][1], A[i][2], A[i][3]);
+      }
+      // re-align the prefetch ring: the row of step n0+K+q sits in slot
+      // (K+q) % PF and must be found in slot q % PF by the next round.
+      if (K % PF != 0)
+      {
+        float4 tm[PF];
+        float th[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q)
+        {
+          tm[q] = pm[(K + q) % PF];
+          th[q] = phv[(K + q) % PF];
+        }
+#pragma unroll
+        for (int q = 0; q < PF; ++q)
+        {
+          pm[q] = tm[q];
+          phv[q] = th[q];
+        }
+      }
+    }
+  }
+
+  template <int R>
+  static void launch_blur_march(const float* src, size_t src_stride, float* dst,
+                                size_t dst_stride, int w, int h, int batch,
+                                const Taps& taps, hipStream_t stream)
+  {
+    constexpr int W = 256;
+    constexpr int PF = 4;
+    const int nstrips = (w + W - 1) / W;
+    // enough waves to fill 256 CUs x 3-4 waves/SIMD, segments >= 32 rows
+    int nseg = (g_march_waves + nstrips * batch - 1) / (nstrips * batch);
+    nseg = std::max(1, std::min(nseg, (h + 31) / 32));
+    const int seg_rows = (h + nseg - 1) / nseg;
+    nseg = (h + seg_rows - 1) / seg_rows;
+    const dim3 grid(nstrips * nseg, batch);
+    hipLaunchKernelGGL((gaussian_blur_march_kernel<R, PF>), grid, dim3(64), 0,
+                       stream, src, src_stride, dst, dst_stride, w, h, seg_rows,
+                       nstrips, taps);
+  }
+
+  template <int R>
+  static void launch_blur_r(const float* src, size_t src_stride, float* dst,
+                            size_t dst_stride, float* dog, size_t dog_stride,
+                            int w, int h, int batch, const Taps& taps,
+                            hipStream_t stream)
+  {
+    const dim3 grid((w + TX - 1) / TX, (h + TY - 1) / TY, batch);
+    hipLaunchKernelGGL(gaussian_blur_kernel<R>, grid, dim3(NT), 0, stream, src,
+                       src_stride, dst, dst_stride, dog, dog_stride, w, h, taps);
+  }
+
+  void launch_gaussian_blur(const float* src, size_t src_stride, float* dst,
+                            size_t dst_stride, float* dog, size_t dog_stride,
+                            int w, int h, int batch, const Taps& taps,
+                            hipStream_t stream)
+  {
+    const int R = taps.size / 2;
+    // fast path: strips of float4 columns need 16-byte aligned rows
+    const bool aligned4 = (w % 4 == 0) && w >= 4 && (src_stride % 4 == 0) &&
+                          (dst_stride % 4 == 0) &&
+                          (reinterpret_cast<uintptr_t>(src) % 16 == 0) &&
+                          (reinterpret_cast<uintptr_t>(dst) % 16 == 0) &&
+                          dog == nullptr;
+    if (aligned4 && g_use_march)
+    {
+#define SARA_MARCH_CASE(r)                                                     \
+  case r:                                                                      \
+    launch_blur_march<r>(src, src_stride, dst, dst_stride, w, h, batch, taps,  \
+                         stream);                                              \
+    return;
+      switch (R)
+      {
+        SARA_MARCH_CASE(5)
+        SARA_MARCH_CASE(6)
+        SARA_MARCH_CASE(8)
+        SARA_MARCH_CASE(10)
+        SARA_MARCH_CASE(12)
+      default:
+        break;
+      }
+#undef SARA_MARCH_CASE
+    }
+#define SARA_BLUR_CASE(r)                                                      \
+  case r:                                                                      \
+    launch_blur_r<r>(src, src_stride, dst, dst_stride, dog, dog_stride, w, h,  \
+                     batch, taps, stream);                                     \
+    return;
+    switch (R)
+    {
+      SARA_BLUR_CASE(1)
+      SARA_BLUR_CASE(2)
+      SARA_BLUR_CASE(3)
+      SARA_BLUR_CASE(4)
+      SARA_BLUR_CASE(5)
+      SARA_BLUR_CASE(6)
+      SARA_BLUR_CASE(7)
+      SARA_BLUR_CASE(8)
+      SARA_BLUR_CASE(9)
+      SARA_BLUR_CASE(10)
+      SARA_BLUR_CASE(11)
+      SARA_BLUR_CASE(12)
+      SARA_BLUR_CASE(13)
+      SARA_BLUR_CASE(14)
+      SARA_BLUR_CASE(15)
+      SARA_BLUR_CASE(16)
+    default:
+      break;
+    }
+#undef SARA_BLUR_CASE
+    const dim3 grid((w + TX - 1) / TX, (h + TY - 1) / TY, batch);
+    const size_t lds =
+        sizeof(float) * size_t(TY + 2 * R) * (size_t(TX + 2 * R) + TX);
+    hipLaunchKernelGGL(gaussian_blur_generic_kernel, grid, dim3(NT), lds, stream,
+                       src, src_stride, dst, dst_stride, dog, dog_stride, w, h,
+                       taps);
+  }
+
+  // ======================================================================== //
+  // Resize / copy / subtract.
+  // ======================================================================== //
+
+  //! scale(): ImageProcessing/Resize.cpp:45-60.
+  __global__ void scale_kernel(const float* __restrict__ src, size_t src_stride,
+                               int sw, int sh, float* __restrict__ dst,
+                               size_t dst_stride, int dw, int dh)
+  {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= dw || y >= dh)
+      return;
+    const size_t b = blockIdx.z;
+    const float sx = float(sw) / float(dw);
+    const float sy = float(sh) / float(dh);
+    const int xi = int(float(x) * sx);
+    const int yi = int(float(y) * sy);
+    dst[b * dst_stride + size_t(y) * dw + x] =
+        src[b * src_stride + size_t(yi) * sw + xi];
+  }
+
+  void launch_scale(const float* src, size_t src_stride, int sw, int sh,
+                    float* dst, size_t dst_stride, int dw, int dh, int batch,
+                    hipStream_t stream)
+  {
+    const dim3 block(64, 4);
+    const dim3 grid((dw + 63) / 64, (dh + 3) / 4, batch);
+    hipLaunchKernelGGL(scale_kernel, grid, block, 0, stream, src, src_stride, sw,
+                       sh, dst, dst_stride, dw, dh);
+  }
+
+  //! enlarge(): ImageProcessing/Resize.cpp:110-126 + interpolate(),
+  //! ImageProcessing/Interpolation.hpp:33-78 (bilinear in double, far border
+  //! replicated, x-fastest accumulation).
+  __global__ void enlarge_kernel(const float* __restrict__ src,
+                                 size_t src_stride, int sw, int sh,
+                                 float* __restrict__ dst, size_t dst_stride,
+                                 int dw, int dh)
+  {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= dw || y >= dh)
+      return;
+    const size_t b = blockIdx.z;
+    const float* s = src + b * src_stride;
+    const double scx = double(sw) / double(dw);
+    const double scy = double(sh) / double(dh);
+    const double px = double(x) * scx;
+    const double py = double(y) * scy;
+    const double ipx = trunc(px), ipy = trunc(py);
+    const double fx = px - ipx, fy = py - ipy;
+    const int x0 = int(ipx), y0 = int(ipy);
+    double value = 0.;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx)
+      {
+        double weight = 1.;
+        weight *= (dx == 0) ? (1. - fx) : fx;
+        weight *= (dy == 0) ? (1. - fy) : fy;
+        const int xx = (x0 + dx < sw) ? x0 + dx : x0 + dx - 1;
+        const int yy = (y0 + dy < sh) ? y0 + dy : y0 + dy - 1;
+        value += weight * double(s[size_t(yy) * sw + xx]);
+      }
+    dst[b * dst_stride + size_t(y) * dw + x] = float(value);
+  }
+
+  void launch_enlarge(const float* src, size_t src_stride, int sw, int sh,
+                      float* dst, size_t dst_stride, int dw, int dh, int batch,
+                      hipStream_t stream)
+  {
+    const dim3 block(64, 4);
+    const dim3 grid((dw + 63) / 64, (dh + 3) / 4, batch);
+    hipLaunchKernelGGL(enlarge_kernel, grid, block, 0, stream, src, src_stride,
+                       sw, sh, dst, dst_stride, dw, dh);
+  }
+
+  __global__ void copy_planes_kernel(const float* __restrict__ src,
+                                     size_t src_stride, float* __restrict__ dst,
+                                     size_t dst_stride, size_t count)
+  {
+    const size_t b = blockIdx.y;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count;
+         i += size_t(gridDim.x) * blockDim.x)
+      dst[b * dst_stride + i] = src[b * src_stride + i];
+  }
+
+  void launch_copy_planes(const float* src, size_t src_stride, float* dst,
+                          size_t dst_stride, size_t count, int batch,
+                          hipStream_t stream)
+  {
+    const int blocks = int(std::min<size_t>((count + 255) / 256, 2048));
+    hipLaunchKernelGGL(copy_planes_kernel, dim3(blocks, batch), dim3(256), 0,
+                       stream, src, src_stride, dst, dst_stride, count);
+  }
+
+  __global__ void subtract_kernel(const float* __restrict__ a,
+                                  const float* __restrict__ b,
+                                  float* __restrict__ out, size_t count)
+  {
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count;
+         i += size_t(gridDim.x) * blockDim.x)
+      out[i] = a[i] - b[i];
+  }
+
+  void launch_subtract(const float* a, const float* b, float* out, size_t count,
+                       hipStream_t stream)
+  {
+    const int blocks = int(std::min<size_t>((count + 255) / 256, 2048));
+    hipLaunchKernelGGL(subtract_kernel, dim3(blocks), dim3(256), 0, stream, a, b,
+                       out, count);
+  }
+
+
+}  // namespace sara_hip

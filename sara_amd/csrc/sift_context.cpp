@@ -182,8 +182,11 @@ struct sara_hip_sift
   bool all_gradient_scales = false;
   bool timers = true;
 
-  // pyramids, one allocation per octave (sized for max dims / max batch)
-  std::vector<float*> G, D, GR;
+  // pyramids, one allocation per octave (sized for max dims / max batch).
+  // The DoG pyramid is never materialised (consumers subtract on the fly);
+  // d_dog_plane is the scratch of the diff_of_gaussians() accessor.
+  std::vector<float*> G, GR;
+  float* d_dog_plane = nullptr;
   float* d_input = nullptr;  // staged host frames, or enlarge/blur scratch
   float* d_full = nullptr;   // first_octave > 0: blurred full-size frames
 
@@ -367,15 +370,15 @@ namespace {
     // ---- HBM: pyramids [frame][scale][h][w] per octave
     const int no = c->max_sched.num_octaves;
     c->G.assign(no, nullptr);
-    c->D.assign(no, nullptr);
     c->GR.assign(no, nullptr);
     for (int o = 0; o < no; ++o)
     {
       const size_t pl = size_t(c->max_sched.oct[o].w) * c->max_sched.oct[o].h;
       TRY_ST(c->alloc(c->G[o], pl * c->S * max_batch));
-      TRY_ST(c->alloc(c->D[o], pl * (c->S - 1) * max_batch));
       TRY_ST(c->alloc(c->GR[o], pl * c->S * max_batch * 2));
     }
+    TRY_ST(c->alloc(c->d_dog_plane, size_t(c->max_sched.base_w) *
+                                        std::max(c->max_sched.base_h, 1)));
     TRY_ST(c->alloc(c->d_input, size_t(max_w) * max_h * max_batch));
     if (pyr.first_octave_index > 0)
       TRY_ST(c->alloc(c->d_full, size_t(max_w) * max_h * max_batch));
@@ -718,7 +721,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     {
       const int w = sc.oct[o].w, h = sc.oct[o].h;
       const size_t pl = size_t(w) * h;
-      const size_t gs = pl * S, ds = pl * (S - 1);
+      const size_t gs = pl * S;
       if (o > 0)
       {
         const int pw = sc.oct[o - 1].w, ph = sc.oct[o - 1].h;
@@ -728,8 +731,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       }
       for (int s = 1; s < S; ++s)
         launch_gaussian_blur(c->G[o] + pl * (s - 1), gs, c->G[o] + pl * s, gs,
-                             c->D[o] + pl * (s - 1), ds, w, h, batch, c->taps[s],
-                             stream);
+                             nullptr, 0, w, h, batch, c->taps[s], stream);
     }
   }
   HIP_TRY(mark(2));
@@ -749,13 +751,13 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     ep.scale_geometric_factor = c->pyr.scale_geometric_factor;
     for (int o = 0; o < sc.num_octaves; ++o)
     {
-      OctaveView dv;
-      dv.base = c->D[o];
+      OctaveView dv;  // the Gaussian octave; DoG layers are formed on the fly
+      dv.base = c->G[o];
       dv.w = sc.oct[o].w;
       dv.h = sc.oct[o].h;
-      dv.scales = S - 1;
+      dv.scales = S;
       dv.plane = size_t(dv.w) * dv.h;
-      dv.frame_stride = dv.plane * (S - 1);
+      dv.frame_stride = dv.plane * S;
       if (dv.w > 2 * c->img_padding && dv.h > 2 * c->img_padding)
         launch_extrema_scan(dv, o, batch, ep, c->d_tab, c->cand, stream);
     }
@@ -948,8 +950,26 @@ sara_hip_status sara_hip_sift_copy_gaussian(sara_hip_sift* c, int frame, int s,
 sara_hip_status sara_hip_sift_copy_dog(sara_hip_sift* c, int frame, int s, int o,
                                        float* dst)
 {
-  return copy_plane(c, c->D, frame, s, o, c ? c->S - 1 : 0, 1, dst,
-                    SARA_HIP_STAGE_PYRAMID);
+  // diff_of_gaussians()(s, o) = gaussians()(s+1, o) - gaussians()(s, o)
+  // (GaussianPyramid.cpp:44-46), formed on demand.
+  const sara_hip_status st = require_result(c, SARA_HIP_STAGE_PYRAMID);
+  if (st != SARA_HIP_OK)
+    return st;
+  if (!dst)
+    return fail(SARA_HIP_INVALID_PARAMS, "null destination");
+  if (frame < 0 || frame >= c->cur_batch || o < 0 || o >= c->cur.num_octaves ||
+      s < 0 || s >= c->S - 1)
+    return fail(SARA_HIP_OUT_OF_RANGE, "frame/scale/octave index out of range");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t pl = size_t(c->cur.oct[o].w) * c->cur.oct[o].h;
+  launch_subtract(c->plane(c->G, o, frame, s + 1, 1, c->S),
+                  c->plane(c->G, o, frame, s, 1, c->S), c->d_dog_plane, pl,
+                  c->last_stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(dst, c->d_dog_plane, pl * sizeof(float),
+                         hipMemcpyDeviceToHost, c->last_stream));
+  HIP_TRY(hipStreamSynchronize(c->last_stream));
+  return SARA_HIP_OK;
 }
 
 sara_hip_status sara_hip_sift_copy_gradient(sara_hip_sift* c, int frame, int s,
