@@ -315,6 +315,13 @@ SARA_HIP_API sara_hip_status sara_hip_scale_space_dog_extremum_map(
     float edge_ratio_thres, float extremum_thres, int img_padding_sz,
     int8_t* out, int device);
 
+/* Host self-check: evaluates, on the CPU, the float atan2 sequence the polar-  */
+/* gradient kernels execute on the GPU (a restatement of glibc 2.35's          */
+/* atan2f), so that tests can prove it bit-identical to the host libm the CPU  */
+/* reference links against.  Not a compute path.                               */
+SARA_HIP_API void sara_hip_selfcheck_atan2f(const float* y, const float* x,
+                                           float* out, size_t count);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

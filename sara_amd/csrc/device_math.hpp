@@ -15,9 +15,9 @@
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #  include <hip/hip_runtime.h>
-#  define SARA_HD __host__ __device__ inline
+#  define SARA_HD __host__ __device__ inline __attribute__((always_inline))
 #else
-#  define SARA_HD inline
+#  define SARA_HD inline __attribute__((always_inline))
 #endif
 
 namespace sara_hip {
@@ -207,6 +207,93 @@ namespace sara_hip {
     default:
       return (z - pi_lo) - pi;
     }
+  }
+
+
+  //! Branch-free restatement of fdlibm_atanf for a NON-NEGATIVE finite
+  //! argument: the four argument reductions share ONE division (numerator and
+  //! denominator are selected per range), the |x| < 2^-29 early-out is
+  //! dropped (x - x*(s1+s2) rounds to x there) and the |x| >= 2^25 case is a
+  //! final select.  Bit-identical to fdlibm_atanf (tests/test_host_math.py).
+  SARA_HD float atanf_nonneg_select(float x)
+  {
+    const int32_t ix = float_as_int(x);
+    const bool r0 = ix < 0x3ee00000;   // |x| < 0.4375      -> id = -1
+    const bool r1 = ix < 0x3f300000;   // < 11/16           -> id = 0
+    const bool r2 = ix < 0x3f980000;   // < 19/16           -> id = 1
+    const bool r3 = ix < 0x401c0000;   // < 2.4375          -> id = 2, else 3
+    const float n0 = 2.0f * x - 1.0f, d0 = 2.0f + x;
+    const float n1 = x - 1.0f, d1 = x + 1.0f;
+    const float n2 = x - 1.5f, d2 = 1.0f + 1.5f * x;
+    const float num = r0 ? x : (r1 ? n0 : (r2 ? n1 : (r3 ? n2 : -1.0f)));
+    const float den = r0 ? 1.0f : (r1 ? d0 : (r2 ? d1 : (r3 ? d2 : x)));
+    const float hi = r1 ? 4.6364760399e-01f
+                        : (r2 ? 7.8539812565e-01f
+                              : (r3 ? 9.8279368877e-01f : 1.5707962513e+00f));
+    const float lo = r1 ? 5.0121582440e-09f
+                        : (r2 ? 3.7748947079e-08f
+                              : (r3 ? 3.4473217170e-08f : 7.5497894159e-08f));
+    const float xr = num / den;
+    const float z = xr * xr;
+    const float w = z * z;
+    const float s1 =
+        z * (3.3333334327e-01f +
+             w * (1.4285714924e-01f +
+                  w * (9.0908870101e-02f +
+                       w * (6.6610731184e-02f +
+                            w * (4.9768779427e-02f + w * 1.6285819933e-02f)))));
+    const float s2 =
+        w * (-2.0000000298e-01f +
+             w * (-1.1111110449e-01f +
+                  w * (-7.6918758452e-02f +
+                       w * (-5.8335702866e-02f + w * -3.6531571299e-02f))));
+    const float small = xr - xr * (s1 + s2);
+    const float big = hi - ((xr * (s1 + s2) - lo) - xr);
+    float r = r0 ? small : big;
+    if (ix >= 0x4c000000)  // |x| >= 2^25
+      r = 1.5707962513e+00f + 7.5497894159e-08f;
+    return r;
+  }
+
+  //! fdlibm_atan2f with the common path branch-free (finite inputs); the
+  //! non-finite inputs take the reference implementation above.
+  SARA_HD float fdlibm_atan2f_fast(float y, float x)
+  {
+    const int32_t hx = float_as_int(x);
+    const int32_t ix = hx & 0x7fffffff;
+    const int32_t hy = float_as_int(y);
+    const int32_t iy = hy & 0x7fffffff;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    // Non-finite inputs: the reference implementation (host self-check only;
+    // pyramid values on the device are finite).
+    if (ix >= 0x7f800000 || iy >= 0x7f800000)
+      return fdlibm_atan2f(y, x);
+#endif
+    const float pi = 3.1415927410e+00f;
+    const float pi_lo = -8.7422776573e-08f;
+    const float pi_o_2 = 1.5707963705e+00f;
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    const int k = (iy - ix) >> 23;
+    // general path: z = atan(|y/x|)
+    const float q = y / x;
+    float z = atanf_nonneg_select(int_as_float(float_as_int(q) & 0x7fffffff));
+    if (k > 60)
+      z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60)
+      z = 0.0f;
+    const float zneg = int_as_float(float_as_int(z) ^ (int32_t) 0x80000000);
+    float r = m == 0 ? z : (m == 1 ? zneg : (m == 2 ? pi - (z - pi_lo)
+                                                   : (z - pi_lo) - pi));
+    if (hx == 0x3f800000)  // x == 1: atanf(y), odd in y
+    {
+      const float a = atanf_nonneg_select(int_as_float(iy));
+      r = hy < 0 ? -a : a;
+    }
+    if (ix == 0)
+      r = hy < 0 ? -pi_o_2 : pi_o_2;
+    if (iy == 0)
+      r = (m == 0 || m == 1) ? y : (m == 2 ? pi : -pi);
+    return r;
   }
 
 }  // namespace sara_hip

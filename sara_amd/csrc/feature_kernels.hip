@@ -54,7 +54,7 @@ namespace sara_hip {
     else
       gy = (f[c + w] - f[c - w]) / 2;
     const float r = 2 * sqrtf(gx * gx + gy * gy);
-    const float theta = fdlibm_atan2f(gy, gx);
+    const float theta = fdlibm_atan2f_fast(gy, gx);
     o[c] = make_float2(r, theta);
   }
 
@@ -155,7 +155,7 @@ namespace sara_hip {
             else
               gy = (cd[c] - cu[c]) / 2;
             res[2 * c] = 2 * sqrtf(gx * gx + gy * gy);
-            res[2 * c + 1] = fdlibm_atan2f(gy, gx);
+            res[2 * c + 1] = fdlibm_atan2f_fast(gy, gx);
           }
           if (col_ok)
           {
@@ -494,9 +494,8 @@ namespace sara_hip {
   //! HBM traffic: 4*(ND+1) B read per pixel, nothing written but candidates.
   template <int ND, int PF>
   __global__ __launch_bounds__(64) void extrema_march_kernel(
-      OctaveView gauss, int octave, ExtremaParams p,
-      const ScaleTable* __restrict__ tabp, CandidateLists cand, int seg_rows,
-      int nstrips)
+      OctaveView gauss, int octave, ExtremaParams p, SiteLists sites,
+      int seg_rows, int nstrips)
   {
     static_assert(PF == 3, "the row loop is unrolled 3x");
     constexpr int NG = ND + 1;
@@ -581,9 +580,17 @@ namespace sara_hip {
             const bool is_max = (v == M), is_min = (v == N);
             if (mine && !(fabsf(v) < thr8) && (is_max || is_min))
             {
-              const DogOctave I{g, w, h, plane, ND};
-              finish_candidate(I, x, y, s, is_max ? 1 : -1, octave, b, p, *tabp,
-                               cand);
+              // classified site: edge test / refinement run in
+              // finish_sites_kernel (keeps this kernel's register budget low)
+              const int slot = atomicAdd(&sites.count[b], 1);
+              if (slot < sites.cap)
+                sites.key[size_t(b) * sites.cap + slot] =
+                    ((((unsigned long long) (octave * kMaxScales + s) << 20 |
+                       (unsigned) y)
+                      << 20 |
+                      (unsigned) x)
+                     << 1) |
+                    (unsigned) is_max;
             }
           }
         }
@@ -591,9 +598,40 @@ namespace sara_hip {
     }
   }
 
+  //! Second half of the fast path: one thread per classified site.
+  __global__ __launch_bounds__(256) void finish_sites_kernel(
+      OctavePyramidView pyr, ExtremaParams p,
+      const ScaleTable* __restrict__ tabp, SiteLists sites, CandidateLists cand)
+  {
+    const int b = blockIdx.y;
+    const int n = min(sites.count[b], sites.cap);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+      return;
+    const unsigned long long key = sites.key[size_t(b) * sites.cap + i];
+    const int o = int(key >> 41) / kMaxScales;
+    const int s = int(key >> 41) % kMaxScales;
+    const int y = int((key >> 21) & 0xfffff);
+    const int x = int((key >> 1) & 0xfffff);
+    const DogOctave I{pyr.base[o] + size_t(b) * pyr.frame_stride[o], pyr.w[o],
+                      pyr.h[o], pyr.plane[o], pyr.scales - 1};
+    finish_candidate(I, x, y, s, (key & 1ull) ? 1 : -1, o, b, p, *tabp, cand);
+  }
+
+  void launch_finish_sites(const OctavePyramidView& pyr, int batch,
+                           const ExtremaParams& p, const ScaleTable* tab,
+                           const SiteLists& sites, const CandidateLists& cand,
+                           hipStream_t stream)
+  {
+    const dim3 grid((sites.cap + 255) / 256, batch);
+    hipLaunchKernelGGL(finish_sites_kernel, grid, dim3(256), 0, stream, pyr, p,
+                       tab, sites, cand);
+  }
+
   void launch_extrema_scan(const OctaveView& gauss, int octave, int batch,
                            const ExtremaParams& p, const ScaleTable* tab,
-                           const CandidateLists& cand, hipStream_t stream)
+                           const CandidateLists& cand, const SiteLists& sites,
+                           hipStream_t stream)
   {
     const int nscan = gauss.scales - 3;  // DoG layers 1 .. (scales-1)-2
     if (nscan <= 0)
@@ -609,8 +647,8 @@ namespace sara_hip {
       const int seg_rows = (gauss.h + nseg - 1) / nseg;
       nseg = (gauss.h + seg_rows - 1) / seg_rows;
       hipLaunchKernelGGL((extrema_march_kernel<5, 3>), dim3(nstrips * nseg, batch),
-                         dim3(64), 0, stream, gauss, octave, p, tab, cand,
-                         seg_rows, nstrips);
+                         dim3(64), 0, stream, gauss, octave, p, sites, seg_rows,
+                         nstrips);
       return;
     }
     const dim3 block(64, 4);
@@ -952,8 +990,9 @@ namespace sara_hip {
   // LDS accumulation of the 128 bins.  ds_add_f32 costs ~192 clk per wave
   // instruction on gfx950 whatever the address pattern (tools/ubench/
   // lds_atomic.hip), ds_add_u32 ~6-16, so contributions are accumulated as a
-  // (hi, lo) pair of 32-bit fixed-point integers: value = hi*2^-14 + lo*2^-34,
-  // exact to 2^-34 per sample and order-independent (deterministic).
+  // 64-bit two's-complement fixed point with 2^-34 resolution (ds_add_u64 costs
+  // about one ds_add_u32): exact to 2^-34 per sample and order-independent, so
+  // the result is deterministic.
   constexpr int kDescCopies = 4;  // histogram replicas per wave
 
   __global__ __launch_bounds__(256) void descriptor_kernel(
@@ -963,8 +1002,7 @@ namespace sara_hip {
       int with_descriptors)
   {
     const GradPyramidView& grad = *gradp;
-    __shared__ int s_hi[4][128 * kDescCopies];
-    __shared__ unsigned s_lo[4][128 * kDescCopies];
+    __shared__ unsigned long long s_acc[4][128 * kDescCopies];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
@@ -1005,8 +1043,7 @@ namespace sara_hip {
                           grad.base[o] + size_t(b) * grad.frame_stride[o]) +
                       size_t(s) * grad.plane[o];
     const float factor = grad.factor[o];
-    int* hist_hi = s_hi[wave];
-    unsigned* hist_lo = s_lo[wave];
+    unsigned long long* hist = s_acc[wave];
     const int copy = lane & (kDescCopies - 1);
 
     // rows / columns of the patch that fall inside the image
@@ -1047,10 +1084,7 @@ namespace sara_hip {
 
 #pragma unroll
       for (int q = 0; q < 2 * kDescCopies; ++q)
-      {
-        hist_hi[q * 64 + lane] = 0;
-        hist_lo[q * 64 + lane] = 0u;
-      }
+        hist[q * 64 + lane] = 0ull;
       __builtin_amdgcn_wave_barrier();
 
       const float ct = float(cos(double(theta)));
@@ -1125,8 +1159,14 @@ namespace sara_hip {
                 const float x14 = c * 16384.f;
                 const float hif = floorf(x14);
                 const int bin = (32 * y_ + 8 * x_ + o_) * kDescCopies + copy;
-                atomicAdd(&hist_hi[bin], int(hif));
-                atomicAdd(&hist_lo[bin], unsigned((x14 - hif) * 1048576.f));
+                // q = hi * 2^20 + lo as one 64-bit two's-complement integer
+                const int hi = int(hif);
+                const unsigned lo = unsigned((x14 - hif) * 1048576.f);
+                // (lo can be exactly 2^20 when x14 is a tiny negative
+                // number and x14 - floor rounds up to 1: add, never OR)
+                const unsigned long long q = (unsigned long long) (
+                    (long long) hi * 1048576ll + (long long) lo);
+                atomicAdd(&hist[bin], q);
               }
             }
           }
@@ -1139,10 +1179,8 @@ namespace sara_hip {
 #pragma unroll
       for (int c = 0; c < kDescCopies; ++c)
       {
-        a0 += double(hist_hi[lane * kDescCopies + c]) * 0x1p-14 +
-              double(hist_lo[lane * kDescCopies + c]) * 0x1p-34;
-        a1 += double(hist_hi[(lane + 64) * kDescCopies + c]) * 0x1p-14 +
-              double(hist_lo[(lane + 64) * kDescCopies + c]) * 0x1p-34;
+        a0 += double((long long) hist[lane * kDescCopies + c]) * 0x1p-34;
+        a1 += double((long long) hist[(lane + 64) * kDescCopies + c]) * 0x1p-34;
       }
       float h0 = float(a0), h1 = float(a1);
       // normalize(): L2, clamp at 0.2, L2; then x512, clamp at 255.

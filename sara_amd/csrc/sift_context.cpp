@@ -6,6 +6,8 @@
 // but batched over frames and with every stage resident in HBM.
 #include "sift_kernels.hpp"
 
+#include "device_math.hpp"
+
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -201,6 +203,7 @@ struct sara_hip_sift
   GradPyramidView* d_grad = nullptr;
 
   CandidateLists cand{};
+  SiteLists sites{};
   OrientationLists ori{};
   int* d_ex_offset = nullptr;
   sara_oeregion* d_feat = nullptr;
@@ -390,6 +393,9 @@ namespace {
     TRY_ST(c->alloc(c->cand.data, rows));
     TRY_ST(c->alloc(c->cand.count, max_batch));
     TRY_ST(c->alloc(c->cand.order, rows));
+    c->sites.cap = 4 * c->cap;
+    TRY_ST(c->alloc(c->sites.key, size_t(max_batch) * c->sites.cap));
+    TRY_ST(c->alloc(c->sites.count, max_batch));
     TRY_ST(c->alloc(c->ori.peak_count, rows));
     TRY_ST(c->alloc(c->ori.peak_theta, rows * kMaxPeaks));
     TRY_ST(c->alloc(c->ori.offset, rows));
@@ -738,6 +744,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
 
   // ---- extrema ------------------------------------------------------------
   HIP_TRY(hipMemsetAsync(c->cand.count, 0, sizeof(int) * batch, stream));
+  HIP_TRY(hipMemsetAsync(c->sites.count, 0, sizeof(int) * batch, stream));
   HIP_TRY(hipMemsetAsync(c->ori.kp_count, 0, sizeof(int) * batch, stream));
   HIP_TRY(hipMemsetAsync(c->ori.frame_offset, 0, sizeof(int) * (batch + 1),
                          stream));
@@ -759,7 +766,22 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       dv.plane = size_t(dv.w) * dv.h;
       dv.frame_stride = dv.plane * S;
       if (dv.w > 2 * c->img_padding && dv.h > 2 * c->img_padding)
-        launch_extrema_scan(dv, o, batch, ep, c->d_tab, c->cand, stream);
+        launch_extrema_scan(dv, o, batch, ep, c->d_tab, c->cand, c->sites,
+                            stream);
+    }
+    {
+      OctavePyramidView pv{};
+      pv.scales = S;
+      pv.octaves = sc.num_octaves;
+      for (int o = 0; o < sc.num_octaves; ++o)
+      {
+        pv.base[o] = c->G[o];
+        pv.w[o] = sc.oct[o].w;
+        pv.h[o] = sc.oct[o].h;
+        pv.plane[o] = size_t(pv.w[o]) * pv.h[o];
+        pv.frame_stride[o] = pv.plane[o] * S;
+      }
+      launch_finish_sites(pv, batch, ep, c->d_tab, c->sites, c->cand, stream);
     }
     launch_rank_candidates(c->cand, batch, stream);
     launch_extrema_offsets(c->cand, c->d_ex_offset, batch, stream);
@@ -1008,6 +1030,12 @@ sara_hip_status sara_hip_sift_extrema_counts(sara_hip_sift* c, int* per_frame,
   if (overflow)
     return fail(SARA_HIP_CAPACITY_EXCEEDED,
                 "a frame produced more extrema than max_keypoints");
+  HIP_TRY(hipMemcpy(c->h_counts, c->sites.count, sizeof(int) * c->cur_batch,
+                    hipMemcpyDeviceToHost));
+  for (int b = 0; b < c->cur_batch; ++b)
+    if (c->h_counts[b] > c->sites.cap)
+      return fail(SARA_HIP_CAPACITY_EXCEEDED,
+                  "a frame produced more classified sites than 4*max_keypoints");
   return SARA_HIP_OK;
 }
 
@@ -1204,6 +1232,13 @@ sara_hip_status sara_hip_scale_space_dog_extremum_map(
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, dout, n, hipMemcpyDeviceToHost));
   return SARA_HIP_OK;
+}
+
+void sara_hip_selfcheck_atan2f(const float* y, const float* x, float* out,
+                               size_t count)
+{
+  for (size_t i = 0; i < count; ++i)
+    out[i] = sara_hip::fdlibm_atan2f_fast(y[i], x[i]);
 }
 
 }  // extern "C"

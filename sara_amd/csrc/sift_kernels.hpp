@@ -61,6 +61,27 @@ namespace sara_hip {
     int cap;
   };
 
+  //! Classified extremum sites of the marching scan, before the edge test and
+  //! the refinement (same key layout as CandidateLists::key).
+  struct SiteLists
+  {
+    unsigned long long* key;  // [frame][cap]
+    int* count;               // [frame] (may exceed cap)
+    int cap;
+  };
+
+  //! Gaussian pyramid of the batch: octave o at base[o], planes
+  //! [frame][scale][h][w].
+  struct OctavePyramidView
+  {
+    const float* base[16];
+    int w[16], h[16];
+    size_t plane[16];
+    size_t frame_stride[16];
+    int scales;
+    int octaves;
+  };
+
   struct OrientationLists
   {
     int* peak_count;   // [frame][cap]
@@ -111,10 +132,20 @@ namespace sara_hip {
                              int batch, hipStream_t stream);
 
   // ---- extrema -------------------------------------------------------------
-  //! Scans DoG scales 1..S-2 of one octave, refines and appends candidates.
-  void launch_extrema_scan(const OctaveView& dog, int octave, int batch,
+  //! Scans DoG scales 1..S-3 of one Gaussian octave.  The fast path only
+  //! classifies and appends to `sites` (finish with launch_finish_sites once
+  //! all octaves are scanned); the general path refines and appends to `cand`
+  //! directly.
+  void launch_extrema_scan(const OctaveView& gauss, int octave, int batch,
                            const ExtremaParams& p, const ScaleTable* tab,
-                           const CandidateLists& cand, hipStream_t stream);
+                           const CandidateLists& cand, const SiteLists& sites,
+                           hipStream_t stream);
+
+  //! Edge test + refinement + contrast test of the classified sites.
+  void launch_finish_sites(const OctavePyramidView& pyr, int batch,
+                           const ExtremaParams& p, const ScaleTable* tab,
+                           const SiteLists& sites, const CandidateLists& cand,
+                           hipStream_t stream);
 
   void launch_extremum_map(const float* a, const float* b, const float* c,
                            int w, int h, float edge_ratio, float thres, int pad,
