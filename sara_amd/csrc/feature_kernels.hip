@@ -58,6 +58,22 @@ namespace sara_hip {
     o[c] = make_float2(r, theta);
   }
 
+  //! Value of the previous / next lane through DPP wave shifts (one VALU op,
+  //! no LDS crossbar round trip).  Lane 0 of shift_from_prev and lane 63 of
+  //! shift_from_next receive their own value.
+  __device__ inline float shift_from_prev(float v)
+  {
+    // wave_shr:1 - lane l reads lane l-1
+    return __int_as_float(__builtin_amdgcn_update_dpp(
+        __float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
+  }
+  __device__ inline float shift_from_next(float v)
+  {
+    // wave_shl:1 - lane l reads lane l+1
+    return __int_as_float(__builtin_amdgcn_update_dpp(
+        __float_as_int(v), __float_as_int(v), 0x130, 0xf, 0xf, false));
+  }
+
   //! Fast path (w % 4 == 0): one wave marches down a strip of 256 columns
   //! (4 per lane, float4 loads, 32-byte stores).  Rows y-1, y, y+1 live in a
   //! register ring (loop unrolled 3x), horizontal neighbours come from the
@@ -127,8 +143,8 @@ namespace sara_hip {
           const float4 dn = ring[i % 3];         // row y+1
           const float emid = ering[(i + 2) % 3];
           // horizontal neighbours of the 4 columns
-          float left = __shfl_up(mid.w, 1);
-          float right = __shfl_down(mid.x, 1);
+          float left = shift_from_prev(mid.w);
+          float right = shift_from_next(mid.x);
           if (lane == 0)
             left = emid;
           if (lane == 63)
@@ -172,9 +188,16 @@ namespace sara_hip {
     const char* e = getenv("SARA_HIP_FEATURES");
     return !(e && std::string(e) == "tile");
   }();
-  static const int g_march_waves = [] {
-    const char* e = getenv("SARA_HIP_MARCH_WAVES");
-    return e ? std::max(64, atoi(e)) : 4096;
+  //! Target number of waves per marching launch (tuning knobs; the defaults
+  //! come from sweeps on MI355X with 64 x 1080p frames: the extremum scan
+  //! likes long segments, the gradient kernel many short ones).
+  static const int g_grad_waves = [] {
+    const char* e = getenv("SARA_HIP_GRAD_WAVES");
+    return e ? std::max(64, atoi(e)) : 8192;
+  }();
+  static const int g_extrema_waves = [] {
+    const char* e = getenv("SARA_HIP_EXTREMA_WAVES");
+    return e ? std::max(64, atoi(e)) : 2048;
   }();
 
   void launch_gradient_polar(const float* src, size_t src_stride, float* dst,
@@ -189,7 +212,7 @@ namespace sara_hip {
     {
       const int nstrips = (w + 255) / 256;
       const int planes = batch * nscales;
-      int nseg = (g_march_waves + nstrips * planes - 1) / (nstrips * planes);
+      int nseg = (g_grad_waves + nstrips * planes - 1) / (nstrips * planes);
       nseg = std::max(1, std::min(nseg, (h + 15) / 16));
       const int seg_rows = (h + nseg - 1) / nseg;
       nseg = (h + seg_rows - 1) / seg_rows;
@@ -557,8 +580,8 @@ namespace sara_hip {
           const float vy = fmaxf(fmaxf(ring[ia][l].y, ring[ib][l].y), ring[ic][l].y);
           const float ux = fminf(fminf(ring[ia][l].x, ring[ib][l].x), ring[ic][l].x);
           const float uy = fminf(fminf(ring[ia][l].y, ring[ib][l].y), ring[ic][l].y);
-          const float vl = __shfl_up(vy, 1), vr = __shfl_down(vx, 1);
-          const float ul = __shfl_up(uy, 1), ur = __shfl_down(ux, 1);
+          const float vl = shift_from_prev(vy), vr = shift_from_next(vx);
+          const float ul = shift_from_prev(uy), ur = shift_from_next(ux);
           m[l] = make_float2(fmaxf(fmaxf(vl, vx), vy), fmaxf(fmaxf(vx, vy), vr));
           mn[l] = make_float2(fminf(fminf(ul, ux), uy), fminf(fminf(ux, uy), ur));
         }
@@ -642,7 +665,7 @@ namespace sara_hip {
     if (aligned2 && g_use_march && gauss.scales == 6)
     {
       const int nstrips = (gauss.w - 2 + 125) / 126;
-      int nseg = (g_march_waves + nstrips * batch - 1) / (nstrips * batch);
+      int nseg = (g_extrema_waves + nstrips * batch - 1) / (nstrips * batch);
       nseg = std::max(1, std::min(nseg, (gauss.h + 15) / 16));
       const int seg_rows = (gauss.h + nseg - 1) / nseg;
       nseg = (gauss.h + seg_rows - 1) / seg_rows;

@@ -39,10 +39,14 @@ namespace sara_hip {
     const char* e = getenv("SARA_HIP_BLUR");
     return !(e && std::string(e) == "tile");
   }();
+  static const int g_march_minrows = [] {
+    const char* e = getenv("SARA_HIP_MARCH_MINROWS");
+    return e ? std::max(0, atoi(e)) : 4;
+  }();
   //! Target number of waves per marching launch (tuning knob).
   static const int g_march_waves = [] {
     const char* e = getenv("SARA_HIP_MARCH_WAVES");
-    return e ? std::max(64, atoi(e)) : 4096;
+    return e ? std::max(64, atoi(e)) : 3072;
   }();
 
   template <int R>
@@ -369,11 +373,16 @@ namespace sara_hip {
                                 const Taps& taps, hipStream_t stream)
   {
     constexpr int W = 256;
-    constexpr int PF = 4;
+    // prefetch depth: the K x 4 partial-sum ring dominates the register
+    // budget, keep the kernel at >= 3 waves/SIMD (<= 168 VGPRs)
+    constexpr int PF = R >= 12 ? 2 : (R >= 10 ? 3 : 4);
     const int nstrips = (w + W - 1) / W;
     // enough waves to fill 256 CUs x 3-4 waves/SIMD, segments >= 32 rows
+    // segments: enough waves to fill the chip, but every segment re-filters
+    // 2R halo rows, so keep them at least g_march_minrows * R rows tall
     int nseg = (g_march_waves + nstrips * batch - 1) / (nstrips * batch);
-    nseg = std::max(1, std::min(nseg, (h + 31) / 32));
+    const int min_rows = std::max(32, g_march_minrows * R);
+    nseg = std::max(1, std::min(nseg, (h + min_rows - 1) / min_rows));
     const int seg_rows = (h + nseg - 1) / nseg;
     nseg = (h + seg_rows - 1) / seg_rows;
     const dim3 grid(nstrips * nseg, batch);
