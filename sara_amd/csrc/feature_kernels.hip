@@ -1150,7 +1150,7 @@ namespace sara_hip {
           py += 1.5f;
           if (fminf(px, py) <= -1.f || fmaxf(px, py) >= 4.f)
             continue;
-          const float weight = expf(-nrm2 / (2.f * 4.f));
+          const float weight = __expf(-nrm2 / (2.f * 4.f));
           const float2 mo = grow[u];
           const float mag = mo.x;
           float a = mo.y - theta;

@@ -12,6 +12,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -175,6 +176,12 @@ struct sara_hip_sift
 
   hipStream_t own_stream = nullptr;
   hipStream_t last_stream = nullptr;
+  // one auxiliary stream per octave > 0: the small octaves' launch-bound
+  // chains overlap the big octave's bandwidth-bound kernels
+  hipStream_t oct_stream[16] = {};
+  hipEvent_t oct_ready[16] = {};  // G(downscale_index, o) is complete
+  hipEvent_t oct_done[16] = {};   // octave o's chain is complete
+  bool multi_stream = true;
 
   Schedule max_sched;
   Schedule cur;
@@ -315,6 +322,15 @@ namespace {
     TRY_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     for (auto& e : c->ev)
       TRY_HIP(hipEventCreate(&e));
+    for (int o = 0; o < 16; ++o)
+    {
+      TRY_HIP(hipEventCreateWithFlags(&c->oct_ready[o], hipEventDisableTiming));
+      TRY_HIP(hipEventCreateWithFlags(&c->oct_done[o], hipEventDisableTiming));
+      if (o > 0 && o < c->max_sched.num_octaves)
+        TRY_HIP(hipStreamCreateWithFlags(&c->oct_stream[o], hipStreamNonBlocking));
+    }
+    if (const char* e = getenv("SARA_HIP_STREAMS"))
+      c->multi_stream = std::string(e) != "1";
 
     // ---- taps and tables (host arithmetic as in GaussianPyramid.hpp:106-121)
     const float k = pyr.scale_geometric_factor;
@@ -584,6 +600,18 @@ sara_hip_status sara_hip_sift_destroy(sara_hip_sift* c)
   for (auto& e : c->ev)
     if (e)
       (void) hipEventDestroy(e);
+  for (int o = 0; o < 16; ++o)
+  {
+    if (c->oct_stream[o])
+    {
+      (void) hipStreamSynchronize(c->oct_stream[o]);
+      (void) hipStreamDestroy(c->oct_stream[o]);
+    }
+    if (c->oct_ready[o])
+      (void) hipEventDestroy(c->oct_ready[o]);
+    if (c->oct_done[o])
+      (void) hipEventDestroy(c->oct_done[o]);
+  }
   if (c->own_stream)
     (void) hipStreamDestroy(c->own_stream);
   delete c;
@@ -723,22 +751,39 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       launch_copy_planes(src, src_stride, G00, g_stride0, pl0, batch, stream);
     }
 
+    // Octave o+1 starts from G(downscale_index, o): its chain runs on its
+    // own stream as soon as that plane exists and is joined at the end.
+    const bool ms = c->multi_stream && sc.num_octaves > 1;
     for (int o = 0; o < sc.num_octaves; ++o)
     {
       const int w = sc.oct[o].w, h = sc.oct[o].h;
       const size_t pl = size_t(w) * h;
       const size_t gs = pl * S;
+      hipStream_t so = (ms && o > 0) ? c->oct_stream[o] : stream;
       if (o > 0)
       {
         const int pw = sc.oct[o - 1].w, ph = sc.oct[o - 1].h;
         const size_t ppl = size_t(pw) * ph;
+        if (ms)
+          HIP_TRY(hipStreamWaitEvent(so, c->oct_ready[o - 1], 0));
         launch_scale(c->G[o - 1] + ppl * sc.downscale_index, ppl * S, pw, ph,
-                     c->G[o], gs, w, h, batch, stream);
+                     c->G[o], gs, w, h, batch, so);
       }
+      if (ms && sc.downscale_index == 0 && o + 1 < sc.num_octaves)
+        HIP_TRY(hipEventRecord(c->oct_ready[o], so));
       for (int s = 1; s < S; ++s)
+      {
         launch_gaussian_blur(c->G[o] + pl * (s - 1), gs, c->G[o] + pl * s, gs,
-                             nullptr, 0, w, h, batch, c->taps[s], stream);
+                             nullptr, 0, w, h, batch, c->taps[s], so);
+        if (ms && s == sc.downscale_index && o + 1 < sc.num_octaves)
+          HIP_TRY(hipEventRecord(c->oct_ready[o], so));
+      }
+      if (ms && o > 0)
+        HIP_TRY(hipEventRecord(c->oct_done[o], so));
     }
+    if (ms)
+      for (int o = 1; o < sc.num_octaves; ++o)
+        HIP_TRY(hipStreamWaitEvent(stream, c->oct_done[o], 0));
   }
   HIP_TRY(mark(2));
 
