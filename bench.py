@@ -130,6 +130,7 @@ def main():
     import sara_amd
     from sara_amd import capi
     from sara_amd.synth import synth_batch
+    from sara_amd.distributed import gatherv_to_root
 
     capi.require_gpu()
     torch.cuda.set_device(local_rank)
@@ -166,43 +167,19 @@ def main():
 
     def gather_to_root(total):
         """gatherv of OERegion[ ] (48 B), descriptors (512 B) and (s,o) pairs
-        to rank 0: counts first, then one grouped send/recv per peer."""
+        to rank 0 (sara_amd/distributed.py)."""
         nonlocal feat_buf, desc_buf, so_buf
-        n_t = torch.tensor([total], device=dev, dtype=torch.int64)
-        all_n = [torch.zeros_like(n_t) for _ in range(world)]
-        dist.all_gather(all_n, n_t)
-        all_n = [int(t.item()) for t in all_n]
         mine_f = torch.empty((total, 48), dtype=torch.uint8, device=dev)
         mine_d = torch.empty((total, 128), dtype=torch.float32, device=dev)
         mine_s = torch.empty((total, 2), dtype=torch.int32, device=dev)
-        capi.check(capi.load().sara_hip_sift_fetch(
-            ctx._h, mine_f.data_ptr(), mine_d.data_ptr(), mine_s.data_ptr(), 1))
+        if total:
+            capi.check(capi.load().sara_hip_sift_fetch(
+                ctx._h, mine_f.data_ptr(), mine_d.data_ptr(), mine_s.data_ptr(),
+                1))
         ctx.synchronize()  # the copies run on the detect stream
-        if rank == 0:
-            tot = sum(all_n)
-            feat_buf = torch.empty((tot, 48), dtype=torch.uint8, device=dev)
-            desc_buf = torch.empty((tot, 128), dtype=torch.float32, device=dev)
-            so_buf = torch.empty((tot, 2), dtype=torch.int32, device=dev)
-            feat_buf[:total] = mine_f
-            desc_buf[:total] = mine_d
-            so_buf[:total] = mine_s
-            ops, at = [], total
-            for r in range(1, world):
-                n = all_n[r]
-                if n:
-                    ops += [dist.P2POp(dist.irecv, feat_buf[at:at + n], r),
-                            dist.P2POp(dist.irecv, desc_buf[at:at + n], r),
-                            dist.P2POp(dist.irecv, so_buf[at:at + n], r)]
-                at += n
-        else:
-            ops = []
-            if total:
-                ops = [dist.P2POp(dist.isend, mine_f, 0),
-                       dist.P2POp(dist.isend, mine_d, 0),
-                       dist.P2POp(dist.isend, mine_s, 0)]
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        outs, _ = gatherv_to_root([mine_f, mine_d, mine_s], root=0)
+        if outs is not None:
+            feat_buf, desc_buf, so_buf = outs
 
     def sync():
         torch.cuda.synchronize()

@@ -1,0 +1,465 @@
+// ========================================================================== //
+// DO::Sara shim over the C-ABI of include/sara_hip_sift.h.
+//
+// Gives the MI355X SIFT front-end the exact C++ surface of the reference path
+// so that its callers compile unchanged:
+//
+//   compute_sift_keypoints()        FeatureDetectors/SIFT.hpp:24-33
+//   ComputeDoGExtrema               FeatureDetectors/DoG.hpp:72-165
+//   ImagePyramidParams/ImagePyramid ImageProcessing/ImagePyramid.hpp:29-340
+//   OERegion, KeypointList, features(), descriptors()
+//                                   Features/Feature.hpp:40-179,
+//                                   Features/KeypointList.hpp:35-96
+//
+// Two modes:
+//  * inside Sara (define SARA_HIP_WITH_SARA_HEADERS): Sara's own Image /
+//    OERegion / Tensor_ types are used; sara_oeregion is byte-compatible with
+//    OERegion (48 bytes, same member offsets), so results are memcpy'd.
+//  * standalone (default): minimal stand-ins with the same member names, no
+//    Eigen required.  This is what tests/cpp/test_shim.cpp builds.
+//
+// Error convention: C status codes are re-thrown as the exception classes the
+// reference throws (std::runtime_error for the scale-count check DoG.hpp:86-89,
+// std::domain_error for size mismatches LinearFiltering.cpp:33-35,
+// std::out_of_range GaussianPyramid.hpp:187-190).
+// ========================================================================== //
+#pragma once
+
+#include <sara_hip_sift.h>
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#ifdef SARA_HIP_WITH_SARA_HEADERS
+#  include <DO/Sara/Core/Image.hpp>
+#  include <DO/Sara/Core/Tensor.hpp>
+#  include <DO/Sara/Features/KeypointList.hpp>
+#  include <DO/Sara/ImageProcessing/ImagePyramid.hpp>
+#endif
+
+namespace DO::Sara {
+
+#ifndef SARA_HIP_WITH_SARA_HEADERS
+  // ---- standalone stand-ins (same names / members as Sara's types) --------
+
+  //! Core/Image/Image.hpp:45-181 restricted to float, 2-D: borrowed buffer,
+  //! pixel (x, y) at y * width + x.
+  template <typename T>
+  class ImageView
+  {
+  public:
+    ImageView() = default;
+    ImageView(T* data, int width, int height)
+      : _data{data}, _w{width}, _h{height}
+    {
+    }
+    auto width() const -> int { return _w; }
+    auto height() const -> int { return _h; }
+    auto data() const -> T* { return _data; }
+    auto operator()(int x, int y) const -> T& { return _data[size_t(y) * _w + x]; }
+
+  protected:
+    T* _data = nullptr;
+    int _w = 0, _h = 0;
+  };
+
+  template <typename T>
+  class Image : public ImageView<T>
+  {
+  public:
+    Image() = default;
+    Image(int width, int height)
+      : _storage(size_t(width) * height)
+    {
+      this->_data = _storage.data();
+      this->_w = width;
+      this->_h = height;
+    }
+    Image(const Image& o) { *this = o; }
+    Image& operator=(const Image& o)
+    {
+      _storage = o._storage;
+      this->_data = _storage.data();
+      this->_w = o._w;
+      this->_h = o._h;
+      return *this;
+    }
+
+  private:
+    std::vector<T> _storage;
+  };
+
+  //! ImageProcessing/ImagePyramid.hpp:29-198.
+  class ImagePyramidParams
+  {
+  public:
+    ImagePyramidParams(const int first_octave_index = -1,
+                       const int scale_count_per_octave = 3 + 3,
+                       const float scale_geometric_factor =
+                           std::pow(2.f, 1.f / 3.f),
+                       const int image_padding_size = 1,
+                       const float scale_camera = 0.5f,
+                       const float scale_initial = 1.6f,
+                       const int num_octaves_max =
+                           std::numeric_limits<int>::max())
+      : _p{first_octave_index, scale_count_per_octave, scale_geometric_factor,
+           image_padding_size, scale_camera, scale_initial, num_octaves_max}
+    {
+    }
+    float scale_camera() const { return _p.scale_camera; }
+    float scale_initial() const { return _p.scale_initial; }
+    float scale_geometric_factor() const { return _p.scale_geometric_factor; }
+    int scale_count_per_octave() const { return _p.scale_count_per_octave; }
+    int image_padding_size() const { return _p.image_padding_size; }
+    int first_octave_index() const { return _p.first_octave_index; }
+    int num_octaves_max() const { return _p.num_octaves_max; }
+    const sara_pyramid_params& c_params() const { return _p; }
+
+  private:
+    sara_pyramid_params _p;
+  };
+
+  //! ImageProcessing/ImagePyramid.hpp:206-340 (host mirror, float pixels).
+  template <typename Pixel, int N = 2>
+  class ImagePyramid
+  {
+  public:
+    using image_type = Image<Pixel>;
+    using octave_type = std::vector<image_type>;
+    void reset(int num_octaves, int num_scales, float scale_initial,
+               float scale_geometric_factor)
+    {
+      _octaves.assign(num_octaves, octave_type(num_scales));
+      _oct_scaling_factors.assign(num_octaves, 0.f);
+      _scale_initial = scale_initial;
+      _scale_geometric_factor = scale_geometric_factor;
+    }
+    image_type& operator()(int s, int o) { return _octaves[o][s]; }
+    const image_type& operator()(int s, int o) const { return _octaves[o][s]; }
+    const octave_type& operator()(int o) const { return _octaves[o]; }
+    Pixel operator()(int x, int y, int s, int o) const
+    {
+      return _octaves[o][s](x, y);
+    }
+    float& octave_scaling_factor(int o) { return _oct_scaling_factors[o]; }
+    float octave_scaling_factor(int o) const { return _oct_scaling_factors[o]; }
+    int octave_count() const { return int(_octaves.size()); }
+    int scale_count_per_octave() const { return int(_octaves.front().size()); }
+    int scale_count() const { return octave_count() * scale_count_per_octave(); }
+    float scale_initial() const { return _scale_initial; }
+    float scale_geometric_factor() const { return _scale_geometric_factor; }
+    double scale_relative_to_octave(int s) const
+    {
+      return std::pow(_scale_geometric_factor, s) * _scale_initial;
+    }
+    double scale(int s, int o) const
+    {
+      return _oct_scaling_factors[o] * scale_relative_to_octave(s);
+    }
+
+  private:
+    float _scale_initial = 0.f, _scale_geometric_factor = 0.f;
+    std::vector<octave_type> _octaves;
+    std::vector<float> _oct_scaling_factors;
+  };
+
+  //! Features/Feature.hpp:40-179: same members, same 48-byte layout.
+  struct alignas(16) OERegion
+  {
+    enum class Type : std::uint8_t
+    {
+      Harris, HarAff, HarLap, FAST, SUSAN, DoG, LoG, DoH, MSER, HesAff, HesLap,
+      Undefined
+    };
+    enum class ExtremumType : std::int8_t
+    {
+      Min = -1, Saddle = 0, Max = 1, Undefined = -2
+    };
+    std::array<float, 2> coords{{0.f, 0.f}};
+    alignas(16) std::array<float, 4> shape_matrix{{0.f, 0.f, 0.f, 0.f}};
+    float orientation{0};
+    float extremum_value{0};
+    Type type{Type::Undefined};
+    ExtremumType extremum_type{ExtremumType::Undefined};
+
+    float x() const { return coords[0]; }
+    float y() const { return coords[1]; }
+    const std::array<float, 2>& center() const { return coords; }
+    //! Features/Feature.cpp:28-39 for the isotropic regions this path emits.
+    float radius(float = 0.f) const { return 1.f / std::sqrt(shape_matrix[0]); }
+    float scale(float radian = 0.f) const { return radius(radian); }
+    bool operator==(const OERegion& o) const
+    {
+      return coords == o.coords && shape_matrix == o.shape_matrix &&
+             orientation == o.orientation && type == o.type;
+    }
+  };
+
+  //! Core/Tensor.hpp:41-45, row-major N x D matrix of descriptors.
+  template <typename T, int N>
+  class Tensor_
+  {
+    static_assert(N == 2, "only matrices are needed on this path");
+
+  public:
+    Tensor_() = default;
+    Tensor_(int rows, int cols) { resize(rows, cols); }
+    void resize(int rows, int cols)
+    {
+      _rows = rows;
+      _cols = cols;
+      _d.assign(size_t(rows) * cols, T{});
+    }
+    int rows() const { return _rows; }
+    int cols() const { return _cols; }
+    std::array<int, 2> sizes() const { return {{_rows, _cols}}; }
+    T* data() { return _d.data(); }
+    const T* data() const { return _d.data(); }
+    T& operator()(int i, int j) { return _d[size_t(i) * _cols + j]; }
+    const T& operator()(int i, int j) const { return _d[size_t(i) * _cols + j]; }
+    const T* operator[](int i) const { return &_d[size_t(i) * _cols]; }
+
+  private:
+    int _rows = 0, _cols = 0;
+    std::vector<T> _d;
+  };
+
+  using Point2i = std::array<int, 2>;
+
+  //! Features/KeypointList.hpp:35-96.
+  template <typename F, typename T>
+  using KeypointList = std::tuple<std::vector<F>, Tensor_<T, 2>>;
+  template <typename F, typename T>
+  inline auto features(const KeypointList<F, T>& k) -> const std::vector<F>&
+  {
+    return std::get<0>(k);
+  }
+  template <typename F, typename T>
+  inline auto descriptors(const KeypointList<F, T>& k) -> const Tensor_<T, 2>&
+  {
+    return std::get<1>(k);
+  }
+  template <typename F, typename T>
+  inline auto size(const KeypointList<F, T>& k)
+  {
+    return descriptors(k).rows();
+  }
+  template <typename F, typename T>
+  inline auto size_consistency_predicate(const KeypointList<F, T>& k)
+  {
+    return int(features(k).size()) == descriptors(k).rows();
+  }
+#endif  // !SARA_HIP_WITH_SARA_HEADERS
+
+  static_assert(sizeof(OERegion) == sizeof(sara_oeregion),
+                "OERegion must stay byte-compatible with sara_oeregion");
+
+  namespace hip_detail {
+
+    [[noreturn]] inline void rethrow(sara_hip_status st)
+    {
+      const std::string msg = sara_hip_last_error();
+      switch (st)
+      {
+      case SARA_HIP_SIZE_MISMATCH:
+        throw std::domain_error{msg};
+      case SARA_HIP_OUT_OF_RANGE:
+        throw std::out_of_range{msg};
+      default:
+        throw std::runtime_error{msg};
+      }
+    }
+
+    inline void check(sara_hip_status st)
+    {
+      if (st != SARA_HIP_OK)
+        rethrow(st);
+    }
+
+    inline sara_pyramid_params to_c(const ImagePyramidParams& p)
+    {
+      sara_pyramid_params c;
+      c.first_octave_index = p.first_octave_index();
+      c.scale_count_per_octave = p.scale_count_per_octave();
+      c.scale_geometric_factor = p.scale_geometric_factor();
+      c.image_padding_size = p.image_padding_size();
+      c.scale_camera = p.scale_camera();
+      c.scale_initial = p.scale_initial();
+      c.num_octaves_max = p.num_octaves_max();
+      return c;
+    }
+
+    struct Deleter
+    {
+      void operator()(sara_hip_sift* c) const { sara_hip_sift_destroy(c); }
+    };
+    using Context = std::unique_ptr<sara_hip_sift, Deleter>;
+
+  }  // namespace hip_detail
+
+  //! FeatureDetectors/SIFT.hpp:24-33.  `parallel` is accepted for signature
+  //! compatibility; `device` selects the GPU (extension, defaulted).
+  inline auto compute_sift_keypoints(
+      const ImageView<float>& image,
+      const ImagePyramidParams& pyramid_params = ImagePyramidParams(),
+      float gauss_truncate = 4.f, float extremum_thres = 0.01f,
+      float edge_ratio_thres = 10.f, int extremum_refinement_iter = 5,
+      bool /*parallel*/ = false, int device = 0)
+      -> KeypointList<OERegion, float>
+  {
+    sara_sift_params p;
+    p.pyramid = hip_detail::to_c(pyramid_params);
+    p.gauss_truncate = gauss_truncate;
+    p.extremum_thres = extremum_thres;
+    p.edge_ratio_thres = edge_ratio_thres;
+    p.extremum_refinement_iter = extremum_refinement_iter;
+    sara_hip_sift* raw = nullptr;
+    hip_detail::check(sara_hip_sift_create(&p, image.width(), image.height(), 1,
+                                           0, device, &raw));
+    hip_detail::Context ctx{raw};
+    hip_detail::check(sara_hip_sift_detect(ctx.get(), image.data(), 0, 1,
+                                           image.width(), image.height(), 0,
+                                           SARA_HIP_STAGE_DESCRIPTOR, nullptr));
+    int total = 0;
+    hip_detail::check(sara_hip_sift_counts(ctx.get(), nullptr, &total));
+    auto feats = std::vector<OERegion>(size_t(total));
+    auto desc = Tensor_<float, 2>{};
+    desc.resize(total, 128);
+    if (total > 0)
+      hip_detail::check(sara_hip_sift_fetch(
+          ctx.get(), reinterpret_cast<sara_oeregion*>(feats.data()),
+          desc.data(), nullptr, 0));
+    return {std::move(feats), std::move(desc)};
+  }
+
+  //! FeatureDetectors/DoG.hpp:72-165.  The pyramids stay in HBM; gaussians()
+  //! and diff_of_gaussians() copy them to the host on first use.
+  class ComputeDoGExtrema
+  {
+  public:
+    ComputeDoGExtrema(
+        const ImagePyramidParams& pyramid_params = ImagePyramidParams(),
+        float gauss_truncate = 4.f, float extremum_thres = 0.01f,
+        float edge_ratio_thres = 10.f, int img_padding_sz = 1,
+        int extremum_refinement_iter = 5, int device = 0)
+      : _pyramid_params{pyramid_params}
+      , _gauss_truncate{gauss_truncate}
+      , _extremum_thres{extremum_thres}
+      , _edge_ratio_thres{edge_ratio_thres}
+      , _img_padding_sz{img_padding_sz}
+      , _extremum_refinement_iter{extremum_refinement_iter}
+      , _device{device}
+    {
+      if (_pyramid_params.scale_count_per_octave() < 4)
+        throw std::runtime_error{
+            "Error: The extraction of DoG extrema needs (1 + 3) = 4 scales per "
+            "octave at the very minimum!"};
+    }
+
+    std::vector<OERegion> operator()(const ImageView<float>& I,
+                                     std::vector<Point2i>* scale_octave_pairs = 0)
+    {
+      const auto cp = hip_detail::to_c(_pyramid_params);
+      sara_hip_sift* raw = nullptr;
+      hip_detail::check(sara_hip_sift_create_dog(
+          &cp, _gauss_truncate, _extremum_thres, _edge_ratio_thres,
+          _img_padding_sz, _extremum_refinement_iter, I.width(), I.height(), 1,
+          0, _device, &raw));
+      _ctx.reset(raw);
+      _have_g = _have_d = false;
+      hip_detail::check(sara_hip_sift_detect(_ctx.get(), I.data(), 0, 1, I.width(),
+                                             I.height(), 0,
+                                             SARA_HIP_STAGE_EXTREMA, nullptr));
+      int total = 0;
+      hip_detail::check(sara_hip_sift_extrema_counts(_ctx.get(), nullptr, &total));
+      auto extrema = std::vector<OERegion>(size_t(total));
+      auto xyso = std::vector<int32_t>(size_t(total) * 5);
+      if (total > 0)
+        hip_detail::check(sara_hip_sift_fetch_extrema(
+            _ctx.get(), reinterpret_cast<sara_oeregion*>(extrema.data()),
+            xyso.data()));
+      // extrema(s, o): the per-(scale, octave) lists of DoG.hpp:160-163.
+      const int no = sara_hip_sift_octave_count(_ctx.get());
+      const int nd = _pyramid_params.scale_count_per_octave() - 1;
+      _extrema.assign(size_t(std::max(no, 0)) * nd, {});
+      if (scale_octave_pairs)
+        scale_octave_pairs->clear();
+      for (int i = 0; i < total; ++i)
+      {
+        const int s = xyso[5 * i + 2], o = xyso[5 * i + 3];
+        _extrema[size_t(o) * nd + s].push_back(extrema[i]);
+        if (scale_octave_pairs)
+          scale_octave_pairs->push_back(Point2i{{s, o}});
+      }
+      return extrema;
+    }
+
+    auto gaussians() const -> const ImagePyramid<float>&
+    {
+      if (!_have_g)
+      {
+        fill(_gaussians, _pyramid_params.scale_count_per_octave(),
+             sara_hip_sift_copy_gaussian);
+        _have_g = true;
+      }
+      return _gaussians;
+    }
+
+    auto diff_of_gaussians() const -> const ImagePyramid<float>&
+    {
+      if (!_have_d)
+      {
+        fill(_diff_of_gaussians, _pyramid_params.scale_count_per_octave() - 1,
+             sara_hip_sift_copy_dog);
+        _have_d = true;
+      }
+      return _diff_of_gaussians;
+    }
+
+    auto extrema(int s, int o) const -> const std::vector<OERegion>&
+    {
+      return _extrema[size_t(o) * (_pyramid_params.scale_count_per_octave() - 1) +
+                      s];
+    }
+
+  private:
+    template <typename CopyFn>
+    void fill(ImagePyramid<float>& P, int scales, CopyFn copy) const
+    {
+      if (!_ctx)
+        throw std::runtime_error{"ComputeDoGExtrema: no image processed yet"};
+      const int no = sara_hip_sift_octave_count(_ctx.get());
+      P.reset(no, scales, _pyramid_params.scale_initial(),
+              _pyramid_params.scale_geometric_factor());
+      for (int o = 0; o < no; ++o)
+      {
+        int w = 0, h = 0;
+        float f = 0.f;
+        hip_detail::check(sara_hip_sift_octave_info(_ctx.get(), o, &w, &h, &f));
+        P.octave_scaling_factor(o) = f;
+        for (int s = 0; s < scales; ++s)
+        {
+          P(s, o) = Image<float>{w, h};
+          hip_detail::check(copy(_ctx.get(), 0, s, o, P(s, o).data()));
+        }
+      }
+    }
+
+    ImagePyramidParams _pyramid_params;
+    float _gauss_truncate, _extremum_thres, _edge_ratio_thres;
+    int _img_padding_sz, _extremum_refinement_iter, _device;
+    hip_detail::Context _ctx;
+    mutable ImagePyramid<float> _gaussians, _diff_of_gaussians;
+    mutable bool _have_g = false, _have_d = false;
+    std::vector<std::vector<OERegion>> _extrema;
+  };
+
+}  // namespace DO::Sara

@@ -1,0 +1,65 @@
+"""Multi-GPU side of the SIFT front-end: frames are independent
+(compute_sift_keypoints is a pure function of one image, SIFT.cpp:27-108), so
+ranks shard them in contiguous blocks with no data-path collective.  The only
+exchange is the gather of the variable-length keypoint arrays to the root:
+counts first (all_gather), then one grouped send/recv per peer - a gatherv,
+which RCCL does not provide natively.  On the GPU boxes the backend is "nccl"
+(= RCCL over xGMI: every peer reaches the root over its own link); the same
+code runs over "gloo" on CPU tensors in the tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_frames, world_size, rank):
+    """Contiguous block of frames of `rank`: frame f goes to rank
+    floor(f * world_size / n_frames)."""
+    lo = (rank * n_frames + world_size - 1) // world_size
+    hi = ((rank + 1) * n_frames + world_size - 1) // world_size
+    return lo, hi
+
+
+def gatherv_to_root(arrays, root=0, group=None):
+    """arrays: list of tensors whose first dimension is this rank's keypoint
+    count n_r (same trailing shapes and dtypes on every rank).  Returns, on the
+    root, (list of concatenated tensors in rank order, counts per rank); on the
+    other ranks (None, counts per rank)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = int(arrays[0].shape[0])
+    for a in arrays:
+        assert int(a.shape[0]) == n
+    dev = arrays[0].device
+    n_t = torch.tensor([n], device=dev, dtype=torch.int64)
+    all_n = [torch.zeros_like(n_t) for _ in range(world)]
+    dist.all_gather(all_n, n_t, group=group)
+    counts = [int(t.item()) for t in all_n]
+    if world == 1:
+        return list(arrays), counts
+
+    if rank == root:
+        total = sum(counts)
+        outs = [torch.empty((total,) + tuple(a.shape[1:]), dtype=a.dtype,
+                            device=dev) for a in arrays]
+        offs, at = [], 0
+        for r in range(world):
+            offs.append(at)
+            at += counts[r]
+        for o, a in zip(outs, arrays):
+            o[offs[root]:offs[root] + n] = a
+        ops = []
+        for r in range(world):
+            if r == root or counts[r] == 0:
+                continue
+            for o in outs:
+                ops.append(dist.P2POp(dist.irecv, o[offs[r]:offs[r] + counts[r]],
+                                      r, group))
+        for req in (dist.batch_isend_irecv(ops) if ops else []):
+            req.wait()
+        return outs, counts
+    ops = []
+    if n:
+        ops = [dist.P2POp(dist.isend, a.contiguous(), root, group) for a in arrays]
+    for req in (dist.batch_isend_irecv(ops) if ops else []):
+        req.wait()
+    return None, counts

@@ -1,0 +1,91 @@
+// Builds against include/DO/Sara/HipSift.hpp (standalone mode) the way a Sara
+// caller would use the reference API (cf. cpp/examples/Sara/FeatureDescriptors/
+// sift_example.cpp:36-92 and SfM/Odometry/OdometryPipeline.cpp:82-90), and
+// dumps the results for tests/test_gpu_cpp_shim.py to compare with the oracle.
+//
+//   test_shim <in.f32> <w> <h> <num_octaves_max> <out.bin>
+#include <DO/Sara/HipSift.hpp>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+namespace sara = DO::Sara;
+
+int main(int argc, char** argv)
+{
+  if (argc < 6)
+    return 2;
+  const int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
+  const int noct = std::atoi(argv[4]);
+  std::vector<float> buf(size_t(w) * h);
+  {
+    std::ifstream in(argv[1], std::ios::binary);
+    in.read(reinterpret_cast<char*>(buf.data()), buf.size() * sizeof(float));
+    if (!in)
+      return 3;
+  }
+  const auto image = sara::ImageView<float>{buf.data(), w, h};
+
+  // Error convention: the scale-count check throws std::runtime_error like
+  // DoG.hpp:86-89.
+  bool threw = false;
+  try
+  {
+    sara::ComputeDoGExtrema bad{sara::ImagePyramidParams(0, 3)};
+  }
+  catch (const std::runtime_error&)
+  {
+    threw = true;
+  }
+  if (!threw)
+    return 4;
+
+  // 1. the OdometryPipeline call: compute_sift_keypoints(image, params).
+  const auto pyr_params = sara::ImagePyramidParams(
+      0, 6, std::pow(2.f, 1.f / 3.f), 1, 0.5f, 1.6f, noct);
+  const auto keys = sara::compute_sift_keypoints(image, pyr_params);
+  const auto& f = sara::features(keys);
+  const auto& d = sara::descriptors(keys);
+  if (!sara::size_consistency_predicate(keys) || d.cols() != 128)
+    return 5;
+
+  // 2. the functor API with its pyramid accessors.
+  auto compute_dogs = sara::ComputeDoGExtrema{pyr_params, 4.f, 0.01f, 10.f, 5, 5};
+  auto so = std::vector<sara::Point2i>{};
+  const auto extrema = compute_dogs(image, &so);
+  const auto& G = compute_dogs.gaussians();
+  const auto& D = compute_dogs.diff_of_gaussians();
+  if (G.octave_count() != D.octave_count() || G.scale_count_per_octave() != 6 ||
+      D.scale_count_per_octave() != 5 || so.size() != extrema.size())
+    return 6;
+  // D(s) = G(s+1) - G(s) at a few sites, through the pixel getters.
+  for (int o = 0; o < G.octave_count(); ++o)
+    for (int s = 0; s < 5; ++s)
+    {
+      const int x = G(s, o).width() / 3, y = G(s, o).height() / 2;
+      if (D(x, y, s, o) != G(x, y, s + 1, o) - G(x, y, s, o))
+        return 7;
+    }
+  size_t per_so = 0;
+  for (int o = 0; o < D.octave_count(); ++o)
+    for (int s = 0; s < D.scale_count_per_octave(); ++s)
+      per_so += compute_dogs.extrema(s, o).size();
+  if (per_so != extrema.size())
+    return 8;
+
+  std::ofstream out(argv[5], std::ios::binary);
+  const int32_t n = int32_t(f.size()), ne = int32_t(extrema.size());
+  out.write(reinterpret_cast<const char*>(&n), 4);
+  out.write(reinterpret_cast<const char*>(&ne), 4);
+  out.write(reinterpret_cast<const char*>(f.data()), sizeof(sara::OERegion) * n);
+  out.write(reinterpret_cast<const char*>(d.data()), sizeof(float) * 128 * n);
+  out.write(reinterpret_cast<const char*>(extrema.data()),
+            sizeof(sara::OERegion) * ne);
+  std::printf("{\"keypoints\": %d, \"extrema\": %d, \"octaves\": %d, "
+              "\"factor1\": %g}\n",
+              n, ne, G.octave_count(),
+              G.octave_count() > 1 ? G.octave_scaling_factor(1) : 0.f);
+  return 0;
+}

@@ -1,0 +1,59 @@
+"""-m gpu: a C++ caller using the reference's API names through
+include/DO/Sara/HipSift.hpp (tests/cpp/test_shim.cpp) gets the oracle's
+keypoints.  The CPU half only checks that the shim compiles and links."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import common
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CPP = os.path.join(HERE, "cpp")
+
+
+def _build():
+    import __graft_entry__
+    from sara_amd import capi
+    if not os.path.exists(capi.LIB_PATH):
+        __graft_entry__.build()
+    subprocess.check_call(["make", "-s", "-C", CPP])
+    return os.path.join(CPP, "test_shim")
+
+
+def test_shim_compiles_against_the_c_abi():
+    exe = _build()
+    assert os.path.exists(exe)
+
+
+@pytest.mark.gpu
+def test_shim_matches_oracle(oracle, tmp_path):
+    from sara_amd.synth import synth
+    exe = _build()
+    w, h, noct = 320, 240, 3
+    img = synth(w, h, 4321)
+    fin, fout = tmp_path / "in.f32", tmp_path / "out.bin"
+    img.tofile(fin)
+    res = subprocess.run([exe, str(fin), str(w), str(h), str(noct), str(fout)],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, (res.returncode, res.stderr)
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    ref = oracle.RefSift(img, oracle.PyramidParams(0, 6, None, 1, 0.5, 1.6, noct))
+    rk, rso, rdesc = ref.keypoints()
+    rext, _ = ref.extrema()
+    raw = np.fromfile(fout, dtype=np.uint8)
+    n, ne = np.frombuffer(raw[:8].tobytes(), dtype=np.int32)
+    assert (n, ne) == (len(rk), len(rext)) == (info["keypoints"], info["extrema"])
+    assert info["octaves"] == noct and info["factor1"] == 2
+    off = 8
+    feats = common.regions_from_bytes(raw[off:off + 48 * n])
+    off += 48 * n
+    desc = np.frombuffer(raw[off:off + 512 * n].tobytes(),
+                         dtype=np.float32).reshape(n, 128)
+    off += 512 * n
+    ext = common.regions_from_bytes(raw[off:off + 48 * ne])
+    common.assert_regions_equal(feats, rk, rtol_shape=1e-6, atol_theta=1e-6)
+    common.assert_regions_equal(ext, rext, rtol_shape=1e-6)
+    assert np.max(np.abs(desc - rdesc)) <= 2e-3
