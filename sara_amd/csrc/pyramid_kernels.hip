@@ -39,6 +39,10 @@ namespace sara_hip {
     const char* e = getenv("SARA_HIP_BLUR");
     return !(e && std::string(e) == "tile");
   }();
+  static const bool g_fuse_decimate = [] {
+    const char* e = getenv("SARA_HIP_FUSE_DECIMATE");
+    return !(e && std::string(e) == "0");
+  }();
   static const int g_march_minrows = [] {
     const char* e = getenv("SARA_HIP_MARCH_MINROWS");
     return e ? std::max(0, atoi(e)) : 4;
@@ -230,11 +234,15 @@ namespace sara_hip {
   // 4 B write.  The DoG layers are NOT materialised: their consumers (extremum
   // scan, refinement) subtract on the fly, see feature_kernels.hip.
   // ------------------------------------------------------------------------ //
-  template <int R, int PF>
+  //! DEC: also write the nearest-neighbour half of the output,
+  //! dec(x, y) = dst(2x, 2y) - exactly downscale(dst, 2) (Resize.cpp:45-84:
+  //! int(x * (w / (w/2))) == 2x for every x < w/2), i.e. the first plane of
+  //! the next octave, without a separate pass over HBM.
+  template <int R, int PF, bool DEC>
   __global__ __launch_bounds__(64) void gaussian_blur_march_kernel(
       const float* __restrict__ src, size_t src_stride,
-      float* __restrict__ dst, size_t dst_stride, int w, int h, int seg_rows,
-      int nstrips, Taps taps)
+      float* __restrict__ dst, size_t dst_stride, float* __restrict__ dec,
+      size_t dec_stride, int w, int h, int seg_rows, int nstrips, Taps taps)
   {
     constexpr int CPL = 4;
     constexpr int K = 2 * R + 1;
@@ -251,6 +259,9 @@ namespace sara_hip {
     const size_t b = blockIdx.y;
     src += b * src_stride;
     dst += b * dst_stride;
+    if (DEC)
+      dec += b * dec_stride;
+    const int dw = w / 2, dh = h / 2;
 
     const int x0 = strip * W;
     const int y0 = seg * seg_rows;
@@ -342,8 +353,13 @@ namespace sara_hip {
 
         const int o = yy - R;
         if ((o >= y0) && (o < y1) && col_ok)
+        {
           *reinterpret_cast<float4*>(dst + size_t(o) * w + col) =
               make_float4(A[i][0], A[i][1], A[i][2], A[i][3]);
+          if (DEC && (o & 1) == 0 && (o >> 1) < dh)
+            *reinterpret_cast<float2*>(dec + size_t(o >> 1) * dw + (col >> 1)) =
+                make_float2(A[i][0], A[i][2]);
+        }
       }
       // re-align the prefetch ring: the row of step n0+K+q sits in slot
       // (K+q) % PF and must be found in slot q % PF by the next round.
@@ -369,8 +385,9 @@ namespace sara_hip {
 
   template <int R>
   static void launch_blur_march(const float* src, size_t src_stride, float* dst,
-                                size_t dst_stride, int w, int h, int batch,
-                                const Taps& taps, hipStream_t stream)
+                                size_t dst_stride, float* dec, size_t dec_stride,
+                                int w, int h, int batch, const Taps& taps,
+                                hipStream_t stream)
   {
     constexpr int W = 256;
     // prefetch depth: the K x 4 partial-sum ring dominates the register
@@ -386,9 +403,14 @@ namespace sara_hip {
     const int seg_rows = (h + nseg - 1) / nseg;
     nseg = (h + seg_rows - 1) / seg_rows;
     const dim3 grid(nstrips * nseg, batch);
-    hipLaunchKernelGGL((gaussian_blur_march_kernel<R, PF>), grid, dim3(64), 0,
-                       stream, src, src_stride, dst, dst_stride, w, h, seg_rows,
-                       nstrips, taps);
+    if (dec)
+      hipLaunchKernelGGL((gaussian_blur_march_kernel<R, PF, true>), grid,
+                         dim3(64), 0, stream, src, src_stride, dst, dst_stride,
+                         dec, dec_stride, w, h, seg_rows, nstrips, taps);
+    else
+      hipLaunchKernelGGL((gaussian_blur_march_kernel<R, PF, false>), grid,
+                         dim3(64), 0, stream, src, src_stride, dst, dst_stride,
+                         dec, dec_stride, w, h, seg_rows, nstrips, taps);
   }
 
   template <int R>
@@ -402,10 +424,10 @@ namespace sara_hip {
                        src_stride, dst, dst_stride, dog, dog_stride, w, h, taps);
   }
 
-  void launch_gaussian_blur(const float* src, size_t src_stride, float* dst,
+  bool launch_gaussian_blur(const float* src, size_t src_stride, float* dst,
                             size_t dst_stride, float* dog, size_t dog_stride,
                             int w, int h, int batch, const Taps& taps,
-                            hipStream_t stream)
+                            hipStream_t stream, float* dec, size_t dec_stride)
   {
     const int R = taps.size / 2;
     // fast path: strips of float4 columns need 16-byte aligned rows
@@ -414,13 +436,19 @@ namespace sara_hip {
                           (reinterpret_cast<uintptr_t>(src) % 16 == 0) &&
                           (reinterpret_cast<uintptr_t>(dst) % 16 == 0) &&
                           dog == nullptr;
+    // the fused half-size output needs 8-byte aligned rows of w/2 floats
+    const bool dec_ok = dec == nullptr ||
+                        ((reinterpret_cast<uintptr_t>(dec) % 8 == 0) &&
+                         (dec_stride % 2 == 0) && g_fuse_decimate);
+    if (!dec_ok)
+      dec = nullptr;
     if (aligned4 && g_use_march)
     {
 #define SARA_MARCH_CASE(r)                                                     \
   case r:                                                                      \
-    launch_blur_march<r>(src, src_stride, dst, dst_stride, w, h, batch, taps,  \
-                         stream);                                              \
-    return;
+    launch_blur_march<r>(src, src_stride, dst, dst_stride, dec, dec_stride, w, \
+                         h, batch, taps, stream);                              \
+    return dec != nullptr;
       switch (R)
       {
         SARA_MARCH_CASE(5)
@@ -437,7 +465,7 @@ namespace sara_hip {
   case r:                                                                      \
     launch_blur_r<r>(src, src_stride, dst, dst_stride, dog, dog_stride, w, h,  \
                      batch, taps, stream);                                     \
-    return;
+    return false;
     switch (R)
     {
       SARA_BLUR_CASE(1)
@@ -466,6 +494,7 @@ namespace sara_hip {
     hipLaunchKernelGGL(gaussian_blur_generic_kernel, grid, dim3(NT), lds, stream,
                        src, src_stride, dst, dst_stride, dog, dog_stride, w, h,
                        taps);
+    return false;
   }
 
   // ======================================================================== //

@@ -754,28 +754,44 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     // Octave o+1 starts from G(downscale_index, o): its chain runs on its
     // own stream as soon as that plane exists and is joined at the end.
     const bool ms = c->multi_stream && sc.num_octaves > 1;
+    bool base_ready = true;  // G(0, o) already written by the previous octave
     for (int o = 0; o < sc.num_octaves; ++o)
     {
       const int w = sc.oct[o].w, h = sc.oct[o].h;
       const size_t pl = size_t(w) * h;
       const size_t gs = pl * S;
       hipStream_t so = (ms && o > 0) ? c->oct_stream[o] : stream;
+      const bool has_next = o + 1 < sc.num_octaves;
       if (o > 0)
       {
         const int pw = sc.oct[o - 1].w, ph = sc.oct[o - 1].h;
         const size_t ppl = size_t(pw) * ph;
         if (ms)
           HIP_TRY(hipStreamWaitEvent(so, c->oct_ready[o - 1], 0));
-        launch_scale(c->G[o - 1] + ppl * sc.downscale_index, ppl * S, pw, ph,
-                     c->G[o], gs, w, h, batch, so);
+        if (!base_ready)
+          launch_scale(c->G[o - 1] + ppl * sc.downscale_index, ppl * S, pw, ph,
+                       c->G[o], gs, w, h, batch, so);
       }
-      if (ms && sc.downscale_index == 0 && o + 1 < sc.num_octaves)
+      base_ready = false;
+      if (ms && sc.downscale_index == 0 && has_next)
         HIP_TRY(hipEventRecord(c->oct_ready[o], so));
       for (int s = 1; s < S; ++s)
       {
-        launch_gaussian_blur(c->G[o] + pl * (s - 1), gs, c->G[o] + pl * s, gs,
-                             nullptr, 0, w, h, batch, c->taps[s], so);
-        if (ms && s == sc.downscale_index && o + 1 < sc.num_octaves)
+        // the blur that produces G(downscale_index, o) also emits its
+        // nearest-neighbour half, i.e. G(0, o+1), when the fast path runs
+        float* dec = nullptr;
+        size_t dec_stride = 0;
+        if (has_next && s == sc.downscale_index)
+        {
+          dec = c->G[o + 1];
+          dec_stride = size_t(sc.oct[o + 1].w) * sc.oct[o + 1].h * S;
+        }
+        const bool fused = launch_gaussian_blur(
+            c->G[o] + pl * (s - 1), gs, c->G[o] + pl * s, gs, nullptr, 0, w, h,
+            batch, c->taps[s], so, dec, dec_stride);
+        if (dec)
+          base_ready = fused;
+        if (ms && s == sc.downscale_index && has_next)
           HIP_TRY(hipEventRecord(c->oct_ready[o], so));
       }
       if (ms && o > 0)

@@ -103,10 +103,15 @@ namespace sara_hip {
   //! dst = gaussian(src) [rows then columns, replicate borders]; when dog is
   //! not null also dog = dst - src.  Planes are w x h; frame b of each
   //! operand lives at base + b*stride.
-  void launch_gaussian_blur(const float* src, size_t src_stride, float* dst,
+  //! When `dec` is given and the fast path runs, the kernel also writes
+  //! dec(x, y) = dst(2x, 2y) (planes of (w/2) x (h/2), frame stride
+  //! dec_stride) and the function returns true; otherwise the caller has to
+  //! run launch_scale itself.
+  bool launch_gaussian_blur(const float* src, size_t src_stride, float* dst,
                             size_t dst_stride, float* dog, size_t dog_stride,
                             int w, int h, int batch, const Taps& taps,
-                            hipStream_t stream);
+                            hipStream_t stream, float* dec = nullptr,
+                            size_t dec_stride = 0);
 
   //! Nearest-neighbour resize (Resize.cpp:31-62).
   void launch_scale(const float* src, size_t src_stride, int sw, int sh,
