@@ -26,7 +26,8 @@ namespace sara_hip {
                                         size_t src_stride,
                                         float2* __restrict__ dst,
                                         size_t dst_stride2, int w, int h,
-                                        int nscales)
+                                        int nscales, unsigned* __restrict__ cmax,
+                                        size_t cmax_stride)
   {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -56,6 +57,12 @@ namespace sara_hip {
     const float r = 2 * sqrtf(gx * gx + gy * gy);
     const float theta = fdlibm_atan2f_fast(gy, gx);
     o[c] = make_float2(r, theta);
+    if (cmax)
+    {
+      const int cw = (w + 15) / 16, ch = (h + 15) / 16;
+      atomicMax(cmax + b * cmax_stride + (s * ch + y / 16) * size_t(cw) + x / 16,
+                __float_as_uint(r));
+    }
   }
 
   //! Value of the previous / next lane through DPP wave shifts (one VALU op,
@@ -83,7 +90,8 @@ namespace sara_hip {
   __global__ __launch_bounds__(64) void gradient_polar_march_kernel(
       const float* __restrict__ src, size_t src_stride,
       float* __restrict__ dst, size_t dst_stride, int w, int h, int nscales,
-      int seg_rows, int nstrips)
+      int seg_rows, int nstrips, unsigned* __restrict__ cmax,
+      size_t cmax_stride)
   {
     constexpr int W = 256;
     const int lane = threadIdx.x;
@@ -114,6 +122,11 @@ namespace sara_hip {
       if (edge_lane)
         e = rowp[ecol];
     };
+
+    // coarse 16x16 magnitude maxima: 4 lanes = 16 columns, running row max
+    const int cw = (w + 15) / 16, ch = (h + 15) / 16;
+    unsigned* cm = cmax ? cmax + b * cmax_stride + s * size_t(ch) * cw : nullptr;
+    float run_max = 0.f;
 
     float4 ring[3];   // source rows (n-2, n-1, n) by n % 3
     float ering[3];
@@ -179,6 +192,24 @@ namespace sara_hip {
             op[0] = make_float4(res[0], res[1], res[2], res[3]);
             op[1] = make_float4(res[4], res[5], res[6], res[7]);
           }
+          if (cm)
+          {
+            float m4 = col_ok ? fmaxf(fmaxf(res[0], res[2]), fmaxf(res[4], res[6]))
+                              : 0.f;
+            // max over the 4 lanes of a 16-column group (quad_perm DPP)
+            m4 = fmaxf(m4, __int_as_float(__builtin_amdgcn_mov_dpp(
+                               __float_as_int(m4), 0xB1, 0xf, 0xf, true)));
+            m4 = fmaxf(m4, __int_as_float(__builtin_amdgcn_mov_dpp(
+                               __float_as_int(m4), 0x4E, 0xf, 0xf, true)));
+            run_max = fmaxf(run_max, m4);
+            if ((y & 15) == 15 || y == y1 - 1)
+            {
+              if ((lane & 3) == 0 && col_ok)
+                atomicMax(cm + size_t(y >> 4) * cw + (col >> 4),
+                          __float_as_uint(run_max));
+              run_max = 0.f;
+            }
+          }
         }
       }
     }
@@ -202,7 +233,8 @@ namespace sara_hip {
 
   void launch_gradient_polar(const float* src, size_t src_stride, float* dst,
                              size_t dst_stride, int w, int h, int nscales,
-                             int batch, hipStream_t stream)
+                             int batch, hipStream_t stream, unsigned* cmax,
+                             size_t cmax_stride)
   {
     const bool aligned4 = (w % 4 == 0) && w >= 4 && h >= 2 &&
                           (src_stride % 4 == 0) && (dst_stride % 4 == 0) &&
@@ -219,14 +251,14 @@ namespace sara_hip {
       hipLaunchKernelGGL((gradient_polar_march_kernel<4>),
                          dim3(nstrips * nseg, planes), dim3(64), 0, stream, src,
                          src_stride, dst, dst_stride, w, h, nscales, seg_rows,
-                         nstrips);
+                         nstrips, cmax, cmax_stride);
       return;
     }
     const dim3 block(64, 4);
     const dim3 grid((w + 63) / 64, (h + 3) / 4, batch * nscales);
     hipLaunchKernelGGL(gradient_polar_kernel, grid, block, 0, stream, src,
                        src_stride, reinterpret_cast<float2*>(dst),
-                       dst_stride / 2, w, h, nscales);
+                       dst_stride / 2, w, h, nscales, cmax, cmax_stride);
   }
 
   // ======================================================================== //
@@ -776,17 +808,21 @@ namespace sara_hip {
     return int((key >> 1) & 0xfffff);
   }
 
-  //! Workgroup -> work item remap that keeps a contiguous slice of a frame's
-  //! (octave, scale, y, x)-sorted list on one XCD (workgroup b runs on XCD
-  //! b % 8), so that neighbouring keypoints share their image rows in that
-  //! XCD's L2.  Returns the logical block index or -1.
-  __device__ inline int xcd_local_block(int bx, int nblk)
+  //! Workgroup -> work item remap.  A frame's (octave, scale, y, x)-sorted
+  //! list is cut into 8 contiguous chunks and each chunk is served by the
+  //! workgroups of one XCD (workgroup b runs on XCD b % 8 when the grid's x
+  //! extent is a multiple of 8), so that neighbouring keypoints share their
+  //! image rows in that XCD's L2.  The chunk -> XCD assignment rotates with the
+  //! frame index: the chunks are not equally expensive (the tail of the list
+  //! holds the large-scale keypoints), and a fixed assignment leaves one XCD
+  //! with all the expensive chunks.  Returns the logical block index or -1.
+  __device__ inline int xcd_local_block(int bx, int frame, int nblk)
   {
     const int chunk = (nblk + 7) >> 3;
     const int j = bx >> 3;
     if (j >= chunk)
       return -1;
-    const int lb = (bx & 7) * chunk + j;
+    const int lb = ((bx + 3 * frame) & 7) * chunk + j;
     return lb < nblk ? lb : -1;
   }
 
@@ -809,7 +845,7 @@ namespace sara_hip {
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int n = min(cand.count[b], cand.cap);
-    const int lb = xcd_local_block(blockIdx.x, (n + 3) >> 2);
+    const int lb = xcd_local_block(blockIdx.x, b, (n + 3) >> 2);
     if (lb < 0)
       return;
     const int idx = lb * 4 + wave;
@@ -920,7 +956,9 @@ namespace sara_hip {
                            const OrientationLists& ori, int batch,
                            hipStream_t stream)
   {
-    const dim3 grid((cand.cap + 3) / 4, batch);
+    // xcd_local_block() spreads ceil(n/4) work items over 8 chunks, so the
+    // grid has to be a multiple of 8 blocks
+    const dim3 grid(8 * (((cand.cap + 3) / 4 + 7) / 8), batch);
     hipLaunchKernelGGL(orientation_kernel, grid, dim3(256), 0, stream, grad, tab,
                        ori_weights, cand, ori);
   }
@@ -1013,9 +1051,9 @@ namespace sara_hip {
   // LDS accumulation of the 128 bins.  ds_add_f32 costs ~192 clk per wave
   // instruction on gfx950 whatever the address pattern (tools/ubench/
   // lds_atomic.hip), ds_add_u32 ~6-16, so contributions are accumulated as a
-  // 64-bit two's-complement fixed point with 2^-34 resolution (ds_add_u64 costs
-  // about one ds_add_u32): exact to 2^-34 per sample and order-independent, so
-  // the result is deterministic.
+  // 64-bit two's-complement fixed point (ds_add_u64 costs about one
+  // ds_add_u32), scaled per patch (see fx_scale in the kernel): the sum is
+  // order-independent, so the result is deterministic.
   constexpr int kDescCopies = 4;  // histogram replicas per wave
 
   __global__ __launch_bounds__(256) void descriptor_kernel(
@@ -1030,7 +1068,7 @@ namespace sara_hip {
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int n = min(cand.count[b], cand.cap);
-    const int lb = xcd_local_block(blockIdx.x, (n + 3) >> 2);
+    const int lb = xcd_local_block(blockIdx.x, b, (n + 3) >> 2);
     if (lb < 0)
       return;
     const int idx = lb * 4 + wave;
@@ -1072,6 +1110,36 @@ namespace sara_hip {
     // rows / columns of the patch that fall inside the image
     const int v_lo = max(-rr, -ry), v_hi = min(rr, h - 1 - ry);
     const int u_min = max(-rr, -rx), u_max = min(rr, w - 1 - rx);
+
+    // Fixed-point scale of the accumulation.  Every contribution is bounded by
+    // |wy*wx*wo*weight*mag| < 2*2*1*1*max(mag); max(mag) over a superset of
+    // the patch comes from the coarse 16x16 magnitude maxima written by the
+    // gradient kernel.  With max(mag) < 2^e the products scaled by 2^(25-e)
+    // stay below 2^29 and convert to int32 with one rounding of 2^-(26-e).
+    float fx_scale = 1.f;
+    double fx_inv = 1.;
+    if (with_descriptors)
+    {
+      const unsigned* cm = grad.cmax[o] + size_t(b) * grad.cmax_frame_stride[o] +
+                           size_t(s) * grad.ch[o] * grad.cw[o];
+      const int cx0 = (rx + u_min) >> 4, cx1 = (rx + u_max) >> 4;
+      const int cy0 = (ry + v_lo) >> 4, cy1 = (ry + v_hi) >> 4;
+      const int ncx = cx1 - cx0 + 1, ncy = cy1 - cy0 + 1;
+      unsigned mxb = 0u;
+      if (ncx > 0 && ncy > 0)
+        for (int q = lane; q < ncx * ncy; q += 64)
+          mxb = max(mxb, cm[size_t(cy0 + q / ncx) * grad.cw[o] + cx0 + q % ncx]);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1)
+        mxb = max(mxb, (unsigned) __shfl_xor((int) mxb, off));
+      const float mx = __uint_as_float(mxb);
+      int e = 0;
+      (void) frexpf(mx, &e);  // mx < 2^e
+      if (!(mx > 0.f) || !(mx < 3.0e38f))
+        e = 0;
+      fx_scale = ldexpf(1.f, 25 - e);
+      fx_inv = ldexp(1., e - 25);
+    }
 
     for (int k = 0; k < npeaks; ++k)
     {
@@ -1159,38 +1227,27 @@ namespace sara_hip {
           const float xif = truncf(px), yif = truncf(py), oif = truncf(a);
           const float xfrac = px - xif, yfrac = py - yif, ofrac = a - oif;
           const int xi = int(xif), yi = int(yif), oi = int(oif);
+          // xi, yi are in 0..3 here (p in (-1, 4), truncation): the dx/dy = 0
+          // bins always exist, the dx/dy = 1 bins exist when xi/yi < 3.
+          const int o0 = oi & 7, o1 = (oi + 1) & 7;
+          const float wo0 = 1 - ofrac, wo1 = ofrac;
 #pragma unroll
           for (int dy = 0; dy < 2; ++dy)
           {
-            const int y_ = yi + dy;
-            if (y_ < 0 || y_ >= 4)
-              continue;
             const float wy = (dy == 0) ? 1 - yfrac : yfrac;
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx)
             {
-              const int x_ = xi + dx;
-              if (x_ < 0 || x_ >= 4)
-                continue;
               const float wx = (dx == 0) ? 1 - xfrac : xfrac;
-#pragma unroll
-              for (int dori = 0; dori < 2; ++dori)
-              {
-                const int o_ = (oi + dori) % 8;
-                const float wo = (dori == 0) ? 1 - ofrac : ofrac;
-                const float c = wy * wx * wo * weight * mag;
-                const float x14 = c * 16384.f;
-                const float hif = floorf(x14);
-                const int bin = (32 * y_ + 8 * x_ + o_) * kDescCopies + copy;
-                // q = hi * 2^20 + lo as one 64-bit two's-complement integer
-                const int hi = int(hif);
-                const unsigned lo = unsigned((x14 - hif) * 1048576.f);
-                // (lo can be exactly 2^20 when x14 is a tiny negative
-                // number and x14 - floor rounds up to 1: add, never OR)
-                const unsigned long long q = (unsigned long long) (
-                    (long long) hi * 1048576ll + (long long) lo);
-                atomicAdd(&hist[bin], q);
-              }
+              if ((dy == 1 && yi >= 3) || (dx == 1 && xi >= 3))
+                continue;
+              const int sb = (32 * (yi + dy) + 8 * (xi + dx)) * kDescCopies + copy;
+              const float c0 = wy * wx * wo0 * weight * mag;
+              const float c1 = wy * wx * wo1 * weight * mag;
+              atomicAdd(&hist[sb + o0 * kDescCopies],
+                        (unsigned long long) (long long) __float2int_rn(c0 * fx_scale));
+              atomicAdd(&hist[sb + o1 * kDescCopies],
+                        (unsigned long long) (long long) __float2int_rn(c1 * fx_scale));
             }
           }
         }
@@ -1202,8 +1259,8 @@ namespace sara_hip {
 #pragma unroll
       for (int c = 0; c < kDescCopies; ++c)
       {
-        a0 += double((long long) hist[lane * kDescCopies + c]) * 0x1p-34;
-        a1 += double((long long) hist[(lane + 64) * kDescCopies + c]) * 0x1p-34;
+        a0 += double((long long) hist[lane * kDescCopies + c]) * fx_inv;
+        a1 += double((long long) hist[(lane + 64) * kDescCopies + c]) * fx_inv;
       }
       float h0 = float(a0), h1 = float(a1);
       // normalize(): L2, clamp at 0.2, L2; then x512, clamp at 255.
@@ -1238,7 +1295,7 @@ namespace sara_hip {
                           float* descriptors, int with_descriptors,
                           hipStream_t stream)
   {
-    const dim3 grid((cand.cap + 3) / 4, batch);
+    const dim3 grid(8 * (((cand.cap + 3) / 4 + 7) / 8), batch);
     hipLaunchKernelGGL(descriptor_kernel, grid, dim3(256), 0, stream, grad, cand,
                        ori, features, scale_octave, descriptors,
                        with_descriptors);

@@ -195,6 +195,7 @@ struct sara_hip_sift
   // The DoG pyramid is never materialised (consumers subtract on the fly);
   // d_dog_plane is the scratch of the diff_of_gaussians() accessor.
   std::vector<float*> G, GR;
+  std::vector<unsigned*> CM;  // coarse 16x16 gradient-magnitude maxima
   float* d_dog_plane = nullptr;
   float* d_input = nullptr;  // staged host frames, or enlarge/blur scratch
   float* d_full = nullptr;   // first_octave > 0: blurred full-size frames
@@ -390,11 +391,15 @@ namespace {
     const int no = c->max_sched.num_octaves;
     c->G.assign(no, nullptr);
     c->GR.assign(no, nullptr);
+    c->CM.assign(no, nullptr);
     for (int o = 0; o < no; ++o)
     {
       const size_t pl = size_t(c->max_sched.oct[o].w) * c->max_sched.oct[o].h;
       TRY_ST(c->alloc(c->G[o], pl * c->S * max_batch));
       TRY_ST(c->alloc(c->GR[o], pl * c->S * max_batch * 2));
+      const size_t cpl = size_t((c->max_sched.oct[o].w + 15) / 16) *
+                         ((c->max_sched.oct[o].h + 15) / 16);
+      TRY_ST(c->alloc(c->CM[o], cpl * c->S * max_batch));
     }
     TRY_ST(c->alloc(c->d_dog_plane, size_t(c->max_sched.base_w) *
                                         std::max(c->max_sched.base_h, 1)));
@@ -681,6 +686,10 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       gv.plane[o] = size_t(gv.w[o]) * gv.h[o];
       gv.frame_stride[o] = gv.plane[o] * 2 * c->S;
       gv.factor[o] = c->cur.oct[o].factor;
+      gv.cmax[o] = c->CM[o];
+      gv.cw[o] = (gv.w[o] + 15) / 16;
+      gv.ch[o] = (gv.h[o] + 15) / 16;
+      gv.cmax_frame_stride[o] = size_t(gv.cw[o]) * gv.ch[o] * c->S;
     }
     HIP_TRY(hipMemcpyAsync(c->d_grad, c->h_grad, sizeof(GradPyramidView),
                            hipMemcpyHostToDevice, stream));
@@ -690,7 +699,17 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   c->last_stage = last_stage;
   c->has_result = false;
   std::fill(std::begin(c->ev_recorded), std::end(c->ev_recorded), false);
+  static const bool debug_sync = getenv("SARA_HIP_DEBUG_SYNC") != nullptr;
   auto mark = [&](int i) -> hipError_t {
+    if (debug_sync)
+    {
+      std::fprintf(stderr, "[sara_hip] stage mark %d: syncing...\n", i);
+      const hipError_t e = hipStreamSynchronize(stream);
+      std::fprintf(stderr, "[sara_hip] stage mark %d: %s\n", i,
+                   hipGetErrorString(e));
+      if (e != hipSuccess)
+        return e;
+    }
     if (!c->timers)
       return hipSuccess;
     c->ev_recorded[i] = true;
@@ -858,8 +877,12 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     {
       const int w = sc.oct[o].w, h = sc.oct[o].h;
       const size_t pl = size_t(w) * h;
+      const size_t cpl = size_t((w + 15) / 16) * ((h + 15) / 16);
+      HIP_TRY(hipMemsetAsync(c->CM[o], 0, cpl * S * batch * sizeof(unsigned),
+                             stream));
       launch_gradient_polar(c->G[o] + pl * s_lo, pl * S, c->GR[o] + pl * 2 * s_lo,
-                            pl * 2 * S, w, h, s_n, batch, stream);
+                            pl * 2 * S, w, h, s_n, batch, stream,
+                            c->CM[o] + cpl * s_lo, cpl * S);
     }
   }
   HIP_TRY(mark(4));

@@ -132,9 +132,14 @@ namespace sara_hip {
 
   // ---- gradients -----------------------------------------------------------
   //! (2*|grad|, atan2(gy,gx)) of `nscales` consecutive planes per frame.
+  //! cmax (optional): coarse map of the gradient magnitude, one uint32 (the
+  //! float's bits, magnitudes are >= 0) per 16x16 block, planes
+  //! [frame][scale][ceil(h/16)][ceil(w/16)], frame stride cmax_stride; the
+  //! kernels atomicMax into it, so it has to be zeroed before the launch.
   void launch_gradient_polar(const float* src, size_t src_stride, float* dst,
                              size_t dst_stride, int w, int h, int nscales,
-                             int batch, hipStream_t stream);
+                             int batch, hipStream_t stream,
+                             unsigned* cmax = nullptr, size_t cmax_stride = 0);
 
   // ---- extrema -------------------------------------------------------------
   //! Scans DoG scales 1..S-3 of one Gaussian octave.  The fast path only
@@ -169,6 +174,10 @@ namespace sara_hip {
     size_t frame_stride[16]; // in floats
     float factor[16];        // octave scaling factor
     int octaves;
+    // coarse magnitude maxima (16x16 blocks), planes [frame][scale][ch][cw]
+    const unsigned* cmax[16];
+    int cw[16], ch[16];
+    size_t cmax_frame_stride[16];  // in uint32
   };
 
   //! grad / tab are device pointers (indexed per wave, so they live in HBM
