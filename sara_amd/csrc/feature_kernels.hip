@@ -222,6 +222,11 @@ namespace sara_hip {
   //! Target number of waves per marching launch (tuning knobs; the defaults
   //! come from sweeps on MI355X with 64 x 1080p frames: the extremum scan
   //! likes long segments, the gradient kernel many short ones).
+  //! Consecutive workgroups (4 keypoints each) that stay on one XCD.
+  static const int g_xcd_run = [] {
+    const char* e = getenv("SARA_HIP_XCD_RUN");
+    return e ? std::max(1, atoi(e)) : 128;
+  }();
   static const int g_grad_waves = [] {
     const char* e = getenv("SARA_HIP_GRAD_WAVES");
     return e ? std::max(64, atoi(e)) : 8192;
@@ -816,13 +821,13 @@ namespace sara_hip {
   //! frame index: the chunks are not equally expensive (the tail of the list
   //! holds the large-scale keypoints), and a fixed assignment leaves one XCD
   //! with all the expensive chunks.  Returns the logical block index or -1.
-  __device__ inline int xcd_local_block(int bx, int frame, int nblk)
+  __device__ inline int xcd_local_block(int bx, int frame, int nblk, int run)
   {
-    const int chunk = (nblk + 7) >> 3;
+    // runs of `run` consecutive logical blocks, dealt round-robin to the XCDs
+    const int x = (bx + 3 * frame) & 7;
     const int j = bx >> 3;
-    if (j >= chunk)
-      return -1;
-    const int lb = ((bx + 3 * frame) & 7) * chunk + j;
+    const int q = j / run, i = j - q * run;
+    const int lb = (q * 8 + x) * run + i;
     return lb < nblk ? lb : -1;
   }
 
@@ -837,7 +842,7 @@ namespace sara_hip {
   __global__ __launch_bounds__(256) void orientation_kernel(
       const GradPyramidView* __restrict__ gradp,
       const ScaleTable* __restrict__ tabp, const double* __restrict__ weights,
-      CandidateLists cand, OrientationLists ori)
+      CandidateLists cand, OrientationLists ori, int xcd_run)
   {
     const GradPyramidView& grad = *gradp;
     const ScaleTable& tab = *tabp;
@@ -845,7 +850,7 @@ namespace sara_hip {
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int n = min(cand.count[b], cand.cap);
-    const int lb = xcd_local_block(blockIdx.x, b, (n + 3) >> 2);
+    const int lb = xcd_local_block(blockIdx.x, b, (n + 3) >> 2, xcd_run);
     if (lb < 0)
       return;
     const int idx = lb * 4 + wave;
@@ -958,9 +963,10 @@ namespace sara_hip {
   {
     // xcd_local_block() spreads ceil(n/4) work items over 8 chunks, so the
     // grid has to be a multiple of 8 blocks
-    const dim3 grid(8 * (((cand.cap + 3) / 4 + 7) / 8), batch);
+    const int unit = 8 * g_xcd_run;
+    const dim3 grid(unit * (((cand.cap + 3) / 4 + unit - 1) / unit), batch);
     hipLaunchKernelGGL(orientation_kernel, grid, dim3(256), 0, stream, grad, tab,
-                       ori_weights, cand, ori);
+                       ori_weights, cand, ori, g_xcd_run);
   }
 
   // ------------------------------------------------------------------------ //
@@ -1060,7 +1066,7 @@ namespace sara_hip {
       const GradPyramidView* __restrict__ gradp, CandidateLists cand,
       OrientationLists ori, sara_oeregion* __restrict__ features,
       int32_t* __restrict__ scale_octave, float* __restrict__ descriptors,
-      int with_descriptors)
+      int with_descriptors, int xcd_run)
   {
     const GradPyramidView& grad = *gradp;
     __shared__ unsigned long long s_acc[4][128 * kDescCopies];
@@ -1068,7 +1074,7 @@ namespace sara_hip {
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int n = min(cand.count[b], cand.cap);
-    const int lb = xcd_local_block(blockIdx.x, b, (n + 3) >> 2);
+    const int lb = xcd_local_block(blockIdx.x, b, (n + 3) >> 2, xcd_run);
     if (lb < 0)
       return;
     const int idx = lb * 4 + wave;
@@ -1295,10 +1301,11 @@ namespace sara_hip {
                           float* descriptors, int with_descriptors,
                           hipStream_t stream)
   {
-    const dim3 grid(8 * (((cand.cap + 3) / 4 + 7) / 8), batch);
+    const int unit = 8 * g_xcd_run;
+    const dim3 grid(unit * (((cand.cap + 3) / 4 + unit - 1) / unit), batch);
     hipLaunchKernelGGL(descriptor_kernel, grid, dim3(256), 0, stream, grad, cand,
                        ori, features, scale_octave, descriptors,
-                       with_descriptors);
+                       with_descriptors, g_xcd_run);
   }
 
   // ------------------------------------------------------------------------ //
