@@ -132,13 +132,22 @@ def main():
     from sara_amd.synth import synth_batch
     from sara_amd.distributed import gatherv_to_root
 
-    capi.require_gpu()
+    ndev = capi.require_gpu()
+    # SARA_BENCH_BACKEND=gloo lets the multi-process path be exercised on a box
+    # with fewer GPUs than ranks (ranks then share devices and the gather is
+    # staged through host memory); the real runs use nccl (= RCCL).
+    backend = os.environ.get("SARA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     B, W, H = args.frames_per_gpu, args.width, args.height
     frames_host = synth_batch(W, H, B, first_index=rank * B,
@@ -150,8 +159,10 @@ def main():
     ctx = sara_amd.SiftContext(W, H, B, params, device=local_rank)
     stream = torch.cuda.current_stream(dev)
 
-    # gather buffers (variable-length arrays, padded to the context capacity)
+    # keypoint arrays gathered on rank 0; the exchange of step i overlaps the
+    # kernels of step i+1 (one gather in flight)
     feat_buf = desc_buf = so_buf = None
+    pending = [None]
 
     def step():
         """One pass over the batch; returns this rank's keypoint count."""
@@ -177,11 +188,23 @@ def main():
                 ctx._h, mine_f.data_ptr(), mine_d.data_ptr(), mine_s.data_ptr(),
                 1))
         ctx.synchronize()  # the copies run on the detect stream
-        outs, _ = gatherv_to_root([mine_f, mine_d, mine_s], root=0)
-        if outs is not None:
-            feat_buf, desc_buf, so_buf = outs
+        if backend != "nccl":
+            mine_f, mine_d, mine_s = mine_f.cpu(), mine_d.cpu(), mine_s.cpu()
+        wait_gather()
+        pending[0] = gatherv_to_root([mine_f, mine_d, mine_s], root=0,
+                                     async_op=True)
+
+    def wait_gather():
+        nonlocal feat_buf, desc_buf, so_buf
+        if pending[0] is not None:
+            outs, _ = pending[0].wait()
+            pending[0] = None
+            if outs is not None:
+                feat_buf, desc_buf, so_buf = outs
 
     def sync():
+        if world > 1:
+            wait_gather()
         torch.cuda.synchronize()
         ctx.synchronize()
         if world > 1:
@@ -202,8 +225,9 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
 
-    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    kp = torch.tensor([kp_local], device=dev, dtype=torch.int64)
+    rdev = dev if backend == "nccl" else torch.device("cpu")
+    el = torch.tensor([elapsed], device=rdev, dtype=torch.float64)
+    kp = torch.tensor([kp_local], device=rdev, dtype=torch.int64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(kp, op=dist.ReduceOp.SUM)

@@ -19,11 +19,27 @@ def shard_range(n_frames, world_size, rank):
     return lo, hi
 
 
-def gatherv_to_root(arrays, root=0, group=None):
+class PendingGather:
+    """Handle of an asynchronous gatherv: keeps the send/receive buffers alive
+    until wait() returns."""
+
+    def __init__(self, outs, counts, reqs, keep):
+        self.outs, self.counts, self._reqs, self._keep = outs, counts, reqs, keep
+
+    def wait(self):
+        for r in self._reqs:
+            r.wait()
+        self._reqs, self._keep = [], None
+        return self.outs, self.counts
+
+
+def gatherv_to_root(arrays, root=0, group=None, async_op=False):
     """arrays: list of tensors whose first dimension is this rank's keypoint
     count n_r (same trailing shapes and dtypes on every rank).  Returns, on the
     root, (list of concatenated tensors in rank order, counts per rank); on the
-    other ranks (None, counts per rank)."""
+    other ranks (None, counts per rank).  With async_op=True the point-to-point
+    transfers are only posted and a PendingGather is returned, so the next
+    batch's kernels overlap the exchange."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n = int(arrays[0].shape[0])
@@ -35,6 +51,8 @@ def gatherv_to_root(arrays, root=0, group=None):
     dist.all_gather(all_n, n_t, group=group)
     counts = [int(t.item()) for t in all_n]
     if world == 1:
+        if async_op:
+            return PendingGather(list(arrays), counts, [], None)
         return list(arrays), counts
 
     if rank == root:
@@ -54,12 +72,19 @@ def gatherv_to_root(arrays, root=0, group=None):
             for o in outs:
                 ops.append(dist.P2POp(dist.irecv, o[offs[r]:offs[r] + counts[r]],
                                       r, group))
-        for req in (dist.batch_isend_irecv(ops) if ops else []):
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        if async_op:
+            return PendingGather(outs, counts, reqs, (outs, arrays))
+        for req in reqs:
             req.wait()
         return outs, counts
     ops = []
+    sends = [a.contiguous() for a in arrays]
     if n:
-        ops = [dist.P2POp(dist.isend, a.contiguous(), root, group) for a in arrays]
-    for req in (dist.batch_isend_irecv(ops) if ops else []):
+        ops = [dist.P2POp(dist.isend, a, root, group) for a in sends]
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    if async_op:
+        return PendingGather(None, counts, reqs, sends)
+    for req in reqs:
         req.wait()
     return None, counts

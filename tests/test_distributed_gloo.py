@@ -58,7 +58,13 @@ def _worker(rank, world, port, n_frames, tmpdir):
     arrays = [torch.from_numpy(cat(regs, (0, 48), np.uint8)),
               torch.from_numpy(cat(descs, (0, 128), np.float32)),
               torch.from_numpy(cat(sos, (0, 2), np.int32))]
+    # blocking and asynchronous forms must agree
     outs, counts = gatherv_to_root(arrays, root=0)
+    pending = gatherv_to_root(arrays, root=0, async_op=True)
+    outs2, counts2 = pending.wait()
+    assert counts2 == counts
+    if rank == 0:
+        assert all(torch.equal(a, b) for a, b in zip(outs, outs2))
     assert counts[rank] == sum(per_frame)
     if rank == 0:
         np.savez(os.path.join(tmpdir, "root.npz"), regs=outs[0].numpy(),
