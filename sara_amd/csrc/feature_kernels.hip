@@ -791,10 +791,10 @@ namespace sara_hip {
   // One wave per extremum.  The CPU path adds the window's pixels to the
   // 36-bin histogram one by one in raster order, rounding to float after every
   // addition (the weight is a double).  To reproduce that exactly, lanes
-  // evaluate 64 pixels at a time (bin, double contribution) and lanes 0..35
-  // each own one bin and replay the 64 contributions in raster order through
-  // v_readlane broadcasts.  Smoothing / peak search are exact lane-parallel
-  // restatements.
+  // evaluate 64 pixels at a time (bin, double contribution); a 64-bit mask per
+  // bin records which lanes hit it (ds_or_b64), and lanes 0..35 each own one
+  // bin and replay only their own contributions, in ascending lane = raster
+  // order.  Smoothing / peak search are exact lane-parallel restatements.
   // ======================================================================== //
   __device__ inline int key_octave(unsigned long long key)
   {
@@ -844,6 +844,8 @@ namespace sara_hip {
       const ScaleTable* __restrict__ tabp, const double* __restrict__ weights,
       CandidateLists cand, OrientationLists ori, int xcd_run)
   {
+    __shared__ unsigned long long s_mask[4][kOriBins];
+    __shared__ double s_contrib[4][64];
     const GradPyramidView& grad = *gradp;
     const ScaleTable& tab = *tabp;
     const int lane = threadIdx.x & 63;
@@ -881,6 +883,8 @@ namespace sara_hip {
     int v = lane / D - R;
     int u = lane % D - R;
     const int dv64 = 64 / D, du64 = 64 % D;
+    unsigned long long* bin_mask = s_mask[wave];
+    double* contrib = s_contrib[wave];
 
     for (int base = 0; base < npx; base += 64)
     {
@@ -899,17 +903,27 @@ namespace sara_hip {
           c = wt[u * u + v * v] * double(mo.x);
         }
       }
-#pragma unroll
-      for (int k = 0; k < 64; ++k)
+      // Which lanes of this chunk fall into which bin: one 64-bit mask per
+      // bin, built with integer LDS atomics.  The owner lane of a bin then
+      // replays exactly its contributions in ascending lane (= raster) order.
+      if (lane < kOriBins)
+        bin_mask[lane] = 0ull;
+      contrib[lane] = c;
+      __builtin_amdgcn_wave_barrier();
+      if (bin >= 0)
+        atomicOr(&bin_mask[bin], 1ull << lane);
+      __builtin_amdgcn_wave_barrier();
+      unsigned long long mine = lane < kOriBins ? bin_mask[lane] : 0ull;
+      while (__ballot(mine != 0ull) != 0ull)
       {
-        const int bk = __builtin_amdgcn_readlane(bin, k);
-        if (bk >= 0)  // wave-uniform
+        if (mine != 0ull)
         {
-          const double ck = readlane_f64(c, k);
-          if (lane == bk)
-            hist = float(double(hist) + ck);
+          const int k = __ffsll((long long) mine) - 1;
+          hist = float(double(hist) + contrib[k]);
+          mine &= mine - 1ull;
         }
       }
+      __builtin_amdgcn_wave_barrier();
       u += du64;
       v += dv64;
       if (u > R)
