@@ -1202,35 +1202,47 @@ namespace sara_hip {
       const float st = float(sin(double(theta)));
       const float T00 = ct / l, T01 = st / l, T10 = (-st) / l, T11 = ct / l;
 
-      for (int v = v_lo; v <= v_hi; ++v)
+      // Four patch rows per pass: each quarter wave (16 lanes) walks one row,
+      // 16 samples at a time, so that short rows do not leave most of the
+      // wave idle.  Row intervals are conservative (the exact float test
+      // below decides), hence the approximate reciprocals.
+      const bool t00_ok = fabsf(T00) > 1e-12f, t10_ok = fabsf(T10) > 1e-12f;
+      const float inv00 = t00_ok ? 1.f / T00 : 0.f;
+      const float inv10 = t10_ok ? 1.f / T10 : 0.f;
+      const int sub = lane >> 4, l16 = lane & 15;
+      for (int vb = v_lo; vb <= v_hi; vb += 4)
       {
-        // Conservative u-interval of the samples with |p.x|, |p.y| < 2.5 in
-        // this patch row (the exact float test below decides).
+        const int v = vb + sub;
         const float fv = float(v);
         float lo = float(u_min), hi = float(u_max);
         {
           const float bx_ = T01 * fv, by_ = T11 * fv;
-          if (fabsf(T00) > 1e-12f)
+          if (t00_ok)
           {
-            const float a = (-2.5f - bx_) / T00, c = (2.5f - bx_) / T00;
+            const float a = (-2.5f - bx_) * inv00, c = (2.5f - bx_) * inv00;
             lo = fmaxf(lo, fminf(a, c) - 1.f);
             hi = fminf(hi, fmaxf(a, c) + 1.f);
           }
           else if (fabsf(bx_) > 2.6f)
             hi = lo - 1.f;
-          if (fabsf(T10) > 1e-12f)
+          if (t10_ok)
           {
-            const float a = (-2.5f - by_) / T10, c = (2.5f - by_) / T10;
+            const float a = (-2.5f - by_) * inv10, c = (2.5f - by_) * inv10;
             lo = fmaxf(lo, fminf(a, c) - 1.f);
             hi = fminf(hi, fmaxf(a, c) + 1.f);
           }
           else if (fabsf(by_) > 2.6f)
             hi = lo - 1.f;
         }
-        const int u_lo = int(floorf(lo)), u_hi = int(ceilf(hi));
-        const float2* grow = g + size_t(ry + v) * w + rx;
-        for (int u = max(u_lo, u_min) + lane; u <= min(u_hi, u_max); u += 64)
+        int u = max(int(floorf(lo)), u_min) + l16;
+        int u_end = min(int(ceilf(hi)), u_max);
+        if (v > v_hi)
+          u_end = u - 1;
+        const float2* grow = g + size_t(ry + min(v, v_hi)) * w + rx;
+        for (; __ballot(u <= u_end) != 0ull; u += 16)
         {
+          if (u > u_end)
+            continue;
           float px = T00 * float(u) + T01 * fv;
           float py = T10 * float(u) + T11 * fv;
           const float nrm2 = px * px + py * py;
