@@ -227,6 +227,11 @@ namespace sara_hip {
     const char* e = getenv("SARA_HIP_XCD_RUN");
     return e ? std::max(1, atoi(e)) : 128;
   }();
+  //! log2 of the lanes that share one patch row in the descriptor kernel.
+  static const int g_desc_row_shift = [] {
+    const char* e = getenv("SARA_HIP_DESC_ROW_SHIFT");
+    return e ? std::min(6, std::max(2, atoi(e))) : 4;
+  }();
   static const int g_grad_waves = [] {
     const char* e = getenv("SARA_HIP_GRAD_WAVES");
     return e ? std::max(64, atoi(e)) : 8192;
@@ -552,12 +557,29 @@ namespace sara_hip {
   //! the per-layer 3x3 maxima are shared by the ND-2 scales scanned.  The rare
   //! classified sites go through finish_candidate().
   //! HBM traffic: 4*(ND+1) B read per pixel, nothing written but candidates.
+  //! Moves `qn` (<= 128) queued keys of one wave to the frame's site list.
+  __device__ inline void flush_sites(const unsigned long long* queue, int qn,
+                                     int lane, int frame, const SiteLists& sites)
+  {
+    int base = 0;
+    if (lane == 0)
+      base = atomicAdd(&sites.count[frame], qn);
+    base = __builtin_amdgcn_readfirstlane(base);
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < qn; i += 64)
+      if (base + i < sites.cap)
+        sites.key[size_t(frame) * sites.cap + base + i] = queue[i];
+    __builtin_amdgcn_wave_barrier();
+  }
+
   template <int ND, int PF>
   __global__ __launch_bounds__(64) void extrema_march_kernel(
       OctaveView gauss, int octave, ExtremaParams p, SiteLists sites,
       int seg_rows, int nstrips)
   {
     static_assert(PF == 3, "the row loop is unrolled 3x");
+    __shared__ unsigned long long s_queue[128];
+    int qn = 0;  // wave-uniform fill of the queue
     constexpr int NG = ND + 1;
     constexpr int STRIDE = 126;
     const int lane = threadIdx.x;
@@ -638,24 +660,36 @@ namespace sara_hip {
             const bool mine = (c == 0 ? lane > 0 : lane < 63) && x >= pad &&
                               x < w - pad;
             const bool is_max = (v == M), is_min = (v == N);
-            if (mine && !(fabsf(v) < thr8) && (is_max || is_min))
+            // Classified sites go to a wave-local LDS queue first and reach
+            // the frame's list in batches: one returning atomic per ~64 sites
+            // instead of one per site (every wave of a frame hits the same
+            // counter, and that serialisation was the kernel's bottleneck).
+            // The edge test / refinement run later in finish_sites_kernel.
+            const bool hit = mine && !(fabsf(v) < thr8) && (is_max || is_min);
+            const unsigned long long hits = __ballot(hit);
+            if (hits != 0ull)
             {
-              // classified site: edge test / refinement run in
-              // finish_sites_kernel (keeps this kernel's register budget low)
-              const int slot = atomicAdd(&sites.count[b], 1);
-              if (slot < sites.cap)
-                sites.key[size_t(b) * sites.cap + slot] =
+              if (hit)
+                s_queue[qn + __popcll(hits & ((1ull << lane) - 1ull))] =
                     ((((unsigned long long) (octave * kMaxScales + s) << 20 |
                        (unsigned) y)
                       << 20 |
                       (unsigned) x)
                      << 1) |
                     (unsigned) is_max;
+              qn += __popcll(hits);
+              if (qn >= 64)
+              {
+                flush_sites(s_queue, qn, lane, b, sites);
+                qn = 0;
+              }
             }
           }
         }
       }
     }
+    if (qn > 0)
+      flush_sites(s_queue, qn, lane, b, sites);
   }
 
   //! Second half of the fast path: one thread per classified site.
@@ -1080,7 +1114,7 @@ namespace sara_hip {
       const GradPyramidView* __restrict__ gradp, CandidateLists cand,
       OrientationLists ori, sara_oeregion* __restrict__ features,
       int32_t* __restrict__ scale_octave, float* __restrict__ descriptors,
-      int with_descriptors, int xcd_run)
+      int with_descriptors, int xcd_run, int row_shift)
   {
     const GradPyramidView& grad = *gradp;
     __shared__ unsigned long long s_acc[4][128 * kDescCopies];
@@ -1209,8 +1243,9 @@ namespace sara_hip {
       const bool t00_ok = fabsf(T00) > 1e-12f, t10_ok = fabsf(T10) > 1e-12f;
       const float inv00 = t00_ok ? 1.f / T00 : 0.f;
       const float inv10 = t10_ok ? 1.f / T10 : 0.f;
-      const int sub = lane >> 4, l16 = lane & 15;
-      for (int vb = v_lo; vb <= v_hi; vb += 4)
+      const int sub = lane >> row_shift, l16 = lane & ((1 << row_shift) - 1);
+      const int rows_per_pass = 64 >> row_shift, lanes_per_row = 1 << row_shift;
+      for (int vb = v_lo; vb <= v_hi; vb += rows_per_pass)
       {
         const int v = vb + sub;
         const float fv = float(v);
@@ -1239,7 +1274,7 @@ namespace sara_hip {
         if (v > v_hi)
           u_end = u - 1;
         const float2* grow = g + size_t(ry + min(v, v_hi)) * w + rx;
-        for (; __ballot(u <= u_end) != 0ull; u += 16)
+        for (; __ballot(u <= u_end) != 0ull; u += lanes_per_row)
         {
           if (u > u_end)
             continue;
@@ -1331,7 +1366,7 @@ namespace sara_hip {
     const dim3 grid(unit * (((cand.cap + 3) / 4 + unit - 1) / unit), batch);
     hipLaunchKernelGGL(descriptor_kernel, grid, dim3(256), 0, stream, grad, cand,
                        ori, features, scale_octave, descriptors,
-                       with_descriptors, g_xcd_run);
+                       with_descriptors, g_xcd_run, g_desc_row_shift);
   }
 
   // ------------------------------------------------------------------------ //
