@@ -284,15 +284,12 @@ namespace sara_hip {
     const float zneg = int_as_float(float_as_int(z) ^ (int32_t) 0x80000000);
     float r = m == 0 ? z : (m == 1 ? zneg : (m == 2 ? pi - (z - pi_lo)
                                                    : (z - pi_lo) - pi));
-    if (hx == 0x3f800000)  // x == 1: atanf(y), odd in y
-    {
-      const float a = atanf_nonneg_select(int_as_float(iy));
-      r = hy < 0 ? -a : a;
-    }
+    // fdlibm's x == 1 shortcut (atanf(y)) and its y == 0 cases for x != 0 are
+    // reproduced by the general path bit for bit (y/1 == y; atan(0) == 0 and
+    // pi - (0 - pi_lo) rounds to pi), so only x == +-0 needs a select.
     if (ix == 0)
-      r = hy < 0 ? -pi_o_2 : pi_o_2;
-    if (iy == 0)
-      r = (m == 0 || m == 1) ? y : (m == 2 ? pi : -pi);
+      r = iy == 0 ? ((m & 2) ? (hy < 0 ? -pi : pi) : y)
+                  : (hy < 0 ? -pi_o_2 : pi_o_2);
     return r;
   }
 

@@ -170,19 +170,14 @@ namespace sara_hip {
           for (int c = 0; c < 4; ++c)
           {
             const int x = col + c;
-            float gx, gy;
-            if (x == 0)
-              gx = (cx[c + 2] - cx[c + 1]) / 2;
-            else if (x == w - 1)
-              gx = (cx[c + 1] - cx[c]) / 2;
-            else
-              gx = (cx[c + 2] - cx[c]) / 2;
-            if (y == 0)
-              gy = (cd[c] - cx[c + 1]) / 2;
-            else if (y == h - 1)
-              gy = (cx[c + 1] - cu[c]) / 2;
-            else
-              gy = (cd[c] - cu[c]) / 2;
+            // one-sided differences on the borders = central differences
+            // with the missing neighbour replaced by the pixel itself
+            const float xp = (x == w - 1) ? cx[c + 1] : cx[c + 2];
+            const float xm = (x == 0) ? cx[c + 1] : cx[c];
+            const float yp = (y == h - 1) ? cx[c + 1] : cd[c];
+            const float ym = (y == 0) ? cx[c + 1] : cu[c];
+            const float gx = (xp - xm) / 2;
+            const float gy = (yp - ym) / 2;
             res[2 * c] = 2 * sqrtf(gx * gx + gy * gy);
             res[2 * c + 1] = fdlibm_atan2f_fast(gy, gx);
           }
@@ -231,6 +226,13 @@ namespace sara_hip {
   static const int g_desc_row_shift = [] {
     const char* e = getenv("SARA_HIP_DESC_ROW_SHIFT");
     return e ? std::min(6, std::max(2, atoi(e))) : 4;
+  }();
+  //! Off by default: measured on MI355X the fused pass takes as long as the
+  //! two separate kernels (3.3 ms per 64 frames either way - the gradient's
+  //! exact atan2/sqrt/div sequence is VALU-bound, not bandwidth-bound).
+  static const bool g_fuse_gradient = [] {
+    const char* e = getenv("SARA_HIP_FUSE_GRADIENT");
+    return e && std::string(e) == "1";
   }();
   static const int g_grad_waves = [] {
     const char* e = getenv("SARA_HIP_GRAD_WAVES");
@@ -572,15 +574,24 @@ namespace sara_hip {
     __builtin_amdgcn_wave_barrier();
   }
 
-  template <int ND, int PF>
+  //! GRAD: the same pass also writes the polar gradients (2|grad|, atan2) of
+  //! the Gaussian planes 1..ND-2 - the only ones the orientation and descriptor
+  //! stages read - and their coarse 16x16 magnitude maxima.  The scan is
+  //! bandwidth-bound with idle VALUs and the gradient is VALU-heavy, so the
+  //! fused pass costs about max(...) instead of the sum and saves re-reading
+  //! the three planes (see gradient_polar_march_kernel for the stand-alone
+  //! form and the reference citations).
+  template <int ND, int PF, bool GRAD>
   __global__ __launch_bounds__(64) void extrema_march_kernel(
       OctaveView gauss, int octave, ExtremaParams p, SiteLists sites,
-      int seg_rows, int nstrips)
+      int seg_rows, int nstrips, float* __restrict__ grad,
+      size_t grad_frame_stride, unsigned* __restrict__ cmax, size_t cmax_stride)
   {
     static_assert(PF == 3, "the row loop is unrolled 3x");
     __shared__ unsigned long long s_queue[128];
     int qn = 0;  // wave-uniform fill of the queue
     constexpr int NG = ND + 1;
+    constexpr int NS = ND - 2;  // scanned scales = gradient planes 1..NS
     constexpr int STRIDE = 126;
     const int lane = threadIdx.x;
     const int strip = blockIdx.x % nstrips;
@@ -608,6 +619,21 @@ namespace sara_hip {
 
     float2 pg[PF][NG];
     float2 ring[3][ND];
+    float2 gring[3][GRAD ? NS : 1];  // Gaussian rows y-1, y, y+1 of planes 1..NS
+    float run_max[GRAD ? NS : 1];
+#pragma unroll
+    for (int t = 0; t < (GRAD ? NS : 1); ++t)
+      run_max[t] = 0.f;
+    const int cw = (w + 15) / 16, ch = (h + 15) / 16;
+    if (GRAD)
+    {
+      grad += size_t(b) * grad_frame_stride;
+      cmax += size_t(b) * cmax_stride;
+    }
+    // column validity of the gradient outputs (interior of the strip, or an
+    // image border column where the one-sided difference needs no neighbour)
+    const bool gvalid0 = (col < w) && (lane > 0 || col == 0);
+    const bool gvalid1 = (col + 1 < w) && (lane < 63 || col + 1 == w - 1);
 #pragma unroll
     for (int q = 0; q < PF; ++q)
       load_row(y0 - 1 + q, pg[q]);
@@ -624,12 +650,92 @@ namespace sara_hip {
         for (int l = 0; l < ND; ++l)
           ring[i][l] = make_float2(pg[i][l + 1].x - pg[i][l].x,
                                    pg[i][l + 1].y - pg[i][l].y);
+        if (GRAD)
+        {
+#pragma unroll
+          for (int t = 0; t < NS; ++t)
+            gring[i][t] = pg[i][t + 1];
+        }
         load_row(yy + PF, pg[i]);
 
         const int y = yy - 1;
+        const int ia = (i + 1) % 3, ib = (i + 2) % 3, ic = i;  // y-1, y, y+1
+        if (GRAD && n >= 2 && y < y1)
+        {
+#pragma unroll
+          for (int t = 0; t < NS; ++t)
+          {
+            const float2 up = gring[ia][t], mid = gring[ib][t], dn = gring[ic][t];
+            const float left = shift_from_prev(mid.y);
+            const float right = shift_from_next(mid.x);
+            // Differential.hpp:46-61: central difference / 2, one-sided on
+            // the image borders
+            float gx0, gx1, gy0, gy1;
+            if (col == 0)
+              gx0 = (mid.y - mid.x) / 2;
+            else
+              gx0 = (mid.y - left) / 2;
+            if (col + 1 == w - 1)
+              gx1 = (mid.y - mid.x) / 2;
+            else
+              gx1 = (right - mid.x) / 2;
+            if (y == 0)
+            {
+              gy0 = (dn.x - mid.x) / 2;
+              gy1 = (dn.y - mid.y) / 2;
+            }
+            else if (y == h - 1)
+            {
+              gy0 = (mid.x - up.x) / 2;
+              gy1 = (mid.y - up.y) / 2;
+            }
+            else
+            {
+              gy0 = (dn.x - up.x) / 2;
+              gy1 = (dn.y - up.y) / 2;
+            }
+            const float r0 = 2 * sqrtf(gx0 * gx0 + gy0 * gy0);
+            const float r1 = 2 * sqrtf(gx1 * gx1 + gy1 * gy1);
+            const float a0 = fdlibm_atan2f_fast(gy0, gx0);
+            const float a1 = fdlibm_atan2f_fast(gy1, gx1);
+            float* op = grad + (size_t(t + 1) * plane + size_t(y) * w + col) * 2;
+            if (gvalid0 && gvalid1)
+              *reinterpret_cast<float4*>(op) = make_float4(r0, a0, r1, a1);
+            else if (gvalid0)
+              *reinterpret_cast<float2*>(op) = make_float2(r0, a0);
+            else if (gvalid1)
+              *reinterpret_cast<float2*>(op + 2) = make_float2(r1, a1);
+            run_max[t] = fmaxf(run_max[t], fmaxf(gvalid0 ? r0 : 0.f,
+                                                 gvalid1 ? r1 : 0.f));
+          }
+          if ((y & 15) == 15 || y == y1 - 1)
+          {
+            // one atomicMax per 16-column cell touched by this wave
+            const int cell = col >> 4;
+#pragma unroll
+            for (int t = 0; t < NS; ++t)
+            {
+              unsigned long long todo = __ballot(col < w);
+              while (todo != 0ull)
+              {
+                const int leader = __ffsll((long long) todo) - 1;
+                const int cid = __builtin_amdgcn_readlane(cell, leader);
+                const bool same = (cell == cid) && (col < w);
+                float m = same ? run_max[t] : 0.f;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1)
+                  m = fmaxf(m, __shfl_xor(m, off));
+                if (lane == leader)
+                  atomicMax(cmax + (size_t(t + 1) * ch + (y >> 4)) * cw + cid,
+                            __float_as_uint(m));
+                todo &= ~__ballot(same);
+              }
+              run_max[t] = 0.f;
+            }
+          }
+        }
         if (n < 2 || y >= y1 || y < pad || y >= h - pad)
           continue;  // wave-uniform
-        const int ia = (i + 1) % 3, ib = (i + 2) % 3, ic = i;  // y-1, y, y+1
 
         float2 m[ND], mn[ND];
 #pragma unroll
@@ -722,14 +828,16 @@ namespace sara_hip {
                        tab, sites, cand);
   }
 
-  void launch_extrema_scan(const OctaveView& gauss, int octave, int batch,
+  bool launch_extrema_scan(const OctaveView& gauss, int octave, int batch,
                            const ExtremaParams& p, const ScaleTable* tab,
                            const CandidateLists& cand, const SiteLists& sites,
-                           hipStream_t stream)
+                           hipStream_t stream, float* grad,
+                           size_t grad_frame_stride, unsigned* cmax,
+                           size_t cmax_stride)
   {
     const int nscan = gauss.scales - 3;  // DoG layers 1 .. (scales-1)-2
     if (nscan <= 0)
-      return;
+      return false;
     const bool aligned2 = (gauss.w % 2 == 0) && gauss.w >= 4 &&
                           (gauss.plane % 2 == 0) &&
                           (reinterpret_cast<uintptr_t>(gauss.base) % 8 == 0);
@@ -740,15 +848,27 @@ namespace sara_hip {
       nseg = std::max(1, std::min(nseg, (gauss.h + 15) / 16));
       const int seg_rows = (gauss.h + nseg - 1) / nseg;
       nseg = (gauss.h + seg_rows - 1) / seg_rows;
-      hipLaunchKernelGGL((extrema_march_kernel<5, 3>), dim3(nstrips * nseg, batch),
-                         dim3(64), 0, stream, gauss, octave, p, sites, seg_rows,
-                         nstrips);
-      return;
+      const bool fuse = grad != nullptr && cmax != nullptr && g_fuse_gradient &&
+                        gauss.h >= 2 &&
+                        (reinterpret_cast<uintptr_t>(grad) % 16 == 0) &&
+                        (grad_frame_stride % 4 == 0);
+      if (fuse)
+        hipLaunchKernelGGL((extrema_march_kernel<5, 3, true>),
+                           dim3(nstrips * nseg, batch), dim3(64), 0, stream,
+                           gauss, octave, p, sites, seg_rows, nstrips, grad,
+                           grad_frame_stride, cmax, cmax_stride);
+      else
+        hipLaunchKernelGGL((extrema_march_kernel<5, 3, false>),
+                           dim3(nstrips * nseg, batch), dim3(64), 0, stream,
+                           gauss, octave, p, sites, seg_rows, nstrips, nullptr,
+                           0, nullptr, 0);
+      return fuse;
     }
     const dim3 block(64, 4);
     const dim3 grid((gauss.w + 63) / 64, (gauss.h + 3) / 4, batch * nscan);
     hipLaunchKernelGGL(extrema_scan_kernel, grid, block, 0, stream, gauss, octave,
                        nscan, p, tab, cand);
+    return false;
   }
 
   __global__ void extremum_map_kernel(const float* __restrict__ a,

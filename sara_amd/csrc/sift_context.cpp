@@ -823,6 +823,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   HIP_TRY(mark(2));
 
   // ---- extrema ------------------------------------------------------------
+  bool grad_fused[16] = {};
   HIP_TRY(hipMemsetAsync(c->cand.count, 0, sizeof(int) * batch, stream));
   HIP_TRY(hipMemsetAsync(c->sites.count, 0, sizeof(int) * batch, stream));
   HIP_TRY(hipMemsetAsync(c->ori.kp_count, 0, sizeof(int) * batch, stream));
@@ -845,9 +846,20 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       dv.scales = S;
       dv.plane = size_t(dv.w) * dv.h;
       dv.frame_stride = dv.plane * S;
+      // With the gradient stage requested, the scan of the fast path also
+      // emits the polar gradients of the planes it has in registers.
+      const bool want_grad =
+          last_stage >= SARA_HIP_STAGE_GRADIENT && !c->all_gradient_scales;
+      const size_t cpl = size_t((dv.w + 15) / 16) * ((dv.h + 15) / 16);
+      grad_fused[o] = false;
+      if (want_grad)
+        HIP_TRY(hipMemsetAsync(c->CM[o], 0, cpl * S * batch * sizeof(unsigned),
+                               stream));
       if (dv.w > 2 * c->img_padding && dv.h > 2 * c->img_padding)
-        launch_extrema_scan(dv, o, batch, ep, c->d_tab, c->cand, c->sites,
-                            stream);
+        grad_fused[o] = launch_extrema_scan(
+            dv, o, batch, ep, c->d_tab, c->cand, c->sites, stream,
+            want_grad ? c->GR[o] : nullptr, dv.plane * 2 * S,
+            want_grad ? c->CM[o] : nullptr, cpl * S);
     }
     {
       OctavePyramidView pv{};
@@ -877,6 +889,8 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     {
       const int w = sc.oct[o].w, h = sc.oct[o].h;
       const size_t pl = size_t(w) * h;
+      if (grad_fused[o])
+        continue;  // written by the extremum scan
       const size_t cpl = size_t((w + 15) / 16) * ((h + 15) / 16);
       HIP_TRY(hipMemsetAsync(c->CM[o], 0, cpl * S * batch * sizeof(unsigned),
                              stream));

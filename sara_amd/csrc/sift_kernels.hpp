@@ -146,10 +146,17 @@ namespace sara_hip {
   //! classifies and appends to `sites` (finish with launch_finish_sites once
   //! all octaves are scanned); the general path refines and appends to `cand`
   //! directly.
-  void launch_extrema_scan(const OctaveView& gauss, int octave, int batch,
+  //! When `grad`/`cmax` are given and the fast path runs, the same pass also
+  //! writes the polar gradients of planes 1..S-3 (octave base
+  //! [frame][scale][h][w][2], frame stride in floats) and their coarse maxima
+  //! (cmax must be zeroed), and the function returns true; otherwise the
+  //! caller runs launch_gradient_polar itself.
+  bool launch_extrema_scan(const OctaveView& gauss, int octave, int batch,
                            const ExtremaParams& p, const ScaleTable* tab,
                            const CandidateLists& cand, const SiteLists& sites,
-                           hipStream_t stream);
+                           hipStream_t stream, float* grad = nullptr,
+                           size_t grad_frame_stride = 0, unsigned* cmax = nullptr,
+                           size_t cmax_stride = 0);
 
   //! Edge test + refinement + contrast test of the classified sites.
   void launch_finish_sites(const OctavePyramidView& pyr, int batch,
