@@ -1040,22 +1040,41 @@ namespace sara_hip {
     unsigned long long* bin_mask = s_mask[wave];
     double* contrib = s_contrib[wave];
 
+    auto sample = [&](int base_, int u_, int v_, float2& mo_) -> bool {
+      const int xx = rx + u_, yy = ry + v_;
+      const bool ok = (base_ + lane < npx) && xx >= 0 && xx < w && yy >= 0 &&
+                      yy < h;
+      mo_ = make_float2(0.f, 0.f);
+      if (ok)
+        mo_ = g[size_t(yy) * w + xx];
+      return ok;
+    };
+    float2 mo_next;
+    bool ok_next = sample(0, u, v, mo_next);
+
     for (int base = 0; base < npx; base += 64)
     {
       int bin = -1;
       double c = 0.;
-      if (base + lane < npx)
+      const float2 mo = mo_next;
+      const bool ok = ok_next;
+      const int uc = u, vc = v;
+      // advance to the next chunk's pixel and start its gather right away
+      u += du64;
+      v += dv64;
+      if (u > R)
       {
-        const int xx = rx + u, yy = ry + v;
-        if (xx >= 0 && xx < w && yy >= 0 && yy < h)
-        {
-          const float2 mo = g[size_t(yy) * w + xx];
-          float a = mo.y;
-          a = a < 0 ? a + float(2. * M_PI) : a;
-          bin = int(floor(double(a / float(2 * M_PI) * kOriBins)));
-          bin %= kOriBins;
-          c = wt[u * u + v * v] * double(mo.x);
-        }
+        u -= D;
+        v += 1;
+      }
+      ok_next = sample(base + 64, u, v, mo_next);
+      if (ok)
+      {
+        float a = mo.y;
+        a = a < 0 ? a + float(2. * M_PI) : a;
+        bin = int(floor(double(a / float(2 * M_PI) * kOriBins)));
+        bin %= kOriBins;
+        c = wt[uc * uc + vc * vc] * double(mo.x);
       }
       // Which lanes of this chunk fall into which bin: one 64-bit mask per
       // bin, built with integer LDS atomics.  The owner lane of a bin then
@@ -1078,13 +1097,6 @@ namespace sara_hip {
         }
       }
       __builtin_amdgcn_wave_barrier();
-      u += du64;
-      v += dv64;
-      if (u > R)
-      {
-        u -= D;
-        v += 1;
-      }
     }
 
     // lowe_smooth_histogram: 6 circular box-blur iterations.
@@ -1394,8 +1406,16 @@ namespace sara_hip {
         if (v > v_hi)
           u_end = u - 1;
         const float2* grow = g + size_t(ry + min(v, v_hi)) * w + rx;
+        // one sample of look-ahead: the gather of the next sample is in
+        // flight while this one is accumulated
+        float2 nxt = make_float2(0.f, 0.f);
+        if (u <= u_end)
+          nxt = grow[u];
         for (; __ballot(u <= u_end) != 0ull; u += lanes_per_row)
         {
+          const float2 mo = nxt;
+          if (u + lanes_per_row <= u_end)
+            nxt = grow[u + lanes_per_row];
           if (u > u_end)
             continue;
           float px = T00 * float(u) + T01 * fv;
@@ -1406,7 +1426,6 @@ namespace sara_hip {
           if (fminf(px, py) <= -1.f || fmaxf(px, py) >= 4.f)
             continue;
           const float weight = __expf(-nrm2 / (2.f * 4.f));
-          const float2 mo = grow[u];
           const float mag = mo.x;
           float a = mo.y - theta;
           a = a < 0.f ? a + 2.f * pi : a;
