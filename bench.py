@@ -278,14 +278,18 @@ def main():
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {
                 "kernel": "gaussian_blur_march_kernel<R> (Gaussian pyramid "
-                          "stage: %d launches/step, the 3 nearest-neighbour "
-                          "octave hand-overs timed with the blurs)" % launches,
+                          "stage = %d blur launches/step on per-octave "
+                          "streams; the octave hand-overs are fused into "
+                          "them; achieved = 48*P*frames / stage time from "
+                          "HIP events)" % (launches - 3),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "launches_per_step": launches - 3,
+                "avg_launch_us": 1e3 * pyr_ms / max(launches - 3, 1),
                 "algorithmic_bytes_per_step": bytes_frame * B,
                 "us_per_frame": 1e3 * pyr_ms / B,
             },
