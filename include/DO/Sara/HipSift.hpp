@@ -97,6 +97,12 @@ namespace DO::Sara {
     std::vector<T> _storage;
   };
 
+  //! Core/Pixel/Typedefs.hpp Rgb8: three contiguous bytes.
+  struct Rgb8
+  {
+    std::uint8_t r, g, b;
+  };
+
   //! ImageProcessing/ImagePyramid.hpp:29-198.
   class ImagePyramidParams
   {
@@ -304,6 +310,21 @@ namespace DO::Sara {
     using Context = std::unique_ptr<sara_hip_sift, Deleter>;
 
   }  // namespace hip_detail
+
+  static_assert(sizeof(Rgb8) == 3, "Rgb8 must be three packed bytes");
+
+  //! ImageProcessing/FastColorConversion.hpp:22-23 (.cpp:42-66): same
+  //! signature, same std::domain_error on a size mismatch.
+  inline auto from_rgb8_to_gray32f(const ImageView<Rgb8>& src,
+                                   ImageView<float>& dst, int device = 0) -> void
+  {
+    if (src.width() != dst.width() || src.height() != dst.height())
+      throw std::domain_error{
+          "Color conversion error: image sizes are not equal!"};
+    hip_detail::check(sara_hip_from_rgb8_to_gray32f(
+        reinterpret_cast<const std::uint8_t*>(src.data()), dst.data(),
+        src.width(), src.height(), device));
+  }
 
   //! FeatureDetectors/SIFT.hpp:24-33.  `parallel` is accepted for signature
   //! compatibility; `device` selects the GPU (extension, defaulted).

@@ -188,6 +188,17 @@ SARA_HIP_API sara_hip_status sara_hip_sift_detect(
     int width, int height, int images_on_device, sara_hip_stage last_stage,
     void* hip_stream);
 
+/* Same as sara_hip_sift_detect() for 8-bit frames, converted to gray32f on the  */
+/* device: channels = 3 for interleaved RGB8     */
+/* (from_rgb8_to_gray32f, ImageProcessing/FastColorConversion.cpp:42-66: /255.0 */
+/* and 0.2125 R + 0.7154 G + 0.0721 B in double, cast to float), channels = 1   */
+/* for gray8 (v / 255.f).  frame_stride is in BYTES (0 -> width*height*channels).*/
+/* 3/4 (RGB8) or 1/4 (gray8) of the PCIe bytes of a float frame.                */
+SARA_HIP_API sara_hip_status sara_hip_sift_detect_u8(
+    sara_hip_sift* ctx, const uint8_t* images, size_t frame_stride, int channels,
+    int batch, int width, int height, int images_on_device,
+    sara_hip_stage last_stage, void* hip_stream);
+
 /* Waits for the last detect() on this context. */
 SARA_HIP_API sara_hip_status sara_hip_sift_synchronize(sara_hip_sift* ctx);
 
@@ -314,6 +325,16 @@ SARA_HIP_API sara_hip_status sara_hip_scale_space_dog_extremum_map(
     const float* a, const float* b, const float* c, int width, int height,
     float edge_ratio_thres, float extremum_thres, int img_padding_sz,
     int8_t* out, int device);
+
+/* from_rgb8_to_gray32f(src, dst) - ImageProcessing/FastColorConversion.cpp:    */
+/* 42-66 (seam: shakti_rgb8u_to_gray32f_cpu) - and the gray8 analogue.          */
+SARA_HIP_API sara_hip_status sara_hip_from_rgb8_to_gray32f(const uint8_t* rgb,
+                                                          float* gray, int width,
+                                                          int height, int device);
+SARA_HIP_API sara_hip_status sara_hip_from_gray8_to_gray32f(const uint8_t* src,
+                                                           float* gray, int width,
+                                                           int height,
+                                                           int device);
 
 /* Host self-check: evaluates, on the CPU, the float atan2 sequence the polar-  */
 /* gradient kernels execute on the GPU (a restatement of glibc 2.35's          */

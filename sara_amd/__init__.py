@@ -24,6 +24,7 @@ __all__ = [
     "compute_sift_keypoints", "SiftContext", "ComputeDoGExtrema",
     "apply_gaussian_filter", "gaussian", "scale", "downscale", "enlarge",
     "gradient_polar_coordinates", "scale_space_dog_extremum_map",
+    "from_rgb8_to_gray32f", "from_gray8_to_gray32f",
     "make_gaussian_kernel", "SaraHipError", "OEREGION_DTYPE",
 ]
 
@@ -195,6 +196,26 @@ class SiftContext:
         self.batch = b
         capi.check(capi.load().sara_hip_sift_detect(
             self._h, a.ctypes.data, 0, b, w, h, 0, int(last_stage), stream))
+        return self
+
+    def detect_u8(self, images, last_stage=STAGE_DESCRIPTOR, stream=None):
+        """8-bit frames converted on the device: H x W or B x H x W (gray8),
+        H x W x 3 or B x H x W x 3 (RGB8, from_rgb8_to_gray32f semantics)."""
+        a = np.ascontiguousarray(images, dtype=np.uint8)
+        if a.ndim == 2 or (a.ndim == 3 and a.shape[-1] == 3):
+            a = a[None]
+        if a.ndim == 3:
+            channels = 1
+        elif a.ndim == 4 and a.shape[-1] == 3:
+            channels = 3
+        else:
+            raise ValueError("images must be (B,)H x W or (B,)H x W x 3 uint8")
+        b, h, w = a.shape[:3]
+        self._keepalive = a
+        self.batch = b
+        capi.check(capi.load().sara_hip_sift_detect_u8(
+            self._h, a.ctypes.data, 0, channels, b, w, h, 0, int(last_stage),
+            stream))
         return self
 
     def detect_device(self, ptr, batch, width, height, frame_stride=0,
@@ -402,6 +423,28 @@ def enlarge(src, dst_width, dst_height, device=0):
         sp, s.shape[1], s.shape[0], d.ctypes.data_as(C.POINTER(C.c_float)),
         dst_width, dst_height, device))
     return d
+
+
+def from_rgb8_to_gray32f(rgb, device=0):
+    """ImageProcessing/FastColorConversion.cpp:42-66: H x W x 3 uint8 ->
+    H x W float32."""
+    a = np.ascontiguousarray(rgb, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("rgb must be H x W x 3 uint8")
+    out = np.zeros(a.shape[:2], np.float32)
+    capi.check(capi.load().sara_hip_from_rgb8_to_gray32f(
+        a.ctypes.data, out.ctypes.data_as(C.POINTER(C.c_float)), a.shape[1],
+        a.shape[0], device))
+    return out
+
+
+def from_gray8_to_gray32f(src, device=0):
+    a = np.ascontiguousarray(src, dtype=np.uint8)
+    out = np.zeros(a.shape, np.float32)
+    capi.check(capi.load().sara_hip_from_gray8_to_gray32f(
+        a.ctypes.data, out.ctypes.data_as(C.POINTER(C.c_float)), a.shape[1],
+        a.shape[0], device))
+    return out
 
 
 def gradient_polar_coordinates(src, device=0):

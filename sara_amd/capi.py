@@ -76,6 +76,8 @@ EXPORTS = [
     "sara_hip_apply_gaussian_filter", "sara_hip_scale", "sara_hip_enlarge",
     "sara_hip_subtract", "sara_hip_gradient_polar_coordinates",
     "sara_hip_scale_space_dog_extremum_map", "sara_hip_selfcheck_atan2f",
+    "sara_hip_sift_detect_u8", "sara_hip_from_rgb8_to_gray32f",
+    "sara_hip_from_gray8_to_gray32f",
 ]
 
 _f32p = C.POINTER(C.c_float)
@@ -145,6 +147,12 @@ def _declare(lib):
     lib.sara_hip_scale_space_dog_extremum_map.argtypes = [
         _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
         C.POINTER(C.c_int8), C.c_int]
+    lib.sara_hip_sift_detect_u8.argtypes = [_vp, _vp, C.c_size_t, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, _vp]
+    for name in ("sara_hip_from_rgb8_to_gray32f",
+                 "sara_hip_from_gray8_to_gray32f"):
+        getattr(lib, name).argtypes = [_vp, _f32p, C.c_int, C.c_int, C.c_int]
     lib.sara_hip_selfcheck_atan2f.argtypes = [_f32p, _f32p, _f32p, C.c_size_t]
     lib.sara_hip_selfcheck_atan2f.restype = None
     return lib

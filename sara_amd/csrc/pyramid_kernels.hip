@@ -613,4 +613,103 @@ namespace sara_hip {
   }
 
 
+  // ======================================================================== //
+  // 8-bit input frames -> gray32f on the device.
+  // Reference: from_rgb8_to_gray32f, ImageProcessing/FastColorConversion.cpp:
+  // 42-66 (fallback branch = DO::Sara::convert): channels to double by /255.0,
+  // 0.2125 R + 0.7154 G + 0.0721 B in double, cast to float
+  // (Core/Pixel/SmartColorConversion.hpp:237-246, ColorConversion.hpp:26-34);
+  // gray8: float(v) / 255.f (Core/Pixel/ChannelConversion.hpp:40-54).
+  // One thread converts 4 pixels: 3 aligned dwords in, one float4 out -
+  // a quarter of the PCIe bytes of a float frame and no host-side pass.
+  // ======================================================================== //
+  __device__ inline float rgb_to_gray(unsigned r, unsigned g, unsigned b)
+  {
+    const double rd = double(r) / 255.0, gd = double(g) / 255.0,
+                 bd = double(b) / 255.0;
+    return float(0.2125 * rd + 0.7154 * gd + 0.0721 * bd);
+  }
+
+  __global__ void rgb8_to_gray32f_kernel(const unsigned char* __restrict__ src,
+                                         size_t src_stride,
+                                         float* __restrict__ dst,
+                                         size_t dst_stride, size_t count)
+  {
+    const size_t b = blockIdx.y;
+    const unsigned char* s = src + b * src_stride;
+    float* d = dst + b * dst_stride;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(s) & 3) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(d) & 15) == 0);
+    const size_t quads = count / 4;
+    for (size_t q = size_t(blockIdx.x) * blockDim.x + threadIdx.x; q < quads;
+         q += size_t(gridDim.x) * blockDim.x)
+    {
+      unsigned w0, w1, w2;
+      if (aligned)
+      {
+        const unsigned* p = reinterpret_cast<const unsigned*>(s + 12 * q);
+        w0 = p[0];
+        w1 = p[1];
+        w2 = p[2];
+      }
+      else
+      {
+        const unsigned char* p = s + 12 * q;
+        w0 = p[0] | (p[1] << 8) | (p[2] << 16) | (unsigned(p[3]) << 24);
+        w1 = p[4] | (p[5] << 8) | (p[6] << 16) | (unsigned(p[7]) << 24);
+        w2 = p[8] | (p[9] << 8) | (p[10] << 16) | (unsigned(p[11]) << 24);
+      }
+      const float g0 = rgb_to_gray(w0 & 255, (w0 >> 8) & 255, (w0 >> 16) & 255);
+      const float g1 = rgb_to_gray(w0 >> 24, w1 & 255, (w1 >> 8) & 255);
+      const float g2 = rgb_to_gray((w1 >> 16) & 255, w1 >> 24, w2 & 255);
+      const float g3 = rgb_to_gray((w2 >> 8) & 255, (w2 >> 16) & 255, w2 >> 24);
+      if (aligned)
+        *reinterpret_cast<float4*>(d + 4 * q) = make_float4(g0, g1, g2, g3);
+      else
+      {
+        d[4 * q] = g0;
+        d[4 * q + 1] = g1;
+        d[4 * q + 2] = g2;
+        d[4 * q + 3] = g3;
+      }
+    }
+    // tail (count not a multiple of 4)
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3))
+    {
+      const size_t i = quads * 4 + threadIdx.x;
+      d[i] = rgb_to_gray(s[3 * i], s[3 * i + 1], s[3 * i + 2]);
+    }
+  }
+
+  __global__ void gray8_to_gray32f_kernel(const unsigned char* __restrict__ src,
+                                          size_t src_stride,
+                                          float* __restrict__ dst,
+                                          size_t dst_stride, size_t count)
+  {
+    const size_t b = blockIdx.y;
+    const unsigned char* s = src + b * src_stride;
+    float* d = dst + b * dst_stride;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count;
+         i += size_t(gridDim.x) * blockDim.x)
+      d[i] = float(s[i]) / 255.f;
+  }
+
+  void launch_u8_to_gray32f(const unsigned char* src, size_t src_stride,
+                            int channels, float* dst, size_t dst_stride,
+                            size_t count, int batch, hipStream_t stream)
+  {
+    if (channels == 3)
+    {
+      const int blocks = int(std::min<size_t>((count / 4 + 255) / 256 + 1, 4096));
+      hipLaunchKernelGGL(rgb8_to_gray32f_kernel, dim3(blocks, batch), dim3(256),
+                         0, stream, src, src_stride, dst, dst_stride, count);
+    }
+    else
+    {
+      const int blocks = int(std::min<size_t>((count + 255) / 256, 4096));
+      hipLaunchKernelGGL(gray8_to_gray32f_kernel, dim3(blocks, batch), dim3(256),
+                         0, stream, src, src_stride, dst, dst_stride, count);
+    }
+  }
+
 }  // namespace sara_hip

@@ -198,6 +198,7 @@ struct sara_hip_sift
   std::vector<unsigned*> CM;  // coarse 16x16 gradient-magnitude maxima
   float* d_dog_plane = nullptr;
   float* d_input = nullptr;  // staged host frames, or enlarge/blur scratch
+  unsigned char* d_u8 = nullptr;  // staged 8-bit host frames (lazy)
   float* d_full = nullptr;   // first_octave > 0: blurred full-size frames
 
   // schedule constants
@@ -921,6 +922,58 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   return SARA_HIP_OK;
 }
 
+sara_hip_status sara_hip_sift_detect_u8(sara_hip_sift* c, const uint8_t* images,
+                                        size_t frame_stride, int channels,
+                                        int batch, int width, int height,
+                                        int images_on_device,
+                                        sara_hip_stage last_stage,
+                                        void* hip_stream)
+{
+  if (!c || !images)
+    return fail(SARA_HIP_INVALID_PARAMS, "null context or images");
+  if (channels != 1 && channels != 3)
+    return fail(SARA_HIP_INVALID_PARAMS, "channels must be 1 (gray8) or 3 (RGB8)");
+  if (batch < 1 || batch > c->max_batch)
+    return fail(SARA_HIP_CAPACITY_EXCEEDED, "batch exceeds max_batch");
+  if (width < 2 || height < 2)
+    return fail(SARA_HIP_INVALID_PARAMS, "image smaller than 2x2");
+  if (width > c->max_w || height > c->max_h)
+    return fail(SARA_HIP_CAPACITY_EXCEEDED,
+                "image larger than the context's max_width/max_height");
+  const size_t px = size_t(width) * height;
+  if (frame_stride == 0)
+    frame_stride = px * channels;
+  if (frame_stride < px * channels)
+    return fail(SARA_HIP_SIZE_MISMATCH, "frame_stride < width*height*channels");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t stream =
+      hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  if (c->last_stream && c->last_stream != stream)
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+  const unsigned char* src = images;
+  size_t src_stride = frame_stride;
+  if (!images_on_device)
+  {
+    if (!c->d_u8)
+    {
+      const sara_hip_status st =
+          c->alloc(c->d_u8, size_t(c->max_w) * c->max_h * 3 * c->max_batch);
+      if (st != SARA_HIP_OK)
+        return st;
+    }
+    HIP_TRY(hipMemcpy2DAsync(c->d_u8, px * channels, images, frame_stride,
+                             px * channels, batch, hipMemcpyHostToDevice,
+                             stream));
+    src = c->d_u8;
+    src_stride = px * channels;
+  }
+  launch_u8_to_gray32f(src, src_stride, channels, c->d_input, px, px, batch,
+                       stream);
+  HIP_TRY(hipGetLastError());
+  return sara_hip_sift_detect(c, c->d_input, px, batch, width, height, 1,
+                              last_stage, stream);
+}
+
 sara_hip_status sara_hip_sift_synchronize(sara_hip_sift* c)
 {
   if (!c)
@@ -1279,6 +1332,40 @@ sara_hip_status sara_hip_subtract(const float* a, const float* b, float* out,
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, dout, count * sizeof(float), hipMemcpyDeviceToHost));
   return SARA_HIP_OK;
+}
+
+static sara_hip_status u8_to_gray(const uint8_t* src, float* gray, int w, int h,
+                                  int channels, int device)
+{
+  if (!src || !gray || w < 1 || h < 1)
+    return fail(SARA_HIP_SIZE_MISMATCH,
+                "Color conversion error: image sizes are not equal!");
+  const sara_hip_status st = select_device(device);
+  if (st != SARA_HIP_OK)
+    return st;
+  DeviceScratch sc;
+  unsigned char* ds = nullptr;
+  float* dd = nullptr;
+  const size_t n = size_t(w) * h;
+  HIP_TRY(sc.get(ds, n * channels));
+  HIP_TRY(sc.get(dd, n));
+  HIP_TRY(hipMemcpy(ds, src, n * channels, hipMemcpyHostToDevice));
+  launch_u8_to_gray32f(ds, 0, channels, dd, 0, n, 1, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(gray, dd, n * sizeof(float), hipMemcpyDeviceToHost));
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_from_rgb8_to_gray32f(const uint8_t* rgb, float* gray,
+                                              int w, int h, int device)
+{
+  return u8_to_gray(rgb, gray, w, h, 3, device);
+}
+
+sara_hip_status sara_hip_from_gray8_to_gray32f(const uint8_t* src, float* gray,
+                                               int w, int h, int device)
+{
+  return u8_to_gray(src, gray, w, h, 1, device);
 }
 
 sara_hip_status sara_hip_gradient_polar_coordinates(const float* src, int w,

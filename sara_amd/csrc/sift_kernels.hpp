@@ -130,6 +130,12 @@ namespace sara_hip {
   void launch_subtract(const float* a, const float* b, float* out, size_t count,
                        hipStream_t stream);
 
+  //! 8-bit frames (channels = 3: interleaved RGB, 1: gray) -> gray32f planes;
+  //! strides in bytes (src) and floats (dst), count = pixels per frame.
+  void launch_u8_to_gray32f(const unsigned char* src, size_t src_stride,
+                            int channels, float* dst, size_t dst_stride,
+                            size_t count, int batch, hipStream_t stream);
+
   // ---- gradients -----------------------------------------------------------
   //! (2*|grad|, atan2(gy,gx)) of `nscales` consecutive planes per frame.
   //! cmax (optional): coarse map of the gradient magnitude, one uint32 (the

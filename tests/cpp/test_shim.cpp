@@ -42,6 +42,37 @@ int main(int argc, char** argv)
   if (!threw)
     return 4;
 
+  // from_rgb8_to_gray32f: size check + the conversion of gray triples.
+  {
+    std::vector<sara::Rgb8> rgb(16 * 4);
+    for (size_t i = 0; i < rgb.size(); ++i)
+      rgb[i] = {std::uint8_t(4 * i), std::uint8_t(255 - i), std::uint8_t(i)};
+    std::vector<float> g(16 * 4), g2(8);
+    auto src = sara::ImageView<sara::Rgb8>{rgb.data(), 16, 4};
+    auto dst = sara::ImageView<float>{g.data(), 16, 4};
+    auto bad = sara::ImageView<float>{g2.data(), 4, 2};
+    bool caught = false;
+    try
+    {
+      sara::from_rgb8_to_gray32f(src, bad);
+    }
+    catch (const std::domain_error&)
+    {
+      caught = true;
+    }
+    if (!caught)
+      return 9;
+    sara::from_rgb8_to_gray32f(src, dst);
+    for (size_t i = 0; i < rgb.size(); ++i)
+    {
+      const double want = 0.2125 * (rgb[i].r / 255.0) +
+                          0.7154 * (rgb[i].g / 255.0) +
+                          0.0721 * (rgb[i].b / 255.0);
+      if (g[i] != float(want))
+        return 10;
+    }
+  }
+
   // 1. the OdometryPipeline call: compute_sift_keypoints(image, params).
   const auto pyr_params = sara::ImagePyramidParams(
       0, 6, std::pow(2.f, 1.f / 3.f), 1, 0.5f, 1.6f, noct);

@@ -178,3 +178,26 @@ def test_subtract():
         a.ctypes.data_as(fp), b.ctypes.data_as(fp), out.ctypes.data_as(fp),
         1000, 0))
     assert np.array_equal(out, a - b)
+
+
+# ---- 8-bit frames converted on the device ------------------
+def test_rgb8_to_gray32f_matches_reference_formula(oracle):
+    rgb = RNG.integers(0, 256, size=(37, 53, 3), dtype=np.uint8)
+    got = sara_amd.from_rgb8_to_gray32f(rgb)
+    assert np.array_equal(got, oracle.rgb8_to_gray32f(rgb))
+    # every (r, g, b) on a coarse lattice + the extremes
+    v = np.array([0, 1, 2, 63, 64, 127, 128, 200, 254, 255], np.uint8)
+    lat = np.stack(np.meshgrid(v, v, v, indexing="ij"), -1).reshape(50, 20, 3)
+    assert np.array_equal(sara_amd.from_rgb8_to_gray32f(lat),
+                          oracle.rgb8_to_gray32f(lat))
+    g8 = RNG.integers(0, 256, size=(19, 31), dtype=np.uint8)
+    assert np.array_equal(sara_amd.from_gray8_to_gray32f(g8),
+                          g8.astype(np.float32) / np.float32(255))
+
+
+def test_rgb8_sunflower_matches_golden_gray():
+    import common
+    from PIL import Image
+    g = np.load(common.GOLDEN + "/sunflower_full.npz")
+    rgb = np.array(Image.open(common.GOLDEN + "/sunflower_rgb8.png"))
+    assert common.sha(sara_amd.from_rgb8_to_gray32f(rgb)) == str(g["gray_sha256"])

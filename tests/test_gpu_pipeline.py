@@ -333,3 +333,28 @@ def test_stage_stops(oracle):
                                     rtol_shape=SHAPE_RTOL, atol_theta=THETA_ATOL)
         t = ctx.stage_times()
         assert t["total"] > 0 and t["pyramid"] > 0
+
+
+def test_detect_u8_equals_detect_on_converted_frames(oracle):
+    """Row f1: RGB8 / gray8 frames converted on the device give the keypoints
+    of the float frames the reference conversion produces."""
+    rng = np.random.default_rng(3)
+    base = (synth_batch(160, 120, 2) * 255).astype(np.uint8)
+    rgb = np.stack([base, np.roll(base, 3, axis=2), 255 - base], axis=-1)
+    rgb[..., 1] = rng.integers(0, 256, size=rgb.shape[:3], dtype=np.uint8) // 8 \
+        + base // 2
+    gray = oracle.rgb8_to_gray32f(rgb)
+    with sara_amd.SiftContext(160, 120, 2, hip_params(0, 3)) as ctx:
+        ctx.detect(gray)
+        want = ctx.fetch()
+        ctx.detect_u8(rgb)
+        got = ctx.fetch()
+        for a, b in zip(want, got):
+            assert a.tobytes() == b.tobytes()
+        assert int(np.sum(want[0])) > 0
+        ctx.detect(base.astype(np.float32) / np.float32(255))
+        want = ctx.fetch()
+        ctx.detect_u8(base)
+        got = ctx.fetch()
+        assert want[1].tobytes() == got[1].tobytes()
+        assert np.array_equal(want[2], got[2])
