@@ -236,11 +236,11 @@ namespace sara_hip {
   }();
   static const int g_grad_waves = [] {
     const char* e = getenv("SARA_HIP_GRAD_WAVES");
-    return e ? std::max(64, atoi(e)) : 8192;
+    return e ? std::max(64, atoi(e)) : 18432;
   }();
   static const int g_extrema_waves = [] {
     const char* e = getenv("SARA_HIP_EXTREMA_WAVES");
-    return e ? std::max(64, atoi(e)) : 2048;
+    return e ? std::max(64, atoi(e)) : 4096;
   }();
 
   void launch_gradient_polar(const float* src, size_t src_stride, float* dst,
@@ -1241,8 +1241,11 @@ namespace sara_hip {
   // ds_add_u32), scaled per patch (see fx_scale in the kernel): the sum is
   // order-independent, so the result is deterministic.
   constexpr int kDescCopies = 4;  // histogram replicas per wave
+#ifndef SARA_DESC_WAVES_PER_EU
+#define SARA_DESC_WAVES_PER_EU 6
+#endif
 
-  __global__ __launch_bounds__(256) void descriptor_kernel(
+  __global__ __launch_bounds__(256, SARA_DESC_WAVES_PER_EU) void descriptor_kernel(
       const GradPyramidView* __restrict__ gradp, CandidateLists cand,
       OrientationLists ori, sara_oeregion* __restrict__ features,
       int32_t* __restrict__ scale_octave, float* __restrict__ descriptors,

@@ -47,10 +47,20 @@ namespace sara_hip {
     const char* e = getenv("SARA_HIP_MARCH_MINROWS");
     return e ? std::max(0, atoi(e)) : 4;
   }();
-  //! Target number of waves per marching launch (tuning knob).
+  //! Target number of waves per marching launch (tuning knobs): 2 per SIMD for
+  //! the 4-column kernel, ~3 (2880 on 1080p x 64) for the 2-column one.
   static const int g_march_waves = [] {
     const char* e = getenv("SARA_HIP_MARCH_WAVES");
-    return e ? std::max(64, atoi(e)) : 3072;
+    return e ? std::max(64, atoi(e)) : 2048;
+  }();
+  static const int g_march2_waves = [] {
+    const char* e = getenv("SARA_HIP_MARCH2_WAVES");
+    return e ? std::max(64, atoi(e)) : 2048;
+  }();
+  //! SARA_HIP_BLUR_ASM=0 keeps the compiler-scheduled kernel for every radius.
+  static const bool g_use_march2 = [] {
+    const char* e = getenv("SARA_HIP_BLUR_ASM");
+    return !(e && std::string(e) == "0");
   }();
 
   template <int R>
@@ -413,6 +423,255 @@ namespace sara_hip {
                          dec, dec_stride, w, h, seg_rows, nstrips, taps);
   }
 
+  // ------------------------------------------------------------------------ //
+  // Hand-scheduled marching blur for the wide kernels (R >= 8), where the
+  // arithmetic, not HBM, is the bound (tools/ubench/blur_limits.hip).
+  //
+  // Same marching scheme as above with three changes:
+  //  * 2 columns per lane (strips of 128): the K x 2 partial-sum ring leaves
+  //    room for 4-5 waves per SIMD instead of 3 (on gfx950 each of a SIMD's
+  //    two VALU pipes serves its own waves, so an odd count idles half a pipe);
+  //  * the column pass shares the product of the symmetric taps: k[j] and
+  //    k[K-1-j] are the same float (make_gaussian_kernel evaluates exp() of the
+  //    same x^2 and divides by the same sum), so t * k[j] is formed once and
+  //    added to the two outputs it belongs to - R+1 multiplies instead of
+  //    2R+1, each output still accumulating its taps in ascending order;
+  //  * both passes are written as asm volatile blocks so that the order (and
+  //    with it the register pressure) is the one written here: multiplies run
+  //    >= 4 instructions ahead of the add that consumes them.
+  // v_mul_f32 / v_add_f32 are IEEE single operations: the results are
+  // bit-identical to the compiler-scheduled kernel (checked by the GPU tests
+  // against the oracle and, kernel against kernel, by blur_limits).
+  // ------------------------------------------------------------------------ //
+  //! s0 += sum_{q<4} v[q] k[q],  s1 += sum_{q<4} v[q+1] k[q]  (ascending q)
+  __device__ __forceinline__ void row4(float& s0, float& s1, float va, float vb,
+                                       float vc, float vd, float ve, float k0,
+                                       float k1, float k2, float k3)
+  {
+    float p0, p1, p2, p3;
+    asm volatile("v_mul_f32 %2, %11, %6\n\tv_mul_f32 %3, %11, %7\n\t"
+                 "v_mul_f32 %4, %12, %7\n\tv_mul_f32 %5, %12, %8\n\t"
+                 "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\t"
+                 "v_mul_f32 %2, %13, %8\n\tv_mul_f32 %3, %13, %9\n\t"
+                 "v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5\n\t"
+                 "v_mul_f32 %4, %14, %9\n\tv_mul_f32 %5, %14, %10\n\t"
+                 "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\t"
+                 "v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5"
+                 : "+v"(s0), "+v"(s1), "=&v"(p0), "=&v"(p1), "=&v"(p2),
+                   "=&v"(p3)
+                 : "v"(va), "v"(vb), "v"(vc), "v"(vd), "v"(ve), "s"(k0),
+                   "s"(k1), "s"(k2), "s"(k3));
+  }
+  __device__ __forceinline__ void row1(float& s0, float& s1, float va, float vb,
+                                       float k0)
+  {
+    float p0, p1;
+    asm volatile("v_mul_f32 %2, %6, %4\n\tv_mul_f32 %3, %6, %5\n\t"
+                 "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3"
+                 : "+v"(s0), "+v"(s1), "=&v"(p0), "=&v"(p1)
+                 : "v"(va), "v"(vb), "s"(k0));
+  }
+  //! taps j and j+1 (neither first nor centre) of two columns: a = output j
+  //! steps old, b = K-1-j steps old, c / d the same for j+1.
+  __device__ __forceinline__ void col2(float& a0, float& a1, float& b0,
+                                       float& b1, float& c0, float& c1,
+                                       float& d0, float& d1, float t0, float t1,
+                                       float kj, float kj1)
+  {
+    float p0, p1, p2, p3;
+    asm volatile("v_mul_f32 %8, %14, %12\n\tv_mul_f32 %9, %14, %13\n\t"
+                 "v_mul_f32 %10, %15, %12\n\tv_mul_f32 %11, %15, %13\n\t"
+                 "v_add_f32 %0, %0, %8\n\tv_add_f32 %1, %1, %9\n\t"
+                 "v_add_f32 %2, %2, %8\n\tv_add_f32 %3, %3, %9\n\t"
+                 "v_add_f32 %4, %4, %10\n\tv_add_f32 %5, %5, %11\n\t"
+                 "v_add_f32 %6, %6, %10\n\tv_add_f32 %7, %7, %11"
+                 : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1),
+                   "+v"(d0), "+v"(d1), "=&v"(p0), "=&v"(p1), "=&v"(p2),
+                   "=&v"(p3)
+                 : "v"(t0), "v"(t1), "s"(kj), "s"(kj1));
+  }
+  __device__ __forceinline__ void col1(float& a0, float& a1, float& b0,
+                                       float& b1, float t0, float t1, float kj)
+  {
+    float p0, p1;
+    asm volatile("v_mul_f32 %4, %8, %6\n\tv_mul_f32 %5, %8, %7\n\t"
+                 "v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5\n\t"
+                 "v_add_f32 %2, %2, %4\n\tv_add_f32 %3, %3, %5"
+                 : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "=&v"(p0), "=&v"(p1)
+                 : "v"(t0), "v"(t1), "s"(kj));
+  }
+  //! first tap (new = 0.f + t k[0]; the oldest output gets the same product
+  //! as its last tap) and centre tap (mid += t k[R]).
+  __device__ __forceinline__ void col_ends(float& new0, float& new1,
+                                           float& old0, float& old1,
+                                           float& mid0, float& mid1, float t0,
+                                           float t1, float k0, float kr)
+  {
+    float p2, p3;
+    asm volatile("v_mul_f32 %0, %10, %8\n\tv_mul_f32 %1, %10, %9\n\t"
+                 "v_mul_f32 %6, %11, %8\n\tv_mul_f32 %7, %11, %9\n\t"
+                 "v_add_f32 %2, %2, %0\n\tv_add_f32 %3, %3, %1\n\t"
+                 "v_add_f32 %0, 0, %0\n\tv_add_f32 %1, 0, %1\n\t"
+                 "v_add_f32 %4, %4, %6\n\tv_add_f32 %5, %5, %7"
+                 : "=&v"(new0), "=&v"(new1), "+v"(old0), "+v"(old1),
+                   "+v"(mid0), "+v"(mid1), "=&v"(p2), "=&v"(p3)
+                 : "v"(t0), "v"(t1), "s"(k0), "s"(kr));
+  }
+
+  template <int R, int PF>
+  __global__ __launch_bounds__(64) void gaussian_blur_march2_kernel(
+      const float* __restrict__ src, size_t src_stride,
+      float* __restrict__ dst, size_t dst_stride, int w, int h, int seg_rows,
+      int nstrips, Taps taps)
+  {
+    constexpr int CPL = 2;
+    constexpr int K = 2 * R + 1;
+    constexpr int W = 64 * CPL;
+    constexpr int RP = ((R + 1) / 2) * 2;  // left halo padded to 8 bytes
+    constexpr int D = RP - R;
+    constexpr int ROWF = RP + W + RP;
+    constexpr int NQ = (D + CPL + 2 * R + 1) / 2;  // b64 reads per window
+    __shared__ __attribute__((aligned(16))) float s_row[2 * ROWF];
+
+    const int lane = threadIdx.x;
+    const int strip = blockIdx.x % nstrips;
+    const int seg = blockIdx.x / nstrips;
+    const size_t b = blockIdx.y;
+    src += b * src_stride;
+    dst += b * dst_stride;
+
+    const int x0 = strip * W;
+    const int y0 = seg * seg_rows;
+    const int y1 = min(h, y0 + seg_rows);
+    const int col = x0 + CPL * lane;
+    const bool col_ok = col < w;  // w % 2 == 0: a float2 is all in or all out
+    int hcol = lane < R ? x0 - R + lane : x0 + W + (lane - R);
+    hcol = hcol < 0 ? 0 : (hcol > w - 1 ? w - 1 : hcol);
+    const int hslot = lane < R ? RP - R + lane : RP + W + (lane - R);
+    const int mcol = col_ok ? col : w - CPL;
+
+    auto load_row = [&](int yy, float2& m, float& hv) {
+      const int gy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+      const float* rowp = src + size_t(gy) * w;
+      m = *reinterpret_cast<const float2*>(rowp + mcol);
+      if (!col_ok)
+        m.x = m.y;  // replicate src(w-1, y)
+      hv = 0.f;
+      if (lane < 2 * R)
+        hv = rowp[hcol];
+    };
+
+    float A[K][CPL];
+    float2 pm[PF];
+    float phv[PF];
+    const int T = (y1 - y0) + 2 * R;  // source rows y0-R .. y1+R-1
+
+#pragma unroll
+    for (int q = 0; q < PF; ++q)
+      load_row(y0 - R + q, pm[q], phv[q]);
+
+    for (int n0 = 0; n0 < T; n0 += K)
+    {
+#pragma unroll
+      for (int i = 0; i < K; ++i)
+      {
+        const int n = n0 + i;
+        const int yy = y0 - R + n;
+        float* rowbuf = s_row + (n & 1) * ROWF;
+        *reinterpret_cast<float2*>(rowbuf + RP + CPL * lane) = pm[i % PF];
+        if (lane < 2 * R)
+          rowbuf[hslot] = phv[i % PF];
+        load_row(yy + PF, pm[i % PF], phv[i % PF]);
+
+        float v[NQ * 2];
+        {
+          const float2* p =
+              reinterpret_cast<const float2*>(rowbuf + CPL * lane);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+          {
+            const float2 x = p[q];
+            v[2 * q] = x.x;
+            v[2 * q + 1] = x.y;
+          }
+        }
+        // row pass on source row n
+        float t0 = 0.f, t1 = 0.f;
+        {
+          constexpr int NB = K / 4;
+#pragma unroll
+          for (int q = 0; q < NB; ++q)
+          {
+            const int j = 4 * q;
+            row4(t0, t1, v[D + j], v[D + j + 1], v[D + j + 2], v[D + j + 3],
+                 v[D + j + 4], taps.k[j], taps.k[j + 1], taps.k[j + 2],
+                 taps.k[j + 3]);
+          }
+#pragma unroll
+          for (int j = 4 * NB; j < K; ++j)
+            row1(t0, t1, v[D + j], v[D + j + 1], taps.k[j]);
+        }
+        // column pass: tap j goes to the output that is j steps old, and the
+        // same product, as tap K-1-j, to the one that is K-1-j steps old
+#define SARA_SL(j) ((i + K - 1 - (j)) % K)
+        col_ends(A[SARA_SL(0)][0], A[SARA_SL(0)][1], A[SARA_SL(K - 1)][0],
+                 A[SARA_SL(K - 1)][1], A[SARA_SL(R)][0], A[SARA_SL(R)][1], t0,
+                 t1, taps.k[0], taps.k[R]);
+#pragma unroll
+        for (int j = 1; j + 1 < R; j += 2)
+          col2(A[SARA_SL(j)][0], A[SARA_SL(j)][1], A[SARA_SL(K - 1 - j)][0],
+               A[SARA_SL(K - 1 - j)][1], A[SARA_SL(j + 1)][0],
+               A[SARA_SL(j + 1)][1], A[SARA_SL(K - 2 - j)][0],
+               A[SARA_SL(K - 2 - j)][1], t0, t1, taps.k[j], taps.k[j + 1]);
+        if ((R - 1) % 2 == 1)
+          col1(A[SARA_SL(R - 1)][0], A[SARA_SL(R - 1)][1], A[SARA_SL(R + 1)][0],
+               A[SARA_SL(R + 1)][1], t0, t1, taps.k[R - 1]);
+#undef SARA_SL
+
+        const int o = yy - R;
+        if ((o >= y0) && (o < y1) && col_ok)
+          *reinterpret_cast<float2*>(dst + size_t(o) * w + col) =
+              make_float2(A[i][0], A[i][1]);
+      }
+      if (K % PF != 0)
+      {
+        float2 tm[PF];
+        float th[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q)
+        {
+          tm[q] = pm[(K + q) % PF];
+          th[q] = phv[(K + q) % PF];
+        }
+#pragma unroll
+        for (int q = 0; q < PF; ++q)
+        {
+          pm[q] = tm[q];
+          phv[q] = th[q];
+        }
+      }
+    }
+  }
+
+  template <int R>
+  static void launch_blur_march2(const float* src, size_t src_stride, float* dst,
+                                 size_t dst_stride, int w, int h, int batch,
+                                 const Taps& taps, hipStream_t stream)
+  {
+    constexpr int W = 128;
+    constexpr int PF = 4;
+    const int nstrips = (w + W - 1) / W;
+    int nseg = (g_march2_waves + nstrips * batch - 1) / (nstrips * batch);
+    const int min_rows = std::max(32, g_march_minrows * R);
+    nseg = std::max(1, std::min(nseg, (h + min_rows - 1) / min_rows));
+    const int seg_rows = (h + nseg - 1) / nseg;
+    nseg = (h + seg_rows - 1) / seg_rows;
+    const dim3 grid(nstrips * nseg, batch);
+    hipLaunchKernelGGL((gaussian_blur_march2_kernel<R, PF>), grid, dim3(64), 0,
+                       stream, src, src_stride, dst, dst_stride, w, h, seg_rows,
+                       nstrips, taps);
+  }
+
   template <int R>
   static void launch_blur_r(const float* src, size_t src_stride, float* dst,
                             size_t dst_stride, float* dog, size_t dog_stride,
@@ -442,6 +701,26 @@ namespace sara_hip {
                          (dec_stride % 2 == 0) && g_fuse_decimate);
     if (!dec_ok)
       dec = nullptr;
+    if (aligned4 && g_use_march && g_use_march2 && dec == nullptr)
+    {
+      switch (R)
+      {
+      case 8:
+        launch_blur_march2<8>(src, src_stride, dst, dst_stride, w, h, batch,
+                              taps, stream);
+        return false;
+      case 10:
+        launch_blur_march2<10>(src, src_stride, dst, dst_stride, w, h, batch,
+                               taps, stream);
+        return false;
+      case 12:
+        launch_blur_march2<12>(src, src_stride, dst, dst_stride, w, h, batch,
+                               taps, stream);
+        return false;
+      default:
+        break;
+      }
+    }
     if (aligned4 && g_use_march)
     {
 #define SARA_MARCH_CASE(r)                                                     \
