@@ -277,19 +277,29 @@ namespace sara_hip {
     // general path: z = atan(|y/x|)
     const float q = y / x;
     float z = atanf_nonneg_select(int_as_float(float_as_int(q) & 0x7fffffff));
-    if (k > 60)
-      z = pi_o_2 + 0.5f * pi_lo;
-    else if (hx < 0 && k < -60)
-      z = 0.0f;
+    // Every candidate below is computed unconditionally and then picked with
+    // plain two-way selects of ready values: written as nested conditionals
+    // with the arithmetic inside the arms, the compiler turns each arm into a
+    // divergent branch (7 exec-mask branches per pixel in the gradient kernel).
+    z = k > 60 ? pi_o_2 + 0.5f * pi_lo : z;
+    const bool tiny = (hx < 0) & (k < -60) & !(k > 60);
+    z = tiny ? 0.0f : z;
     const float zneg = int_as_float(float_as_int(z) ^ (int32_t) 0x80000000);
-    float r = m == 0 ? z : (m == 1 ? zneg : (m == 2 ? pi - (z - pi_lo)
-                                                   : (z - pi_lo) - pi));
+    const float zl = z - pi_lo;
+    const float q2 = pi - zl;   // m == 2
+    const float q3 = zl - pi;   // m == 3
+    const float lower = (m & 1) ? zneg : z;
+    const float upper = (m & 1) ? q3 : q2;
+    float r = (m & 2) ? upper : lower;
     // fdlibm's x == 1 shortcut (atanf(y)) and its y == 0 cases for x != 0 are
     // reproduced by the general path bit for bit (y/1 == y; atan(0) == 0 and
     // pi - (0 - pi_lo) rounds to pi), so only x == +-0 needs a select.
-    if (ix == 0)
-      r = iy == 0 ? ((m & 2) ? (hy < 0 ? -pi : pi) : y)
-                  : (hy < 0 ? -pi_o_2 : pi_o_2);
+    const int32_t sy = hy & (int32_t) 0x80000000;
+    const float pi_sy = int_as_float(float_as_int(pi) | sy);
+    const float pi_o_2_sy = int_as_float(float_as_int(pi_o_2) | sy);
+    const float x0y0 = (m & 2) ? pi_sy : y;
+    const float x0 = iy == 0 ? x0y0 : pi_o_2_sy;
+    r = ix == 0 ? x0 : r;
     return r;
   }
 

@@ -12,6 +12,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 
 namespace sara_hip {
@@ -459,8 +460,8 @@ namespace sara_hip {
                  "v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5"
                  : "+v"(s0), "+v"(s1), "=&v"(p0), "=&v"(p1), "=&v"(p2),
                    "=&v"(p3)
-                 : "v"(va), "v"(vb), "v"(vc), "v"(vd), "v"(ve), "s"(k0),
-                   "s"(k1), "s"(k2), "s"(k3));
+                 : "v"(va), "v"(vb), "v"(vc), "v"(vd), "v"(ve), "v"(k0),
+                   "v"(k1), "v"(k2), "v"(k3));
   }
   __device__ __forceinline__ void row1(float& s0, float& s1, float va, float vb,
                                        float k0)
@@ -469,7 +470,7 @@ namespace sara_hip {
     asm volatile("v_mul_f32 %2, %6, %4\n\tv_mul_f32 %3, %6, %5\n\t"
                  "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3"
                  : "+v"(s0), "+v"(s1), "=&v"(p0), "=&v"(p1)
-                 : "v"(va), "v"(vb), "s"(k0));
+                 : "v"(va), "v"(vb), "v"(k0));
   }
   //! taps j and j+1 (neither first nor centre) of two columns: a = output j
   //! steps old, b = K-1-j steps old, c / d the same for j+1.
@@ -488,7 +489,7 @@ namespace sara_hip {
                  : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1),
                    "+v"(d0), "+v"(d1), "=&v"(p0), "=&v"(p1), "=&v"(p2),
                    "=&v"(p3)
-                 : "v"(t0), "v"(t1), "s"(kj), "s"(kj1));
+                 : "v"(t0), "v"(t1), "v"(kj), "v"(kj1));
   }
   __device__ __forceinline__ void col1(float& a0, float& a1, float& b0,
                                        float& b1, float t0, float t1, float kj)
@@ -498,7 +499,7 @@ namespace sara_hip {
                  "v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5\n\t"
                  "v_add_f32 %2, %2, %4\n\tv_add_f32 %3, %3, %5"
                  : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "=&v"(p0), "=&v"(p1)
-                 : "v"(t0), "v"(t1), "s"(kj));
+                 : "v"(t0), "v"(t1), "v"(kj));
   }
   //! first tap (new = 0.f + t k[0]; the oldest output gets the same product
   //! as its last tap) and centre tap (mid += t k[R]).
@@ -515,7 +516,7 @@ namespace sara_hip {
                  "v_add_f32 %4, %4, %6\n\tv_add_f32 %5, %5, %7"
                  : "=&v"(new0), "=&v"(new1), "+v"(old0), "+v"(old1),
                    "+v"(mid0), "+v"(mid1), "=&v"(p2), "=&v"(p3)
-                 : "v"(t0), "v"(t1), "s"(k0), "s"(kr));
+                 : "v"(t0), "v"(t1), "v"(k0), "v"(kr));
   }
 
   template <int R, int PF>
@@ -561,6 +562,15 @@ namespace sara_hip {
         hv = rowp[hcol];
     };
 
+    // The R+1 distinct taps live in VGPRs: a VALU instruction with an SGPR
+    // source issues at half the rate of an all-VGPR one when its neighbours
+    // read SGPRs too (tools/ubench/valu_ops.hip), and half of this kernel's
+    // instructions are multiplies by a tap.
+    float tk[R + 1];
+#pragma unroll
+    for (int j = 0; j <= R; ++j)
+      asm volatile("v_mov_b32 %0, %1" : "=v"(tk[j]) : "s"(taps.k[j]));
+#define SARA_TK(j) tk[(j) <= R ? (j) : 2 * R - (j)]
     float A[K][CPL];
     float2 pm[PF];
     float phv[PF];
@@ -604,28 +614,28 @@ namespace sara_hip {
           {
             const int j = 4 * q;
             row4(t0, t1, v[D + j], v[D + j + 1], v[D + j + 2], v[D + j + 3],
-                 v[D + j + 4], taps.k[j], taps.k[j + 1], taps.k[j + 2],
-                 taps.k[j + 3]);
+                 v[D + j + 4], SARA_TK(j), SARA_TK(j + 1), SARA_TK(j + 2),
+                 SARA_TK(j + 3));
           }
 #pragma unroll
           for (int j = 4 * NB; j < K; ++j)
-            row1(t0, t1, v[D + j], v[D + j + 1], taps.k[j]);
+            row1(t0, t1, v[D + j], v[D + j + 1], SARA_TK(j));
         }
         // column pass: tap j goes to the output that is j steps old, and the
         // same product, as tap K-1-j, to the one that is K-1-j steps old
 #define SARA_SL(j) ((i + K - 1 - (j)) % K)
         col_ends(A[SARA_SL(0)][0], A[SARA_SL(0)][1], A[SARA_SL(K - 1)][0],
                  A[SARA_SL(K - 1)][1], A[SARA_SL(R)][0], A[SARA_SL(R)][1], t0,
-                 t1, taps.k[0], taps.k[R]);
+                 t1, SARA_TK(0), SARA_TK(R));
 #pragma unroll
         for (int j = 1; j + 1 < R; j += 2)
           col2(A[SARA_SL(j)][0], A[SARA_SL(j)][1], A[SARA_SL(K - 1 - j)][0],
                A[SARA_SL(K - 1 - j)][1], A[SARA_SL(j + 1)][0],
                A[SARA_SL(j + 1)][1], A[SARA_SL(K - 2 - j)][0],
-               A[SARA_SL(K - 2 - j)][1], t0, t1, taps.k[j], taps.k[j + 1]);
+               A[SARA_SL(K - 2 - j)][1], t0, t1, SARA_TK(j), SARA_TK(j + 1));
         if ((R - 1) % 2 == 1)
           col1(A[SARA_SL(R - 1)][0], A[SARA_SL(R - 1)][1], A[SARA_SL(R + 1)][0],
-               A[SARA_SL(R + 1)][1], t0, t1, taps.k[R - 1]);
+               A[SARA_SL(R + 1)][1], t0, t1, SARA_TK(R - 1));
 #undef SARA_SL
 
         const int o = yy - R;
@@ -652,6 +662,8 @@ namespace sara_hip {
       }
     }
   }
+
+#undef SARA_TK
 
   template <int R>
   static void launch_blur_march2(const float* src, size_t src_stride, float* dst,
@@ -701,7 +713,11 @@ namespace sara_hip {
                          (dec_stride % 2 == 0) && g_fuse_decimate);
     if (!dec_ok)
       dec = nullptr;
-    if (aligned4 && g_use_march && g_use_march2 && dec == nullptr)
+    // the hand-scheduled kernel shares the products of mirrored taps
+    bool symmetric = true;
+    for (int j = 0; j < R; ++j)
+      symmetric &= std::memcmp(&taps.k[j], &taps.k[2 * R - j], sizeof(float)) == 0;
+    if (aligned4 && g_use_march && g_use_march2 && dec == nullptr && symmetric)
     {
       switch (R)
       {

@@ -6,7 +6,4 @@ for l in sys.stdin:
         d=json.loads(l); print(d['value'], d['ms_per_step'], d.get('stage_ms_per_step') or d['config'].get('stage_ms_per_step') or [k for k in d])
 "; }
 run SARA_HIP_STREAMS=0
-run SARA_HIP_STREAMS=0 SARA_HIP_BLUR_ASM=0
-run SARA_HIP_STREAMS=0 SARA_HIP_MARCH2_WAVES=2048
-run SARA_HIP_STREAMS=0 SARA_HIP_MARCH2_WAVES=4096
 run A=1

@@ -492,6 +492,78 @@ __device__ __forceinline__ void col_ends(float& new0, float& new1, float& old0,
                : "v"(t0), "v"(t1), "s"(k0), "s"(kr));
 }
 
+#define ROW4V_ASM                                                                 \
+  "v_mul_f32 %2, %11, %6\n\tv_mul_f32 %3, %11, %7\n\t"                           \
+  "v_mul_f32 %4, %12, %7\n\tv_mul_f32 %5, %12, %8\n\t"                           \
+  "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\t"                             \
+  "v_mul_f32 %2, %13, %8\n\tv_mul_f32 %3, %13, %9\n\t"                           \
+  "v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5\n\t"                             \
+  "v_mul_f32 %4, %14, %9\n\tv_mul_f32 %5, %14, %10\n\t"                          \
+  "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\t"                             \
+  "v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5"
+
+//! s0 += sum_{q<4} v[q] k[q],  s1 += sum_{q<4} v[q+1] k[q]  (ascending q)
+__device__ __forceinline__ void row4v(float& s0, float& s1, float va, float vb,
+                                     float vc, float vd, float ve, float k0,
+                                     float k1, float k2, float k3)
+{
+  float p0, p1, p2, p3;
+  asm volatile(ROW4V_ASM
+               : "+v"(s0), "+v"(s1), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
+               : "v"(va), "v"(vb), "v"(vc), "v"(vd), "v"(ve), "v"(k0), "v"(k1),
+                 "v"(k2), "v"(k3));
+}
+__device__ __forceinline__ void row1v(float& s0, float& s1, float va, float vb,
+                                     float k0)
+{
+  float p0, p1;
+  asm volatile("v_mul_f32 %2, %6, %4\n\tv_mul_f32 %3, %6, %5\n\t"
+               "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3"
+               : "+v"(s0), "+v"(s1), "=&v"(p0), "=&v"(p1)
+               : "v"(va), "v"(vb), "v"(k0));
+}
+//! taps j and j+1 (neither first nor centre) of two columns
+__device__ __forceinline__ void col2v(float& a0, float& a1, float& b0, float& b1,
+                                     float& c0, float& c1, float& d0, float& d1,
+                                     float t0, float t1, float kj, float kj1)
+{
+  float p0, p1, p2, p3;
+  asm volatile("v_mul_f32 %8, %14, %12\n\tv_mul_f32 %9, %14, %13\n\t"
+               "v_mul_f32 %10, %15, %12\n\tv_mul_f32 %11, %15, %13\n\t"
+               "v_add_f32 %0, %0, %8\n\tv_add_f32 %1, %1, %9\n\t"
+               "v_add_f32 %2, %2, %8\n\tv_add_f32 %3, %3, %9\n\t"
+               "v_add_f32 %4, %4, %10\n\tv_add_f32 %5, %5, %11\n\t"
+               "v_add_f32 %6, %6, %10\n\tv_add_f32 %7, %7, %11"
+               : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1),
+                 "+v"(d0), "+v"(d1), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
+               : "v"(t0), "v"(t1), "v"(kj), "v"(kj1));
+}
+__device__ __forceinline__ void col1v(float& a0, float& a1, float& b0, float& b1,
+                                     float t0, float t1, float kj)
+{
+  float p0, p1;
+  asm volatile("v_mul_f32 %4, %8, %6\n\tv_mul_f32 %5, %8, %7\n\t"
+               "v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5\n\t"
+               "v_add_f32 %2, %2, %4\n\tv_add_f32 %3, %3, %5"
+               : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "=&v"(p0), "=&v"(p1)
+               : "v"(t0), "v"(t1), "v"(kj));
+}
+//! first tap (new = 0 + t k0, old += t k0) and centre tap (mid += t kR)
+__device__ __forceinline__ void col_endsv(float& new0, float& new1, float& old0,
+                                         float& old1, float& mid0, float& mid1,
+                                         float t0, float t1, float k0, float kr)
+{
+  float p2, p3;
+  asm volatile("v_mul_f32 %0, %10, %8\n\tv_mul_f32 %1, %10, %9\n\t"
+               "v_mul_f32 %6, %11, %8\n\tv_mul_f32 %7, %11, %9\n\t"
+               "v_add_f32 %2, %2, %0\n\tv_add_f32 %3, %3, %1\n\t"
+               "v_add_f32 %0, 0, %0\n\tv_add_f32 %1, 0, %1\n\t"
+               "v_add_f32 %4, %4, %6\n\tv_add_f32 %5, %5, %7"
+               : "=&v"(new0), "=&v"(new1), "+v"(old0), "+v"(old1), "+v"(mid0),
+                 "+v"(mid1), "=&v"(p2), "=&v"(p3)
+               : "v"(t0), "v"(t1), "v"(k0), "v"(kr));
+}
+
 template <int R, int PF, int CPL, int NOMEM>
 __global__ __launch_bounds__(64) void march3(const float* __restrict__ src,
                                              size_t src_stride,
@@ -630,6 +702,181 @@ __global__ __launch_bounds__(64) void march3(const float* __restrict__ src,
         if ((R - 1) % 2 == 1)
           col1(A[SL(R - 1)][c], A[SL(R - 1)][c + 1], A[SL(R + 1)][c],
                A[SL(R + 1)][c + 1], t[c], t[c + 1], taps.k[R - 1]);
+      }
+#undef SL
+      const int o = yy - R;
+      if ((o >= y0) && (o < y1) && col_ok && (!NOMEM || never))
+      {
+        vec ov;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+          (&ov.x)[c] = A[i][c];
+        *reinterpret_cast<vec*>(dst + size_t(o) * w + col) = ov;
+      }
+    }
+    if (K % PF != 0)
+    {
+      vec tm[PF];
+      float th[PF];
+#pragma unroll
+      for (int q = 0; q < PF; ++q)
+      {
+        tm[q] = pm[(K + q) % PF];
+        th[q] = phv[(K + q) % PF];
+      }
+#pragma unroll
+      for (int q = 0; q < PF; ++q)
+      {
+        pm[q] = tm[q];
+        phv[q] = th[q];
+      }
+    }
+  }
+}
+
+template <int R, int PF, int CPL, int NOMEM>
+__global__ __launch_bounds__(64) void march3v(const float* __restrict__ src,
+                                             size_t src_stride,
+                                             float* __restrict__ dst,
+                                             size_t dst_stride, int w, int h,
+                                             int seg_rows, int nstrips,
+                                             Taps taps, int never)
+{
+  using vec = typename VecOf<CPL>::type;
+  constexpr int K = 2 * R + 1;
+  constexpr int W = 64 * CPL;
+  constexpr int RP = ((R + CPL - 1) / CPL) * CPL;
+  constexpr int D = RP - R;
+  constexpr int ROWF = RP + W + RP;
+  constexpr int NQ = (D + CPL + 2 * R + CPL - 1) / CPL;
+  __shared__ __attribute__((aligned(16))) float s_row[2 * ROWF];
+
+  const int lane = threadIdx.x;
+  const int strip = blockIdx.x % nstrips;
+  const int seg = blockIdx.x / nstrips;
+  const size_t b = blockIdx.y;
+  src += b * src_stride;
+  dst += b * dst_stride;
+  const int x0 = strip * W;
+  const int y0 = seg * seg_rows;
+  const int y1 = min(h, y0 + seg_rows);
+  const int col = x0 + CPL * lane;
+  const bool col_ok = col < w;
+  int hcol = lane < R ? x0 - R + lane : x0 + W + (lane - R);
+  hcol = hcol < 0 ? 0 : (hcol > w - 1 ? w - 1 : hcol);
+  const int hslot = lane < R ? RP - R + lane : RP + W + (lane - R);
+  const int mcol = col_ok ? col : w - CPL;
+
+  auto load_row = [&](int yy, vec& m, float& hv) {
+    if (NOMEM)
+    {
+      (&m.x)[0] += 1.f;
+      return;
+    }
+    const int gy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+    const float* rowp = src + size_t(gy) * w;
+    m = *reinterpret_cast<const vec*>(rowp + mcol);
+    if (!col_ok)
+    {
+      const float last = (&m.x)[CPL - 1];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c)
+        (&m.x)[c] = last;
+    }
+    hv = 0.f;
+    if (lane < 2 * R)
+      hv = rowp[hcol];
+  };
+
+  float tk[R + 1];
+#pragma unroll
+  for (int j = 0; j <= R; ++j)
+    asm volatile("v_mov_b32 %0, %1" : "=v"(tk[j]) : "s"(taps.k[j]));
+#define TK(j) tk[(j) <= R ? (j) : 2 * R - (j)]
+  float A[K][CPL];
+  vec pm[PF];
+  float phv[PF];
+  const int T = (y1 - y0) + 2 * R;
+#pragma unroll
+  for (int q = 0; q < PF; ++q)
+  {
+    pm[q] = vec{};
+    phv[q] = 0.f;
+    load_row(y0 - R + q, pm[q], phv[q]);
+  }
+
+  for (int n0 = 0; n0 < T; n0 += K)
+  {
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+    {
+      const int n = n0 + i;
+      const int yy = y0 - R + n;
+      float* rowbuf = s_row + (n & 1) * ROWF;
+      if (NOMEM < 2)
+      {
+        *reinterpret_cast<vec*>(rowbuf + RP + CPL * lane) = pm[i % PF];
+        if (lane < 2 * R)
+          rowbuf[hslot] = phv[i % PF];
+      }
+      load_row(yy + PF, pm[i % PF], phv[i % PF]);
+      float v[NQ * CPL];
+      if (NOMEM >= 2)
+      {
+#pragma unroll
+        for (int q = 0; q < NQ * CPL; ++q)
+          asm volatile("v_mov_b32 %0, %1" : "=v"(v[q]) : "v"(phv[q % PF]));
+      }
+      else
+      {
+        const vec* p = reinterpret_cast<const vec*>(rowbuf + CPL * lane);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+        {
+          const vec x = p[q];
+#pragma unroll
+          for (int c = 0; c < CPL; ++c)
+            v[CPL * q + c] = (&x.x)[c];
+        }
+      }
+      float t[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; c += 2)
+      {
+        float s0 = 0.f, s1 = 0.f;
+        constexpr int NB = K / 4;
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+        {
+          const int j = 4 * q;
+          row4v(s0, s1, v[D + c + j], v[D + c + j + 1], v[D + c + j + 2],
+               v[D + c + j + 3], v[D + c + j + 4], TK(j), TK(j + 1),
+               TK(j + 2), TK(j + 3));
+        }
+#pragma unroll
+        for (int j = 4 * NB; j < K; ++j)
+          row1v(s0, s1, v[D + c + j], v[D + c + j + 1], TK(j));
+        t[c] = s0;
+        t[c + 1] = s1;
+      }
+      // column pass: tap j to the output that is j steps old, tap K-1-j (the
+      // same product) to the one that is K-1-j steps old
+#define SL(j) ((i + K - 1 - (j)) % K)
+#pragma unroll
+      for (int c = 0; c < CPL; c += 2)
+      {
+        col_endsv(A[SL(0)][c], A[SL(0)][c + 1], A[SL(K - 1)][c],
+                 A[SL(K - 1)][c + 1], A[SL(R)][c], A[SL(R)][c + 1], t[c],
+                 t[c + 1], TK(0), TK(R));
+#pragma unroll
+        for (int j = 1; j + 1 < R; j += 2)
+          col2v(A[SL(j)][c], A[SL(j)][c + 1], A[SL(K - 1 - j)][c],
+               A[SL(K - 1 - j)][c + 1], A[SL(j + 1)][c], A[SL(j + 1)][c + 1],
+               A[SL(K - 2 - j)][c], A[SL(K - 2 - j)][c + 1], t[c], t[c + 1],
+               TK(j), TK(j + 1));
+        if ((R - 1) % 2 == 1)
+          col1v(A[SL(R - 1)][c], A[SL(R - 1)][c + 1], A[SL(R + 1)][c],
+               A[SL(R + 1)][c + 1], t[c], t[c + 1], TK(R - 1));
       }
 #undef SL
       const int o = yy - R;
@@ -973,7 +1220,7 @@ void run2(const float* src, float* dst, int w, int h, int batch, const char* tag
          bytes / best / 1e9);
 }
 
-template <int R, int PF, int CPL, int NOMEM>
+template <int R, int PF, int CPL, int NOMEM, bool TAPV = false>
 void run3(const float* src, float* dst, float* ref, int w, int h, int batch,
           const char* tag)
 {
@@ -999,8 +1246,12 @@ void run3(const float* src, float* dst, float* ref, int w, int h, int batch,
   for (int rep = 0; rep < 5; ++rep)
   {
     hipEventRecord(a);
-    march3<R, PF, CPL, NOMEM><<<grid, 64>>>(src, stride, dst, stride, w, h,
-                                            seg_rows, nstrips, taps, 0);
+    if (TAPV)
+      march3v<R, PF, CPL, NOMEM><<<grid, 64>>>(src, stride, dst, stride, w, h,
+                                               seg_rows, nstrips, taps, 0);
+    else
+      march3<R, PF, CPL, NOMEM><<<grid, 64>>>(src, stride, dst, stride, w, h,
+                                              seg_rows, nstrips, taps, 0);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms;
@@ -1103,6 +1354,9 @@ void sweep3(const float* src, float* dst, float* ref, int w, int h, int batch)
   run3<R, 4, 2, 0>(src, dst, ref, w, h, batch, "v3");
   run3<R, 4, 2, 1>(src, dst, ref, w, h, batch, "v3 nomem");
   run3<R, 4, 2, 2>(src, dst, ref, w, h, batch, "v3 nolds");
+  run3<R, 4, 2, 0, true>(src, dst, ref, w, h, batch, "v3 tapv");
+  run3<R, 4, 2, 1, true>(src, dst, ref, w, h, batch, "v3 tapv nomem");
+  run3<R, 4, 2, 2, true>(src, dst, ref, w, h, batch, "v3 tapv nolds");
   run3<R, 6, 2, 0>(src, dst, ref, w, h, batch, "v3 pf6");
   run4<R, 4, 0, 0>(src, dst, ref, w, h, batch, "v4");
   run4<R, 4, 1, 0>(src, dst, ref, w, h, batch, "v4 nomem");
