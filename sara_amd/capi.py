@@ -10,7 +10,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsara_hip_sift.so")
+# SARA_HIP_SIFT_LIB: A/B a differently built library (tools/ab_build.sh).
+LIB_PATH = os.environ.get("SARA_HIP_SIFT_LIB") or os.path.join(
+    _HERE, "lib", "libsara_hip_sift.so")
 
 # status codes (sara_hip_status)
 OK, INVALID_PARAMS, SIZE_MISMATCH, OUT_OF_RANGE, CAPACITY_EXCEEDED, \

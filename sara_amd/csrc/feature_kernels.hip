@@ -86,8 +86,11 @@ namespace sara_hip {
   //! register ring (loop unrolled 3x), horizontal neighbours come from the
   //! adjacent lane through ds_bpermute and, at the strip edges, from one extra
   //! scalar load.  HBM traffic: 4 B read + 8 B written per pixel.
+#ifndef SARA_GRAD_WAVES_PER_EU
+#define SARA_GRAD_WAVES_PER_EU 6
+#endif
   template <int PF>
-  __global__ __launch_bounds__(64) void gradient_polar_march_kernel(
+  __global__ __launch_bounds__(64, SARA_GRAD_WAVES_PER_EU) void gradient_polar_march_kernel(
       const float* __restrict__ src, size_t src_stride,
       float* __restrict__ dst, size_t dst_stride, int w, int h, int nscales,
       int seg_rows, int nstrips, unsigned* __restrict__ cmax,
@@ -581,8 +584,11 @@ namespace sara_hip {
   //! fused pass costs about max(...) instead of the sum and saves re-reading
   //! the three planes (see gradient_polar_march_kernel for the stand-alone
   //! form and the reference citations).
+#ifndef SARA_EXTREMA_WAVES_PER_EU
+#define SARA_EXTREMA_WAVES_PER_EU 4
+#endif
   template <int ND, int PF, bool GRAD>
-  __global__ __launch_bounds__(64) void extrema_march_kernel(
+  __global__ __launch_bounds__(64, GRAD ? 2 : SARA_EXTREMA_WAVES_PER_EU) void extrema_march_kernel(
       OctaveView gauss, int octave, ExtremaParams p, SiteLists sites,
       int seg_rows, int nstrips, float* __restrict__ grad,
       size_t grad_frame_stride, unsigned* __restrict__ cmax, size_t cmax_stride)
@@ -1240,9 +1246,12 @@ namespace sara_hip {
   // 64-bit two's-complement fixed point (ds_add_u64 costs about one
   // ds_add_u32), scaled per patch (see fx_scale in the kernel): the sum is
   // order-independent, so the result is deterministic.
-  constexpr int kDescCopies = 4;  // histogram replicas per wave
+#ifndef SARA_DESC_COPIES
+#define SARA_DESC_COPIES 4
+#endif
+  constexpr int kDescCopies = SARA_DESC_COPIES;  // histogram replicas per wave
 #ifndef SARA_DESC_WAVES_PER_EU
-#define SARA_DESC_WAVES_PER_EU 6
+#define SARA_DESC_WAVES_PER_EU 8
 #endif
 
   __global__ __launch_bounds__(256, SARA_DESC_WAVES_PER_EU) void descriptor_kernel(

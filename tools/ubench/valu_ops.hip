@@ -56,6 +56,17 @@ __global__ __launch_bounds__(64) void k(float* out, float a, float b, int iters)
   if (OP == 38) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(d[i & 1]));              \
   if (OP == 39) asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(d[i & 1]));              \
   if (OP == 40) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(d[i & 1]));          \
+  if (OP == 43) { if (i & 1) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(b)); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(b)); } \
+  if (OP == 44) { if (i & 1) asm volatile("v_cmp_gt_f32 vcc, %0, %1\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(b) : "vcc"); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(b)); } \
+  if (OP == 45) { if (i & 1) asm volatile("v_cmp_gt_f32 %2, %0, %1\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(b), "s"(m)); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(b)); } \
+  if (OP == 46) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x[i]) : "v"(b));            \
+  if (OP == 47) { if (i & 1) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x[i]) : "v"(b)); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(b)); } \
+  if (OP == 48) { if (i & 1) asm volatile("v_and_b32 %0, %1, %0" : "+v"(x[i]) : "v"(b)); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(b)); } \
+  if (OP == 49) { if (i & 1) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(x[i]) ); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(b)); } \
+  if (OP == 50) { if (i & 1) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[i]) ); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(b)); } \
+  if (OP == 51) { if ((i & 3) == 1) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[i]) ); else asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(b)); } \
+  if (OP == 52) asm volatile("v_and_b32 %0, %1, %0" : "+v"(x[i]) : "v"(b));            \
+  if (OP == 53) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x[i]) : "v"(b));        \
   if (OP == 41) asm volatile("v_mul_f32 %0, 0.5, %0" : "+v"(x[i]));                    \
   if (OP == 42) asm volatile("v_mul_f32 %0, 0x3f7fbe77, %0" : "+v"(x[i]));
       double d[2] = {1.0, 2.0};
@@ -116,6 +127,17 @@ int main()
   run<38>("v_pk_mul_f32");
   run<39>("v_pk_add_f32");
   run<40>("v_pk_fma_f32");
+  run<43>("cndmask(vcc)/add alt");
+  run<44>("cmp+nop+cndmask vcc/add");
+  run<45>("cmp+nop+cndmask sgpr/add");
+  run<46>("v_max_f32 vgpr");
+  run<47>("max/add alt");
+  run<52>("v_and_b32 vgpr");
+  run<48>("and/add alt");
+  run<49>("cvt_i32/add alt");
+  run<50>("rcp/add alt");
+  run<51>("rcp/3 add");
+  run<53>("v_fma_f32 x,b,x");
   run<0>("v_fma_f32");
   run<1>("v_mul_f32");
   run<14>("v_add_f32");
