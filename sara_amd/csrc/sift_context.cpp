@@ -182,12 +182,6 @@ struct sara_hip_sift
   hipEvent_t oct_ready[16] = {};  // G(downscale_index, o) is complete
   hipEvent_t oct_done[16] = {};   // octave o's chain is complete
   bool multi_stream = true;
-  // Polar gradients on a side stream next to the extremum scan (both only
-  // read the Gaussian pyramid): 0 = off, 1 = gradient kernels enqueued first,
-  // 2 = extremum scan enqueued first.
-  int overlap_gradient = 0;
-  hipStream_t aux_stream = nullptr;
-  hipEvent_t aux_fork = nullptr, aux_join = nullptr;
 
   Schedule max_sched;
   Schedule cur;
@@ -339,11 +333,6 @@ namespace {
     }
     if (const char* e = getenv("SARA_HIP_STREAMS"))
       c->multi_stream = std::string(e) != "1";
-    if (const char* e = getenv("SARA_HIP_OVERLAP_GRADIENT"))
-      c->overlap_gradient = atoi(e);
-    TRY_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-    TRY_HIP(hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
-    TRY_HIP(hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
 
     // ---- taps and tables (host arithmetic as in GaussianPyramid.hpp:106-121)
     const float k = pyr.scale_geometric_factor;
@@ -629,15 +618,6 @@ sara_hip_status sara_hip_sift_destroy(sara_hip_sift* c)
     if (c->oct_done[o])
       (void) hipEventDestroy(c->oct_done[o]);
   }
-  if (c->aux_stream)
-  {
-    (void) hipStreamSynchronize(c->aux_stream);
-    (void) hipStreamDestroy(c->aux_stream);
-  }
-  if (c->aux_fork)
-    (void) hipEventDestroy(c->aux_fork);
-  if (c->aux_join)
-    (void) hipEventDestroy(c->aux_join);
   if (c->own_stream)
     (void) hipStreamDestroy(c->own_stream);
   delete c;
@@ -843,50 +823,8 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   }
   HIP_TRY(mark(2));
 
-  // The polar gradients read the Gaussian pyramid only, like the extremum
-  // scan: optionally they run next to it on the side stream.
-  bool grad_fused[16] = {};
-  const int overlap =
-      (last_stage >= SARA_HIP_STAGE_GRADIENT && !c->all_gradient_scales)
-          ? c->overlap_gradient
-          : 0;
-  auto enqueue_gradients = [&](hipStream_t gs) -> hipError_t {
-    if (last_stage < SARA_HIP_STAGE_GRADIENT)
-      return hipSuccess;
-    if (gs != stream)
-    {
-      hipError_t e = hipEventRecord(c->aux_fork, stream);
-      if (e != hipSuccess)
-        return e;
-      e = hipStreamWaitEvent(gs, c->aux_fork, 0);
-      if (e != hipSuccess)
-        return e;
-    }
-    const int s_lo = c->all_gradient_scales ? 0 : 1;
-    const int s_n = c->all_gradient_scales ? S : S - 3;
-    for (int o = 0; o < sc.num_octaves; ++o)
-    {
-      const int w = sc.oct[o].w, h = sc.oct[o].h;
-      const size_t pl = size_t(w) * h;
-      if (grad_fused[o])
-        continue;  // written by the extremum scan
-      const size_t cpl = size_t((w + 15) / 16) * ((h + 15) / 16);
-      const hipError_t e = hipMemsetAsync(
-          c->CM[o], 0, cpl * S * batch * sizeof(unsigned), gs);
-      if (e != hipSuccess)
-        return e;
-      launch_gradient_polar(c->G[o] + pl * s_lo, pl * S, c->GR[o] + pl * 2 * s_lo,
-                            pl * 2 * S, w, h, s_n, batch, gs,
-                            c->CM[o] + cpl * s_lo, cpl * S);
-    }
-    if (gs != stream)
-      return hipEventRecord(c->aux_join, gs);
-    return hipSuccess;
-  };
-  if (overlap == 1)
-    HIP_TRY(enqueue_gradients(c->aux_stream));
-
   // ---- extrema ------------------------------------------------------------
+  bool grad_fused[16] = {};
   HIP_TRY(hipMemsetAsync(c->cand.count, 0, sizeof(int) * batch, stream));
   HIP_TRY(hipMemsetAsync(c->sites.count, 0, sizeof(int) * batch, stream));
   HIP_TRY(hipMemsetAsync(c->ori.kp_count, 0, sizeof(int) * batch, stream));
@@ -911,8 +849,8 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       dv.frame_stride = dv.plane * S;
       // With the gradient stage requested, the scan of the fast path also
       // emits the polar gradients of the planes it has in registers.
-      const bool want_grad = last_stage >= SARA_HIP_STAGE_GRADIENT &&
-                             !c->all_gradient_scales && !overlap;
+      const bool want_grad =
+          last_stage >= SARA_HIP_STAGE_GRADIENT && !c->all_gradient_scales;
       const size_t cpl = size_t((dv.w + 15) / 16) * ((dv.h + 15) / 16);
       grad_fused[o] = false;
       if (want_grad)
@@ -944,12 +882,24 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   HIP_TRY(mark(3));
 
   // ---- polar gradients ----------------------------------------------------
-  if (overlap == 2)
-    HIP_TRY(enqueue_gradients(c->aux_stream));
-  if (overlap)
-    HIP_TRY(hipStreamWaitEvent(stream, c->aux_join, 0));
-  else
-    HIP_TRY(enqueue_gradients(stream));
+  if (last_stage >= SARA_HIP_STAGE_GRADIENT)
+  {
+    const int s_lo = c->all_gradient_scales ? 0 : 1;
+    const int s_n = c->all_gradient_scales ? S : S - 3;
+    for (int o = 0; o < sc.num_octaves; ++o)
+    {
+      const int w = sc.oct[o].w, h = sc.oct[o].h;
+      const size_t pl = size_t(w) * h;
+      if (grad_fused[o])
+        continue;  // written by the extremum scan
+      const size_t cpl = size_t((w + 15) / 16) * ((h + 15) / 16);
+      HIP_TRY(hipMemsetAsync(c->CM[o], 0, cpl * S * batch * sizeof(unsigned),
+                             stream));
+      launch_gradient_polar(c->G[o] + pl * s_lo, pl * S, c->GR[o] + pl * 2 * s_lo,
+                            pl * 2 * S, w, h, s_n, batch, stream,
+                            c->CM[o] + cpl * s_lo, cpl * S);
+    }
+  }
   HIP_TRY(mark(4));
 
   // ---- orientations -------------------------------------------------------

@@ -5,11 +5,8 @@ for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); print(round(d['value']/1e6,2), round(d['ms_per_step'],3), d.get('stage_ms_per_step'))
 "; }
-for rep in 1 2; do
-for v in base g8 g4 e6 e8; do
-run SARA_HIP_SIFT_LIB=sara_amd/lib/ab/lib_$v.so
+for rep in 1 2 3; do
+run SARA_HIP_OVERLAP_STAGES=0
+run SARA_HIP_OVERLAP_STAGES=1
 done
-run SARA_HIP_SIFT_LIB=sara_amd/lib/ab/lib_g8.so SARA_HIP_GRAD_WAVES=16384
-run SARA_HIP_SIFT_LIB=sara_amd/lib/ab/lib_e6.so SARA_HIP_EXTREMA_WAVES=6144
-run SARA_HIP_SIFT_LIB=sara_amd/lib/ab/lib_e8.so SARA_HIP_EXTREMA_WAVES=8192
-done
+run SARA_HIP_STREAMS=1
