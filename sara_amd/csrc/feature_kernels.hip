@@ -16,6 +16,16 @@
 
 namespace sara_hip {
 
+  //! (magnitude, angle) pairs through a pointer that is explicitly in the
+  //! global address space (see orientation_kernel).
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef const f32x2 __attribute__((address_space(1))) * global_float2_ptr;
+  __device__ __forceinline__ float2 load_pair(global_float2_ptr p, size_t i)
+  {
+    const f32x2 v = p[i];
+    return make_float2(v.x, v.y);
+  }
+
   // ======================================================================== //
   // Polar gradients.  Reference: gradient_polar_coordinates,
   // FeatureDescriptors/Orientation.cpp:24-56; Gradient functor,
@@ -1031,9 +1041,13 @@ namespace sara_hip {
     const int R = tab.ori_radius[s];
     const double* wt = weights + tab.ori_woff[s];
     const int w = grad.w[o], h = grad.h[o];
-    const float2* g = reinterpret_cast<const float2*>(
-                          grad.base[o] + size_t(b) * grad.frame_stride[o]) +
-                      size_t(s) * grad.plane[o];
+    // explicitly a global-memory pointer: through a generic pointer these
+    // gathers become flat_load, which counts on lgkmcnt as well, so waiting
+    // for a sample would also wait for every LDS atomic still in flight
+    const global_float2_ptr g =
+        (global_float2_ptr) reinterpret_cast<const f32x2*>(
+            grad.base[o] + size_t(b) * grad.frame_stride[o]) +
+        size_t(s) * grad.plane[o];
 
     const int D = 2 * R + 1;
     const int npx = D * D;
@@ -1052,7 +1066,7 @@ namespace sara_hip {
                       yy < h;
       mo_ = make_float2(0.f, 0.f);
       if (ok)
-        mo_ = g[size_t(yy) * w + xx];
+        mo_ = load_pair(g, size_t(yy) * w + xx);
       return ok;
     };
     float2 mo_next;
@@ -1298,9 +1312,13 @@ namespace sara_hip {
     const int rx = int(roundf(d.x));
     const int ry = int(roundf(d.y));
     const int w = grad.w[o], h = grad.h[o];
-    const float2* g = reinterpret_cast<const float2*>(
-                          grad.base[o] + size_t(b) * grad.frame_stride[o]) +
-                      size_t(s) * grad.plane[o];
+    // explicitly a global-memory pointer: through a generic pointer these
+    // gathers become flat_load, which counts on lgkmcnt as well, so waiting
+    // for a sample would also wait for every LDS atomic still in flight
+    const global_float2_ptr g =
+        (global_float2_ptr) reinterpret_cast<const f32x2*>(
+            grad.base[o] + size_t(b) * grad.frame_stride[o]) +
+        size_t(s) * grad.plane[o];
     const float factor = grad.factor[o];
     unsigned long long* hist = s_acc[wave];
     const int copy = lane & (kDescCopies - 1);
@@ -1417,17 +1435,17 @@ namespace sara_hip {
         int u_end = min(int(ceilf(hi)), u_max);
         if (v > v_hi)
           u_end = u - 1;
-        const float2* grow = g + size_t(ry + min(v, v_hi)) * w + rx;
+        const global_float2_ptr grow = g + size_t(ry + min(v, v_hi)) * w + rx;
         // one sample of look-ahead: the gather of the next sample is in
         // flight while this one is accumulated
         float2 nxt = make_float2(0.f, 0.f);
         if (u <= u_end)
-          nxt = grow[u];
+          nxt = load_pair(grow, u);
         for (; __ballot(u <= u_end) != 0ull; u += lanes_per_row)
         {
           const float2 mo = nxt;
           if (u + lanes_per_row <= u_end)
-            nxt = grow[u + lanes_per_row];
+            nxt = load_pair(grow, u + lanes_per_row);
           if (u > u_end)
             continue;
           float px = T00 * float(u) + T01 * fv;

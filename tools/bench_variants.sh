@@ -5,8 +5,6 @@ for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); print(round(d['value']/1e6,2), round(d['ms_per_step'],3), d.get('stage_ms_per_step'))
 "; }
-for rep in 1 2 3; do
-run SARA_HIP_OVERLAP_STAGES=0
-run SARA_HIP_OVERLAP_STAGES=1
+for rep in 1 2; do
+run A=1
 done
-run SARA_HIP_STREAMS=1
