@@ -358,3 +358,42 @@ def test_detect_u8_equals_detect_on_converted_frames(oracle):
         got = ctx.fetch()
         assert want[1].tobytes() == got[1].tobytes()
         assert np.array_equal(want[2], got[2])
+
+
+def _fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(n):
+        # half of the widths are multiples of 4 (marching kernels), the others
+        # take the tiled / generic kernels
+        w = int(rng.integers(12, 90)) * 4 if i % 2 == 0 else int(rng.integers(40, 360))
+        h = int(rng.integers(33, 300))
+        first = int(rng.choice([0, 0, 0, 1, -1])) if max(w, h) <= 200 else 0
+        scales = int(rng.choice([6, 6, 5, 7, 4]))
+        kfac = None if scales == 6 else float(
+            np.float32(2.0) ** (np.float32(1.0) / np.float32(scales - 3)))
+        cam = float(rng.choice([0.5, 0.5, 1.0, 0.8]))
+        noct = int(rng.integers(1, 6))
+        thres = float(rng.choice([0.01, 0.01, 0.02, 0.005]))
+        edge = float(rng.choice([10.0, 10.0, 6.0, 20.0]))
+        iters = int(rng.choice([5, 5, 2, 3]))
+        cases.append((i, w, h, first, scales, kfac, cam, noct, thres, edge, iters))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(16, 20260929),
+                         ids=lambda c: "fuzz%d_%dx%d" % (c[0], c[1], c[2]))
+def test_fuzz_parity(oracle, case):
+    """Random image sizes and detector parameters: every plane, site, keypoint
+    and descriptor against the oracle, same bars as everywhere else."""
+    i, w, h, first, scales, kfac, cam, noct, thres, edge, iters = case
+    img = synth(w, h, 4000 + i)
+    ref = oracle.RefSift(img, ref_params(oracle, first, noct, cam, scales, kfac),
+                         extremum_thres=thres, edge_ratio_thres=edge,
+                         extremum_refinement_iter=iters)
+    with sara_amd.SiftContext(w, h, 1, hip_params(first, noct, cam, scales, kfac),
+                              extremum_thres=thres, edge_ratio_thres=edge,
+                              extremum_refinement_iter=iters) as ctx:
+        ctx.detect(img)
+        compare_full(ctx, ref)
+        compare_lists(run_lists(ctx), ref, 0)
