@@ -58,6 +58,14 @@ namespace sara_hip {
     const char* e = getenv("SARA_HIP_MARCH2_WAVES");
     return e ? std::max(64, atoi(e)) : 2048;
   }();
+  //! Below this many pixels per launch (width x height x batch) the marching
+  //! kernels cannot fill the chip - a wave is a serial chain of row steps - and
+  //! the tiled kernel is used instead (240x135 x 64 frames: 12-20 us per blur
+  //! against 23-59 us).
+  static const size_t g_march_min_pixels = [] {
+    const char* e = getenv("SARA_HIP_MARCH_MIN_PIXELS");
+    return e ? size_t(atoll(e)) : size_t(4) << 20;
+  }();
   //! SARA_HIP_BLUR_ASM=0 keeps the compiler-scheduled kernel for every radius.
   static const bool g_use_march2 = [] {
     const char* e = getenv("SARA_HIP_BLUR_ASM");
@@ -702,7 +710,9 @@ namespace sara_hip {
   {
     const int R = taps.size / 2;
     // fast path: strips of float4 columns need 16-byte aligned rows
-    const bool aligned4 = (w % 4 == 0) && w >= 4 && (src_stride % 4 == 0) &&
+    const bool big_enough = size_t(w) * h * batch >= g_march_min_pixels;
+    const bool aligned4 = big_enough && (w % 4 == 0) && w >= 4 &&
+                          (src_stride % 4 == 0) &&
                           (dst_stride % 4 == 0) &&
                           (reinterpret_cast<uintptr_t>(src) % 16 == 0) &&
                           (reinterpret_cast<uintptr_t>(dst) % 16 == 0) &&

@@ -7,4 +7,8 @@ for l in sys.stdin:
 "; }
 for rep in 1 2; do
 run A=1
+run SARA_HIP_GRAD_MARCH_MIN_PIXELS=8000000
+run SARA_HIP_GRAD_MARCH_MIN_PIXELS=30000000
+run SARA_HIP_EXTREMA_MARCH_MIN_PIXELS=4000000
+run SARA_HIP_EXTREMA_MARCH_MIN_PIXELS=10000000
 done
