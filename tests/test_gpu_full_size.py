@@ -102,3 +102,50 @@ def test_4k_five_octaves():
     assert np.all(np.diff(so_key) >= 0)
     assert set(np.unique(kso[:, 0])) <= {1, 2, 3}
     assert np.isfinite(kdesc).all()
+
+
+def test_default_small_launch_threshold(oracle, tmp_path):
+    """conftest.py lowers SARA_HIP_MARCH_MIN_PIXELS so that small test images
+    reach the marching / fused kernels; this case runs in a fresh process with
+    the shipped default (small octaves through the tiled kernel, the big ones
+    through the fused and hand-scheduled ones) on a 12 x 640x480 batch, whose
+    octaves straddle the 4 Mpx threshold, and checks frame 5 against the
+    oracle."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "run.py"
+    out = tmp_path / "out.npz"
+    script.write_text(
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import sara_amd\n"
+        "from sara_amd.synth import synth_batch\n"
+        "frames = synth_batch(640, 480, 12)\n"
+        "p = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=4)\n"
+        "with sara_amd.SiftContext(640, 480, 12, p) as ctx:\n"
+        "    ctx.detect(frames)\n"
+        "    kc, kreg, kdesc, kso = ctx.fetch()\n"
+        "    g = [ctx.gaussian(s, o, 5) for o in range(4) for s in range(6)]\n"
+        "np.savez(%r, kc=kc, kreg=kreg.view(np.uint8), kdesc=kdesc, kso=kso,\n"
+        "         **{'g%%d' %% i: a for i, a in enumerate(g)})\n"
+        % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(out)))
+    env = dict(os.environ)
+    env.pop("SARA_HIP_MARCH_MIN_PIXELS", None)
+    subprocess.run([sys.executable, str(script)], check=True, env=env)
+    got = np.load(out)
+    frames = synth_batch(640, 480, 12)
+    ref = oracle.RefSift(frames[5], oracle.PyramidParams(0, 6, None, 1, 0.5, 1.6, 4))
+    i = 0
+    for o in range(4):
+        for s in range(6):
+            assert np.array_equal(got["g%d" % i], ref.gaussian(s, o)), (s, o)
+            i += 1
+    rk, rso, rdesc = ref.keypoints()
+    kc = got["kc"]
+    off = int(kc[:5].sum())
+    assert int(kc[5]) == len(rk)
+    kreg = common.regions_from_bytes(got["kreg"])[off:off + len(rk)]
+    common.assert_regions_equal(kreg, rk, rtol_shape=1e-6, atol_theta=1e-6)
+    assert np.array_equal(got["kso"][off:off + len(rk)], rso)
+    assert np.max(np.abs(got["kdesc"][off:off + len(rk)] - rdesc)) <= 2e-3

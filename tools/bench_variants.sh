@@ -6,9 +6,10 @@ for l in sys.stdin:
         d=json.loads(l); print(round(d['value']/1e6,2), round(d['ms_per_step'],3), d.get('stage_ms_per_step'))
 "; }
 for rep in 1 2; do
-run A=1
-run SARA_HIP_GRAD_MARCH_MIN_PIXELS=8000000
-run SARA_HIP_GRAD_MARCH_MIN_PIXELS=30000000
-run SARA_HIP_EXTREMA_MARCH_MIN_PIXELS=4000000
-run SARA_HIP_EXTREMA_MARCH_MIN_PIXELS=10000000
+run SARA_HIP_FUSE_BLUR_PAIR=0
+run SARA_HIP_FUSE_BLUR_PAIR=1
+run SARA_HIP_FUSE_BLUR_PAIR=1 SARA_HIP_PAIR_WAVES=3072
+run SARA_HIP_FUSE_BLUR_PAIR=1 SARA_HIP_PAIR_WAVES=4096
 done
+run SARA_HIP_STREAMS=1 SARA_HIP_FUSE_BLUR_PAIR=0
+run SARA_HIP_STREAMS=1 SARA_HIP_FUSE_BLUR_PAIR=1

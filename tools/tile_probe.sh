@@ -1,9 +1,10 @@
+# per-launch blur durations of one serial step (kernel trace)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 D=$R/gpurun_out/tile
 mkdir -p $D
 cd $R
-SARA_HIP_BLUR=tile SARA_HIP_STREAMS=1 rocprofv3 --kernel-trace --output-format csv -d $D -o tile -- python bench.py --steps 3 --warmup 1 --cpu-frames 0 > $D/tile.log 2>&1
+SARA_HIP_STREAMS=1 rocprofv3 --kernel-trace --output-format csv -d $D -o tile -- python bench.py --steps 3 --warmup 1 --cpu-frames 0 > $D/tile.log 2>&1
 python - <<'PY'
 import csv
 rows=list(csv.DictReader(open('gpurun_out/tile/tile_kernel_trace.csv')))
