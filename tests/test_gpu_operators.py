@@ -36,9 +36,13 @@ def test_blur_of_constant_is_constant():
 
 
 @pytest.mark.parametrize("shape", [(3, 3), (5, 64), (64, 5), (33, 65), (97, 131),
-                                   (270, 480), (135, 240), (67, 119)])
-@pytest.mark.parametrize("sigma", [0.5, 1.2262735, 1.5198685, 1.946588, 3.0900156,
-                                   4.1])
+                                   (270, 480), (135, 240), (67, 119),
+                                   # strip edges of the marching kernels (128- and
+                                   # 256-column strips) and several row segments
+                                   (40, 256), (90, 260), (50, 124), (300, 132),
+                                   (26, 384)])
+@pytest.mark.parametrize("sigma", [0.5, 1.2262735, 1.5198685, 1.946588, 2.4525296,
+                                   3.0900156, 4.1])
 def test_gaussian_filter_matches_oracle_bit_exact(oracle, shape, sigma):
     src = RNG.random(shape, dtype=np.float32)
     got = sara_amd.apply_gaussian_filter(src, sigma)
