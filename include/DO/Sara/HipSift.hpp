@@ -361,6 +361,102 @@ namespace DO::Sara {
     return {std::move(feats), std::move(desc)};
   }
 
+#ifndef SARA_HIP_WITH_SARA_HEADERS
+  //! Match/Match.hpp:29-174 reduced to what AnnMatcher fills in: pointers and
+  //! indices of the two keypoints, score (squared-distance ratio), rank and
+  //! direction.
+  class Match
+  {
+  public:
+    enum class Direction
+    {
+      SourceToTarget = 0,
+      TargetToSource = 1
+    };
+    Match() = default;
+    Match(const OERegion* x, const OERegion* y, float score, Direction dir,
+          int x_index, int y_index)
+      : _x{x}, _y{y}, _x_index{x_index}, _y_index{y_index}, _score{score}
+      , _matching_dir{dir}
+    {
+    }
+    const OERegion& x() const { return *_x; }
+    const OERegion& y() const { return *_y; }
+    int x_index() const { return _x_index; }
+    int y_index() const { return _y_index; }
+    int rank() const { return _rank; }
+    int& rank() { return _rank; }
+    float score() const { return _score; }
+    Direction matching_direction() const { return _matching_dir; }
+    bool operator==(const Match& m) const { return _x == m._x && _y == m._y; }
+
+  private:
+    const OERegion* _x = nullptr;
+    const OERegion* _y = nullptr;
+    int _x_index = -1, _y_index = -1, _rank = -1;
+    float _score = std::numeric_limits<float>::max();
+    Direction _matching_dir = Direction::SourceToTarget;
+  };
+
+  //! FeatureMatching/AnnMatcher.hpp:32-66 (two key sets): the neighbour
+  //! search runs exhaustively on the GPU with FLANN's distance arithmetic.
+  class AnnMatcher
+  {
+  public:
+    AnnMatcher(const KeypointList<OERegion, float>& keys1,
+               const KeypointList<OERegion, float>& keys2,
+               float sift_ratio_thres = 1.2f, int device = 0)
+      : _keys1{keys1}, _keys2{keys2}, _ratio{sift_ratio_thres}, _device{device}
+    {
+      if (!size_consistency_predicate(_keys1) ||
+          !size_consistency_predicate(_keys2))
+        throw std::runtime_error{
+            "The list of keypoints are inconsistent in size!"};
+    }
+
+    auto compute_matches() -> std::vector<Match>
+    {
+      const auto& f1 = features(_keys1);
+      const auto& f2 = features(_keys2);
+      const auto& d1 = descriptors(_keys1);
+      const auto& d2 = descriptors(_keys2);
+      auto raw = std::vector<sara_match>(f1.size() + f2.size() + 1);
+      int count = 0;
+      hip_detail::check(sara_hip_match_descriptors(
+          d1.data(), int(f1.size()), d2.data(), int(f2.size()),
+          f1.empty() ? int(d2.cols()) : int(d1.cols()), _ratio, 0, raw.data(),
+          int(raw.size()), &count, _device));
+      auto matches = std::vector<Match>{};
+      matches.reserve(size_t(count));
+      for (int i = 0; i < count; ++i)
+      {
+        const auto& r = raw[size_t(i)];
+        auto m = Match{&f1[size_t(r.x_index)], &f2[size_t(r.y_index)], r.score,
+                       static_cast<Match::Direction>(r.direction), r.x_index,
+                       r.y_index};
+        m.rank() = r.rank;
+        matches.push_back(m);
+      }
+      return matches;
+    }
+
+  private:
+    const KeypointList<OERegion, float>& _keys1;
+    const KeypointList<OERegion, float>& _keys2;
+    float _ratio;
+    int _device;
+  };
+
+  //! SfM/Helpers/KeypointMatching.cpp:19-25.
+  inline auto match(const KeypointList<OERegion, float>& keys1,
+                    const KeypointList<OERegion, float>& keys2, float lowe_ratio)
+      -> std::vector<Match>
+  {
+    AnnMatcher matcher{keys1, keys2, lowe_ratio};
+    return matcher.compute_matches();
+  }
+#endif  // !SARA_HIP_WITH_SARA_HEADERS (inside Sara: see INTEGRATION.md)
+
   //! FeatureDetectors/DoG.hpp:72-165.  The pyramids stay in HBM; gaussians()
   //! and diff_of_gaussians() copy them to the host on first use.
   class ComputeDoGExtrema

@@ -336,6 +336,37 @@ SARA_HIP_API sara_hip_status sara_hip_from_gray8_to_gray32f(const uint8_t* src,
                                                            int height,
                                                            int device);
 
+/* ---- descriptor matching -------------------- */
+/* One match of AnnMatcher::compute_matches (FeatureMatching/AnnMatcher.cpp:    */
+/* 203-268; Match/Match.hpp:166-173): indices into the first (x) and second (y) */
+/* key set, score = squared-distance ratio best / second best, rank, direction  */
+/* (0 = SourceToTarget, 1 = TargetToSource).                                    */
+typedef struct sara_match
+{
+  int32_t x_index;
+  int32_t y_index;
+  float score;
+  int32_t rank;
+  int32_t direction;
+} sara_match;
+
+/* match(keys1, keys2, lowe_ratio) - SfM/Helpers/KeypointMatching.cpp:19-25 ->  */
+/* AnnMatcher{keys1, keys2, ratio}.compute_matches(): nearest / second nearest  */
+/* neighbour in both directions, Lowe's ratio on SQUARED distances against      */
+/* ratio^2, duplicates (x, y) removed, sorted by score.  The neighbour search   */
+/* is exhaustive (what the reference's FLANN kd-trees approximate), with        */
+/* FLANN's squared-L2 arithmetic.  desc1: n1 x dim, desc2: n2 x dim row-major   */
+/* floats (host pointers, or device pointers when on_device != 0); dim <= 128.  */
+/* matches: host array of `capacity` records (n1 + n2 always suffices);         */
+/* *count = number of matches found; SARA_HIP_CAPACITY_EXCEEDED if it does not  */
+/* fit.  Empty key sets: SARA_HIP_RUNTIME_ERROR, like the reference's           */
+/* std::runtime_error (AnnMatcher.cpp:44-45); ratios above 1 (FLANN radius      */
+/* search, :132-136) are not supported: SARA_HIP_INVALID_PARAMS.                */
+SARA_HIP_API sara_hip_status sara_hip_match_descriptors(
+    const float* desc1, int n1, const float* desc2, int n2, int dim,
+    float sift_ratio_thres, int on_device, sara_match* matches, int capacity,
+    int* count, int device);
+
 /* Host self-check: evaluates, on the CPU, the float atan2 sequence the polar-  */
 /* gradient kernels execute on the GPU (a restatement of glibc 2.35's          */
 /* atan2f), so that tests can prove it bit-identical to the host libm the CPU  */

@@ -1306,4 +1306,138 @@ namespace sara_ref {
     R.times.total_ms = elapsed;
   }
 
+
+  // ======================================================================== //
+  // Descriptor matching.
+  //
+  // Reference: AnnMatcher::compute_matches and append_nearest_neighbors,
+  // FeatureMatching/AnnMatcher.cpp:59-268 (two key sets, not self-matching),
+  // called by match(), SfM/Helpers/KeypointMatching.cpp:19-25.  The reference
+  // queries FLANN kd-trees (un-vendored search heuristics: 8 randomised trees,
+  // 32 checks), whose answers are *approximations* of the exact nearest
+  // neighbours and depend on FLANN's random seeds.  This restatement replaces
+  // the tree query by an exhaustive search - what FLANN converges to with
+  // unlimited checks - and keeps everything else: FLANN's squared L2 distance
+  // in its own summation order (third-party/flann/.../dist.h:150-178: groups
+  // of four, float accumulator), Lowe's ratio on squared distances with the
+  // squared threshold, both directions, sort by (x, y, score), unique on
+  // (x, y), final sort by score.  PARITY UNPINNED against the reference's FLANN
+  // results; pinned by the reference's only matcher test
+  // (test_featurematching_matching.cpp:29-62: one match, score 0).
+  // Distance ties: the lower index wins (FLANN: traversal order).
+  // ======================================================================== //
+  struct Match
+  {
+    int32_t x_index;   //!< index in the first key set
+    int32_t y_index;   //!< index in the second key set
+    float score;       //!< squared-distance ratio best / second best
+    int32_t rank;      //!< 1 (only the best neighbour passes a ratio <= 1)
+    int32_t direction; //!< 0 = SourceToTarget, 1 = TargetToSource
+  };
+
+  //! flann::L2<float>::operator() (dist.h:150-178) without the early exit.
+  inline float flann_l2(const float* a, const float* b, int size)
+  {
+    float result = 0.f;
+    int i = 0;
+    for (; i + 3 < size; i += 4)
+    {
+      const float d0 = a[i] - b[i], d1 = a[i + 1] - b[i + 1];
+      const float d2 = a[i + 2] - b[i + 2], d3 = a[i + 3] - b[i + 3];
+      result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+    for (; i < size; ++i)
+    {
+      const float d0 = a[i] - b[i];
+      result += d0 * d0;
+    }
+    return result;
+  }
+
+  //! append_nearest_neighbors for every row of `q` against `t`
+  //! (AnnMatcher.cpp:59-170, self_matching == false, squared ratio <= 1).
+  inline void append_matches(const float* q, int nq, const float* t, int nt,
+                             int dim, float squared_ratio_thres, int direction,
+                             std::vector<Match>& matches)
+  {
+    if (nt == 0)
+      return;
+    for (int i = 0; i < nq; ++i)
+    {
+      if (nt == 1)
+      {
+        // AnnMatcher.cpp:87-101: a single candidate gets score 1.
+        if (1.f < squared_ratio_thres)
+          matches.push_back(direction == 0 ? Match{i, 0, 1.f, 1, direction}
+                                           : Match{0, i, 1.f, 1, direction});
+        continue;
+      }
+      float d0 = std::numeric_limits<float>::max(), d1 = d0;
+      int i0 = -1;
+      for (int j = 0; j < nt; ++j)
+      {
+        const float d = flann_l2(q + size_t(i) * dim, t + size_t(j) * dim, dim);
+        if (d < d0)
+        {
+          d1 = d0;
+          d0 = d;
+          i0 = j;
+        }
+        else if (d < d1)
+          d1 = d;
+      }
+      // AnnMatcher.cpp:126-130, 139-147.
+      const float score = d1 > 0.f ? d0 / d1 : 0.f;
+      if (score > squared_ratio_thres)
+        continue;
+      matches.push_back(direction == 0 ? Match{i, i0, score, 1, direction}
+                                       : Match{i0, i, score, 1, direction});
+    }
+  }
+
+  inline std::vector<Match> compute_matches(const float* desc1, int n1,
+                                            const float* desc2, int n2, int dim,
+                                            float sift_ratio_thres)
+  {
+    // create_flann_matrix, AnnMatcher.cpp:42-54.
+    if (n1 == 0 || n2 == 0)
+      throw std::runtime_error{"Error: the list of key-points is empty!"};
+    if (sift_ratio_thres > 1.f)
+      throw std::runtime_error{
+          "ratio thresholds above 1 (FLANN radius search) are not restated"};
+    const float thres2 = sift_ratio_thres * sift_ratio_thres;
+    std::vector<Match> matches;
+    append_matches(desc1, n1, desc2, n2, dim, thres2, 0, matches);
+    append_matches(desc2, n2, desc1, n1, dim, thres2, 1, matches);
+    // AnnMatcher.cpp:239-258.
+    std::sort(matches.begin(), matches.end(), [](const Match& a, const Match& b) {
+      if (a.x_index != b.x_index)
+        return a.x_index < b.x_index;
+      if (a.y_index != b.y_index)
+        return a.y_index < b.y_index;
+      if (a.score != b.score)
+        return a.score < b.score;
+      // equal scores from the two directions (e.g. bit-identical
+      // descriptors, score 0): std::sort leaves their order unspecified in
+      // the reference; SourceToTarget first is one valid outcome
+      return a.direction < b.direction;
+    });
+    matches.erase(std::unique(matches.begin(), matches.end(),
+                              [](const Match& a, const Match& b) {
+                                return a.x_index == b.x_index &&
+                                       a.y_index == b.y_index;
+                              }),
+                  matches.end());
+    // The reference's final std::sort by score leaves equal scores in an
+    // unspecified order; (score, x, y) is one valid outcome of it.
+    std::sort(matches.begin(), matches.end(), [](const Match& a, const Match& b) {
+      if (a.score != b.score)
+        return a.score < b.score;
+      if (a.x_index != b.x_index)
+        return a.x_index < b.x_index;
+      return a.y_index < b.y_index;
+    });
+    return matches;
+  }
+
 }  // namespace sara_ref

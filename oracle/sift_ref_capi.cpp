@@ -258,6 +258,31 @@ float ref_rgb8_to_gray32f(unsigned char r, unsigned char g, unsigned char b)
   return rgb8_to_gray32f(r, g, b);
 }
 
+// ---- descriptor matching (row f2) ---------------------------------------- //
+//! -> number of matches (written up to `capacity`), or -1 with ref_last_error.
+int ref_compute_matches(const float* desc1, int n1, const float* desc2, int n2,
+                        int dim, float sift_ratio_thres, Match* out,
+                        int capacity)
+{
+  try
+  {
+    const auto m = compute_matches(desc1, n1, desc2, n2, dim, sift_ratio_thres);
+    for (int i = 0; i < int(m.size()) && i < capacity; ++i)
+      out[i] = m[i];
+    return int(m.size());
+  }
+  catch (const std::exception& e)
+  {
+    g_last_error = e.what();
+    return -1;
+  }
+}
+
+float ref_flann_l2(const float* a, const float* b, int size)
+{
+  return flann_l2(a, b, size);
+}
+
 // ---- whole-pipeline handle ---------------------------------------------- //
 
 struct ref_sift

@@ -15,7 +15,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import (OEREGION_DTYPE, STAGE_DESCRIPTOR, STAGE_EXTREMA,
+from .capi import (MATCH_DTYPE, OEREGION_DTYPE, STAGE_DESCRIPTOR, STAGE_EXTREMA,
                    STAGE_GRADIENT, STAGE_ORIENTATION, STAGE_PYRAMID,
                    SaraHipError)
 
@@ -24,7 +24,8 @@ __all__ = [
     "compute_sift_keypoints", "SiftContext", "ComputeDoGExtrema",
     "apply_gaussian_filter", "gaussian", "scale", "downscale", "enlarge",
     "gradient_polar_coordinates", "scale_space_dog_extremum_map",
-    "from_rgb8_to_gray32f", "from_gray8_to_gray32f",
+    "from_rgb8_to_gray32f", "from_gray8_to_gray32f", "AnnMatcher", "match",
+    "MATCH_DTYPE",
     "make_gaussian_kernel", "SaraHipError", "OEREGION_DTYPE",
 ]
 
@@ -445,6 +446,52 @@ def from_gray8_to_gray32f(src, device=0):
         a.ctypes.data, out.ctypes.data_as(C.POINTER(C.c_float)), a.shape[1],
         a.shape[0], device))
     return out
+
+
+class AnnMatcher:
+    """FeatureMatching/AnnMatcher.hpp:40-66 for two key sets: Lowe's ratio
+    matching in both directions on squared L2 distances, duplicates removed,
+    sorted by score.  The neighbour search is exhaustive on the GPU (the
+    reference's FLANN kd-trees approximate it).  ``compute_matches`` returns a
+    structured array (x_index, y_index, score, rank, direction)."""
+
+    def __init__(self, keys1, keys2, sift_ratio_thres=1.2, device=0):
+        self._d1 = self._descriptors(keys1)
+        self._d2 = self._descriptors(keys2)
+        if (isinstance(keys1, KeypointList) and
+                len(keys1.regions) != len(self._d1)) or \
+           (isinstance(keys2, KeypointList) and
+                len(keys2.regions) != len(self._d2)):
+            # AnnMatcher.cpp:181-184
+            raise RuntimeError("The list of keypoints are inconsistent in size!")
+        self._ratio = float(sift_ratio_thres)
+        self._device = device
+
+    @staticmethod
+    def _descriptors(keys):
+        d = keys.descriptor_matrix if isinstance(keys, KeypointList) else keys
+        d = np.ascontiguousarray(d, dtype=np.float32)
+        if d.ndim != 2:
+            raise ValueError("descriptors must be an N x dim matrix")
+        return d
+
+    def compute_matches(self):
+        d1, d2 = self._d1, self._d2
+        if d1.shape[0] and d2.shape[0] and d1.shape[1] != d2.shape[1]:
+            raise ValueError("descriptor dimensions differ")
+        cap = d1.shape[0] + d2.shape[0]
+        out = np.zeros(max(cap, 1), MATCH_DTYPE)
+        count = C.c_int(0)
+        capi.check(capi.load().sara_hip_match_descriptors(
+            d1.ctypes.data, d1.shape[0], d2.ctypes.data, d2.shape[0],
+            d1.shape[1] if d1.shape[0] else (d2.shape[1] if d2.ndim == 2 else 0),
+            self._ratio, 0, out.ctypes.data, cap, C.byref(count), self._device))
+        return out[:count.value]
+
+
+def match(keys1, keys2, lowe_ratio, device=0):
+    """SfM/Helpers/KeypointMatching.cpp:19-25."""
+    return AnnMatcher(keys1, keys2, lowe_ratio, device).compute_matches()
 
 
 def gradient_polar_coordinates(src, device=0):

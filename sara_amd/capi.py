@@ -29,6 +29,8 @@ OPT_ALL_GRADIENT_SCALES = 1
 OPT_STAGE_TIMERS = 2
 
 #: numpy view of sara_oeregion (48 bytes, Features/Feature.hpp:155-177).
+MATCH_DTYPE = np.dtype([("x_index", "<i4"), ("y_index", "<i4"), ("score", "<f4"),
+                        ("rank", "<i4"), ("direction", "<i4")])
 OEREGION_DTYPE = np.dtype(
     {
         "names": ["coords", "shape_matrix", "orientation", "extremum_value",
@@ -79,7 +81,7 @@ EXPORTS = [
     "sara_hip_subtract", "sara_hip_gradient_polar_coordinates",
     "sara_hip_scale_space_dog_extremum_map", "sara_hip_selfcheck_atan2f",
     "sara_hip_sift_detect_u8", "sara_hip_from_rgb8_to_gray32f",
-    "sara_hip_from_gray8_to_gray32f",
+    "sara_hip_from_gray8_to_gray32f", "sara_hip_match_descriptors",
 ]
 
 _f32p = C.POINTER(C.c_float)
@@ -155,6 +157,9 @@ def _declare(lib):
     for name in ("sara_hip_from_rgb8_to_gray32f",
                  "sara_hip_from_gray8_to_gray32f"):
         getattr(lib, name).argtypes = [_vp, _f32p, C.c_int, C.c_int, C.c_int]
+    lib.sara_hip_match_descriptors.argtypes = [
+        _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, C.c_int,
+        C.POINTER(C.c_int), C.c_int]
     lib.sara_hip_selfcheck_atan2f.argtypes = [_f32p, _f32p, _f32p, C.c_size_t]
     lib.sara_hip_selfcheck_atan2f.restype = None
     return lib

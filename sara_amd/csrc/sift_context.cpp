@@ -1368,6 +1368,101 @@ sara_hip_status sara_hip_from_gray8_to_gray32f(const uint8_t* src, float* gray,
   return u8_to_gray(src, gray, w, h, 1, device);
 }
 
+sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,
+                                           const float* desc2, int n2, int dim,
+                                           float sift_ratio_thres, int on_device,
+                                           sara_match* matches, int capacity,
+                                           int* count, int device)
+{
+  if (count)
+    *count = 0;
+  if (!desc1 || !desc2 || !matches || !count || n1 < 0 || n2 < 0 || capacity < 0)
+    return fail(SARA_HIP_INVALID_PARAMS, "null pointer or negative size");
+  if (n1 == 0 || n2 == 0)
+    return fail(SARA_HIP_RUNTIME_ERROR, "Error: the list of key-points is empty!");
+  if (dim < 1 || dim > 128)
+    return fail(SARA_HIP_INVALID_PARAMS, "descriptor dimension must be in 1..128");
+  if (!(sift_ratio_thres <= 1.f))
+    return fail(SARA_HIP_INVALID_PARAMS,
+                "ratio thresholds above 1 (FLANN radius search) are not "
+                "supported");
+  const sara_hip_status st = select_device(device);
+  if (st != SARA_HIP_OK)
+    return st;
+  const float thres2 = sift_ratio_thres * sift_ratio_thres;
+  DeviceScratch sc;
+  const float *d1 = desc1, *d2 = desc2;
+  if (!on_device)
+  {
+    float *a = nullptr, *b = nullptr;
+    HIP_TRY(sc.get(a, size_t(n1) * dim));
+    HIP_TRY(sc.get(b, size_t(n2) * dim));
+    HIP_TRY(hipMemcpy(a, desc1, size_t(n1) * dim * sizeof(float),
+                      hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b, desc2, size_t(n2) * dim * sizeof(float),
+                      hipMemcpyHostToDevice));
+    d1 = a;
+    d2 = b;
+  }
+  int chunk = 0, nch12 = 0, nch21 = 0;
+  match_partials_per_query(n2, &chunk, &nch12, n1);
+  match_partials_per_query(n1, &chunk, &nch21, n2);
+  const size_t npart = std::max(size_t(nch12) * n1, size_t(nch21) * n2);
+  float *p0 = nullptr, *p1 = nullptr;
+  int *pi = nullptr, *d_count = nullptr;
+  sara_match* d_out = nullptr;
+  const int cap_dev = n1 + n2;
+  HIP_TRY(sc.get(p0, npart));
+  HIP_TRY(sc.get(p1, npart));
+  HIP_TRY(sc.get(pi, npart));
+  HIP_TRY(sc.get(d_count, 1));
+  HIP_TRY(sc.get(d_out, size_t(cap_dev)));
+  HIP_TRY(hipMemset(d_count, 0, sizeof(int)));
+  // A single candidate gets score 1 (AnnMatcher.cpp:87-101), which never
+  // passes a squared ratio <= 1: those directions contribute nothing.
+  if (n2 >= 2)
+    launch_match_direction(d1, n1, d2, n2, dim, thres2, 0, p0, p1, pi, d_out,
+                           cap_dev, d_count, nullptr);
+  if (n1 >= 2)
+    launch_match_direction(d2, n2, d1, n1, dim, thres2, 1, p0, p1, pi, d_out,
+                           cap_dev, d_count, nullptr);
+  HIP_TRY(hipGetLastError());
+  int found = 0;
+  HIP_TRY(hipMemcpy(&found, d_count, sizeof(int), hipMemcpyDeviceToHost));
+  std::vector<sara_match> m(size_t(std::max(found, 0)));
+  if (found > 0)
+    HIP_TRY(hipMemcpy(m.data(), d_out, size_t(found) * sizeof(sara_match),
+                      hipMemcpyDeviceToHost));
+  // AnnMatcher.cpp:239-258: sort by (x, y, score), unique on (x, y), sort by
+  // score (equal scores: by (x, y), one of the orders std::sort may leave).
+  std::sort(m.begin(), m.end(), [](const sara_match& a, const sara_match& b) {
+    if (a.x_index != b.x_index)
+      return a.x_index < b.x_index;
+    if (a.y_index != b.y_index)
+      return a.y_index < b.y_index;
+    if (a.score != b.score)
+      return a.score < b.score;
+    return a.direction < b.direction;
+  });
+  m.erase(std::unique(m.begin(), m.end(),
+                      [](const sara_match& a, const sara_match& b) {
+                        return a.x_index == b.x_index && a.y_index == b.y_index;
+                      }),
+          m.end());
+  std::sort(m.begin(), m.end(), [](const sara_match& a, const sara_match& b) {
+    if (a.score != b.score)
+      return a.score < b.score;
+    if (a.x_index != b.x_index)
+      return a.x_index < b.x_index;
+    return a.y_index < b.y_index;
+  });
+  *count = int(m.size());
+  if (int(m.size()) > capacity)
+    return fail(SARA_HIP_CAPACITY_EXCEEDED, "more matches than `capacity`");
+  std::copy(m.begin(), m.end(), matches);
+  return SARA_HIP_OK;
+}
+
 sara_hip_status sara_hip_gradient_polar_coordinates(const float* src, int w,
                                                     int h, float* mag_ori,
                                                     int device)

@@ -221,4 +221,16 @@ namespace sara_hip {
   void launch_extrema_offsets(const CandidateLists& cand, int* ex_offset,
                               int batch, hipStream_t stream);
 
+  // ---- descriptor matching (match_kernels.hip) ----------------------------
+  //! Chunking of the candidates of one direction: -> number of partial
+  //! (best, second best) records per query.
+  size_t match_partials_per_query(int nt, int* chunk, int* nchunks, int nq);
+  //! Nearest and second nearest rows of `t` for every row of `q` (exhaustive,
+  //! FLANN's squared L2), ratio test, append to out[*count ...].
+  void launch_match_direction(const float* q, int nq, const float* t, int nt,
+                              int dim, float squared_ratio_thres, int direction,
+                              float* part_d0, float* part_d1, int* part_i0,
+                              sara_match* out, int capacity, int* count,
+                              hipStream_t stream);
+
 }  // namespace sara_hip

@@ -82,6 +82,21 @@ int main(int argc, char** argv)
   if (!sara::size_consistency_predicate(keys) || d.cols() != 128)
     return 5;
 
+  // matching the keypoints against themselves: every keypoint whose
+  // descriptor is unique finds itself with score 0 in both directions, kept
+  // once (AnnMatcher.cpp:239-254).
+  if (f.size() >= 3)
+  {
+    const auto matches = sara::match(keys, keys, 0.6f);
+    if (matches.empty())
+      return 11;
+    for (const auto& m : matches)
+      if (m.x_index() != m.y_index() && m.score() != 0.f)
+        return 12;
+    if (&matches.front().x() != &f[size_t(matches.front().x_index())])
+      return 13;
+  }
+
   // 2. the functor API with its pyramid accessors.
   auto compute_dogs = sara::ComputeDoGExtrema{pyr_params, 4.f, 0.01f, 10.f, 5, 5};
   auto so = std::vector<sara::Point2i>{};

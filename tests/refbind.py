@@ -339,6 +339,39 @@ def sift_descriptor(grad, x, y, s, theta, normalize=True):
     return out
 
 
+MATCH_DTYPE = np.dtype([("x_index", "<i4"), ("y_index", "<i4"), ("score", "<f4"),
+                        ("rank", "<i4"), ("direction", "<i4")])
+
+
+def compute_matches(desc1, desc2, sift_ratio_thres):
+    """Exhaustive-search restatement of AnnMatcher::compute_matches
+    (FeatureMatching/AnnMatcher.cpp:203-268) -> structured array MATCH_DTYPE."""
+    a, pa = _f(desc1)
+    b, pb = _f(desc2)
+    n1, n2 = a.shape[0], b.shape[0]
+    dim = a.shape[1] if a.ndim == 2 else b.shape[1]
+    cap = n1 + n2
+    out = np.zeros(max(cap, 1), MATCH_DTYPE)
+    fn = lib().ref_compute_matches
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                   C.c_void_p, C.c_int]
+    n = fn(a.ctypes.data, n1, b.ctypes.data, n2, dim, sift_ratio_thres,
+           out.ctypes.data, cap)
+    if n < 0:
+        raise RuntimeError(lib().ref_last_error().decode())
+    return out[:n]
+
+
+def flann_l2(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    fn = lib().ref_flann_l2
+    fn.restype = C.c_float
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    return float(fn(a.ctypes.data, b.ctypes.data, a.size))
+
+
 def rgb8_to_gray32f(rgb):
     """Vectorised restatement of the reference's Rgb8 -> float conversion
     (double arithmetic, final cast), checked against the C oracle in tests."""

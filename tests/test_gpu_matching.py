@@ -1,0 +1,83 @@
+"""-m gpu: descriptor matching through the C-ABI
+against the oracle's exhaustive-search restatement of AnnMatcher::compute_
+matches.  Bar: identical match sets and bit-identical scores (FLANN's squared
+L2 summation order is reproduced on the device)."""
+import numpy as np
+import pytest
+
+import sara_amd
+from sara_amd.synth import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_same(got, want):
+    assert len(got) == len(want)
+    assert np.array_equal(got["x_index"], want["x_index"])
+    assert np.array_equal(got["y_index"], want["y_index"])
+    assert np.array_equal(got["score"], want["score"])
+    assert np.array_equal(got["rank"], want["rank"])
+    assert np.array_equal(got["direction"], want["direction"])
+
+
+def test_reference_matcher_case():
+    """test_featurematching_matching.cpp:29-62."""
+    d1 = np.zeros((1, 2), np.float32)
+    d2 = np.stack([np.arange(10), np.arange(10)], axis=1).astype(np.float32)
+    m = sara_amd.AnnMatcher(d1, d2, 0.6).compute_matches()
+    assert len(m) == 1
+    assert (m[0]["x_index"], m[0]["y_index"], m[0]["score"]) == (0, 0, 0.0)
+
+
+@pytest.mark.parametrize("n1,n2,dim", [(40, 55, 128), (300, 129, 128), (65, 64, 32),
+                                       (7, 200, 6), (2, 2, 128), (1, 70, 128),
+                                       (130, 1, 128), (33, 500, 127)])
+def test_random_descriptors_match_oracle(oracle, n1, n2, dim):
+    rng = np.random.default_rng(n1 * 1000 + n2)
+    d1 = rng.random((n1, dim), dtype=np.float32)
+    k = min(n1, n2) // 2
+    d2 = rng.random((n2, dim), dtype=np.float32)
+    d2[:k] = d1[:k] + rng.normal(0, 2e-3, (k, dim)).astype(np.float32)
+    for ratio in (0.6, 0.9, 1.0):
+        assert_same(sara_amd.match(d1, d2, ratio),
+                    oracle.compute_matches(d1, d2, ratio))
+
+
+def test_sift_keypoints_of_shifted_frames(oracle):
+    """The consumer's use: keypoints of a frame against those of the same scene
+    shifted by a few pixels (match(), KeypointMatching.cpp:19-25)."""
+    img = synth(360, 300, 21)
+    a = np.ascontiguousarray(img[:280, :320])
+    b = np.ascontiguousarray(img[8:288, 24:344])
+    p = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=3)
+    ka = sara_amd.compute_sift_keypoints(a, p)
+    kb = sara_amd.compute_sift_keypoints(b, p)
+    got = sara_amd.match(ka, kb, 0.6)
+    want = oracle.compute_matches(ka.descriptor_matrix, kb.descriptor_matrix, 0.6)
+    assert_same(got, want)
+    assert len(got) > 0.2 * min(len(ka), len(kb))
+    # matched keypoints differ by the shift (24, 8)
+    xa = ka.regions["coords"][got["x_index"]]
+    xb = kb.regions["coords"][got["y_index"]]
+    d = xa - xb
+    good = (np.abs(d[:, 0] - 24) < 1.5) & (np.abs(d[:, 1] - 8) < 1.5)
+    assert good.mean() > 0.9
+
+
+def test_duplicates_and_ties(oracle):
+    rng = np.random.default_rng(5)
+    d1 = rng.random((20, 128), dtype=np.float32)
+    d2 = np.concatenate([d1[:10], d1[:10], rng.random((15, 128), dtype=np.float32)])
+    # exact duplicates: best == second best == 0 -> score 0 (d1 > 0 test fails)
+    assert_same(sara_amd.match(d1, d2, 0.8), oracle.compute_matches(d1, d2, 0.8))
+
+
+def test_error_behaviour():
+    d = np.zeros((4, 128), np.float32)
+    with pytest.raises(sara_amd.SaraHipError):
+        sara_amd.match(np.zeros((0, 128), np.float32), d, 0.6)   # empty key set
+    with pytest.raises(sara_amd.SaraHipError):
+        sara_amd.match(d, d, 1.2)                                 # radius search
+    with pytest.raises(sara_amd.SaraHipError):
+        sara_amd.match(np.zeros((4, 200), np.float32),
+                       np.zeros((4, 200), np.float32), 0.6)       # dim > 128

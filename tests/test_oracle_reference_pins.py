@@ -252,3 +252,37 @@ def test_oeregion_scale_roundtrip(oracle):
     for s in (1.6, 2.0159, 3.2, 5.0797, 1.7342):
         got = oracle.lib().ref_oeregion_scale(s)
         assert abs(got - np.float32(s)) <= 2e-7 * s
+
+
+# ---- descriptor matching ----------------------
+def test_ann_matching_reference_case(oracle):
+    """test_featurematching_matching.cpp:29-62: one point (0, 0) against ten
+    points (i, i), ratio 0.6 -> exactly one match {0, 0} with score 0."""
+    d1 = np.zeros((1, 2), np.float32)
+    d2 = np.stack([np.arange(10), np.arange(10)], axis=1).astype(np.float32)
+    m = oracle.compute_matches(d1, d2, 0.6)
+    assert len(m) == 1
+    assert (m[0]["x_index"], m[0]["y_index"], m[0]["score"]) == (0, 0, 0.0)
+
+
+def test_matching_restatement_properties(oracle):
+    rng = np.random.default_rng(11)
+    d1 = rng.random((40, 128), dtype=np.float32)
+    d2 = np.concatenate([d1[:25] + rng.normal(0, 1e-3, (25, 128)).astype(np.float32),
+                         rng.random((30, 128), dtype=np.float32)])
+    m = oracle.compute_matches(d1, d2, 0.6)
+    # the 25 perturbed copies are mutual nearest neighbours, found from both
+    # sides and kept once (AnnMatcher.cpp:239-254)
+    pairs = {(int(a), int(b)) for a, b in zip(m["x_index"], m["y_index"])}
+    assert pairs == {(i, i) for i in range(25)}
+    assert np.all(np.diff(m["score"]) >= 0)
+    assert np.all(m["score"] <= np.float32(0.6) * np.float32(0.6))
+    # FLANN's distance: groups of four, float accumulator (dist.h:150-178)
+    a, b = d1[3], d2[7]
+    acc = np.float32(0)
+    for i in range(0, 128, 4):
+        d = a[i:i + 4] - b[i:i + 4]
+        acc = acc + (((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3])
+    assert oracle.flann_l2(a, b) == float(acc)
+    with pytest.raises(RuntimeError):
+        oracle.compute_matches(np.zeros((0, 128), np.float32), d2, 0.6)
