@@ -277,7 +277,7 @@ def main():
             },
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {
-                "kernel": "gaussian_blur_march_kernel<R> (Gaussian pyramid "
+                "kernel": "gaussian_blur_march{,2}_kernel<R> (Gaussian pyramid "
                           "stage = %d blur launches/step on per-octave "
                           "streams; the octave hand-overs are fused into "
                           "them; achieved = 48*P*frames / stage time from "
