@@ -256,6 +256,23 @@ class SiftContext:
             self._h, C.byref(f), C.byref(d), C.byref(s), C.byref(o)))
         return f.value, d.value, s.value, o.value
 
+    def match_frames(self, i, j, lowe_ratio):
+        """match() (SfM/Helpers/KeypointMatching.cpp:19-25) between the
+        keypoints of frames i and j of the last detect(), descriptors read
+        where they are in HBM (sara_hip_sift_device_results)."""
+        counts, _ = self.counts()
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        _, d_desc, _, _ = self.device_results()
+        n1, n2 = int(counts[i]), int(counts[j])
+        cap = n1 + n2
+        out = np.zeros(max(cap, 1), MATCH_DTYPE)
+        count = C.c_int(0)
+        capi.check(capi.load().sara_hip_match_descriptors(
+            d_desc + int(off[i]) * 512, n1, d_desc + int(off[j]) * 512, n2, 128,
+            float(lowe_ratio), 1, out.ctypes.data, cap, C.byref(count),
+            self.device))
+        return out[:count.value]
+
     def keypoint_lists(self, with_descriptors=True):
         c, regions, desc, so = self.fetch(with_descriptors)
         out, at = [], 0

@@ -81,3 +81,19 @@ def test_error_behaviour():
     with pytest.raises(sara_amd.SaraHipError):
         sara_amd.match(np.zeros((4, 200), np.float32),
                        np.zeros((4, 200), np.float32), 0.6)       # dim > 128
+
+
+def test_match_frames_on_device(oracle):
+    """Frames of one batch matched where their descriptors are in HBM."""
+    img = synth(360, 300, 21)
+    frames = np.stack([img[:280, :320], img[8:288, 24:344], img[4:284, 10:330]])
+    p = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=3)
+    with sara_amd.SiftContext(320, 280, 3, p) as ctx:
+        ctx.detect(np.ascontiguousarray(frames))
+        kl = ctx.keypoint_lists()
+        for (i, j) in ((0, 1), (2, 0), (1, 1)):
+            got = ctx.match_frames(i, j, 0.6)
+            want = oracle.compute_matches(kl[i].descriptor_matrix,
+                                          kl[j].descriptor_matrix, 0.6)
+            assert_same(got, want)
+            assert len(got) > 0
