@@ -990,14 +990,19 @@ sara_hip_status sara_hip_sift_counts(sara_hip_sift* c, int* per_frame, int* tota
   if (st != SARA_HIP_OK)
     return st;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipMemcpyAsync(c->h_counts, c->ori.kp_count, sizeof(int) * c->cur_batch,
+  // both count arrays in one round trip (h_counts holds 2*(max_batch+1) ints)
+  int* h_kp = c->h_counts;
+  int* h_ex = c->h_counts + c->max_batch + 1;
+  HIP_TRY(hipMemcpyAsync(h_kp, c->ori.kp_count, sizeof(int) * c->cur_batch,
+                         hipMemcpyDeviceToHost, c->last_stream));
+  HIP_TRY(hipMemcpyAsync(h_ex, c->cand.count, sizeof(int) * c->cur_batch,
                          hipMemcpyDeviceToHost, c->last_stream));
   HIP_TRY(hipStreamSynchronize(c->last_stream));
   int sum = 0;
   bool overflow = false;
   for (int b = 0; b < c->cur_batch; ++b)
   {
-    const int n = c->h_counts[b];
+    const int n = h_kp[b];
     overflow = overflow || n > c->cap;
     if (per_frame)
       per_frame[b] = std::min(n, c->cap);
@@ -1009,10 +1014,8 @@ sara_hip_status sara_hip_sift_counts(sara_hip_sift* c, int* per_frame, int* tota
     return fail(SARA_HIP_CAPACITY_EXCEEDED,
                 "a frame produced more keypoints than max_keypoints");
   // the extremum list can also overflow without the keypoint list doing so
-  HIP_TRY(hipMemcpy(c->h_counts, c->cand.count, sizeof(int) * c->cur_batch,
-                    hipMemcpyDeviceToHost));
   for (int b = 0; b < c->cur_batch; ++b)
-    if (c->h_counts[b] > c->cap)
+    if (h_ex[b] > c->cap)
       return fail(SARA_HIP_CAPACITY_EXCEEDED,
                   "a frame produced more extrema than max_keypoints");
   return SARA_HIP_OK;
