@@ -266,7 +266,10 @@ SARA_HIP_API sara_hip_status sara_hip_sift_fetch_extrema(sara_hip_sift* ctx,
                                                         int32_t* xyso_type);
 
 /* Device time of each stage of the last detect() in milliseconds (hipEvent),  */
-/* indexed by SARA_HIP_TIME_*.  Synchronises.                                  */
+/* indexed by SARA_HIP_TIME_*.  Synchronises.  Batches of up to 8 frames on the */
+/* context's own stream replay a captured HIP graph (launch-bound regime); then */
+/* only SARA_HIP_TIME_TOTAL is measured and the per-stage entries are 0         */
+/* (environment SARA_HIP_GRAPH=0 restores plain launches and stage times).      */
 SARA_HIP_API sara_hip_status sara_hip_sift_stage_times(sara_hip_sift* ctx,
                                                       float* ms);
 

@@ -11,6 +11,8 @@ Tolerances (stated once, used everywhere below):
     last-ulp differences; the reference itself accepts 2e-1 CPU<->Halide,
     test_halide_sift_descriptor.cpp:210,303).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -331,8 +333,19 @@ def test_stage_stops(oracle):
         kc, kreg, kdesc, kso = ctx.fetch(with_descriptors=False)
         common.assert_regions_equal(kreg, ref.keypoints()[0],
                                     rtol_shape=SHAPE_RTOL, atol_theta=THETA_ATOL)
+        # one frame replays a captured HIP graph: total time only
         t = ctx.stage_times()
-        assert t["total"] > 0 and t["pyramid"] > 0
+        assert t["total"] > 0
+    os.environ["SARA_HIP_GRAPH"] = "0"
+    try:
+        with sara_amd.SiftContext(200, 150, 1, hip_params(0, 3)) as ctx:
+            ctx.detect(img, last_stage=sara_amd.STAGE_ORIENTATION)
+            kc2, kreg2, _, _ = ctx.fetch(with_descriptors=False)
+            assert kreg2.tobytes() == kreg.tobytes()
+            t = ctx.stage_times()
+            assert t["total"] > 0 and t["pyramid"] > 0
+    finally:
+        del os.environ["SARA_HIP_GRAPH"]
 
 
 def test_detect_u8_equals_detect_on_converted_frames(oracle):
