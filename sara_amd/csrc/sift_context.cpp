@@ -221,6 +221,13 @@ struct sara_hip_sift
   sara_oeregion* d_ex_regions = nullptr;
   int32_t* d_ex_xyso = nullptr;
 
+  // counting sort of the extrema (launch_rank_candidates_bucketed)
+  int* d_bucket_hist = nullptr;    // [max_batch][bucket_stride]
+  int* d_bucket_cursor = nullptr;  // [max_batch][bucket_stride]
+  int* d_grouped = nullptr;        // [max_batch][cap]
+  int bucket_stride = 0;
+  RowBuckets row_buckets{};        // of the current schedule
+  bool bucketed_rank = true;       // SARA_HIP_RANK=count restores the O(n^2) kernel
   int* h_counts = nullptr;  // pinned, 2*(max_batch+1)
   // Small batches are launch-bound (about 60 launches in 0.7 ms for one 1080p
   // frame): the enqueue sequence of detect() is captured once per (size,
@@ -429,6 +436,18 @@ namespace {
     TRY_ST(c->alloc(c->cand.data, rows));
     TRY_ST(c->alloc(c->cand.count, max_batch));
     TRY_ST(c->alloc(c->cand.order, rows));
+    {
+      // one bucket per image row of every plane of the largest schedule
+      int total = 0;
+      for (int o = 0; o < c->max_sched.num_octaves; ++o)
+        total += c->S * c->max_sched.oct[o].h;
+      c->bucket_stride = total + 1;
+      TRY_ST(c->alloc(c->d_bucket_hist, size_t(max_batch) * c->bucket_stride));
+      TRY_ST(c->alloc(c->d_bucket_cursor, size_t(max_batch) * c->bucket_stride));
+      TRY_ST(c->alloc(c->d_grouped, rows));
+      if (const char* e = getenv("SARA_HIP_RANK"))
+        c->bucketed_rank = std::string(e) != "count";
+    }
     c->sites.cap = 4 * c->cap;
     TRY_ST(c->alloc(c->sites.key, size_t(max_batch) * c->sites.cap));
     TRY_ST(c->alloc(c->sites.count, max_batch));
@@ -694,6 +713,19 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     c->cur = make_schedule(c->pyr, width, height);
     c->cur_w = width;
     c->cur_h = height;
+    {
+      RowBuckets& rb = c->row_buckets;
+      std::memset(&rb, 0, sizeof(rb));
+      int at = 0;
+      for (int o = 0; o < c->cur.num_octaves && o < 16; ++o)
+        for (int sidx = 0; sidx < c->S; ++sidx)
+        {
+          rb.base[o * kMaxScales + sidx] = at;
+          at += c->cur.oct[o].h;
+        }
+      rb.total = at;
+      rb.stride = c->bucket_stride;
+    }
     GradPyramidView& gv = *c->h_grad;
     std::memset(&gv, 0, sizeof(gv));
     gv.octaves = c->cur.num_octaves;
@@ -915,7 +947,13 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       }
       launch_finish_sites(pv, batch, ep, c->d_tab, c->sites, c->cand, stream);
     }
-    launch_rank_candidates(c->cand, batch, stream);
+    if (c->bucketed_rank && c->row_buckets.total < c->bucket_stride &&
+        sc.num_octaves <= 16)
+      launch_rank_candidates_bucketed(c->cand, c->row_buckets, c->d_bucket_hist,
+                                      c->d_bucket_cursor, c->d_grouped, batch,
+                                      stream);
+    else
+      launch_rank_candidates(c->cand, batch, stream);
     launch_extrema_offsets(c->cand, c->d_ex_offset, batch, stream);
   }
   HIP_TRY(mark(3));

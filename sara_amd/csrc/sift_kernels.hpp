@@ -61,6 +61,17 @@ namespace sara_hip {
     int cap;
   };
 
+  //! Buckets of the counting sort that orders a frame's extrema: one per image
+  //! row of every (octave, scale) plane.  base[o * kMaxScales + s] = first
+  //! bucket of that plane; `total` buckets per frame, rows of `stride` ints
+  //! (>= total + 1) in the per-frame arrays.
+  struct RowBuckets
+  {
+    int base[16 * kMaxScales];
+    int total;
+    int stride;
+  };
+
   //! Classified extremum sites of the marching scan, before the edge test and
   //! the refinement (same key layout as CandidateLists::key).
   struct SiteLists
@@ -175,6 +186,12 @@ namespace sara_hip {
                            int8_t* out, hipStream_t stream);
 
   //! order[b][rank] = slot, rank = number of smaller keys in the frame.
+  //! Same result through a counting sort on the (octave, scale, y) key prefix
+  //! (hist, cursor: [batch][rb.stride] ints; grouped: [batch][cap] ints).
+  void launch_rank_candidates_bucketed(const CandidateLists& cand,
+                                       const RowBuckets& rb, int* hist,
+                                       int* cursor, int* grouped, int batch,
+                                       hipStream_t stream);
   void launch_rank_candidates(const CandidateLists& cand, int batch,
                               hipStream_t stream);
 
