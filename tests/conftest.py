@@ -18,8 +18,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")
 
 
+def _usable_cpus():
+    """CPUs this process may use: affinity capped by the cgroup quota (the GPU
+    boxes show 256 logical CPUs under a 16-CPU quota; an OpenMP team of 256 is
+    about 100x slower than one of 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import refbind
     refbind.build()
+    refbind.lib().ref_omp_set_threads(_usable_cpus())
     return refbind
