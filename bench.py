@@ -147,7 +147,7 @@ def main():
     import sara_amd
     from sara_amd import capi
     from sara_amd.synth import synth_batch
-    from sara_amd.distributed import gatherv_to_root
+    from sara_amd.distributed import exchange_counts, gatherv_to_root
 
     ndev = capi.require_gpu()
     # SARA_BENCH_BACKEND=gloo lets the multi-process path be exercised on a box
@@ -165,6 +165,15 @@ def main():
                                     device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    # keypoint counts travel through host tensors on a gloo group: no wait for
+    # the kernels in flight, no extra device synchronisation per step
+    count_group = None
+    if world > 1 and backend == "nccl":
+        count_group = dist.new_group(backend="gloo")
+        # establish the RCCL communicator collectively before the first
+        # point-to-point exchange
+        dist.all_reduce(torch.zeros(1, device=dev))
+        torch.cuda.synchronize()
 
     B, W, H = args.frames_per_gpu, args.width, args.height
     frames_host = synth_batch(W, H, B, first_index=rank * B,
@@ -176,40 +185,52 @@ def main():
     ctx = sara_amd.SiftContext(W, H, B, params, device=local_rank)
     stream = torch.cuda.current_stream(dev)
 
-    # keypoint arrays gathered on rank 0; the exchange of step i overlaps the
-    # kernels of step i+1 (one gather in flight)
+    # Keypoint arrays are gathered on rank 0.  Step i stages its results in
+    # fresh device tensors (one device-to-device copy on the detect stream);
+    # their exchange is posted right after the kernels of step i+1 have been
+    # enqueued, so the GPU never waits for the host-side part of the gather
+    # and the transfers overlap the next step's compute.
     feat_buf = desc_buf = so_buf = None
-    pending = [None]
+    pending = [None]   # point-to-point transfers in flight
+    staged = [None]    # results staged on the device, exchange not posted yet
 
     def step():
         """One pass over the batch; returns this rank's keypoint count."""
         ctx.detect_device(frames.data_ptr(), B, W, H, last_stage=args.stage,
                           stream=stream.cuda_stream)
+        if world > 1 and staged[0] is not None:
+            post_gather(staged[0])
+            staged[0] = None
         if args.stage < 4:
             c, _, _ = ctx.extrema() if args.stage >= 2 else (np.zeros(B), 0, 0)
             return int(np.sum(c))
         counts, total = ctx.counts()
         if world > 1:
-            gather_to_root(total)
+            staged[0] = stage_results(total)
         return total
 
-    def gather_to_root(total):
-        """gatherv of OERegion[ ] (48 B), descriptors (512 B) and (s,o) pairs
-        to rank 0 (sara_amd/distributed.py)."""
-        nonlocal feat_buf, desc_buf, so_buf
+    def stage_results(total):
+        """OERegion[ ] (48 B), descriptors (512 B) and (s,o) pairs of this step
+        copied out of the context's buffers (which the next detect() reuses)."""
         mine_f = torch.empty((total, 48), dtype=torch.uint8, device=dev)
         mine_d = torch.empty((total, 128), dtype=torch.float32, device=dev)
         mine_s = torch.empty((total, 2), dtype=torch.int32, device=dev)
         if total:
             capi.check(capi.load().sara_hip_sift_fetch(
                 ctx._h, mine_f.data_ptr(), mine_d.data_ptr(), mine_s.data_ptr(),
-                1))
-        ctx.synchronize()  # the copies run on the detect stream
+                1))  # asynchronous, on the detect stream
+        return [mine_f, mine_d, mine_s], total
+
+    def post_gather(item):
+        """gatherv to rank 0 (sara_amd/distributed.py).  RCCL orders the
+        transfers after everything already enqueued on the detect stream."""
+        tensors, total = item
         if backend != "nccl":
-            mine_f, mine_d, mine_s = mine_f.cpu(), mine_d.cpu(), mine_s.cpu()
+            tensors = [t.cpu() for t in tensors]  # gloo: host staging
+        counts_all = exchange_counts(total, count_group)
         wait_gather()
-        pending[0] = gatherv_to_root([mine_f, mine_d, mine_s], root=0,
-                                     async_op=True)
+        pending[0] = gatherv_to_root(tensors, root=0, async_op=True,
+                                     counts=counts_all)
 
     def wait_gather():
         nonlocal feat_buf, desc_buf, so_buf
@@ -221,6 +242,9 @@ def main():
 
     def sync():
         if world > 1:
+            if staged[0] is not None:
+                post_gather(staged[0])
+                staged[0] = None
             wait_gather()
         torch.cuda.synchronize()
         ctx.synchronize()

@@ -33,23 +33,39 @@ class PendingGather:
         return self.outs, self.counts
 
 
-def gatherv_to_root(arrays, root=0, group=None, async_op=False):
+def exchange_counts(n, group=None):
+    """Every rank's keypoint count, exchanged through HOST tensors on `group`
+    (a gloo group): unlike a device-side all_gather this neither waits for the
+    kernels already enqueued on the GPU nor adds a device synchronisation."""
+    world = dist.get_world_size(group)
+    n_t = torch.tensor([int(n)], dtype=torch.int64)
+    all_n = [torch.zeros_like(n_t) for _ in range(world)]
+    dist.all_gather(all_n, n_t, group=group)
+    return [int(t.item()) for t in all_n]
+
+
+def gatherv_to_root(arrays, root=0, group=None, async_op=False, counts=None):
     """arrays: list of tensors whose first dimension is this rank's keypoint
     count n_r (same trailing shapes and dtypes on every rank).  Returns, on the
     root, (list of concatenated tensors in rank order, counts per rank); on the
     other ranks (None, counts per rank).  With async_op=True the point-to-point
     transfers are only posted and a PendingGather is returned, so the next
-    batch's kernels overlap the exchange."""
+    batch's kernels overlap the exchange.  `counts` (from exchange_counts)
+    skips the all_gather of the counts on the arrays' device."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n = int(arrays[0].shape[0])
     for a in arrays:
         assert int(a.shape[0]) == n
     dev = arrays[0].device
-    n_t = torch.tensor([n], device=dev, dtype=torch.int64)
-    all_n = [torch.zeros_like(n_t) for _ in range(world)]
-    dist.all_gather(all_n, n_t, group=group)
-    counts = [int(t.item()) for t in all_n]
+    if counts is None:
+        n_t = torch.tensor([n], device=dev, dtype=torch.int64)
+        all_n = [torch.zeros_like(n_t) for _ in range(world)]
+        dist.all_gather(all_n, n_t, group=group)
+        counts = [int(t.item()) for t in all_n]
+    else:
+        counts = [int(c) for c in counts]
+        assert len(counts) == world and counts[rank] == n
     if world == 1:
         if async_op:
             return PendingGather(list(arrays), counts, [], None)

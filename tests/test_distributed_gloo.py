@@ -12,7 +12,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from sara_amd.distributed import gatherv_to_root, shard_range
+from sara_amd.distributed import (exchange_counts, gatherv_to_root,
+                                  shard_range)
 
 
 def test_shard_range_partitions():
@@ -63,8 +64,20 @@ def _worker(rank, world, port, n_frames, tmpdir):
     pending = gatherv_to_root(arrays, root=0, async_op=True)
     outs2, counts2 = pending.wait()
     assert counts2 == counts
+    # the bench's form: counts exchanged on a separate (gloo) group first,
+    # several exchanges in flight one after the other
+    side = dist.new_group(backend="gloo")
+    counts3 = exchange_counts(arrays[0].shape[0], side)
+    assert counts3 == counts
+    p3 = gatherv_to_root(arrays, root=0, async_op=True, counts=counts3)
+    p4 = gatherv_to_root(arrays, root=0, async_op=True,
+                         counts=exchange_counts(arrays[0].shape[0], side))
+    outs3, _ = p3.wait()
+    outs4, _ = p4.wait()
     if rank == 0:
         assert all(torch.equal(a, b) for a, b in zip(outs, outs2))
+        assert all(torch.equal(a, b) for a, b in zip(outs, outs3))
+        assert all(torch.equal(a, b) for a, b in zip(outs, outs4))
     assert counts[rank] == sum(per_frame)
     if rank == 0:
         np.savez(os.path.join(tmpdir, "root.npz"), regs=outs[0].numpy(),
