@@ -9,6 +9,8 @@
  *   ImagePyramidParams / ImagePyramid   ImageProcessing/ImagePyramid.hpp:29-340
  *   OERegion / KeypointList             Features/Feature.hpp:40-179,
  *                                       Features/KeypointList.hpp:35-96
+ *   from_rgb8_to_gray32f()              ImageProcessing/FastColorConversion.cpp:42-66
+ *   AnnMatcher::compute_matches()       FeatureMatching/AnnMatcher.cpp:203-268
  *
  * Plain C: pointers, sizes and PODs only.  No exceptions cross this boundary;
  * every entry point returns a sara_hip_status and the message is available
