@@ -290,7 +290,8 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "SIFT keypoints/sec @1080p (4 octaves, 3 scales/oct)",
+            "metric": "SIFT keypoints/sec @1080p (4 octaves, 3 scales/oct); "
+                      "1/2/4/8 GPU",
             "value": kp_total / elapsed,
             "unit": "keypoints/s",
             "n_gpus": world,
