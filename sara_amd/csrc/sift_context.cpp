@@ -669,6 +669,7 @@ sara_hip_status sara_hip_sift_set_option(sara_hip_sift* c, int option, int value
   {
   case SARA_HIP_OPT_ALL_GRADIENT_SCALES:
     c->all_gradient_scales = value != 0;
+    c->graph_stage = -1;  // the captured launch sequence depends on it
     return SARA_HIP_OK;
   case SARA_HIP_OPT_STAGE_TIMERS:
     c->timers = value != 0;

@@ -410,3 +410,24 @@ def test_fuzz_parity(oracle, case):
         ctx.detect(img)
         compare_full(ctx, ref)
         compare_lists(run_lists(ctx), ref, 0)
+
+
+def test_option_change_after_graph_capture(oracle):
+    """A one-frame detect() is captured into a HIP graph; an option that
+    changes the launch sequence afterwards must not replay the stale graph."""
+    img = synth(160, 120, 12)
+    ref = oracle.RefSift(img, ref_params(oracle, 0, 3))
+    with sara_amd.SiftContext(160, 120, 1, hip_params(0, 3)) as ctx:
+        ctx.detect(img)
+        ctx.detect(img)  # replay
+        kc, kreg, kdesc, kso = ctx.fetch()
+        ctx.set_option(sara_amd.capi.OPT_ALL_GRADIENT_SCALES, 1)
+        ctx.detect(img)
+        # scale 0 and S-1 gradients exist only with the option on
+        assert np.array_equal(ctx.gradient(0, 0), ref.gradient(0, 0))
+        assert np.array_equal(ctx.gradient(5, 1), ref.gradient(5, 1))
+        kc2, kreg2, kdesc2, kso2 = ctx.fetch()
+        assert kreg2.tobytes() == kreg.tobytes() and np.array_equal(kdesc, kdesc2)
+        ctx.set_option(sara_amd.capi.OPT_ALL_GRADIENT_SCALES, 0)
+        ctx.detect(img)
+        assert ctx.fetch()[1].tobytes() == kreg.tobytes()
