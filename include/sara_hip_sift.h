@@ -201,6 +201,22 @@ SARA_HIP_API sara_hip_status sara_hip_sift_detect_u8(
     int batch, int width, int height, int images_on_device,
     sara_hip_stage last_stage, void* hip_stream);
 
+/* Double-buffered upload (the "upload path" of SURVEY.md section 8f, row f1):   */
+/* stage() copies the NEXT batch of host frames into one of two staging buffers */
+/* on a copy stream and returns at once; detect_staged() runs the pipeline on   */
+/* the batch staged last.  Calling stage(i+1) right after detect_staged(i) lets */
+/* the PCIe transfer run under the kernels of batch i, so a stream of host      */
+/* frames is bounded by max(compute, upload) instead of their sum.              */
+/* channels: 0 = float frames (frame_stride in floats), 1 = gray8, 3 = RGB8     */
+/* (frame_stride in bytes; converted on the device as sara_hip_sift_detect_u8). */
+/* `images` must stay valid (ideally pinned) until detect_staged() returns.     */
+SARA_HIP_API sara_hip_status sara_hip_sift_stage(sara_hip_sift* ctx,
+                                                const void* images,
+                                                size_t frame_stride, int channels,
+                                                int batch, int width, int height);
+SARA_HIP_API sara_hip_status sara_hip_sift_detect_staged(
+    sara_hip_sift* ctx, sara_hip_stage last_stage, void* hip_stream);
+
 /* Waits for the last detect() on this context. */
 SARA_HIP_API sara_hip_status sara_hip_sift_synchronize(sara_hip_sift* ctx);
 

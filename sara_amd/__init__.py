@@ -219,6 +219,35 @@ class SiftContext:
             stream))
         return self
 
+    def stage(self, images):
+        """Start the upload of the NEXT batch (float32 B x H x W, uint8 B x H x
+        W, or uint8 B x H x W x 3) on the copy stream; returns at once.  The
+        array is kept alive until the next stage()."""
+        a = np.ascontiguousarray(images)
+        if a.dtype == np.uint8:
+            if a.ndim == 2 or (a.ndim == 3 and a.shape[-1] == 3):
+                a = a[None]
+            channels = 3 if a.ndim == 4 else 1
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            if a.ndim == 2:
+                a = a[None]
+            channels = 0
+        b, h, w = a.shape[:3]
+        self._staged_keepalive = a
+        self._staged_batch = b
+        capi.check(capi.load().sara_hip_sift_stage(
+            self._h, a.ctypes.data, 0, channels, b, w, h))
+        return self
+
+    def detect_staged(self, last_stage=STAGE_DESCRIPTOR, stream=None):
+        """Run the pipeline on the batch staged last."""
+        self.batch = self._staged_batch
+        self._keepalive = self._staged_keepalive
+        capi.check(capi.load().sara_hip_sift_detect_staged(
+            self._h, int(last_stage), stream))
+        return self
+
     def detect_device(self, ptr, batch, width, height, frame_stride=0,
                       last_stage=STAGE_DESCRIPTOR, stream=None):
         """Frames already resident in HBM at raw device pointer ``ptr``."""

@@ -82,6 +82,7 @@ EXPORTS = [
     "sara_hip_scale_space_dog_extremum_map", "sara_hip_selfcheck_atan2f",
     "sara_hip_sift_detect_u8", "sara_hip_from_rgb8_to_gray32f",
     "sara_hip_from_gray8_to_gray32f", "sara_hip_match_descriptors",
+    "sara_hip_sift_stage", "sara_hip_sift_detect_staged",
 ]
 
 _f32p = C.POINTER(C.c_float)
@@ -157,6 +158,9 @@ def _declare(lib):
     for name in ("sara_hip_from_rgb8_to_gray32f",
                  "sara_hip_from_gray8_to_gray32f"):
         getattr(lib, name).argtypes = [_vp, _f32p, C.c_int, C.c_int, C.c_int]
+    lib.sara_hip_sift_stage.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int,
+                                        C.c_int, C.c_int]
+    lib.sara_hip_sift_detect_staged.argtypes = [_vp, C.c_int, _vp]
     lib.sara_hip_match_descriptors.argtypes = [
         _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, C.c_int,
         C.POINTER(C.c_int), C.c_int]

@@ -199,6 +199,15 @@ struct sara_hip_sift
   float* d_dog_plane = nullptr;
   float* d_input = nullptr;  // staged host frames, or enlarge/blur scratch
   unsigned char* d_u8 = nullptr;  // staged 8-bit host frames (lazy)
+  // double-buffered upload (sara_hip_sift_stage / _detect_staged), lazy
+  void* d_stage[2] = {nullptr, nullptr};
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t stage_ready[2] = {nullptr, nullptr};  // copy into buffer k done
+  hipEvent_t stage_free[2] = {nullptr, nullptr};   // last pipeline using k done
+  bool stage_used[2] = {false, false};
+  int stage_next = 0;      // buffer the next stage() writes
+  int staged = -1;         // buffer holding the batch detect_staged() will run
+  int staged_channels = 0, staged_batch = 0, staged_w = 0, staged_h = 0;
   float* d_full = nullptr;   // first_octave > 0: blurred full-size frames
 
   // schedule constants
@@ -650,6 +659,18 @@ sara_hip_status sara_hip_sift_destroy(sara_hip_sift* c)
       (void) hipEventDestroy(c->oct_ready[o]);
     if (c->oct_done[o])
       (void) hipEventDestroy(c->oct_done[o]);
+  }
+  for (int k = 0; k < 2; ++k)
+  {
+    if (c->stage_ready[k])
+      (void) hipEventDestroy(c->stage_ready[k]);
+    if (c->stage_free[k])
+      (void) hipEventDestroy(c->stage_free[k]);
+  }
+  if (c->copy_stream)
+  {
+    (void) hipStreamSynchronize(c->copy_stream);
+    (void) hipStreamDestroy(c->copy_stream);
   }
   if (c->graph_exec)
     (void) hipGraphExecDestroy(c->graph_exec);
@@ -1109,6 +1130,95 @@ sara_hip_status sara_hip_sift_detect_u8(sara_hip_sift* c, const uint8_t* images,
   HIP_TRY(hipGetLastError());
   return sara_hip_sift_detect(c, c->d_input, px, batch, width, height, 1,
                               last_stage, stream);
+}
+
+sara_hip_status sara_hip_sift_stage(sara_hip_sift* c, const void* images,
+                                    size_t frame_stride, int channels, int batch,
+                                    int width, int height)
+{
+  if (!c || !images)
+    return fail(SARA_HIP_INVALID_PARAMS, "null context or images");
+  if (channels != 0 && channels != 1 && channels != 3)
+    return fail(SARA_HIP_INVALID_PARAMS,
+                "channels must be 0 (float), 1 (gray8) or 3 (RGB8)");
+  if (batch < 1 || batch > c->max_batch)
+    return fail(SARA_HIP_CAPACITY_EXCEEDED, "batch exceeds max_batch");
+  if (width < 2 || height < 2)
+    return fail(SARA_HIP_INVALID_PARAMS, "image smaller than 2x2");
+  if (width > c->max_w || height > c->max_h)
+    return fail(SARA_HIP_CAPACITY_EXCEEDED,
+                "image larger than the context's max_width/max_height");
+  const size_t px = size_t(width) * height;
+  const size_t elem = channels == 0 ? sizeof(float) : size_t(channels);
+  if (frame_stride == 0)
+    frame_stride = channels == 0 ? px : px * channels;
+  const size_t stride_bytes = channels == 0 ? frame_stride * sizeof(float)
+                                            : frame_stride;
+  if (stride_bytes < px * elem)
+    return fail(SARA_HIP_SIZE_MISMATCH, "frame_stride smaller than a frame");
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->copy_stream)
+  {
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k)
+    {
+      HIP_TRY(hipEventCreateWithFlags(&c->stage_ready[k], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&c->stage_free[k], hipEventDisableTiming));
+      unsigned char* p = nullptr;
+      const sara_hip_status st =
+          c->alloc(p, size_t(c->max_w) * c->max_h * sizeof(float) * c->max_batch);
+      if (st != SARA_HIP_OK)
+        return st;
+      c->d_stage[k] = p;
+    }
+  }
+  const int k = c->stage_next;
+  // the pipeline that last read this buffer must be done with it
+  if (c->stage_used[k])
+    HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->stage_free[k], 0));
+  HIP_TRY(hipMemcpy2DAsync(c->d_stage[k], px * elem, images, stride_bytes,
+                           px * elem, batch, hipMemcpyHostToDevice,
+                           c->copy_stream));
+  HIP_TRY(hipEventRecord(c->stage_ready[k], c->copy_stream));
+  c->staged = k;
+  c->stage_next = 1 - k;
+  c->staged_channels = channels;
+  c->staged_batch = batch;
+  c->staged_w = width;
+  c->staged_h = height;
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_sift_detect_staged(sara_hip_sift* c,
+                                            sara_hip_stage last_stage,
+                                            void* hip_stream)
+{
+  if (!c)
+    return fail(SARA_HIP_INVALID_PARAMS, "null context");
+  if (c->staged < 0)
+    return fail(SARA_HIP_NOT_READY, "no batch has been staged");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t stream =
+      hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  const int k = c->staged;
+  c->staged = -1;
+  HIP_TRY(hipStreamWaitEvent(stream, c->stage_ready[k], 0));
+  const size_t px = size_t(c->staged_w) * c->staged_h;
+  sara_hip_status st;
+  if (c->staged_channels == 0)
+    st = sara_hip_sift_detect(c, static_cast<const float*>(c->d_stage[k]), px,
+                              c->staged_batch, c->staged_w, c->staged_h, 1,
+                              last_stage, hip_stream);
+  else
+    st = sara_hip_sift_detect_u8(c, static_cast<const uint8_t*>(c->d_stage[k]),
+                                 px * c->staged_channels, c->staged_channels,
+                                 c->staged_batch, c->staged_w, c->staged_h, 1,
+                                 last_stage, hip_stream);
+  if (st != SARA_HIP_OK)
+    return st;
+  HIP_TRY(hipEventRecord(c->stage_free[k], stream));
+  c->stage_used[k] = true;
+  return SARA_HIP_OK;
 }
 
 sara_hip_status sara_hip_sift_synchronize(sara_hip_sift* c)

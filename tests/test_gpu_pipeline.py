@@ -431,3 +431,33 @@ def test_option_change_after_graph_capture(oracle):
         ctx.set_option(sara_amd.capi.OPT_ALL_GRADIENT_SCALES, 0)
         ctx.detect(img)
         assert ctx.fetch()[1].tobytes() == kreg.tobytes()
+
+
+def test_staged_upload_pipeline(oracle):
+    """stage() / detect_staged(): the next batch uploads on the copy stream
+    while the current one is computed; results equal plain detect()."""
+    batches = [synth_batch(160, 120, 3, first_index=10 * i) for i in range(4)]
+    u8 = (batches[1] * 255).astype(np.uint8)
+    with sara_amd.SiftContext(160, 120, 3, hip_params(0, 3)) as ctx:
+        want = []
+        for b in batches:
+            ctx.detect(b)
+            want.append(ctx.fetch())
+        ctx.detect_u8(u8)
+        want_u8 = ctx.fetch()
+        got = []
+        ctx.stage(batches[0])
+        for i in range(len(batches)):
+            ctx.detect_staged()
+            if i + 1 < len(batches):
+                ctx.stage(batches[i + 1])      # overlaps the kernels of batch i
+            got.append(ctx.fetch())
+        for a, b in zip(want, got):
+            for x, y in zip(a, b):
+                assert x.tobytes() == y.tobytes()
+        ctx.stage(u8)
+        ctx.detect_staged()
+        for x, y in zip(want_u8, ctx.fetch()):
+            assert x.tobytes() == y.tobytes()
+        with pytest.raises(sara_amd.SaraHipError):
+            ctx.detect_staged()                # nothing staged

@@ -35,3 +35,20 @@ with sara_amd.SiftContext(W, H, B, params) as ctx:
             n += ctx.counts()[1]
         dt = (time.perf_counter() - t0) / steps
         print(f"{name}: {dt * 1e3:.2f} ms per 64-frame step, {n / steps / dt / 1e6:.1f} M keypoints/s", flush=True)
+        # double-buffered: stage(i+1) is issued right after detect_staged(i)
+        ctx.stage(host)
+        for _ in range(2):
+            ctx.detect_staged()
+            ctx.stage(host)
+            ctx.counts()
+        t0 = time.perf_counter()
+        n = 0
+        for _ in range(steps):
+            ctx.detect_staged()
+            ctx.stage(host)
+            n += ctx.counts()[1]
+        dt = (time.perf_counter() - t0) / steps
+        ctx.detect_staged()
+        ctx.counts()
+        print(f"    double-buffered (stage / detect_staged): {dt * 1e3:.2f} ms per step, "
+              f"{n / steps / dt / 1e6:.1f} M keypoints/s", flush=True)
