@@ -796,6 +796,15 @@ namespace sara_hip {
     const dim3 grid((w + TX - 1) / TX, (h + TY - 1) / TY, batch);
     const size_t lds =
         sizeof(float) * size_t(TY + 2 * R) * (size_t(TX + 2 * R) + TX);
+    // radii above ~36 need more than the default 64 KB of dynamic LDS
+    static size_t lds_allowed = 64 * 1024;
+    if (lds > lds_allowed)
+    {
+      (void) hipFuncSetAttribute(
+          reinterpret_cast<const void*>(gaussian_blur_generic_kernel),
+          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      lds_allowed = 160 * 1024;
+    }
     hipLaunchKernelGGL(gaussian_blur_generic_kernel, grid, dim3(NT), lds, stream,
                        src, src_stride, dst, dst_stride, dog, dog_stride, w, h,
                        taps);

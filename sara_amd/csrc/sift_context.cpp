@@ -371,7 +371,7 @@ namespace {
       const float trunc = pyr.first_octave_index > 0 ? gauss_truncate : 4.f;
       if (!to_taps(gaussian_taps(c->max_sched.init_sigma, trunc), c->init_taps))
         return cleanup(fail(SARA_HIP_INVALID_PARAMS,
-                            "initial Gaussian needs more than 65 taps"));
+                            "initial Gaussian needs more than 113 taps"));
       c->have_init_taps = true;
     }
     c->taps.resize(c->S);
@@ -383,7 +383,7 @@ namespace {
         const double sigma = std::sqrt(double(ks * ks - sigma_s_1 * sigma_s_1));
         if (!to_taps(gaussian_taps(static_cast<float>(sigma), 4.f), c->taps[s]))
           return cleanup(fail(SARA_HIP_INVALID_PARAMS,
-                              "a pyramid Gaussian needs more than 65 taps"));
+                              "a pyramid Gaussian needs more than 113 taps"));
         sigma_s_1 *= k;
       }
     }
@@ -1498,7 +1498,7 @@ sara_hip_status sara_hip_apply_gaussian_filter(const float* src, float* dst,
                 "Source and destination image sizes are not equal!");
   Taps taps;
   if (!to_taps(gaussian_taps(sigma, gauss_truncate), taps))
-    return fail(SARA_HIP_INVALID_PARAMS, "Gaussian needs more than 65 taps");
+    return fail(SARA_HIP_INVALID_PARAMS, "Gaussian needs more than 113 taps");
   const sara_hip_status st = select_device(device);
   if (st != SARA_HIP_OK)
     return st;

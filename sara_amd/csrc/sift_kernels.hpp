@@ -11,7 +11,7 @@
 
 namespace sara_hip {
 
-  constexpr int kMaxRadius = 32;          // Gaussian taps <= 65
+  constexpr int kMaxRadius = 56;          // Gaussian taps <= 113 (LDS: 160 KB)
   constexpr int kMaxTaps = 2 * kMaxRadius + 1;
   constexpr int kMaxScales = 16;          // scale_count_per_octave upper bound
   constexpr int kMaxPeaks = 18;           // a 36-bin histogram has <= 18 peaks

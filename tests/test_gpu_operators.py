@@ -58,8 +58,13 @@ def test_gaussian_filter_generic_radius_path(oracle):
                           oracle.apply_gaussian_filter(src, 5.0))
     assert np.array_equal(sara_amd.apply_gaussian_filter(src, 7.9),
                           oracle.apply_gaussian_filter(src, 7.9))
+    # up to 113 taps (radius 56: what 160 KB of LDS hold); sigma = 11.09 is the
+    # largest increment of a 4-scale pyramid with k = 2 (89 taps)
+    for sigma in (9.0, 11.085125, 14.0):
+        assert np.array_equal(sara_amd.apply_gaussian_filter(src, sigma),
+                              oracle.apply_gaussian_filter(src, sigma))
     with pytest.raises(sara_amd.SaraHipError):
-        sara_amd.apply_gaussian_filter(src, 9.0)  # 73 taps > 65
+        sara_amd.apply_gaussian_filter(src, 14.5)  # 117 taps > 113
 
 
 def test_gaussian_filter_truncate_argument(oracle):

@@ -461,3 +461,16 @@ def test_staged_upload_pipeline(oracle):
             assert x.tobytes() == y.tobytes()
         with pytest.raises(sara_amd.SaraHipError):
             ctx.detect_staged()                # nothing staged
+
+
+def test_one_scale_per_octave(oracle):
+    """ImagePyramidParams(0, 1 + 3, 2.0): one scale per octave, k = 2 - the
+    last increment is sigma = 11.09, an 89-tap Gaussian (runtime-radius kernel
+    with more than 64 KB of LDS)."""
+    img = synth(200, 168, 31)
+    ref = oracle.RefSift(img, ref_params(oracle, 0, 3, 0.5, 4, 2.0))
+    with sara_amd.SiftContext(200, 168, 1, hip_params(0, 3, 0.5, 4, 2.0)) as ctx:
+        ctx.detect(img)
+        compare_full(ctx, ref)
+        ne, nk = compare_lists(run_lists(ctx), ref, 0)
+    assert ne > 0
