@@ -1,6 +1,7 @@
 """One-off wider fuzz of the GPU/oracle parity (same checks as
-tests/test_gpu_pipeline.py::test_fuzz_parity, more cases, other seeds).
-  python tools/fuzz_more.py [n_cases] [seed]"""
+tests/test_gpu_pipeline.py::test_fuzz_parity, more cases, other seeds, plus
+batches, gauss_truncate, 8-bit input and the matcher).
+  python tools/fuzz_more.py [n_cases] [seed] [size_factor]"""
 import os, sys
 os.environ.setdefault("SARA_HIP_MARCH_MIN_PIXELS", "0")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +10,7 @@ sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np
 import conftest, refbind as rb
 import test_gpu_pipeline as T
+import test_gpu_matching as M
 import sara_amd
 from sara_amd.synth import synth
 
@@ -16,20 +18,44 @@ rb.build()
 rb.lib().ref_omp_set_threads(conftest._usable_cpus())
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 777
+size_factor = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+rng = np.random.default_rng(seed + 1)
 bad = 0
 for case in T._fuzz_cases(n, seed):
     i, w, h, first, scales, kfac, cam, noct, thres, edge, iters = case
+    w, h = w * size_factor, h * size_factor
+    if size_factor > 1 and first < 0:
+        first = 0
     try:
-        img = synth(w, h, 9000 + i + seed)
-        ref = rb.RefSift(img, T.ref_params(rb, first, noct, cam, scales, kfac),
-                         extremum_thres=thres, edge_ratio_thres=edge,
-                         extremum_refinement_iter=iters)
-        with sara_amd.SiftContext(w, h, 1, T.hip_params(first, noct, cam, scales, kfac),
-                                  extremum_thres=thres, edge_ratio_thres=edge,
+        batch = int(rng.choice([1, 1, 2, 5]))
+        trunc = float(rng.choice([4.0, 4.0, 3.0, 2.5]))
+        imgs = np.stack([synth(w, h, 9000 + 7 * i + seed + b) for b in range(batch)])
+        use_u8 = bool(rng.integers(0, 4) == 0)
+        if use_u8:
+            u8 = np.clip(imgs * 255.0, 0, 255).astype(np.uint8)
+            imgs = u8.astype(np.float32) / np.float32(255)
+        with sara_amd.SiftContext(w, h, batch, T.hip_params(first, noct, cam, scales, kfac),
+                                  gauss_truncate=trunc, extremum_thres=thres,
+                                  edge_ratio_thres=edge,
                                   extremum_refinement_iter=iters) as ctx:
-            ctx.detect(img)
-            T.compare_full(ctx, ref)
-            T.compare_lists(T.run_lists(ctx), ref, 0)
+            if use_u8:
+                ctx.detect_u8(u8)
+            else:
+                ctx.detect(imgs)
+            lists = T.run_lists(ctx)
+            descs = []
+            for b in range(batch):
+                ref = rb.RefSift(imgs[b], T.ref_params(rb, first, noct, cam, scales, kfac),
+                                 gauss_truncate=trunc, extremum_thres=thres,
+                                 edge_ratio_thres=edge, extremum_refinement_iter=iters)
+                T.compare_full(ctx, ref, frame=b)
+                T.compare_lists(lists, ref, b)
+                descs.append(ref.keypoints()[2])
+            if batch >= 2 and len(descs[0]) >= 2 and len(descs[1]) >= 2:
+                ratio = float(rng.choice([0.6, 0.8, 1.0]))
+                M.assert_same(ctx.match_frames(0, 1, ratio),
+                              rb.compute_matches(ctx.keypoint_lists()[0].descriptor_matrix,
+                                                 ctx.keypoint_lists()[1].descriptor_matrix, ratio))
     except Exception as e:  # noqa
         bad += 1
         print("FAIL", case, repr(e)[:300], flush=True)
