@@ -182,6 +182,14 @@ struct sara_hip_sift
   hipEvent_t oct_ready[16] = {};  // G(downscale_index, o) is complete
   hipEvent_t oct_done[16] = {};   // octave o's chain is complete
   bool multi_stream = true;
+  // The polar gradients read the Gaussian pyramid only, like the extremum
+  // scan: they are enqueued first, on a side stream, so that the short
+  // latency-bound kernels of the extrema stage (refinement, ordering) run
+  // next to them (3.14 -> 2.99 ms for the two stages; SARA_HIP_SIDE_GRADIENT=0
+  // restores the sequential order and the separate stage times).
+  bool side_gradient = true;
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t aux_fork = nullptr, aux_join = nullptr;
 
   Schedule max_sched;
   Schedule cur;
@@ -359,6 +367,11 @@ namespace {
     }
     if (const char* e = getenv("SARA_HIP_STREAMS"))
       c->multi_stream = std::string(e) != "1";
+    if (const char* e = getenv("SARA_HIP_SIDE_GRADIENT"))
+      c->side_gradient = std::string(e) != "0";
+    TRY_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    TRY_HIP(hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
+    TRY_HIP(hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
     if (const char* e = getenv("SARA_HIP_GRAPH"))
       c->use_graph = std::string(e) != "0";
     if (const char* e = getenv("SARA_HIP_GRAPH_MAX_BATCH"))
@@ -676,6 +689,15 @@ sara_hip_status sara_hip_sift_destroy(sara_hip_sift* c)
     (void) hipGraphExecDestroy(c->graph_exec);
   if (c->graph)
     (void) hipGraphDestroy(c->graph);
+  if (c->aux_stream)
+  {
+    (void) hipStreamSynchronize(c->aux_stream);
+    (void) hipStreamDestroy(c->aux_stream);
+  }
+  if (c->aux_fork)
+    (void) hipEventDestroy(c->aux_fork);
+  if (c->aux_join)
+    (void) hipEventDestroy(c->aux_join);
   if (c->own_stream)
     (void) hipStreamDestroy(c->own_stream);
   delete c;
@@ -916,8 +938,43 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   }
   HIP_TRY(mark(2));
 
-  // ---- extrema ------------------------------------------------------------
+  // ---- polar gradients (enqueue helper; on the side stream when enabled) ---
   bool grad_fused[16] = {};
+  static const bool fuse_gradient_env = [] {
+    const char* e = getenv("SARA_HIP_FUSE_GRADIENT");
+    return e && std::string(e) == "1";
+  }();
+  const bool want_gradients = last_stage >= SARA_HIP_STAGE_GRADIENT;
+  const bool side = c->side_gradient && want_gradients && !fuse_gradient_env &&
+                    !debug_sync;
+  auto enqueue_gradients = [&](hipStream_t gs) -> sara_hip_status {
+    const int s_lo = c->all_gradient_scales ? 0 : 1;
+    const int s_n = c->all_gradient_scales ? S : S - 3;
+    for (int o = 0; o < sc.num_octaves; ++o)
+    {
+      const int w = sc.oct[o].w, h = sc.oct[o].h;
+      const size_t pl = size_t(w) * h;
+      if (grad_fused[o])
+        continue;  // written by the extremum scan
+      const size_t cpl = size_t((w + 15) / 16) * ((h + 15) / 16);
+      HIP_TRY(hipMemsetAsync(c->CM[o], 0, cpl * S * batch * sizeof(unsigned), gs));
+      launch_gradient_polar(c->G[o] + pl * s_lo, pl * S, c->GR[o] + pl * 2 * s_lo,
+                            pl * 2 * S, w, h, s_n, batch, gs,
+                            c->CM[o] + cpl * s_lo, cpl * S);
+    }
+    return SARA_HIP_OK;
+  };
+  if (side)
+  {
+    HIP_TRY(hipEventRecord(c->aux_fork, stream));
+    HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
+    const sara_hip_status gst = enqueue_gradients(c->aux_stream);
+    if (gst != SARA_HIP_OK)
+      return gst;
+    HIP_TRY(hipEventRecord(c->aux_join, c->aux_stream));
+  }
+
+  // ---- extrema ------------------------------------------------------------
   HIP_TRY(hipMemsetAsync(c->cand.count, 0, sizeof(int) * batch, stream));
   HIP_TRY(hipMemsetAsync(c->sites.count, 0, sizeof(int) * batch, stream));
   HIP_TRY(hipMemsetAsync(c->ori.kp_count, 0, sizeof(int) * batch, stream));
@@ -942,8 +999,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       dv.frame_stride = dv.plane * S;
       // With the gradient stage requested, the scan of the fast path also
       // emits the polar gradients of the planes it has in registers.
-      const bool want_grad =
-          last_stage >= SARA_HIP_STAGE_GRADIENT && !c->all_gradient_scales;
+      const bool want_grad = want_gradients && !c->all_gradient_scales && !side;
       const size_t cpl = size_t((dv.w + 15) / 16) * ((dv.h + 15) / 16);
       grad_fused[o] = false;
       if (want_grad)
@@ -981,23 +1037,13 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   HIP_TRY(mark(3));
 
   // ---- polar gradients ----------------------------------------------------
-  if (last_stage >= SARA_HIP_STAGE_GRADIENT)
+  if (side)
+    HIP_TRY(hipStreamWaitEvent(stream, c->aux_join, 0));
+  else if (want_gradients)
   {
-    const int s_lo = c->all_gradient_scales ? 0 : 1;
-    const int s_n = c->all_gradient_scales ? S : S - 3;
-    for (int o = 0; o < sc.num_octaves; ++o)
-    {
-      const int w = sc.oct[o].w, h = sc.oct[o].h;
-      const size_t pl = size_t(w) * h;
-      if (grad_fused[o])
-        continue;  // written by the extremum scan
-      const size_t cpl = size_t((w + 15) / 16) * ((h + 15) / 16);
-      HIP_TRY(hipMemsetAsync(c->CM[o], 0, cpl * S * batch * sizeof(unsigned),
-                             stream));
-      launch_gradient_polar(c->G[o] + pl * s_lo, pl * S, c->GR[o] + pl * 2 * s_lo,
-                            pl * 2 * S, w, h, s_n, batch, stream,
-                            c->CM[o] + cpl * s_lo, cpl * S);
-    }
+    const sara_hip_status gst = enqueue_gradients(stream);
+    if (gst != SARA_HIP_OK)
+      return gst;
   }
   HIP_TRY(mark(4));
 
