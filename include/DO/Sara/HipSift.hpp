@@ -31,8 +31,11 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <fstream>
+#include <iostream>
 #include <limits>
 #include <memory>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -262,6 +265,94 @@ namespace DO::Sara {
   inline auto size_consistency_predicate(const KeypointList<F, T>& k)
   {
     return int(features(k).size()) == descriptors(k).rows();
+  }
+  // ---- Features/IO.hpp:77-143: the readable keypoint format (SURVEY.md
+  // section 8f, row f3).  One header line "N dim", then per keypoint
+  //   x y m00 m10 m01 m11 orientation type d0 ... d(dim-1)
+  // where the four shape coefficients (column-major, written through
+  // Map<RowVector4f>) and the descriptor row are Eigen expressions: Eigen's
+  // operator<< right-aligns every coefficient of an expression to the widest
+  // one (Eigen/src/Core/IO.h, default IOFormat).  Reading goes through
+  // OERegion's operator>> (Features/Feature.cpp:88-95), which fills the shape
+  // matrix ROW-major - the reference's own transposition quirk, harmless for
+  // the symmetric matrices it stores.
+  namespace hip_detail {
+    template <typename T>
+    inline void print_eigen_row(std::ostream& os, const T* v, int n)
+    {
+      std::size_t width = 0;
+      for (int i = 0; i < n; ++i)
+      {
+        std::stringstream sstr;
+        sstr.copyfmt(os);
+        sstr << v[i];
+        width = std::max(width, sstr.str().length());
+      }
+      for (int i = 0; i < n; ++i)
+      {
+        if (i)
+          os << " ";
+        if (width)
+          os.width(std::streamsize(width));
+        os << v[i];
+      }
+    }
+  }  // namespace hip_detail
+
+  template <typename T>
+  inline bool write_keypoints(const std::vector<OERegion>& features,
+                              const Tensor_<T, 2>& descriptors,
+                              const std::string& name)
+  {
+    std::ofstream file{name.c_str()};
+    if (!file.is_open())
+    {
+      std::cerr << "Can't open file" << std::endl;
+      return false;
+    }
+    file << features.size() << " " << descriptors.cols() << std::endl;
+    for (std::size_t i = 0; i < features.size(); ++i)
+    {
+      const OERegion& feat = features[i];
+      file << feat.x() << ' ' << feat.y() << ' ';
+      hip_detail::print_eigen_row(file, feat.shape_matrix.data(), 4);
+      file << ' ';
+      file << feat.orientation << ' ';
+      file << int(feat.type) << ' ';
+      hip_detail::print_eigen_row(file, descriptors[int(i)], descriptors.cols());
+      file << std::endl;
+    }
+    return true;
+  }
+
+  template <typename T>
+  inline bool read_keypoints(std::vector<OERegion>& features,
+                             Tensor_<T, 2>& descriptors, const std::string& name)
+  {
+    std::ifstream file{name.c_str()};
+    if (!file.is_open())
+    {
+      std::cerr << "Can't open file " << name << std::endl;
+      return false;
+    }
+    int num_features = 0, descriptor_dim = 0;
+    file >> num_features >> descriptor_dim;
+    features.assign(std::size_t(num_features), OERegion{});
+    descriptors.resize(num_features, descriptor_dim);
+    for (int i = 0; i < num_features; ++i)
+    {
+      OERegion& f = features[std::size_t(i)];
+      int feature_type = 0;
+      file >> f.coords[0] >> f.coords[1];
+      // row-major fill of the column-major 2x2 (Core/EigenExtension.hpp:163-170)
+      file >> f.shape_matrix[0] >> f.shape_matrix[2] >> f.shape_matrix[1] >>
+          f.shape_matrix[3];
+      file >> f.orientation >> feature_type;
+      f.type = static_cast<decltype(f.type)>(feature_type);
+      for (int j = 0; j < descriptor_dim; ++j)
+        file >> descriptors(i, j);
+    }
+    return true;
   }
 #endif  // !SARA_HIP_WITH_SARA_HEADERS
 

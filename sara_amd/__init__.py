@@ -25,7 +25,7 @@ __all__ = [
     "apply_gaussian_filter", "gaussian", "scale", "downscale", "enlarge",
     "gradient_polar_coordinates", "scale_space_dog_extremum_map",
     "from_rgb8_to_gray32f", "from_gray8_to_gray32f", "AnnMatcher", "match",
-    "MATCH_DTYPE",
+    "MATCH_DTYPE", "write_keypoints", "read_keypoints",
     "make_gaussian_kernel", "SaraHipError", "OEREGION_DTYPE",
 ]
 
@@ -538,6 +538,68 @@ class AnnMatcher:
 def match(keys1, keys2, lowe_ratio, device=0):
     """SfM/Helpers/KeypointMatching.cpp:19-25."""
     return AnnMatcher(keys1, keys2, lowe_ratio, device).compute_matches()
+
+
+def _ostream_float(v):
+    """std::ostream << float with the default precision (6): %g."""
+    return "%g" % float(np.float32(v))
+
+
+def _eigen_row(values):
+    """Eigen's operator<< for a row expression (Eigen/src/Core/IO.h, default
+    IOFormat): every coefficient right-aligned to the widest one."""
+    txt = [_ostream_float(v) for v in values]
+    width = max((len(t) for t in txt), default=0)
+    return " ".join(t.rjust(width) for t in txt)
+
+
+def write_keypoints(features, descriptors, name):
+    """Features/IO.hpp:110-143: "N dim", then per keypoint
+    ``x y m00 m10 m01 m11 orientation type d0 ... d(dim-1)`` (shape matrix in
+    storage = column-major order).  ``features``: KeypointList.regions-like
+    structured array; ``descriptors``: N x dim."""
+    if isinstance(features, KeypointList):
+        descriptors = features.descriptor_matrix if descriptors is None \
+            else descriptors
+        features = features.regions
+    d = np.asarray(descriptors, dtype=np.float32)
+    try:
+        f = open(name, "w", newline="\n")
+    except OSError:
+        return False
+    with f:
+        f.write("%d %d\n" % (len(features), d.shape[1] if d.ndim == 2 else 0))
+        for i, r in enumerate(features):
+            f.write("%s %s %s %s %d %s\n" % (
+                _ostream_float(r["coords"][0]), _ostream_float(r["coords"][1]),
+                _eigen_row(r["shape_matrix"]), _ostream_float(r["orientation"]),
+                int(r["type"]), _eigen_row(d[i])))
+    return True
+
+
+def read_keypoints(name):
+    """Features/IO.hpp:77-108 -> KeypointList.  As in the reference, the four
+    shape coefficients are read ROW-major (OERegion's operator>>,
+    Features/Feature.cpp:88-95 with Core/EigenExtension.hpp:163-170) although
+    they were written in storage order."""
+    with open(name) as f:
+        tok = f.read().split()
+    n, dim = int(tok[0]), int(tok[1])
+    regions = np.zeros(n, OEREGION_DTYPE)
+    # fields the format does not carry keep OERegion's defaults
+    regions["extremum_type"] = -2
+    desc = np.zeros((n, dim), np.float32)
+    at = 2
+    for i in range(n):
+        v = tok[at:at + 8 + dim]
+        at += 8 + dim
+        regions["coords"][i] = (np.float32(v[0]), np.float32(v[1]))
+        m00, m01, m10, m11 = (np.float32(x) for x in v[2:6])
+        regions["shape_matrix"][i] = (m00, m10, m01, m11)  # column-major storage
+        regions["orientation"][i] = np.float32(v[6])
+        regions["type"][i] = int(v[7])
+        desc[i] = np.array(v[8:8 + dim], dtype=np.float32)
+    return KeypointList(regions, desc)
 
 
 def gradient_polar_coordinates(src, device=0):

@@ -97,6 +97,27 @@ int main(int argc, char** argv)
       return 13;
   }
 
+  // readable keypoint format (Features/IO.hpp:77-143): write, read back;
+  // the file is also compared byte for byte with the Python writer.
+  {
+    const std::string txt = std::string(argv[5]) + ".txt";
+    if (!sara::write_keypoints(f, d, txt))
+      return 14;
+    auto f2 = std::vector<sara::OERegion>{};
+    auto d2 = sara::Tensor_<float, 2>{};
+    if (!sara::read_keypoints(f2, d2, txt) || f2.size() != f.size() ||
+        d2.rows() != d.rows() || d2.cols() != 128)
+      return 15;
+    for (size_t i = 0; i < f.size(); ++i)
+    {
+      // six significant digits survive the text round trip
+      if (std::abs(f2[i].x() - f[i].x()) > 1e-3f * (1.f + std::abs(f[i].x())) ||
+          f2[i].type != f[i].type ||
+          std::abs(d2(int(i), 5) - d(int(i), 5)) > 1e-3f * (1.f + d(int(i), 5)))
+        return 16;
+    }
+  }
+
   // 2. the functor API with its pyramid accessors.
   auto compute_dogs = sara::ComputeDoGExtrema{pyr_params, 4.f, 0.01f, 10.f, 5, 5};
   auto so = std::vector<sara::Point2i>{};

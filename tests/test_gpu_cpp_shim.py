@@ -54,6 +54,17 @@ def test_shim_matches_oracle(oracle, tmp_path):
                          dtype=np.float32).reshape(n, 128)
     off += 512 * n
     ext = common.regions_from_bytes(raw[off:off + 48 * ne])
+    # the readable keypoint file of the C++ shim (Features/IO.hpp:110-143,
+    # written with real iostreams) and the Python writer agree byte for byte
+    import sara_amd
+    txt = str(fout) + ".txt"
+    py_txt = str(tmp_path / "py.txt")
+    assert sara_amd.write_keypoints(feats, desc, py_txt)
+    assert open(txt, "rb").read() == open(py_txt, "rb").read()
+    back = sara_amd.read_keypoints(txt)
+    assert len(back) == n and back.descriptor_matrix.shape == (n, 128)
+    assert np.allclose(back.regions["coords"], feats["coords"], rtol=1e-5)
+    assert np.array_equal(back.regions["type"], feats["type"])
     common.assert_regions_equal(feats, rk, rtol_shape=1e-6, atol_theta=1e-6)
     common.assert_regions_equal(ext, rext, rtol_shape=1e-6)
     assert np.max(np.abs(desc - rdesc)) <= 2e-3

@@ -63,3 +63,42 @@ def test_atan2f_gradient_like_inputs():
     gx[::7] = 0
     gy[::11] = 0
     assert _same_bits(_mine(gy, gx), _libm(gy, gx))
+
+
+# ---- keypoint text format ---------------------
+def test_keypoint_text_round_trip(tmp_path):
+    """test_features_data_structures.cpp:84-124 restated on the Python mirror:
+    write_keypoints / read_keypoints round trip."""
+    import sara_amd
+    n = 10
+    regions = np.zeros(n, sara_amd.OEREGION_DTYPE)
+    desc = np.zeros((n, 3), np.float32)
+    for i in range(n):
+        desc[i] = float(i)
+        regions["type"][i] = 5
+        regions["coords"][i] = (i, i)
+        regions["shape_matrix"][i] = (1, 0, 0, 1)
+        regions["orientation"][i] = float(i)
+        regions["extremum_type"][i] = 1
+    path = str(tmp_path / "keypoints.txt")
+    assert sara_amd.write_keypoints(regions, desc, path)
+    lines = open(path).read().splitlines()
+    assert lines[0] == "10 3"
+    # Eigen aligns the coefficients of one expression to the widest one
+    assert lines[4] == "3 3 1 0 0 1 3 5 3 3 3"
+    back = sara_amd.read_keypoints(path)
+    assert np.array_equal(back.regions["coords"], regions["coords"])
+    assert np.array_equal(back.regions["shape_matrix"], regions["shape_matrix"])
+    assert np.array_equal(back.regions["orientation"], regions["orientation"])
+    assert np.array_equal(back.regions["type"], regions["type"])
+    assert np.array_equal(back.descriptor_matrix, desc)
+    # alignment and %g formatting on non-trivial values; the shape matrix comes
+    # back transposed (written in storage order, read row-major)
+    regions["shape_matrix"][0] = (0.25, 1.5e-7, 123456.789, -2)
+    desc[0] = (0.5, 100.25, 1e-5)
+    sara_amd.write_keypoints(regions[:1], desc[:1], path)
+    want = "0 0    0.25 1.5e-07  123457      -2 0 5    0.5 100.25  1e-05"
+    assert open(path).read().splitlines()[1] == want
+    back = sara_amd.read_keypoints(path)
+    assert np.allclose(back.regions["shape_matrix"][0],
+                       [0.25, 123457.0, 1.5e-7, -2], rtol=1e-6)
