@@ -120,8 +120,24 @@ def cpu_baseline(args, frames):
         for k, v in r.times().items():
             stage[k] = stage.get(k, 0.0) + v / n
     dt = time.perf_counter() - t0
+    # the same port on one thread, one frame (SURVEY.md 8d asks for both)
+    rb.lib().ref_omp_set_threads(1)
+    t1 = time.perf_counter()
+    kp1 = len(rb.RefSift(frames[0], params, parallel=True).keypoints()[0])
+    dt1 = time.perf_counter() - t1
+    rb.lib().ref_omp_set_threads(cores)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
         "value": kp / dt, "unit": "keypoints/s", "cores": cores, "kind": "port",
+        "cpu_model": model,
+        "value_single_thread": kp1 / dt1,
         "sample": "%d synthetic %dx%d frames, full SIFT, %d octaves; %.2f s "
                   "wall; OpenMP on the reference's pragmas" %
                   (n, args.width, args.height, args.octaves, dt),
