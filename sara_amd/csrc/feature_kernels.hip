@@ -235,6 +235,12 @@ namespace sara_hip {
     const char* e = getenv("SARA_HIP_XCD_RUN");
     return e ? std::max(1, atoi(e)) : 128;
   }();
+  //! Run-groups (8 * SARA_HIP_XCD_RUN blocks of 4 keypoints) in the grid of the
+  //! per-keypoint kernels per frame; the blocks loop over the rest.
+  static const int g_persist_units = [] {
+    const char* e = getenv("SARA_HIP_PERSIST_UNITS");
+    return e ? std::max(1, atoi(e)) : 1;
+  }();
   //! log2 of the lanes that share one patch row in the descriptor kernel.
   static const int g_desc_row_shift = [] {
     const char* e = getenv("SARA_HIP_DESC_ROW_SHIFT");
@@ -1144,9 +1150,13 @@ namespace sara_hip {
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int n = min(cand.count[b], cand.cap);
-    const int lb = xcd_local_block(blockIdx.x, b, (n + 3) >> 2, xcd_run);
-    if (lb < 0)
-      return;
+    // Persistent blocks: the grid holds one run-group of blocks per frame and
+    // every block walks the frame's work items with that stride (a grid sized
+    // for the list capacity launches ~3 empty waves for every useful one).
+    const int nblk = (n + 3) >> 2;
+    const int unit = 8 * xcd_run;
+    const int positions = unit * ((nblk + unit - 1) / unit);
+    auto item = [&](int lb) {
     const int idx = lb * 4 + wave;
     if (idx >= n)
       return;
@@ -1275,6 +1285,13 @@ namespace sara_hip {
     }
     if (lane == 0)
       ori.peak_count[row + idx] = __popcll(mask);
+    };
+    for (int bx = blockIdx.x; bx < positions; bx += gridDim.x)
+    {
+      const int lb = xcd_local_block(bx, b, nblk, xcd_run);
+      if (lb >= 0)
+        item(lb);
+    }
   }
 
   void launch_orientations(const GradPyramidView* grad, const ScaleTable* tab,
@@ -1286,7 +1303,8 @@ namespace sara_hip {
     // xcd_local_block() spreads ceil(n/4) work items over 8 chunks, so the
     // grid has to be a multiple of 8 blocks
     const int unit = 8 * g_xcd_run;
-    const dim3 grid(unit * (((cand.cap + 3) / 4 + unit - 1) / unit), batch);
+    const int needed = unit * (((cand.cap + 3) / 4 + unit - 1) / unit);
+    const dim3 grid(std::min(needed, unit * g_persist_units), batch);
     hipLaunchKernelGGL(orientation_kernel, grid, dim3(256), 0, stream, grad, tab,
                        ori_weights, cand, ori, g_xcd_run);
   }
@@ -1402,9 +1420,11 @@ namespace sara_hip {
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int n = min(cand.count[b], cand.cap);
-    const int lb = xcd_local_block(blockIdx.x, b, (n + 3) >> 2, xcd_run);
-    if (lb < 0)
-      return;
+    // persistent blocks, see orientation_kernel
+    const int nblk = (n + 3) >> 2;
+    const int unit = 8 * xcd_run;
+    const int positions = unit * ((nblk + unit - 1) / unit);
+    auto item = [&](int lb) {
     const int idx = lb * 4 + wave;
     if (idx >= n)
       return;
@@ -1644,6 +1664,13 @@ namespace sara_hip {
       descriptors[out * 128 + 64 + lane] = h1;
       __builtin_amdgcn_wave_barrier();
     }
+    };
+    for (int bx = blockIdx.x; bx < positions; bx += gridDim.x)
+    {
+      const int lb = xcd_local_block(bx, b, nblk, xcd_run);
+      if (lb >= 0)
+        item(lb);
+    }
   }
 
   void launch_descriptors(const GradPyramidView* grad,
@@ -1654,7 +1681,8 @@ namespace sara_hip {
                           hipStream_t stream)
   {
     const int unit = 8 * g_xcd_run;
-    const dim3 grid(unit * (((cand.cap + 3) / 4 + unit - 1) / unit), batch);
+    const int needed = unit * (((cand.cap + 3) / 4 + unit - 1) / unit);
+    const dim3 grid(std::min(needed, unit * g_persist_units), batch);
     hipLaunchKernelGGL(descriptor_kernel, grid, dim3(256), 0, stream, grad, cand,
                        ori, features, scale_octave, descriptors,
                        with_descriptors, g_xcd_run, g_desc_row_shift);
