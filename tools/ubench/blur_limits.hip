@@ -735,6 +735,204 @@ __global__ __launch_bounds__(64) void march3(const float* __restrict__ src,
 }
 
 template <int R, int PF, int CPL, int NOMEM>
+__global__ __launch_bounds__(64) void march3p(const float* __restrict__ src,
+                                             size_t src_stride,
+                                             float* __restrict__ dst,
+                                             size_t dst_stride, int w, int h,
+                                             int seg_rows, int nstrips,
+                                             Taps taps, int never,
+                                             unsigned long long* prof)
+{
+  // per-phase cycle sums of this wave: vm wait, LDS stage+read, row pass,
+  // column pass, store/loop overhead
+  unsigned long long ph[5] = {0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_readcyclecounter();
+#define PHASE(x)                                          \
+  {                                                        \
+    const unsigned long long tn = __builtin_readcyclecounter(); \
+    ph[x] += tn - tprev;                                   \
+    tprev = tn;                                            \
+  }
+
+  using vec = typename VecOf<CPL>::type;
+  constexpr int K = 2 * R + 1;
+  constexpr int W = 64 * CPL;
+  constexpr int RP = ((R + CPL - 1) / CPL) * CPL;
+  constexpr int D = RP - R;
+  constexpr int ROWF = RP + W + RP;
+  constexpr int NQ = (D + CPL + 2 * R + CPL - 1) / CPL;
+  __shared__ __attribute__((aligned(16))) float s_row[2 * ROWF];
+
+  const int lane = threadIdx.x;
+  const int strip = blockIdx.x % nstrips;
+  const int seg = blockIdx.x / nstrips;
+  const size_t b = blockIdx.y;
+  src += b * src_stride;
+  dst += b * dst_stride;
+  const int x0 = strip * W;
+  const int y0 = seg * seg_rows;
+  const int y1 = min(h, y0 + seg_rows);
+  const int col = x0 + CPL * lane;
+  const bool col_ok = col < w;
+  int hcol = lane < R ? x0 - R + lane : x0 + W + (lane - R);
+  hcol = hcol < 0 ? 0 : (hcol > w - 1 ? w - 1 : hcol);
+  const int hslot = lane < R ? RP - R + lane : RP + W + (lane - R);
+  const int mcol = col_ok ? col : w - CPL;
+
+  auto load_row = [&](int yy, vec& m, float& hv) {
+    if (NOMEM)
+    {
+      (&m.x)[0] += 1.f;
+      return;
+    }
+    const int gy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+    const float* rowp = src + size_t(gy) * w;
+    m = *reinterpret_cast<const vec*>(rowp + mcol);
+    if (!col_ok)
+    {
+      const float last = (&m.x)[CPL - 1];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c)
+        (&m.x)[c] = last;
+    }
+    hv = 0.f;
+    if (lane < 2 * R)
+      hv = rowp[hcol];
+  };
+
+  float A[K][CPL];
+  vec pm[PF];
+  float phv[PF];
+  const int T = (y1 - y0) + 2 * R;
+#pragma unroll
+  for (int q = 0; q < PF; ++q)
+  {
+    pm[q] = vec{};
+    phv[q] = 0.f;
+    load_row(y0 - R + q, pm[q], phv[q]);
+  }
+
+  for (int n0 = 0; n0 < T; n0 += K)
+  {
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+    {
+      const int n = n0 + i;
+      const int yy = y0 - R + n;
+      float* rowbuf = s_row + (n & 1) * ROWF;
+      PHASE(4)
+      asm volatile("" ::"v"((&pm[i % PF].x)[0]), "v"(phv[i % PF]));
+      PHASE(0)
+      if (NOMEM < 2)
+      {
+        *reinterpret_cast<vec*>(rowbuf + RP + CPL * lane) = pm[i % PF];
+        if (lane < 2 * R)
+          rowbuf[hslot] = phv[i % PF];
+      }
+      load_row(yy + PF, pm[i % PF], phv[i % PF]);
+      float v[NQ * CPL];
+      if (NOMEM >= 2)
+      {
+#pragma unroll
+        for (int q = 0; q < NQ * CPL; ++q)
+          asm volatile("v_mov_b32 %0, %1" : "=v"(v[q]) : "v"(phv[q % PF]));
+      }
+      else
+      {
+        const vec* p = reinterpret_cast<const vec*>(rowbuf + CPL * lane);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+        {
+          const vec x = p[q];
+#pragma unroll
+          for (int c = 0; c < CPL; ++c)
+            v[CPL * q + c] = (&x.x)[c];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PHASE(1)
+      float t[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; c += 2)
+      {
+        float s0 = 0.f, s1 = 0.f;
+        constexpr int NB = K / 4;
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+        {
+          const int j = 4 * q;
+          row4(s0, s1, v[D + c + j], v[D + c + j + 1], v[D + c + j + 2],
+               v[D + c + j + 3], v[D + c + j + 4], taps.k[j], taps.k[j + 1],
+               taps.k[j + 2], taps.k[j + 3]);
+        }
+#pragma unroll
+        for (int j = 4 * NB; j < K; ++j)
+          row1(s0, s1, v[D + c + j], v[D + c + j + 1], taps.k[j]);
+        t[c] = s0;
+        t[c + 1] = s1;
+      }
+      asm volatile("" ::"v"(t[0]), "v"(t[1]));
+      PHASE(2)
+#define SL(j) ((i + K - 1 - (j)) % K)
+#pragma unroll
+      for (int c = 0; c < CPL; c += 2)
+      {
+        col_ends(A[SL(0)][c], A[SL(0)][c + 1], A[SL(K - 1)][c],
+                 A[SL(K - 1)][c + 1], A[SL(R)][c], A[SL(R)][c + 1], t[c],
+                 t[c + 1], taps.k[0], taps.k[R]);
+#pragma unroll
+        for (int j = 1; j + 1 < R; j += 2)
+          col2(A[SL(j)][c], A[SL(j)][c + 1], A[SL(K - 1 - j)][c],
+               A[SL(K - 1 - j)][c + 1], A[SL(j + 1)][c], A[SL(j + 1)][c + 1],
+               A[SL(K - 2 - j)][c], A[SL(K - 2 - j)][c + 1], t[c], t[c + 1],
+               taps.k[j], taps.k[j + 1]);
+        if ((R - 1) % 2 == 1)
+          col1(A[SL(R - 1)][c], A[SL(R - 1)][c + 1], A[SL(R + 1)][c],
+               A[SL(R + 1)][c + 1], t[c], t[c + 1], taps.k[R - 1]);
+      }
+#undef SL
+      asm volatile("" ::"v"(A[i][0]), "v"(A[i][1]));
+      PHASE(3)
+      const int o = yy - R;
+      if ((o >= y0) && (o < y1) && col_ok && (!NOMEM || never))
+      {
+        vec ov;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+          (&ov.x)[c] = A[i][c];
+        *reinterpret_cast<vec*>(dst + size_t(o) * w + col) = ov;
+      }
+    }
+    if (K % PF != 0)
+    {
+      vec tm[PF];
+      float th[PF];
+#pragma unroll
+      for (int q = 0; q < PF; ++q)
+      {
+        tm[q] = pm[(K + q) % PF];
+        th[q] = phv[(K + q) % PF];
+      }
+#pragma unroll
+      for (int q = 0; q < PF; ++q)
+      {
+        pm[q] = tm[q];
+        phv[q] = th[q];
+      }
+    }
+  }
+  if (lane == 0)
+  {
+    const size_t id = size_t(blockIdx.y) * gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      prof[id * 6 + q] = ph[q];
+    prof[id * 6 + 5] = (unsigned long long) T;
+  }
+#undef PHASE
+}
+
+template <int R, int PF, int CPL, int NOMEM>
 __global__ __launch_bounds__(64) void march3v(const float* __restrict__ src,
                                              size_t src_stride,
                                              float* __restrict__ dst,
@@ -1104,6 +1302,215 @@ __global__ __launch_bounds__(64) void march4(const float* __restrict__ src,
 #undef VF
 }
 
+template <int R, int PF, int NOMEM, int LDSPAD, int V4MODE = 3>
+__global__ __launch_bounds__(64) void march4p(const float* __restrict__ src,
+                                             size_t src_stride,
+                                             float* __restrict__ dst,
+                                             size_t dst_stride, int w, int h,
+                                             int seg_rows, int nstrips,
+                                             Taps taps, int never,
+                                             unsigned long long* prof)
+{
+  unsigned long long ph[5] = {0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_readcyclecounter();
+#define PHASE(x)                                          \
+  {                                                        \
+    const unsigned long long tn = __builtin_readcyclecounter(); \
+    ph[x] += tn - tprev;                                   \
+    tprev = tn;                                            \
+  }
+
+  constexpr int CPL = 2;
+  using vec = float2;
+  constexpr int K = 2 * R + 1;
+  constexpr int W = 64 * CPL;
+  constexpr int RP = ((R + CPL - 1) / CPL) * CPL;
+  constexpr int D = RP - R;
+  constexpr int ROWF = RP + W + RP;
+  constexpr int NQ = (D + CPL + 2 * R + CPL - 1) / CPL;
+  __shared__ __attribute__((aligned(16))) float s_row[LDSPAD ? LDSPAD / 4 : 2 * ROWF];
+
+  const int lane = threadIdx.x;
+  const int strip = blockIdx.x % nstrips;
+  const int seg = blockIdx.x / nstrips;
+  const size_t b = blockIdx.y;
+  src += b * src_stride;
+  dst += b * dst_stride;
+  const int x0 = strip * W;
+  const int y0 = seg * seg_rows;
+  const int y1 = min(h, y0 + seg_rows);
+  const int col = x0 + CPL * lane;
+  const bool col_ok = col < w;
+  int hcol = lane < R ? x0 - R + lane : x0 + W + (lane - R);
+  hcol = hcol < 0 ? 0 : (hcol > w - 1 ? w - 1 : hcol);
+  const int hslot = lane < R ? RP - R + lane : RP + W + (lane - R);
+  const int mcol = col_ok ? col : w - CPL;
+  if (LDSPAD && never)
+    s_row[LDSPAD / 4 - 64 + lane] = 0.f;
+
+  auto load_row = [&](int yy, vec& m, float& hv) {
+    if (NOMEM)
+    {
+      m.x += 1.f;
+      return;
+    }
+    const int gy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+    const float* rowp = src + size_t(gy) * w;
+    m = *reinterpret_cast<const vec*>(rowp + mcol);
+    if (!col_ok)
+      m.x = m.y;
+    hv = 0.f;
+    if (lane < 2 * R)
+      hv = rowp[hcol];
+  };
+  auto stage = [&](int n, const vec& m, float hv) {
+    float* rowbuf = s_row + (n & 1) * ROWF;
+    *reinterpret_cast<vec*>(rowbuf + RP + CPL * lane) = m;
+    if (lane < 2 * R)
+      rowbuf[hslot] = hv;
+  };
+  float2 v[NQ];
+  // LDS byte address of this lane's window in slot 0; slot 1 is ROWF*4 further
+  const unsigned lds_base =
+      unsigned(reinterpret_cast<uintptr_t>(s_row)) + 8u * lane;
+  auto read_window = [&](int n) {
+    const unsigned a = lds_base + ((n & 1) ? ROWF * 4u : 0u);
+    if (V4MODE & 1)
+    {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        asm volatile("ds_read_b64 %0, %1 offset:%2"
+                     : "=v"(v[q])
+                     : "v"(a), "n"(8 * q)
+                     : "memory");
+    }
+    else
+    {
+      const float2* p = reinterpret_cast<const float2*>(
+          s_row + (n & 1) * ROWF + CPL * lane);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        v[q] = p[q];
+    }
+  };
+#define VF(i_) (((i_) & 1) ? v[(i_) >> 1].y : v[(i_) >> 1].x)
+
+  float A[K][CPL];
+  vec pm[PF];
+  float phv[PF];
+  const int T = (y1 - y0) + 2 * R;
+#pragma unroll
+  for (int q = 0; q < PF; ++q)
+  {
+    pm[q] = vec{};
+    phv[q] = 0.f;
+    load_row(y0 - R + q, pm[q], phv[q]);
+  }
+  if (V4MODE & 2)
+  {
+    stage(0, pm[0], phv[0]);
+    load_row(y0 - R + PF, pm[0], phv[0]);
+    read_window(0);
+  }
+
+  for (int n0 = 0; n0 < T; n0 += K)
+  {
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+    {
+      const int n = n0 + i;
+      const int yy = y0 - R + n;
+      float t[CPL];
+      if (!(V4MODE & 2))
+      {
+        stage(n, pm[i % PF], phv[i % PF]);
+        load_row(yy + PF, pm[i % PF], phv[i % PF]);
+        read_window(n);
+      }
+      {
+        float s0 = 0.f, s1 = 0.f;
+        PHASE(4)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PHASE(0)
+        constexpr int NB = K / 4;
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+        {
+          const int j = 4 * q;
+          row4(s0, s1, VF(D + j), VF(D + j + 1), VF(D + j + 2), VF(D + j + 3),
+               VF(D + j + 4), taps.k[j], taps.k[j + 1], taps.k[j + 2],
+               taps.k[j + 3]);
+        }
+#pragma unroll
+        for (int j = 4 * NB; j < K; ++j)
+          row1(s0, s1, VF(D + j), VF(D + j + 1), taps.k[j]);
+        t[0] = s0;
+        t[1] = s1;
+      }
+      asm volatile("" ::"v"(t[0]), "v"(t[1]));
+      PHASE(1)
+      if (V4MODE & 2)
+      {
+        stage(n + 1, pm[(i + 1) % PF], phv[(i + 1) % PF]);
+        load_row(yy + 1 + PF, pm[(i + 1) % PF], phv[(i + 1) % PF]);
+        read_window(n + 1);
+      }
+      PHASE(2)
+#define SL(j) ((i + K - 1 - (j)) % K)
+      {
+        constexpr int c = 0;
+        col_ends(A[SL(0)][c], A[SL(0)][c + 1], A[SL(K - 1)][c],
+                 A[SL(K - 1)][c + 1], A[SL(R)][c], A[SL(R)][c + 1], t[c],
+                 t[c + 1], taps.k[0], taps.k[R]);
+#pragma unroll
+        for (int j = 1; j + 1 < R; j += 2)
+          col2(A[SL(j)][c], A[SL(j)][c + 1], A[SL(K - 1 - j)][c],
+               A[SL(K - 1 - j)][c + 1], A[SL(j + 1)][c], A[SL(j + 1)][c + 1],
+               A[SL(K - 2 - j)][c], A[SL(K - 2 - j)][c + 1], t[c], t[c + 1],
+               taps.k[j], taps.k[j + 1]);
+        if ((R - 1) % 2 == 1)
+          col1(A[SL(R - 1)][c], A[SL(R - 1)][c + 1], A[SL(R + 1)][c],
+               A[SL(R + 1)][c + 1], t[c], t[c + 1], taps.k[R - 1]);
+      }
+#undef SL
+      asm volatile("" ::"v"(A[i][0]), "v"(A[i][1]));
+      PHASE(3)
+      const int o = yy - R;
+      if ((o >= y0) && (o < y1) && col_ok && (!NOMEM || never))
+        *reinterpret_cast<vec*>(dst + size_t(o) * w + col) =
+            make_float2(A[i][0], A[i][1]);
+    }
+    if (K % PF != 0)
+    {
+      vec tm[PF];
+      float th[PF];
+#pragma unroll
+      for (int q = 0; q < PF; ++q)
+      {
+        tm[q] = pm[(K + q) % PF];
+        th[q] = phv[(K + q) % PF];
+      }
+#pragma unroll
+      for (int q = 0; q < PF; ++q)
+      {
+        pm[q] = tm[q];
+        phv[q] = th[q];
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef VF
+  if (lane == 0)
+  {
+    const size_t id = size_t(blockIdx.y) * gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      prof[id * 6 + q] = ph[q];
+    prof[id * 6 + 5] = (unsigned long long) T;
+  }
+#undef PHASE
+}
+
 static Taps make_taps(int R)
 {
   Taps t;
@@ -1345,6 +1752,77 @@ void run4(const float* src, float* dst, float* ref, int w, int h, int batch,
          bytes / best / 1e9, bad);
 }
 
+template <int R, int V4MODE>
+void run4p(const float* src, float* dst, int w, int h, int batch)
+{
+  constexpr int CPL = 2;
+  const int nstrips = (w + 64 * CPL - 1) / (64 * CPL);
+  int nseg = (g_waves + nstrips * batch - 1) / (nstrips * batch);
+  const int min_rows = std::max(32, g_minrows * R);
+  nseg = std::max(1, std::min(nseg, (h + min_rows - 1) / min_rows));
+  const int seg_rows = (h + nseg - 1) / nseg;
+  nseg = (h + seg_rows - 1) / seg_rows;
+  const dim3 grid(nstrips * nseg, batch);
+  const Taps taps = make_taps(R);
+  const size_t stride = size_t(w) * h;
+  const size_t nb = size_t(grid.x) * grid.y;
+  unsigned long long* prof;
+  hipMalloc(&prof, nb * 48);
+  for (int rep = 0; rep < 2; ++rep)
+    march4p<R, 4, 0, 0, V4MODE><<<grid, 64>>>(src, stride, dst, stride, w, h,
+                                              seg_rows, nstrips, taps, 0, prof);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> hp(nb * 6);
+  hipMemcpy(hp.data(), prof, nb * 48, hipMemcpyDeviceToHost);
+  double sum[5] = {0, 0, 0, 0, 0}, steps = 0;
+  for (size_t i = 0; i < nb; ++i)
+  {
+    for (int q = 0; q < 5; ++q)
+      sum[q] += double(hp[i * 6 + q]);
+    steps += double(hp[i * 6 + 5]);
+  }
+  printf("R=%2d v4 mode %d waves=%zu: cycles per step and wave: window wait %.0f  row pass %.0f  "
+         "stage+issue reads %.0f  column pass %.0f  store+loop %.0f  (total %.0f)\n",
+         R, V4MODE, nb, sum[0] / steps, sum[1] / steps, sum[2] / steps, sum[3] / steps,
+         sum[4] / steps, (sum[0] + sum[1] + sum[2] + sum[3] + sum[4]) / steps);
+  hipFree(prof);
+}
+
+template <int R, int PF, int CPL>
+void run3p(const float* src, float* dst, int w, int h, int batch)
+{
+  const int nstrips = (w + 64 * CPL - 1) / (64 * CPL);
+  int nseg = (g_waves + nstrips * batch - 1) / (nstrips * batch);
+  const int min_rows = std::max(32, g_minrows * R);
+  nseg = std::max(1, std::min(nseg, (h + min_rows - 1) / min_rows));
+  const int seg_rows = (h + nseg - 1) / nseg;
+  nseg = (h + seg_rows - 1) / seg_rows;
+  const dim3 grid(nstrips * nseg, batch);
+  const Taps taps = make_taps(R);
+  const size_t stride = size_t(w) * h;
+  const size_t nb = size_t(grid.x) * grid.y;
+  unsigned long long* prof;
+  hipMalloc(&prof, nb * 48);
+  for (int rep = 0; rep < 2; ++rep)
+    march3p<R, PF, CPL, 0><<<grid, 64>>>(src, stride, dst, stride, w, h, seg_rows,
+                                         nstrips, taps, 0, prof);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> hp(nb * 6);
+  hipMemcpy(hp.data(), prof, nb * 48, hipMemcpyDeviceToHost);
+  double sum[5] = {0, 0, 0, 0, 0}, steps = 0;
+  for (size_t i = 0; i < nb; ++i)
+  {
+    for (int q = 0; q < 5; ++q)
+      sum[q] += double(hp[i * 6 + q]);
+    steps += double(hp[i * 6 + 5]);
+  }
+  printf("R=%2d CPL=%d waves=%zu: cycles per step and wave: vmwait %.0f  lds stage+read %.0f  "
+         "row pass %.0f  column pass %.0f  store+loop %.0f  (total %.0f)\n",
+         R, CPL, nb, sum[0] / steps, sum[1] / steps, sum[2] / steps, sum[3] / steps,
+         sum[4] / steps, (sum[0] + sum[1] + sum[2] + sum[3] + sum[4]) / steps);
+  hipFree(prof);
+}
+
 template <int R, int PF>
 void sweep3(const float* src, float* dst, float* ref, int w, int h, int batch)
 {
@@ -1426,6 +1904,16 @@ int main(int argc, char** argv)
     sweep<10, 3>(src, dst, w, h, batch);
     sweep<8, 4>(src, dst, w, h, batch);
     sweep<5, 4>(src, dst, w, h, batch);
+  }
+  if (getenv("PHASES"))
+  {
+    run4p<12, 2>(src, dst, w, h, batch);
+    run4p<12, 0>(src, dst, w, h, batch);
+    run3p<12, 4, 2>(src, dst, w, h, batch);
+    run3p<10, 4, 2>(src, dst, w, h, batch);
+    run3p<8, 4, 2>(src, dst, w, h, batch);
+    run3p<5, 4, 2>(src, dst, w, h, batch);
+    return 0;
   }
   if (!getenv("SWEEP2"))
   {
