@@ -579,7 +579,10 @@ __global__ __launch_bounds__(64) void march3(const float* __restrict__ src,
   constexpr int D = RP - R;
   constexpr int ROWF = RP + W + RP;
   constexpr int NQ = (D + CPL + 2 * R + CPL - 1) / CPL;
-  __shared__ __attribute__((aligned(16))) float s_row[2 * ROWF];
+  // NOMEM == 4: real memory traffic, halo lanes handled without exec-mask
+  // branches (the other lanes write a dummy LDS slot / re-load their column)
+  constexpr bool BRFREE = NOMEM == 4;
+  __shared__ __attribute__((aligned(16))) float s_row[2 * ROWF + 64];
 
   const int lane = threadIdx.x;
   const int strip = blockIdx.x % nstrips;
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(64) void march3(const float* __restrict__ src,
   const int mcol = col_ok ? col : w - CPL;
 
   auto load_row = [&](int yy, vec& m, float& hv) {
-    if (NOMEM)
+    if (NOMEM == 1 || NOMEM == 2)
     {
       (&m.x)[0] += 1.f;
       return;
@@ -613,9 +616,14 @@ __global__ __launch_bounds__(64) void march3(const float* __restrict__ src,
       for (int c = 0; c < CPL; ++c)
         (&m.x)[c] = last;
     }
-    hv = 0.f;
-    if (lane < 2 * R)
-      hv = rowp[hcol];
+    if (BRFREE)
+      hv = rowp[lane < 2 * R ? hcol : mcol];
+    else
+    {
+      hv = 0.f;
+      if (lane < 2 * R)
+        hv = rowp[hcol];
+    }
   };
 
   float A[K][CPL];
@@ -638,15 +646,20 @@ __global__ __launch_bounds__(64) void march3(const float* __restrict__ src,
       const int n = n0 + i;
       const int yy = y0 - R + n;
       float* rowbuf = s_row + (n & 1) * ROWF;
-      if (NOMEM < 2)
+      if (NOMEM < 2 || BRFREE)
       {
         *reinterpret_cast<vec*>(rowbuf + RP + CPL * lane) = pm[i % PF];
-        if (lane < 2 * R)
+        if (BRFREE)
+        {
+          float* hp = lane < 2 * R ? rowbuf + hslot : s_row + 2 * ROWF + lane;
+          *hp = phv[i % PF];
+        }
+        else if (lane < 2 * R)
           rowbuf[hslot] = phv[i % PF];
       }
       load_row(yy + PF, pm[i % PF], phv[i % PF]);
       float v[NQ * CPL];
-      if (NOMEM >= 2)
+      if (NOMEM == 2)
       {
 #pragma unroll
         for (int q = 0; q < NQ * CPL; ++q)
@@ -705,7 +718,7 @@ __global__ __launch_bounds__(64) void march3(const float* __restrict__ src,
       }
 #undef SL
       const int o = yy - R;
-      if ((o >= y0) && (o < y1) && col_ok && (!NOMEM || never))
+      if ((o >= y0) && (o < y1) && col_ok && (NOMEM == 0 || BRFREE || never))
       {
         vec ov;
 #pragma unroll
@@ -1666,7 +1679,7 @@ void run3(const float* src, float* dst, float* ref, int w, int h, int batch,
     best = std::min(best, ms);
   }
   long bad = -1;
-  if (ref && !NOMEM)
+  if (ref && (NOMEM == 0 || NOMEM == 4))
   {
     // bit-exactness against the first-generation kernel
     const int ns1 = (w + 255) / 256;
@@ -1832,6 +1845,7 @@ void sweep3(const float* src, float* dst, float* ref, int w, int h, int batch)
   run3<R, 4, 2, 0>(src, dst, ref, w, h, batch, "v3");
   run3<R, 4, 2, 1>(src, dst, ref, w, h, batch, "v3 nomem");
   run3<R, 4, 2, 2>(src, dst, ref, w, h, batch, "v3 nolds");
+  run3<R, 4, 2, 4>(src, dst, ref, w, h, batch, "v3 brfree");
   run3<R, 4, 2, 0, true>(src, dst, ref, w, h, batch, "v3 tapv");
   run3<R, 4, 2, 1, true>(src, dst, ref, w, h, batch, "v3 tapv nomem");
   run3<R, 4, 2, 2, true>(src, dst, ref, w, h, batch, "v3 tapv nolds");
