@@ -255,6 +255,53 @@ namespace sara_hip {
     return r;
   }
 
+  //! The same reduction driven by a table instead of selects: row `id` (number
+  //! of range thresholds the argument has reached, 0..4) holds (a, b, c, d,
+  //! atanhi, atanlo) with numerator a*x + b and denominator c*x + d.  Every
+  //! row reproduces the select version bit for bit: multiplications by 0, 1
+  //! and 2 are exact, x + 0 == x for x >= 0, and with atanhi = atanlo = 0 the
+  //! combination hi - ((xr*s - lo) - xr) equals xr - xr*s (negation commutes
+  //! with rounding).  The gradient kernel keeps the table in LDS: two loads
+  //! replace 15 selects and 5 compares per pixel (v_cndmask / v_cmp issue at
+  //! about half the rate of plain arithmetic on gfx950).
+  constexpr int kAtanTableFloats = 40;
+#define SARA_ATAN_TABLE_INIT                                                    \
+  {                                                                            \
+    1.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f,                                    \
+    2.f, -1.f, 1.f, 2.f, 4.6364760399e-01f, 5.0121582440e-09f, 0.f, 0.f,       \
+    1.f, -1.f, 1.f, 1.f, 7.8539812565e-01f, 3.7748947079e-08f, 0.f, 0.f,       \
+    1.f, -1.5f, 1.5f, 1.f, 9.8279368877e-01f, 3.4473217170e-08f, 0.f, 0.f,     \
+    0.f, -1.f, 1.f, 0.f, 1.5707962513e+00f, 7.5497894159e-08f, 0.f, 0.f        \
+  }
+
+  SARA_HD float atanf_nonneg_table(float x, const float* tab)
+  {
+    const int32_t ix = float_as_int(x);
+    const int id = int(ix >= 0x3ee00000) + int(ix >= 0x3f300000) +
+                   int(ix >= 0x3f980000) + int(ix >= 0x401c0000);
+    const float* t = tab + 8 * id;
+    const float a = t[0], b = t[1], c = t[2], d = t[3], hi = t[4], lo = t[5];
+    const float num = a * x + b;
+    const float den = c * x + d;
+    const float xr = num / den;
+    const float z = xr * xr;
+    const float w = z * z;
+    const float s1 =
+        z * (3.3333334327e-01f +
+             w * (1.4285714924e-01f +
+                  w * (9.0908870101e-02f +
+                       w * (6.6610731184e-02f +
+                            w * (4.9768779427e-02f + w * 1.6285819933e-02f)))));
+    const float s2 =
+        w * (-2.0000000298e-01f +
+             w * (-1.1111110449e-01f +
+                  w * (-7.6918758452e-02f +
+                       w * (-5.8335702866e-02f + w * -3.6531571299e-02f))));
+    float r = hi - ((xr * (s1 + s2) - lo) - xr);
+    r = ix >= 0x4c000000 ? 1.5707962513e+00f + 7.5497894159e-08f : r;  // >= 2^25
+    return r;
+  }
+
   //! fdlibm_atan2f with the common path branch-free (finite inputs); the
   //! non-finite inputs take the reference implementation above.
   SARA_HD float fdlibm_atan2f_fast(float y, float x)
@@ -284,13 +331,60 @@ namespace sara_hip {
     z = k > 60 ? pi_o_2 + 0.5f * pi_lo : z;
     const bool tiny = (hx < 0) & (k < -60) & !(k > 60);
     z = tiny ? 0.0f : z;
-    const float zneg = int_as_float(float_as_int(z) ^ (int32_t) 0x80000000);
-    const float zl = z - pi_lo;
-    const float q2 = pi - zl;   // m == 2
-    const float q3 = zl - pi;   // m == 3
-    const float lower = (m & 1) ? zneg : z;
-    const float upper = (m & 1) ? q3 : q2;
-    float r = (m & 2) ? upper : lower;
+    // m = 0: z, 1: -z, 2: pi - (z - pi_lo), 3: (z - pi_lo) - pi.  Rounding
+    // commutes with negation, so case 2 is -(case 3) (z - pi_lo never equals
+    // pi, no signed-zero issue): one select and a sign flip for m in {1, 2}.
+    const float q3 = (z - pi_lo) - pi;
+    const float base = (m & 2) ? q3 : z;
+    const int32_t flip = (int32_t) ((uint32_t) ((m ^ (m >> 1)) & 1) << 31);
+    float r = int_as_float(float_as_int(base) ^ flip);
+    // fdlibm's x == 1 shortcut (atanf(y)) and its y == 0 cases for x != 0 are
+    // reproduced by the general path bit for bit (y/1 == y; atan(0) == 0 and
+    // pi - (0 - pi_lo) rounds to pi), so only x == +-0 needs a select.
+    const int32_t sy = hy & (int32_t) 0x80000000;
+    const float pi_sy = int_as_float(float_as_int(pi) | sy);
+    const float pi_o_2_sy = int_as_float(float_as_int(pi_o_2) | sy);
+    const float x0y0 = (m & 2) ? pi_sy : y;
+    const float x0 = iy == 0 ? x0y0 : pi_o_2_sy;
+    r = ix == 0 ? x0 : r;
+    return r;
+  }
+
+  //! fdlibm_atan2f_fast with the table-driven reduction.
+  SARA_HD float fdlibm_atan2f_table(float y, float x, const float* tab)
+  {
+    const int32_t hx = float_as_int(x);
+    const int32_t ix = hx & 0x7fffffff;
+    const int32_t hy = float_as_int(y);
+    const int32_t iy = hy & 0x7fffffff;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    // Non-finite inputs: the reference implementation (host self-check only;
+    // pyramid values on the device are finite).
+    if (ix >= 0x7f800000 || iy >= 0x7f800000)
+      return fdlibm_atan2f(y, x);
+#endif
+    const float pi = 3.1415927410e+00f;
+    const float pi_lo = -8.7422776573e-08f;
+    const float pi_o_2 = 1.5707963705e+00f;
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    const int k = (iy - ix) >> 23;
+    // general path: z = atan(|y/x|)
+    const float q = y / x;
+    float z = atanf_nonneg_table(int_as_float(float_as_int(q) & 0x7fffffff), tab);
+    // Every candidate below is computed unconditionally and then picked with
+    // plain two-way selects of ready values: written as nested conditionals
+    // with the arithmetic inside the arms, the compiler turns each arm into a
+    // divergent branch (7 exec-mask branches per pixel in the gradient kernel).
+    z = k > 60 ? pi_o_2 + 0.5f * pi_lo : z;
+    const bool tiny = (hx < 0) & (k < -60) & !(k > 60);
+    z = tiny ? 0.0f : z;
+    // m = 0: z, 1: -z, 2: pi - (z - pi_lo), 3: (z - pi_lo) - pi.  Rounding
+    // commutes with negation, so case 2 is -(case 3) (z - pi_lo never equals
+    // pi, no signed-zero issue): one select and a sign flip for m in {1, 2}.
+    const float q3 = (z - pi_lo) - pi;
+    const float base = (m & 2) ? q3 : z;
+    const int32_t flip = (int32_t) ((uint32_t) ((m ^ (m >> 1)) & 1) << 31);
+    float r = int_as_float(float_as_int(base) ^ flip);
     // fdlibm's x == 1 shortcut (atanf(y)) and its y == 0 cases for x != 0 are
     // reproduced by the general path bit for bit (y/1 == y; atan(0) == 0 and
     // pi - (0 - pi_lo) rounds to pi), so only x == +-0 needs a select.

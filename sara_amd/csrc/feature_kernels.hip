@@ -99,6 +99,10 @@ namespace sara_hip {
 #ifndef SARA_GRAD_WAVES_PER_EU
 #define SARA_GRAD_WAVES_PER_EU 6
 #endif
+#ifndef SARA_ATAN_TABLE
+#define SARA_ATAN_TABLE 1
+#endif
+  constexpr bool g_atan_table = SARA_ATAN_TABLE != 0;
   template <int PF>
   __global__ __launch_bounds__(64, SARA_GRAD_WAVES_PER_EU) void gradient_polar_march_kernel(
       const float* __restrict__ src, size_t src_stride,
@@ -108,6 +112,15 @@ namespace sara_hip {
   {
     constexpr int W = 256;
     const int lane = threadIdx.x;
+    // argument-reduction table of atanf (device_math.hpp) in LDS
+    __shared__ __attribute__((aligned(16))) float s_atan[kAtanTableFloats];
+    {
+      const float init[kAtanTableFloats] = SARA_ATAN_TABLE_INIT;
+      if (lane < kAtanTableFloats)
+        s_atan[lane] = init[lane];
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+    }
     const int strip = blockIdx.x % nstrips;
     const int seg = blockIdx.x / nstrips;
     const int z = blockIdx.y;
@@ -192,7 +205,8 @@ namespace sara_hip {
             const float gx = (xp - xm) / 2;
             const float gy = (yp - ym) / 2;
             res[2 * c] = 2 * sqrtf(gx * gx + gy * gy);
-            res[2 * c + 1] = fdlibm_atan2f_fast(gy, gx);
+            res[2 * c + 1] = g_atan_table ? fdlibm_atan2f_table(gy, gx, s_atan)
+                                          : fdlibm_atan2f_fast(gy, gx);
           }
           if (col_ok)
           {

@@ -1814,7 +1814,14 @@ void sara_hip_selfcheck_atan2f(const float* y, const float* x, float* out,
                                size_t count)
 {
   for (size_t i = 0; i < count; ++i)
-    out[i] = sara_hip::fdlibm_atan2f_fast(y[i], x[i]);
+  {
+    // both restatements the kernels use must agree; a mismatch is reported
+    // as NaN so that the comparison with libm fails
+    static const float tab[sara_hip::kAtanTableFloats] = SARA_ATAN_TABLE_INIT;
+    const float a = sara_hip::fdlibm_atan2f_fast(y[i], x[i]);
+    const float b = sara_hip::fdlibm_atan2f_table(y[i], x[i], tab);
+    out[i] = std::memcmp(&a, &b, sizeof(float)) == 0 ? a : std::nanf("");
+  }
 }
 
 }  // extern "C"
