@@ -548,6 +548,15 @@ namespace DO::Sara {
   }
 #endif  // !SARA_HIP_WITH_SARA_HEADERS (inside Sara: see INTEGRATION.md)
 
+  //! FeatureDescriptors/RootSIFT.hpp:45-53 applied to the descriptor matrix of a
+  //! keypoint list (ComputeRootSIFTDescriptor wraps the base operator and
+  //! post-processes every descriptor the same way): rows /= L1 norm, then sqrt.
+  inline void root_sift(Tensor_<float, 2>& descriptors, int device = 0)
+  {
+    hip_detail::check(sara_hip_root_sift(descriptors.data(), descriptors.rows(),
+                                         descriptors.cols(), 0, device));
+  }
+
   //! FeatureDetectors/DoG.hpp:72-165.  The pyramids stay in HBM; gaussians()
   //! and diff_of_gaussians() copy them to the host on first use.
   class ComputeDoGExtrema

@@ -297,7 +297,10 @@ enum
   SARA_HIP_OPT_ALL_GRADIENT_SCALES = 1, /* 1: polar gradients of all S scales  */
                                         /* as the reference does (default 0:   */
                                         /* only the consumed ones)             */
-  SARA_HIP_OPT_STAGE_TIMERS = 2         /* 1: record per-stage hipEvents        */
+  SARA_HIP_OPT_STAGE_TIMERS = 2,        /* 1: record per-stage hipEvents        */
+  SARA_HIP_OPT_ROOT_SIFT = 3            /* 1: descriptors leave the descriptor  */
+                                        /* kernel as RootSIFT (see              */
+                                        /* sara_hip_root_sift; default 0)       */
 };
 SARA_HIP_API sara_hip_status sara_hip_sift_set_option(sara_hip_sift* ctx,
                                                      int option, int value);
@@ -370,6 +373,18 @@ typedef struct sara_match
   int32_t rank;
   int32_t direction;
 } sara_match;
+
+/* ComputeRootSIFTDescriptor's post-processing (FeatureDescriptors/RootSIFT.hpp */
+/* :45-53) on an n x dim row-major descriptor matrix, in place: every row is     */
+/* divided by its L1 norm, then every bin replaced by the square root of its     */
+/* magnitude with its sign kept (Sara's descriptor has negative bins, see        */
+/* DESIGN.md section 9; all-zero rows are left untouched), so every non-zero row */
+/* has unit L2 norm afterwards.  desc: host pointer, or device pointer when      */
+/* on_device != 0.  The reference's two lines are written against Eigen 2 and    */
+/* no longer compile, so the parity of this entry is pinned on the restatement   */
+/* of their intent only.                                                         */
+SARA_HIP_API sara_hip_status sara_hip_root_sift(float* desc, int n, int dim,
+                                               int on_device, int device);
 
 /* match(keys1, keys2, lowe_ratio) - SfM/Helpers/KeypointMatching.cpp:19-25 ->  */
 /* AnnMatcher{keys1, keys2, ratio}.compute_matches(): nearest / second nearest  */

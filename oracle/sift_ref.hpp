@@ -1028,6 +1028,28 @@ namespace sara_ref {
     }
   }
 
+  //! FeatureDescriptors/RootSIFT.hpp:45-53: the descriptor of the base operator
+  //! (already normalised and scaled to 0..255) divided by its L1 norm, then the
+  //! square root of every bin.  The reference's two lines use Eigen 2's
+  //! `.cwise()` and no longer compile (nothing includes the header), so this is
+  //! a restatement of their intent - PARITY UNPINNED; left-to-right float sum
+  //! for lpNorm<1>(); an all-zero descriptor is left as it is (the reference
+  //! would divide 0 by 0).  The base descriptor has negative bins (modf() of a
+  //! patch coordinate in (-1, 0) gives a negative fraction, SIFT.hpp:209-232,
+  //! about one bin in ten), whose plain square root would be NaN: the root is
+  //! taken of the magnitude and the sign kept, so that <root(a), root(a)> = 1
+  //! still holds.
+  inline void root_sift(float* h, int dim)
+  {
+    float l1 = 0.f;
+    for (int i = 0; i < dim; ++i)
+      l1 += std::abs(h[i]);
+    if (!(l1 > 0.f))
+      return;
+    for (int i = 0; i < dim; ++i)
+      h[i] = std::copysign(std::sqrt(std::abs(h[i]) / l1), h[i]);
+  }
+
   //! FeatureDescriptors/SIFT.hpp:62-145 (+ normalize :241-252).  The
   //! unqualified sqrt/cos/sin bind to the double C functions; T's entries are
   //! rounded to float by Eigen's comma initialiser.

@@ -283,6 +283,12 @@ float ref_flann_l2(const float* a, const float* b, int size)
   return flann_l2(a, b, size);
 }
 
+void ref_root_sift(float* desc, int n, int dim)
+{
+  for (int i = 0; i < n; ++i)
+    root_sift(desc + size_t(i) * dim, dim);
+}
+
 // ---- whole-pipeline handle ---------------------------------------------- //
 
 struct ref_sift

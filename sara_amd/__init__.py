@@ -25,7 +25,7 @@ __all__ = [
     "apply_gaussian_filter", "gaussian", "scale", "downscale", "enlarge",
     "gradient_polar_coordinates", "scale_space_dog_extremum_map",
     "from_rgb8_to_gray32f", "from_gray8_to_gray32f", "AnnMatcher", "match",
-    "MATCH_DTYPE", "write_keypoints", "read_keypoints",
+    "MATCH_DTYPE", "write_keypoints", "read_keypoints", "root_sift",
     "make_gaussian_kernel", "SaraHipError", "OEREGION_DTYPE",
 ]
 
@@ -491,6 +491,18 @@ def from_gray8_to_gray32f(src, device=0):
     capi.check(capi.load().sara_hip_from_gray8_to_gray32f(
         a.ctypes.data, out.ctypes.data_as(C.POINTER(C.c_float)), a.shape[1],
         a.shape[0], device))
+    return out
+
+
+def root_sift(desc, device=0):
+    """FeatureDescriptors/RootSIFT.hpp:45-53 as a post-processing of a
+    descriptor matrix: rows divided by their L1 norm, then the square root of
+    every bin.  Returns a new N x dim float32 array (computed on the GPU)."""
+    out = np.array(desc, dtype=np.float32, order="C", copy=True)
+    if out.ndim != 2 or out.shape[1] < 1:
+        raise ValueError("desc must be N x dim")
+    capi.check(capi.load().sara_hip_root_sift(out.ctypes.data, out.shape[0],
+                                              out.shape[1], 0, device))
     return out
 
 

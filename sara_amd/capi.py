@@ -27,6 +27,7 @@ TIME_NAMES = ["upload", "pyramid", "extrema", "gradient", "orientation",
 
 OPT_ALL_GRADIENT_SCALES = 1
 OPT_STAGE_TIMERS = 2
+OPT_ROOT_SIFT = 3
 
 #: numpy view of sara_oeregion (48 bytes, Features/Feature.hpp:155-177).
 MATCH_DTYPE = np.dtype([("x_index", "<i4"), ("y_index", "<i4"), ("score", "<f4"),
@@ -82,7 +83,7 @@ EXPORTS = [
     "sara_hip_scale_space_dog_extremum_map", "sara_hip_selfcheck_atan2f",
     "sara_hip_sift_detect_u8", "sara_hip_from_rgb8_to_gray32f",
     "sara_hip_from_gray8_to_gray32f", "sara_hip_match_descriptors",
-    "sara_hip_sift_stage", "sara_hip_sift_detect_staged",
+    "sara_hip_sift_stage", "sara_hip_sift_detect_staged", "sara_hip_root_sift",
 ]
 
 _f32p = C.POINTER(C.c_float)
@@ -164,6 +165,7 @@ def _declare(lib):
     lib.sara_hip_match_descriptors.argtypes = [
         _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, C.c_int,
         C.POINTER(C.c_int), C.c_int]
+    lib.sara_hip_root_sift.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.sara_hip_selfcheck_atan2f.argtypes = [_f32p, _f32p, _f32p, C.c_size_t]
     lib.sara_hip_selfcheck_atan2f.restype = None
     return lib

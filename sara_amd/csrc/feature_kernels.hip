@@ -1426,7 +1426,7 @@ namespace sara_hip {
       const GradPyramidView* __restrict__ gradp, CandidateLists cand,
       OrientationLists ori, sara_oeregion* __restrict__ features,
       int32_t* __restrict__ scale_octave, float* __restrict__ descriptors,
-      int with_descriptors, int xcd_run, int row_shift)
+      int with_descriptors, int root_sift, int xcd_run, int row_shift)
   {
     const GradPyramidView& grad = *gradp;
     __shared__ unsigned long long s_acc[4][128 * kDescCopies];
@@ -1674,6 +1674,17 @@ namespace sara_hip {
       }
       h0 = fminf(h0 * 512.f, 255.f);
       h1 = fminf(h1 * 512.f, 255.f);
+      if (root_sift)
+      {
+        // RootSIFT.hpp:48-50: h /= lpNorm<1>(h); h = sqrt(h) - of the magnitude,
+        // sign kept: the base descriptor has negative bins.
+        const float l1 = wave_sum(fabsf(h0) + fabsf(h1));
+        if (l1 > 0.f)
+        {
+          h0 = copysignf(sqrtf(fabsf(h0) / l1), h0);
+          h1 = copysignf(sqrtf(fabsf(h1) / l1), h1);
+        }
+      }
       descriptors[out * 128 + lane] = h0;
       descriptors[out * 128 + 64 + lane] = h1;
       __builtin_amdgcn_wave_barrier();
@@ -1692,14 +1703,45 @@ namespace sara_hip {
                           const OrientationLists& ori, int batch,
                           sara_oeregion* features, int32_t* scale_octave,
                           float* descriptors, int with_descriptors,
-                          hipStream_t stream)
+                          int root_sift, hipStream_t stream)
   {
     const int unit = 8 * g_xcd_run;
     const int needed = unit * (((cand.cap + 3) / 4 + unit - 1) / unit);
     const dim3 grid(std::min(needed, unit * g_persist_units), batch);
     hipLaunchKernelGGL(descriptor_kernel, grid, dim3(256), 0, stream, grad, cand,
                        ori, features, scale_octave, descriptors,
-                       with_descriptors, g_xcd_run, g_desc_row_shift);
+                       with_descriptors, root_sift, g_xcd_run, g_desc_row_shift);
+  }
+
+  // ------------------------------------------------------------------------ //
+  // RootSIFT on a descriptor matrix (FeatureDescriptors/RootSIFT.hpp:45-53):
+  // one wave per row, row /= its L1 norm, then the signed square root of
+  // every bin.
+  // ------------------------------------------------------------------------ //
+  __global__ __launch_bounds__(256) void root_sift_kernel(float* __restrict__ desc,
+                                                          int n, int dim)
+  {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n)
+      return;
+    float* h = desc + size_t(row) * dim;
+    float part = 0.f;
+    for (int i = lane; i < dim; i += 64)
+      part += fabsf(h[i]);
+    const float l1 = wave_sum(part);
+    if (!(l1 > 0.f))
+      return;
+    for (int i = lane; i < dim; i += 64)
+      h[i] = copysignf(sqrtf(fabsf(h[i]) / l1), h[i]);
+  }
+
+  void launch_root_sift(float* desc, int n, int dim, hipStream_t stream)
+  {
+    if (n <= 0)
+      return;
+    hipLaunchKernelGGL(root_sift_kernel, dim3((n + 3) / 4), dim3(256), 0, stream,
+                       desc, n, dim);
   }
 
   // ------------------------------------------------------------------------ //

@@ -197,6 +197,7 @@ struct sara_hip_sift
   sara_hip_stage last_stage = SARA_HIP_STAGE_PYRAMID;
   bool has_result = false;
   bool all_gradient_scales = false;
+  bool root_sift = false;
   bool timers = true;
 
   // pyramids, one allocation per octave (sized for max dims / max batch).
@@ -717,6 +718,10 @@ sara_hip_status sara_hip_sift_set_option(sara_hip_sift* c, int option, int value
   case SARA_HIP_OPT_STAGE_TIMERS:
     c->timers = value != 0;
     return SARA_HIP_OK;
+  case SARA_HIP_OPT_ROOT_SIFT:
+    c->root_sift = value != 0;
+    c->graph_stage = -1;
+    return SARA_HIP_OK;
   default:
     return fail(SARA_HIP_INVALID_PARAMS, "unknown option");
   }
@@ -1060,7 +1065,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   if (last_stage >= SARA_HIP_STAGE_ORIENTATION)
     launch_descriptors(c->d_grad, c->cand, c->ori, batch, c->d_feat, c->d_so,
                        c->d_desc, last_stage >= SARA_HIP_STAGE_DESCRIPTOR ? 1 : 0,
-                       stream);
+                       c->root_sift ? 1 : 0, stream);
   HIP_TRY(mark(6));
   HIP_TRY(hipGetLastError());
   return SARA_HIP_OK;
@@ -1662,6 +1667,33 @@ sara_hip_status sara_hip_from_gray8_to_gray32f(const uint8_t* src, float* gray,
                                                int w, int h, int device)
 {
   return u8_to_gray(src, gray, w, h, 1, device);
+}
+
+sara_hip_status sara_hip_root_sift(float* desc, int n, int dim, int on_device,
+                                   int device)
+{
+  if (!desc || n < 0 || dim < 1)
+    return fail(SARA_HIP_INVALID_PARAMS, "null pointer, negative count or empty rows");
+  if (n == 0)
+    return SARA_HIP_OK;
+  const sara_hip_status st = select_device(device);
+  if (st != SARA_HIP_OK)
+    return st;
+  DeviceScratch sc;
+  float* d = desc;
+  const size_t bytes = size_t(n) * dim * sizeof(float);
+  if (!on_device)
+  {
+    HIP_TRY(sc.get(d, size_t(n) * dim));
+    HIP_TRY(hipMemcpy(d, desc, bytes, hipMemcpyHostToDevice));
+  }
+  launch_root_sift(d, n, dim, nullptr);
+  HIP_TRY(hipGetLastError());
+  if (!on_device)
+    HIP_TRY(hipMemcpy(desc, d, bytes, hipMemcpyDeviceToHost));
+  else
+    HIP_TRY(hipStreamSynchronize(nullptr));
+  return SARA_HIP_OK;
 }
 
 sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,

@@ -227,7 +227,8 @@ namespace sara_hip {
                           const OrientationLists& ori, int batch,
                           sara_oeregion* features, int32_t* scale_octave,
                           float* descriptors, int with_descriptors,
-                          hipStream_t stream);
+                          int root_sift, hipStream_t stream);
+  void launch_root_sift(float* desc, int n, int dim, hipStream_t stream);
 
   //! Sorted extrema (before orientation assignment) as OERegion + site.
   void launch_gather_extrema(const CandidateLists& cand, const int* ex_offset,

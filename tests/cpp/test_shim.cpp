@@ -118,6 +118,24 @@ int main(int argc, char** argv)
     }
   }
 
+  // RootSIFT post-processing (FeatureDescriptors/RootSIFT.hpp:45-53): every
+  // non-zero row has unit L2 norm afterwards.
+  {
+    auto r = d;
+    sara::root_sift(r);
+    for (int i = 0; i < r.rows(); ++i)
+    {
+      double l1 = 0., z = 0.;
+      for (int j = 0; j < r.cols(); ++j)
+      {
+        l1 += d(i, j);
+        z += double(r(i, j)) * r(i, j);
+      }
+      if (l1 > 0. && std::abs(z - 1.) > 1e-5)
+        return 17;
+    }
+  }
+
   // 2. the functor API with its pyramid accessors.
   auto compute_dogs = sara::ComputeDoGExtrema{pyr_params, 4.f, 0.01f, 10.f, 5, 5};
   auto so = std::vector<sara::Point2i>{};

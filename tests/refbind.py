@@ -372,6 +372,15 @@ def flann_l2(a, b):
     return float(fn(a.ctypes.data, b.ctypes.data, a.size))
 
 
+def root_sift(desc):
+    out = np.array(desc, np.float32, order="C", copy=True).reshape(-1, np.shape(desc)[-1])
+    fn = lib().ref_root_sift
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    fn(out.ctypes.data, out.shape[0], out.shape[1])
+    return out.reshape(np.shape(desc))
+
+
 def rgb8_to_gray32f(rgb):
     """Vectorised restatement of the reference's Rgb8 -> float conversion
     (double arithmetic, final cast), checked against the C oracle in tests."""

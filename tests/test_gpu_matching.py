@@ -97,3 +97,42 @@ def test_match_frames_on_device(oracle):
                                           kl[j].descriptor_matrix, 0.6)
             assert_same(got, want)
             assert len(got) > 0
+
+
+# ---- RootSIFT ---------------------------------
+@pytest.mark.parametrize("n,dim", [(1, 128), (257, 128), (50, 6), (13, 200)])
+def test_root_sift_operator_matches_oracle(oracle, n, dim):
+    """RootSIFT.hpp:45-53: row /= L1 norm, then sqrt.  The device sums |h| in a
+    different order than the oracle's left-to-right loop over 128 floats: rtol 4e-6."""
+    rng = np.random.default_rng(n + dim)
+    d = (rng.random((n, dim), dtype=np.float32) * 255).astype(np.float32)
+    d[rng.random((n, dim)) < 0.3] = 0
+    d[rng.random((n, dim)) < 0.1] *= -1   # Sara's descriptor has negative bins
+    if n > 4:
+        d[3] = 0                      # all-zero descriptor: left untouched
+    got = sara_amd.root_sift(d)
+    want = oracle.root_sift(d)
+    assert np.allclose(got, want, rtol=4e-6, atol=0)
+    nz = np.abs(d).sum(1) > 0
+    assert np.allclose((got[nz].astype(np.float64) ** 2).sum(1), 1, atol=1e-5)
+    assert np.array_equal(got[~nz], d[~nz])
+
+
+def test_root_sift_option_of_the_pipeline(oracle):
+    """SARA_HIP_OPT_ROOT_SIFT: the descriptor kernel emits RootSIFT rows; equal
+    to post-processing the plain descriptors, everything else unchanged."""
+    img = synth(320, 240, 5)
+    p = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=3)
+    with sara_amd.SiftContext(320, 240, 1, p) as ctx:
+        plain = ctx.detect(img).keypoint_lists()[0]
+        ctx.set_option(sara_amd.capi.OPT_ROOT_SIFT, 1)
+        root = ctx.detect(img).keypoint_lists()[0]
+        ctx.set_option(sara_amd.capi.OPT_ROOT_SIFT, 0)
+        again = ctx.detect(img).keypoint_lists()[0]
+    assert len(plain) > 100
+    assert plain.regions.tobytes() == root.regions.tobytes()
+    assert np.array_equal(plain.descriptor_matrix, again.descriptor_matrix)
+    want = oracle.root_sift(plain.descriptor_matrix)
+    assert np.allclose(root.descriptor_matrix, want, rtol=4e-6, atol=0)
+    assert np.allclose((root.descriptor_matrix.astype(np.float64) ** 2).sum(1), 1,
+                       atol=1e-5)

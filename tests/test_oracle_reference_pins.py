@@ -286,3 +286,19 @@ def test_matching_restatement_properties(oracle):
     assert oracle.flann_l2(a, b) == float(acc)
     with pytest.raises(RuntimeError):
         oracle.compute_matches(np.zeros((0, 128), np.float32), d2, 0.6)
+
+
+def test_root_sift_restatement(oracle):
+    """FeatureDescriptors/RootSIFT.hpp:45-53 (dead code in the reference: Eigen 2
+    API) - h /= lpNorm<1>(h); h = sqrt(h).  Known answers by hand."""
+    d = np.array([[1, 3, 0, 12], [0, 0, 0, 0], [2, -2, 2, 2]], np.float32)
+    got = oracle.root_sift(d)
+    want = np.array([[0.25, np.sqrt(np.float32(3) / np.float32(16)), 0,
+                      np.sqrt(np.float32(0.75))], [0, 0, 0, 0],
+                     [0.5, -0.5, 0.5, 0.5]], np.float32)
+    assert np.array_equal(got, want)
+    # Hellinger kernel: <root(a), root(b)> = sum sqrt(a_i b_i) / sqrt(|a|_1 |b|_1)
+    rng = np.random.default_rng(0)
+    a, b = rng.random((2, 128), dtype=np.float32)
+    ra, rb = oracle.root_sift(a[None])[0], oracle.root_sift(b[None])[0]
+    assert abs(float(ra @ rb) - np.sqrt(a * b).sum() / np.sqrt(a.sum() * b.sum())) < 1e-5
