@@ -298,9 +298,23 @@ enum
                                         /* as the reference does (default 0:   */
                                         /* only the consumed ones)             */
   SARA_HIP_OPT_STAGE_TIMERS = 2,        /* 1: record per-stage hipEvents        */
-  SARA_HIP_OPT_ROOT_SIFT = 3            /* 1: descriptors leave the descriptor  */
+  SARA_HIP_OPT_ROOT_SIFT = 3,           /* 1: descriptors leave the descriptor  */
                                         /* kernel as RootSIFT (see              */
                                         /* sara_hip_root_sift; default 0)       */
+  /* The two switches of the "corrected" detector mode (default 0 = what the    */
+  /* reference's default build computes):                                       */
+  SARA_HIP_OPT_SIGNED_EXTREMUM_TYPE = 4,      /* 1: host loop of the             */
+                                        /* DO_SARA_USE_HALIDE branch            */
+                                        /* (RefineExtremum.cpp:226-361): int8    */
+                                        /* map, so DoG minima are refined like  */
+                                        /* maxima, and sites whose refined      */
+                                        /* scale leaves (sigma(s)/4, 4 sigma(s))*/
+                                        /* are rejected (:307-325)              */
+  SARA_HIP_OPT_DOWNSCALE_AT_DOUBLE_SIGMA = 5  /* 1: octave o+1 is sub-sampled    */
+                                        /* from scale round(log 2 / log k), the */
+                                        /* one at 2 sigma_0, instead of floor() */
+                                        /* (GaussianPyramid.hpp:97-100), which   */
+                                        /* is one lower for k = float(2^(1/3))  */
 };
 SARA_HIP_API sara_hip_status sara_hip_sift_set_option(sara_hip_sift* ctx,
                                                      int option, int value);

@@ -41,6 +41,32 @@
 
 namespace sara_ref {
 
+  //! Switches of the "corrected" detector mode;
+  //! 0 = the reference's default (non-Halide) build, which everything pinned in
+  //! this file describes.
+  //!  * kModeSignedExtremumType: the host loop of the DO_SARA_USE_HALIDE branch
+  //!    (RefineExtremum.cpp:226-361): the map is int8, so minima reach
+  //!    refine_extremum as type -1 and are refined like maxima (quirk Q2 gone),
+  //!    and a refined scale outside (sigma(s) / 4, 4 sigma(s)) rejects the
+  //!    site (:307-325).  The map itself is still classified by the default
+  //!    rules: the Halide-generated classifier cannot be built here.
+  //!  * kModeDownscaleAtDoubleSigma: octave o + 1 is sub-sampled from the
+  //!    scale whose sigma is 2 sigma_0, round(log 2 / log k), instead of
+  //!    floor(...) which float rounding of k turns into one scale lower
+  //!    (quirk Q3, GaussianPyramid.hpp:97-100).
+  //! PARITY UNPINNED: no build of the reference produces this combination.
+  enum
+  {
+    kModeSignedExtremumType = 1,
+    kModeDownscaleAtDoubleSigma = 2
+  };
+  inline int& detector_mode()
+  {
+    static int mode = 0;
+    return mode;
+  }
+
+
   // ------------------------------------------------------------------------ //
   // Containers.  Image.hpp:45-181: x-fastest storage, pixel (x,y) at y*w+x.
   // ------------------------------------------------------------------------ //
@@ -411,8 +437,11 @@ namespace sara_ref {
 
     const float k = params.scale_geometric_factor;
     const int num_scales = params.scale_count_per_octave;
+    const double scales_per_doubling = std::log(double(2.f)) / std::log(double(k));
     const int downscale_index =
-        static_cast<int>(std::floor(std::log(double(2.f)) / std::log(double(k))));
+        (detector_mode() & kModeDownscaleAtDoubleSigma)
+            ? static_cast<int>(std::round(scales_per_doubling))
+            : static_cast<int>(std::floor(scales_per_doubling));
 
     Pyramid<Image> G;
     G.reset(std::max(num_octaves, 0), num_scales, init_sigma, k);
@@ -789,6 +818,7 @@ namespace sara_ref {
 
       map[xy] = static_cast<std::uint8_t>(type);  // -1 -> 255 (Q2)
     }
+    const bool signed_type = (detector_mode() & kModeSignedExtremumType) != 0;
 
     std::vector<float> location_refined(static_cast<size_t>(wh) * 3, 0.f);
     std::vector<float> extremum_value(static_cast<size_t>(wh), 0.f);
@@ -803,9 +833,20 @@ namespace sara_ref {
       float* pos = &location_refined[size_t(xy) * 3];
       float& val = extremum_value[xy];
       val = I(s, o)(x, y);
-      refine_extremum(I, x, y, s, o, int(type), pos, val, img_padding_sz,
-                      refine_iterations);
-      if (std::abs(val) < extremum_thres)
+      refine_extremum(I, x, y, s, o,
+                      signed_type ? int(static_cast<std::int8_t>(type)) : int(type),
+                      pos, val, img_padding_sz, refine_iterations);
+      bool scale_implausible = false;
+      if (signed_type)
+      {
+        // RefineExtremum.cpp:307-318
+        const float scale_approx =
+            static_cast<float>(I.scale_relative_to_octave(s));
+        const float ratio_max = 4.f, ratio_min = 1 / ratio_max;
+        scale_implausible =
+            !(ratio_min * scale_approx < pos[2] && pos[2] < ratio_max * scale_approx);
+      }
+      if (std::abs(val) < extremum_thres || scale_implausible)
         map[xy] = 0;
     }
 

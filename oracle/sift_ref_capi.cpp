@@ -289,6 +289,14 @@ void ref_root_sift(float* desc, int n, int dim)
     root_sift(desc + size_t(i) * dim, dim);
 }
 
+//! Detector mode bits (kMode*, sift_ref.hpp); returns the previous value.
+int ref_set_detector_mode(int mode)
+{
+  const int old = detector_mode();
+  detector_mode() = mode;
+  return old;
+}
+
 // ---- whole-pipeline handle ---------------------------------------------- //
 
 struct ref_sift

@@ -365,7 +365,9 @@ namespace sara_hip {
   }
 
   //! refine_extremum.  type: 1 maximum, 255 minimum (the reference's uint8
-  //! map stores -1 as 255, so minima are never refined).  pos = (x, y, sigma).
+  //! map stores -1 as 255, so minima are never refined), or -1 minimum with
+  //! SARA_HIP_OPT_SIGNED_EXTREMUM_TYPE (the int8 map of RefineExtremum.cpp:246).
+  //! pos = (x, y, sigma).
   __device__ inline void refine_extremum(const DogOctave& I, int x, int y, int s,
                                          int type, float pos[3], float& val,
                                          int border_sz, int num_iter,
@@ -404,8 +406,9 @@ namespace sara_hip {
                           4.f;
 
       // (lambda * float(type)).maxCoeff() >= 0: with type in {1, 255} the
-      // Newton step is taken only when H is negative definite.
-      if (definiteness3(H) != -1)
+      // Newton step is taken only when H is negative definite, with type -1
+      // only when it is positive definite.
+      if (definiteness3(H) != (type == -1 ? +1 : -1))
       {
         hh[0] = hh[1] = hh[2] = 0.f;
         break;
@@ -523,10 +526,19 @@ namespace sara_hip {
 
     float pos[3];
     float val = v;
-    refine_extremum(I, x, y, s, type == 1 ? 1 : 255, pos, val, p.img_padding_sz,
-                    p.refine_iters, tab, p.scale_geometric_factor);
+    refine_extremum(I, x, y, s, type == 1 ? 1 : (p.signed_type ? -1 : 255), pos,
+                    val, p.img_padding_sz, p.refine_iters, tab,
+                    p.scale_geometric_factor);
     if (fabsf(val) < p.extremum_thres)
       return;
+    if (p.signed_type)
+    {
+      // RefineExtremum.cpp:307-318: refined scale within (1/4, 4) of sigma(s),
+      // compared in double as there.
+      const double approx = tab.sigma_d[s];
+      if (!(0.25 * approx < double(pos[2]) && double(pos[2]) < 4. * approx))
+        return;
+    }
 
     const int slot = atomicAdd(&cand.count[frame], 1);
     if (slot < cand.cap)

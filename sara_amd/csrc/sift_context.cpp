@@ -91,7 +91,8 @@ namespace {
   };
 
   //! Geometry part of gaussian_pyramid(), GaussianPyramid.hpp:43-122.
-  Schedule make_schedule(const sara_pyramid_params& p, int w, int h)
+  Schedule make_schedule(const sara_pyramid_params& p, int w, int h,
+                         bool downscale_at_double_sigma = false)
   {
     Schedule s;
     s.resize_factor = std::pow(2.f, -static_cast<float>(p.first_octave_index));
@@ -130,8 +131,12 @@ namespace {
                                     std::log(double(2.f))),
                    p.num_octaves_max);
     s.num_octaves = std::max(n, 0);
-    s.downscale_index = static_cast<int>(std::floor(
-        std::log(double(2.f)) / std::log(double(p.scale_geometric_factor))));
+    // GaussianPyramid.hpp:97-100: floor(); round() is the scale at 2 sigma_0
+    // the float value of k misses (SARA_HIP_OPT_DOWNSCALE_AT_DOUBLE_SIGMA).
+    const double per_doubling =
+        std::log(double(2.f)) / std::log(double(p.scale_geometric_factor));
+    s.downscale_index = static_cast<int>(
+        downscale_at_double_sigma ? std::round(per_doubling) : std::floor(per_doubling));
     s.oct.resize(s.num_octaves);
     for (int o = 0; o < s.num_octaves; ++o)
     {
@@ -198,6 +203,8 @@ struct sara_hip_sift
   bool has_result = false;
   bool all_gradient_scales = false;
   bool root_sift = false;
+  bool signed_type = false;
+  bool downscale_at_double_sigma = false;
   bool timers = true;
 
   // pyramids, one allocation per octave (sized for max dims / max batch).
@@ -408,6 +415,7 @@ namespace {
       const float sigma = static_cast<float>(std::pow(double(k), double(s)) *
                                              double(pyr.scale_initial));
       c->h_tab.sigma[s] = sigma;
+      c->h_tab.sigma_d[s] = std::pow(double(k), double(s)) * double(pyr.scale_initial);
       const float sw = sigma * 1.5f;
       c->h_tab.ori_sigma[s] = sw;
       const int R = static_cast<int>(std::round(sw * 3.f));
@@ -722,6 +730,24 @@ sara_hip_status sara_hip_sift_set_option(sara_hip_sift* c, int option, int value
     c->root_sift = value != 0;
     c->graph_stage = -1;
     return SARA_HIP_OK;
+  case SARA_HIP_OPT_SIGNED_EXTREMUM_TYPE:
+    c->signed_type = value != 0;
+    c->graph_stage = -1;
+    return SARA_HIP_OK;
+  case SARA_HIP_OPT_DOWNSCALE_AT_DOUBLE_SIGMA:
+  {
+    const bool on = value != 0;
+    if (make_schedule(c->pyr, c->max_sched.base_w, c->max_sched.base_h, on)
+            .downscale_index >= c->S)
+      return fail(SARA_HIP_INVALID_PARAMS,
+                  "downscale index round(log 2 / log k) >= scale count");
+    if (c->last_stream)
+      HIP_TRY(hipStreamSynchronize(c->last_stream));
+    c->downscale_at_double_sigma = on;
+    c->cur_w = c->cur_h = -1;  // rebuild the schedule on the next detect
+    c->graph_stage = -1;
+    return SARA_HIP_OK;
+  }
   default:
     return fail(SARA_HIP_INVALID_PARAMS, "unknown option");
   }
@@ -759,7 +785,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   {
     if (c->last_stream)
       HIP_TRY(hipStreamSynchronize(c->last_stream));
-    c->cur = make_schedule(c->pyr, width, height);
+    c->cur = make_schedule(c->pyr, width, height, c->downscale_at_double_sigma);
     c->cur_w = width;
     c->cur_h = height;
     {
@@ -993,6 +1019,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     ep.img_padding_sz = c->img_padding;
     ep.refine_iters = c->refine_iters;
     ep.scale_geometric_factor = c->pyr.scale_geometric_factor;
+    ep.signed_type = c->signed_type ? 1 : 0;
     for (int o = 0; o < sc.num_octaves; ++o)
     {
       OctaveView dv;  // the Gaussian octave; DoG layers are formed on the fly

@@ -37,6 +37,7 @@ namespace sara_hip {
   struct ScaleTable
   {
     float sigma[kMaxScales];     // float(pow(k, s) * sigma0), ImagePyramid.hpp:316-319
+    double sigma_d[kMaxScales];  // the same before rounding (scale plausibility test)
     int ori_radius[kMaxScales];  // int_round(sigma*1.5f*3.f), Orientation.hpp:105-108
     float ori_sigma[kMaxScales]; // sigma * 1.5f
     int ori_woff[kMaxScales];    // offset of the weight table of scale s
@@ -49,6 +50,7 @@ namespace sara_hip {
     int img_padding_sz;
     int refine_iters;
     float scale_geometric_factor;
+    int signed_type;  // SARA_HIP_OPT_SIGNED_EXTREMUM_TYPE
   };
 
   //! Unordered candidate lists of the extremum scan, per frame.

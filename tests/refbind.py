@@ -372,6 +372,27 @@ def flann_l2(a, b):
     return float(fn(a.ctypes.data, b.ctypes.data, a.size))
 
 
+MODE_SIGNED_EXTREMUM_TYPE = 1
+MODE_DOWNSCALE_AT_DOUBLE_SIGMA = 2
+
+
+class detector_mode:
+    """with detector_mode(bits): ... - the oracle's "corrected" switches."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        fn = lib().ref_set_detector_mode
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_int]
+        self.old = fn(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        lib().ref_set_detector_mode(self.old)
+
+
 def root_sift(desc):
     out = np.array(desc, np.float32, order="C", copy=True).reshape(-1, np.shape(desc)[-1])
     fn = lib().ref_root_sift

@@ -474,3 +474,51 @@ def test_one_scale_per_octave(oracle):
         compare_full(ctx, ref)
         ne, nk = compare_lists(run_lists(ctx), ref, 0)
     assert ne > 0
+
+
+# ---- "corrected" detector mode ----------------
+@pytest.mark.parametrize("bits", [1, 2, 3])
+@pytest.mark.parametrize("w,h,seed", [(640, 480, 1234), (333, 250, 7)])
+def test_corrected_mode_switches(oracle, bits, w, h, seed):
+    """bit 0: SARA_HIP_OPT_SIGNED_EXTREMUM_TYPE (host loop of the Halide branch,
+    RefineExtremum.cpp:226-361: minima refined, scale plausibility test);
+    bit 1: SARA_HIP_OPT_DOWNSCALE_AT_DOUBLE_SIGMA (octaves from G(3, o)).  Same
+    bars as the default mode, against the oracle run with the same switches."""
+    img = synth(w, h, seed)
+    with oracle.detector_mode(bits):
+        ref = oracle.RefSift(img, ref_params(oracle, 0, 4))
+    with oracle.detector_mode(0):
+        ref_default = oracle.RefSift(img, ref_params(oracle, 0, 4))
+    with sara_amd.SiftContext(w, h, 1, hip_params(0, 4)) as ctx:
+        ctx.detect(img)
+        compare_lists(run_lists(ctx), ref_default, 0)
+        ctx.set_option(sara_amd.capi.OPT_SIGNED_EXTREMUM_TYPE, bits & 1)
+        ctx.set_option(sara_amd.capi.OPT_DOWNSCALE_AT_DOUBLE_SIGMA, (bits >> 1) & 1)
+        ctx.detect(img)
+        compare_full(ctx, ref)
+        ne, nk = compare_lists(run_lists(ctx), ref, 0)
+        assert ne > 50
+        got = ctx.extrema()[1]
+        ctx.set_option(sara_amd.capi.OPT_SIGNED_EXTREMUM_TYPE, 0)
+        ctx.set_option(sara_amd.capi.OPT_DOWNSCALE_AT_DOUBLE_SIGMA, 0)
+        ctx.detect(img)
+        compare_lists(run_lists(ctx), ref_default, 0)
+    # the switches change what they should
+    d_reg = ref_default.extrema()[0]
+    if bits & 1:
+        # some minima now sit at sub-pixel positions
+        mins = got[got["extremum_type"] == -1]["coords"]
+        assert np.any(mins != np.round(mins))
+        dmins = d_reg[d_reg["extremum_type"] == -1]["coords"]
+        assert np.all(dmins == np.round(dmins))
+    if bits & 2:
+        assert not np.array_equal(ref.gaussian(0, 1), ref_default.gaussian(0, 1))
+
+
+def test_downscale_option_rejected_when_out_of_range():
+    # 4 scales, k = 1.2: log 2 / log k = 3.8 - floor() = 3 is a valid index,
+    # round() = 4 is not
+    p = hip_params(0, 3, scales=4, k=1.2)
+    with sara_amd.SiftContext(128, 128, 1, p) as ctx:
+        with pytest.raises(sara_amd.SaraHipError):
+            ctx.set_option(sara_amd.capi.OPT_DOWNSCALE_AT_DOUBLE_SIGMA, 1)

@@ -302,3 +302,39 @@ def test_root_sift_restatement(oracle):
     a, b = rng.random((2, 128), dtype=np.float32)
     ra, rb = oracle.root_sift(a[None])[0], oracle.root_sift(b[None])[0]
     assert abs(float(ra @ rb) - np.sqrt(a * b).sum() / np.sqrt(a.sum() * b.sum())) < 1e-5
+
+
+def test_corrected_mode_switches_of_the_restatement(oracle):
+    """SURVEY.md section 8f row f4.  Default: quirk Q2 (minima never refined:
+    integer positions) and Q3 (octave o+1 from G(2, o)).  Signed extremum type
+    (host loop of RefineExtremum.cpp:226-361): minima refined; downscale at the
+    doubled sigma: octave 1 is the nearest-neighbour half of G(3, 0)."""
+    from sara_amd.synth import synth
+    img = synth(200, 160, 3)
+    p = oracle.PyramidParams(0, 6, None, 1, 0.5, 1.6, 3)
+    base = oracle.RefSift(img, p, stop_after=3)
+    reg = base.extrema()[0]
+    mins = reg[reg["extremum_type"] == -1]["coords"]
+    assert len(mins) > 10 and np.all(mins == np.round(mins))
+    assert np.array_equal(base.gaussian(0, 1), base.gaussian(2, 0)[::2, ::2][:80, :100])
+    with oracle.detector_mode(oracle.MODE_SIGNED_EXTREMUM_TYPE):
+        signed = oracle.RefSift(img, p, stop_after=3)
+    sreg = signed.extrema()[0]
+    smins = sreg[sreg["extremum_type"] == -1]["coords"]
+    assert np.any(smins != np.round(smins))
+    # maxima are untouched by the switch, except for those whose refined scale
+    # is implausible (:307-325)
+    smax, dmax = sreg[sreg["extremum_type"] == 1], reg[reg["extremum_type"] == 1]
+    kept = {(c.tobytes(), m.tobytes(), float(v)) for c, m, v in
+            zip(dmax["coords"], dmax["shape_matrix"], dmax["extremum_value"])}
+    assert 0 < len(smax) <= len(dmax)
+    assert all((c.tobytes(), m.tobytes(), float(v)) in kept for c, m, v in
+               zip(smax["coords"], smax["shape_matrix"], smax["extremum_value"]))
+    assert np.array_equal(signed.gaussian(0, 1), base.gaussian(0, 1))
+    with oracle.detector_mode(oracle.MODE_DOWNSCALE_AT_DOUBLE_SIGMA):
+        fixed = oracle.RefSift(img, p, stop_after=3)
+    assert np.array_equal(fixed.gaussian(0, 1), fixed.gaussian(3, 0)[::2, ::2][:80, :100])
+    assert np.array_equal(fixed.gaussian(3, 0), base.gaussian(3, 0))
+    # and the mode is restored
+    again = oracle.RefSift(img, p, stop_after=3)
+    assert again.extrema()[0].tobytes() == reg.tobytes()
