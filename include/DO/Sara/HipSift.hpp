@@ -26,6 +26,9 @@
 #pragma once
 
 #include <sara_hip_sift.h>
+#ifdef SARA_HIP_WITH_HDF5
+#  include <sara_keypoint_h5.h>
+#endif
 
 #include <array>
 #include <cmath>
@@ -358,6 +361,59 @@ namespace DO::Sara {
 
   static_assert(sizeof(OERegion) == sizeof(sara_oeregion),
                 "OERegion must stay byte-compatible with sara_oeregion");
+
+#if defined(SARA_HIP_WITH_HDF5) && !defined(SARA_HIP_WITH_SARA_HEADERS)
+  //! Core/HDF5.hpp:160-193 reduced to what keypoint files need: a file name
+  //! and an access mode (HDF5's own flag values); every call below opens and
+  //! closes the file through libsara_keypoint_h5.so.
+  struct H5File
+  {
+    enum : unsigned { AccRdOnly = 0x0u, AccRdWr = 0x1u, AccTrunc = 0x2u };
+    H5File(const std::string& filename_, unsigned flags_)
+      : filename{filename_}
+      , flags{flags_}
+      , truncate_pending{(flags_ & AccTrunc) != 0}
+    {
+    }
+    std::string filename;
+    unsigned flags;
+    bool truncate_pending;
+  };
+
+  //! Features/IO.hpp:146-157.
+  inline auto read_keypoints(H5File& h5_file, const std::string& group_name)
+      -> KeypointList<OERegion, float>
+  {
+    int n = 0, dim = 0;
+    if (sara_h5_keypoints_sizes(h5_file.filename.c_str(), group_name.c_str(), &n,
+                                &dim))
+      throw std::runtime_error{sara_h5_last_error()};
+    auto features = std::vector<OERegion>(std::size_t(n));
+    auto descriptors = Tensor_<float, 2>{n, dim};
+    if (sara_h5_read_keypoints(h5_file.filename.c_str(), group_name.c_str(),
+                               reinterpret_cast<sara_oeregion*>(features.data()),
+                               descriptors.data()))
+      throw std::runtime_error{sara_h5_last_error()};
+    return {features, descriptors};
+  }
+
+  //! Features/IO.hpp:159-167.
+  inline auto write_keypoints(H5File& h5_file, const std::string& group_name,
+                              const KeypointList<OERegion, float>& keys,
+                              bool overwrite = false) -> void
+  {
+    const auto& f = features(keys);
+    const auto& v = descriptors(keys);
+    if (h5_file.flags == H5File::AccRdOnly)
+      throw std::runtime_error{"Error: the file is opened read-only"};
+    if (sara_h5_write_keypoints(
+            h5_file.filename.c_str(), h5_file.truncate_pending ? 1 : 0,
+            group_name.c_str(), reinterpret_cast<const sara_oeregion*>(f.data()),
+            int(f.size()), v.data(), v.cols(), overwrite ? 1 : 0))
+      throw std::runtime_error{sara_h5_last_error()};
+    h5_file.truncate_pending = false;
+  }
+#endif
 
   namespace hip_detail {
 

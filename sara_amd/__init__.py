@@ -25,7 +25,7 @@ __all__ = [
     "apply_gaussian_filter", "gaussian", "scale", "downscale", "enlarge",
     "gradient_polar_coordinates", "scale_space_dog_extremum_map",
     "from_rgb8_to_gray32f", "from_gray8_to_gray32f", "AnnMatcher", "match",
-    "MATCH_DTYPE", "write_keypoints", "read_keypoints", "root_sift",
+    "MATCH_DTYPE", "write_keypoints", "read_keypoints", "root_sift", "H5File",
     "make_gaussian_kernel", "SaraHipError", "OEREGION_DTYPE",
 ]
 
@@ -565,11 +565,84 @@ def _eigen_row(values):
     return " ".join(t.rjust(width) for t in txt)
 
 
-def write_keypoints(features, descriptors, name):
+class H5File:
+    """Core/HDF5.hpp:160-177 for keypoint files: a file name and how to open it
+    ("w" = H5F_ACC_TRUNC, "a" = read-write, "r" = read-only).  Used with
+    write_keypoints(h5_file, group_name, keys, overwrite) and
+    read_keypoints(h5_file, group_name) - Features/IO.hpp:146-167.  Every call
+    opens and closes the file (libsara_keypoint_h5.so over libhdf5)."""
+
+    def __init__(self, filename, flags="r"):
+        if flags not in ("r", "w", "a"):
+            raise ValueError("flags must be 'r', 'w' or 'a'")
+        self.filename, self.flags = str(filename), flags
+        self._truncate_pending = flags == "w"
+        _h5lib()
+
+    def _write(self, group, keys, overwrite):
+        if self.flags == "r":
+            raise RuntimeError("file opened read-only")
+        regions = np.ascontiguousarray(keys.regions, dtype=OEREGION_DTYPE)
+        desc = np.ascontiguousarray(keys.descriptor_matrix, dtype=np.float32)
+        if desc.ndim != 2 or desc.shape[0] != len(regions):
+            raise ValueError("descriptors must be N x dim")
+        st = _h5lib().sara_h5_write_keypoints(
+            self.filename.encode(), int(self._truncate_pending), group.encode(),
+            regions.ctypes.data, len(regions), desc.ctypes.data, desc.shape[1],
+            int(bool(overwrite)))
+        if st:
+            raise RuntimeError(_h5lib().sara_h5_last_error().decode())
+        self._truncate_pending = False
+
+    def _read(self, group):
+        lib = _h5lib()
+        n, dim = C.c_int(), C.c_int()
+        if lib.sara_h5_keypoints_sizes(self.filename.encode(), group.encode(),
+                                       C.byref(n), C.byref(dim)):
+            raise RuntimeError(lib.sara_h5_last_error().decode())
+        regions = np.zeros(n.value, OEREGION_DTYPE)
+        desc = np.zeros((n.value, dim.value), np.float32)
+        if lib.sara_h5_read_keypoints(self.filename.encode(), group.encode(),
+                                      regions.ctypes.data, desc.ctypes.data):
+            raise RuntimeError(lib.sara_h5_last_error().decode())
+        return KeypointList(regions, desc)
+
+
+_h5 = None
+
+
+def _h5lib():
+    global _h5
+    if _h5 is None:
+        import os
+        path = os.path.join(os.path.dirname(capi.LIB_PATH), "libsara_keypoint_h5.so")
+        if not os.path.exists(path):
+            raise RuntimeError(
+                path + " is not built (needs libhdf5's C headers: "
+                "make -C sara_amd/csrc)")
+        lib = C.CDLL(path)
+        lib.sara_h5_write_keypoints.argtypes = [
+            C.c_char_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p,
+            C.c_int, C.c_int]
+        lib.sara_h5_keypoints_sizes.argtypes = [
+            C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.sara_h5_read_keypoints.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p,
+                                               C.c_void_p]
+        lib.sara_h5_last_error.restype = C.c_char_p
+        _h5 = lib
+    return _h5
+
+
+def write_keypoints(features, descriptors, name, overwrite=False):
     """Features/IO.hpp:110-143: "N dim", then per keypoint
     ``x y m00 m10 m01 m11 orientation type d0 ... d(dim-1)`` (shape matrix in
     storage = column-major order).  ``features``: KeypointList.regions-like
-    structured array; ``descriptors``: N x dim."""
+    structured array; ``descriptors``: N x dim.
+
+    HDF5 overload (Features/IO.hpp:159-167):
+    ``write_keypoints(h5_file, group_name, keys, overwrite=False)``."""
+    if isinstance(features, H5File):
+        return features._write(descriptors, name, overwrite)
     if isinstance(features, KeypointList):
         descriptors = features.descriptor_matrix if descriptors is None \
             else descriptors
@@ -589,11 +662,16 @@ def write_keypoints(features, descriptors, name):
     return True
 
 
-def read_keypoints(name):
+def read_keypoints(name, group_name=None):
     """Features/IO.hpp:77-108 -> KeypointList.  As in the reference, the four
     shape coefficients are read ROW-major (OERegion's operator>>,
     Features/Feature.cpp:88-95 with Core/EigenExtension.hpp:163-170) although
-    they were written in storage order."""
+    they were written in storage order.
+
+    HDF5 overload (Features/IO.hpp:146-157):
+    ``read_keypoints(h5_file, group_name)``."""
+    if isinstance(name, H5File):
+        return name._read(group_name)
     with open(name) as f:
         tok = f.read().split()
     n, dim = int(tok[0]), int(tok[1])
