@@ -34,10 +34,18 @@ for case in T._fuzz_cases(n, seed):
         if use_u8:
             u8 = np.clip(imgs * 255.0, 0, 255).astype(np.uint8)
             imgs = u8.astype(np.float32) / np.float32(255)
+        # "corrected" mode switches and RootSIFT on a third of the cases
+        mode = int(rng.choice([0, 0, 0, 0, 1, 2, 3]))
+        root = bool(rng.integers(0, 3) == 0)
+        import math
+        if (mode & 2) and round(math.log(2.0) / math.log(kfac if kfac else 2 ** (1 / 3))) >= scales:
+            mode &= 1
         with sara_amd.SiftContext(w, h, batch, T.hip_params(first, noct, cam, scales, kfac),
                                   gauss_truncate=trunc, extremum_thres=thres,
                                   edge_ratio_thres=edge,
                                   extremum_refinement_iter=iters) as ctx:
+            ctx.set_option(sara_amd.capi.OPT_SIGNED_EXTREMUM_TYPE, mode & 1)
+            ctx.set_option(sara_amd.capi.OPT_DOWNSCALE_AT_DOUBLE_SIGMA, (mode >> 1) & 1)
             if use_u8:
                 ctx.detect_u8(u8)
             else:
@@ -45,12 +53,21 @@ for case in T._fuzz_cases(n, seed):
             lists = T.run_lists(ctx)
             descs = []
             for b in range(batch):
-                ref = rb.RefSift(imgs[b], T.ref_params(rb, first, noct, cam, scales, kfac),
-                                 gauss_truncate=trunc, extremum_thres=thres,
-                                 edge_ratio_thres=edge, extremum_refinement_iter=iters)
+                with rb.detector_mode(mode):
+                    ref = rb.RefSift(imgs[b], T.ref_params(rb, first, noct, cam, scales, kfac),
+                                     gauss_truncate=trunc, extremum_thres=thres,
+                                     edge_ratio_thres=edge, extremum_refinement_iter=iters)
                 T.compare_full(ctx, ref, frame=b)
                 T.compare_lists(lists, ref, b)
                 descs.append(ref.keypoints()[2])
+            if root and int(lists[3].sum()):
+                ctx.set_option(sara_amd.capi.OPT_ROOT_SIFT, 1)
+                (ctx.detect_u8(u8) if use_u8 else ctx.detect(imgs))
+                got = ctx.fetch()[2]
+                want = rb.root_sift(lists[5])
+                assert np.allclose(got, want, rtol=1e-5, atol=1e-7), "root sift"
+                ctx.set_option(sara_amd.capi.OPT_ROOT_SIFT, 0)
+                (ctx.detect_u8(u8) if use_u8 else ctx.detect(imgs))
             if batch >= 2 and len(descs[0]) >= 2 and len(descs[1]) >= 2:
                 ratio = float(rng.choice([0.6, 0.8, 1.0]))
                 M.assert_same(ctx.match_frames(0, 1, ratio),
