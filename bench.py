@@ -41,8 +41,9 @@ def parse():
     ap.add_argument("--unique-frames", type=int, default=4,
                     help="distinct synthetic frames generated per rank (the "
                          "rest are their flips)")
-    ap.add_argument("--cpu-frames", type=int, default=3,
-                    help="frames of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=24,
+                    help="frames of the cpu_baseline sample, about 10 s of CPU work "
+                         "(0 = skip)")
     ap.add_argument("--stage", type=int, default=5,
                     help="last pipeline stage (5 = full SIFT)")
     return ap.parse_args()

@@ -424,6 +424,14 @@ SARA_HIP_API sara_hip_status sara_hip_match_descriptors(
 SARA_HIP_API void sara_hip_selfcheck_atan2f(const float* y, const float* x,
                                            float* out, size_t count);
 
+/* Device self-check: the polar-gradient kernel replaces the compiler's IEEE    */
+/* sqrt and one of its divisions by shorter correctly-rounded sequences and the */
+/* range selection of atanf by a table look-up.  This runs, on the GPU, every   */
+/* non-negative float through both forms: mismatches[0] = atanf reduction,      */
+/* mismatches[1] = square root (both must be 0).  Not a compute path.           */
+SARA_HIP_API sara_hip_status sara_hip_selfcheck_device_math(
+    unsigned long long* mismatches, int device);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -397,4 +397,153 @@ namespace sara_hip {
     return r;
   }
 
+  // ------------------------------------------------------------------------ //
+  // Device-only short forms.  The compiler's IEEE sqrt and division cost 16 and
+  // 11 VALU instructions (range scaling, fix-ups); on the operand ranges below
+  // a hardware seed plus one or two FMA corrections already rounds correctly.
+  // Both were compared with the IEEE forms on every float of their domain on
+  // the device (tools/ubench/fast_math_check.hip, and sara_hip_selfcheck_
+  // device_math at test time).
+  // ------------------------------------------------------------------------ //
+#if defined(__HIPCC__)
+  //! sqrtf(x), correctly rounded for x == 0 and 2^-102 <= x <= FLT_MAX (below,
+  //! the residual g*g - x underflows; +inf gives 0): callers test
+  //! sqrt_short_ok() and fall back to sqrtf().
+  __device__ inline float sqrt_rn_short(float x)
+  {
+    const float y = __builtin_amdgcn_rsqf(x);  // +inf for x == 0
+    const float g = x * y;                     // NaN for x == 0
+    const float h = 0.5f * y;
+    const float d = __builtin_fmaf(-g, g, x);
+    return fmaxf(__builtin_fmaf(d, h, g), 0.f);  // maxNum: NaN -> 0
+  }
+
+  //! frexp exponent of x (0 for x == 0): the short form is exact from -101 up,
+  //! -96 leaves a margin.
+  __device__ inline int sqrt_short_exponent(float x)
+  {
+    return __builtin_amdgcn_frexp_expf(x);
+  }
+  constexpr int kSqrtShortMinExponent = -96;
+
+  //! n / d, correctly rounded for the quotients of the atanf reduction
+  //! ((a x + b) / (c x + d) of SARA_ATAN_TABLE_INIT for 0 <= x < 2^126): no
+  //! operand scaling, one reciprocal refinement, one quotient refinement.
+  __device__ inline float div_rn_short(float n, float d)
+  {
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    const float q = n * r;
+    const float rem = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(rem, r, q);
+  }
+#endif
+
+  //! Look-up form of the table: one row per 2^18-aligned block of float bit
+  //! patterns between the first and the last range threshold (all four
+  //! thresholds are multiples of 2^18), so that the row address is a shift, a
+  //! clamp and a scaled add of the argument's bits instead of four compares.
+  constexpr int kAtanLutLo = 0x3ee00000 >> 18;  // first threshold block: 0xFB8
+  constexpr int kAtanLutHi = 0x401c0000 >> 18;  // last threshold block: 0x1007
+  constexpr int kAtanLutRows = kAtanLutHi - kAtanLutLo + 2;  // + "below" row
+  constexpr int kAtanLutFloats = 8 * kAtanLutRows;
+
+  //! Row of the 5-row table that serves LUT row j.
+  SARA_HD int atan_lut_source_row(int j)
+  {
+    const int32_t first = (kAtanLutLo - 1 + j) << 18;  // smallest pattern of the block
+    return int(first >= 0x3ee00000) + int(first >= 0x3f300000) +
+           int(first >= 0x3f980000) + int(first >= 0x401c0000);
+  }
+
+  SARA_HD float atanf_nonneg_lut(float x, const float* lut)
+  {
+    const int32_t ix = float_as_int(x);
+    // block index relative to the "below" row, clamped to the table
+    int v = (ix >> 18) - (kAtanLutLo - 1);
+    v = v < 0 ? 0 : v;
+    v = v > kAtanLutRows - 1 ? kAtanLutRows - 1 : v;
+    const float* t = lut + 8 * v;
+    const float a = t[0], b = t[1], c = t[2], d = t[3], hi = t[4], lo = t[5];
+    const float num = a * x + b;
+    const float den = c * x + d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float xr = div_rn_short(num, den);
+#else
+    const float xr = num / den;
+#endif
+    const float z = xr * xr;
+    const float w = z * z;
+    const float s1 =
+        z * (3.3333334327e-01f +
+             w * (1.4285714924e-01f +
+                  w * (9.0908870101e-02f +
+                       w * (6.6610731184e-02f +
+                            w * (4.9768779427e-02f + w * 1.6285819933e-02f)))));
+    const float s2 =
+        w * (-2.0000000298e-01f +
+             w * (-1.1111110449e-01f +
+                  w * (-7.6918758452e-02f +
+                       w * (-5.8335702866e-02f + w * -3.6531571299e-02f))));
+    float r = hi - ((xr * (s1 + s2) - lo) - xr);
+    r = ix >= 0x4c000000 ? 1.5707962513e+00f + 7.5497894159e-08f : r;  // >= 2^25
+    return r;
+  }
+
+  //! atan2f(y, x) for finite y and x != +-0 with the look-up reduction.
+  //! Compared with fdlibm_atan2f_fast two more of fdlibm's shortcuts are
+  //! dropped because the general path already returns their values:
+  //!  * k = exponent(y) - exponent(x) > 60 (result pi/2): then |y/x| >= 2^60
+  //!    (or overflows to +inf), which the reduction's own |x| >= 2^25 case
+  //!    maps to atanhi[3] + atanlo[3] - the same float as pi/2 + pi_lo/2;
+  //!  * x < 0 and k < -60 (z = 0): then z = atanf(|y/x|) <= 2^-59 while
+  //!    half an ulp of pi_lo is 2^-48, so z - pi_lo == -pi_lo exactly and the
+  //!    quadrant formulas give the same result as with z = 0.
+  //! (tests/test_host_math.py holds the cases; x == +-0 is not covered here:
+  //! see atan2f_zero_x.)
+  SARA_HD float atan2f_lut_nonzero_x(float y, float x, const float* lut)
+  {
+    const int32_t hx = float_as_int(x);
+    const int32_t hy = float_as_int(y);
+    const float pi = 3.1415927410e+00f;
+    const float pi_lo = -8.7422776573e-08f;
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    const float q = y / x;
+    const float z = atanf_nonneg_lut(int_as_float(float_as_int(q) & 0x7fffffff), lut);
+    // m = 0: z, 1: -z, 2: pi - (z - pi_lo), 3: (z - pi_lo) - pi
+    const float q3 = (z - pi_lo) - pi;
+    const float base = (m & 2) ? q3 : z;
+    const int32_t flip = (int32_t) ((uint32_t) ((m ^ (m >> 1)) & 1) << 31);
+    return int_as_float(float_as_int(base) ^ flip);
+  }
+
+  //! atan2f(y, +-0): +-pi/2 by the sign of y; for y == +-0, y itself (x = +0)
+  //! or +-pi (x = -0).
+  SARA_HD float atan2f_zero_x(float y, float x)
+  {
+    const int32_t hx = float_as_int(x);
+    const int32_t hy = float_as_int(y);
+    const float pi = 3.1415927410e+00f;
+    const float pi_o_2 = 1.5707963705e+00f;
+    const int32_t sy = hy & (int32_t) 0x80000000;
+    const float pi_sy = int_as_float(float_as_int(pi) | sy);
+    const float pi_o_2_sy = int_as_float(float_as_int(pi_o_2) | sy);
+    const float x0y0 = hx < 0 ? pi_sy : y;
+    return (hy & 0x7fffffff) == 0 ? x0y0 : pi_o_2_sy;
+  }
+
+  //! fdlibm_atan2f_fast with the look-up reduction (finite inputs).
+  SARA_HD float fdlibm_atan2f_lut(float y, float x, const float* lut)
+  {
+    const int32_t ix = float_as_int(x) & 0x7fffffff;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    const int32_t iy = float_as_int(y) & 0x7fffffff;
+    if (ix >= 0x7f800000 || iy >= 0x7f800000)
+      return fdlibm_atan2f(y, x);
+#endif
+    const float r = atan2f_lut_nonzero_x(y, x, lut);
+    return ix == 0 ? atan2f_zero_x(y, x) : r;
+  }
+
 }  // namespace sara_hip

@@ -100,9 +100,24 @@ namespace sara_hip {
 #define SARA_GRAD_WAVES_PER_EU 6
 #endif
 #ifndef SARA_ATAN_TABLE
-#define SARA_ATAN_TABLE 1
+#define SARA_ATAN_TABLE 2
 #endif
-  constexpr bool g_atan_table = SARA_ATAN_TABLE != 0;
+  // 0: select chains, 1: 5-row table + IEEE division and sqrt, 2 (default):
+  // look-up table + the short sqrt / division sequences of device_math.hpp
+  constexpr int g_atan_table = SARA_ATAN_TABLE;
+
+  //! Fills the look-up form of the atanf reduction table (device_math.hpp).
+  __device__ inline void fill_atan_lut(float* lut, int tid, int nthreads)
+  {
+    const float init[kAtanTableFloats] = SARA_ATAN_TABLE_INIT;
+    for (int j = tid; j < kAtanLutRows; j += nthreads)
+    {
+      const int src = atan_lut_source_row(j);
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        lut[8 * j + q] = init[8 * src + q];
+    }
+  }
   template <int PF>
   __global__ __launch_bounds__(64, SARA_GRAD_WAVES_PER_EU) void gradient_polar_march_kernel(
       const float* __restrict__ src, size_t src_stride,
@@ -113,11 +128,17 @@ namespace sara_hip {
     constexpr int W = 256;
     const int lane = threadIdx.x;
     // argument-reduction table of atanf (device_math.hpp) in LDS
-    __shared__ __attribute__((aligned(16))) float s_atan[kAtanTableFloats];
+    __shared__ __attribute__((aligned(16))) float
+        s_atan[g_atan_table == 2 ? kAtanLutFloats : kAtanTableFloats];
     {
-      const float init[kAtanTableFloats] = SARA_ATAN_TABLE_INIT;
-      if (lane < kAtanTableFloats)
-        s_atan[lane] = init[lane];
+      if (g_atan_table == 2)
+        fill_atan_lut(s_atan, lane, 64);
+      else
+      {
+        const float init[kAtanTableFloats] = SARA_ATAN_TABLE_INIT;
+        if (lane < kAtanTableFloats)
+          s_atan[lane] = init[lane];
+      }
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
     }
@@ -188,25 +209,75 @@ namespace sara_hip {
             left = emid;
           if (lane == 63)
             right = emid;
+          // Differential.hpp:46-61: one-sided differences on the image border
+          // = central differences with the missing neighbour replaced by the
+          // pixel itself.  Rows and the left column get that from the clamped
+          // loads (row -1 is row 0, column -1 is column 0); only the column
+          // after the last one (w is a multiple of 4 here) needs a select.
+          if (col + 4 >= w)
+            right = mid.w;
           const float cx[6] = {left, mid.x, mid.y, mid.z, mid.w, right};
           const float cu[4] = {up.x, up.y, up.z, up.w};
           const float cd[4] = {dn.x, dn.y, dn.z, dn.w};
           float res[8];
+          float ss[4];
+          float gxs[4], gys[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c)
           {
-            const int x = col + c;
-            // one-sided differences on the borders = central differences
-            // with the missing neighbour replaced by the pixel itself
-            const float xp = (x == w - 1) ? cx[c + 1] : cx[c + 2];
-            const float xm = (x == 0) ? cx[c + 1] : cx[c];
-            const float yp = (y == h - 1) ? cx[c + 1] : cd[c];
-            const float ym = (y == 0) ? cx[c + 1] : cu[c];
-            const float gx = (xp - xm) / 2;
-            const float gy = (yp - ym) / 2;
-            res[2 * c] = 2 * sqrtf(gx * gx + gy * gy);
-            res[2 * c + 1] = g_atan_table ? fdlibm_atan2f_table(gy, gx, s_atan)
-                                          : fdlibm_atan2f_fast(gy, gx);
+            const float gx = (cx[c + 2] - cx[c]) / 2;
+            const float gy = (cd[c] - cu[c]) / 2;
+            gxs[c] = gx;
+            gys[c] = gy;
+            ss[c] = gx * gx + gy * gy;
+            res[2 * c + 1] = g_atan_table == 2   ? atan2f_lut_nonzero_x(gy, gx, s_atan)
+                             : g_atan_table == 1 ? fdlibm_atan2f_table(gy, gx, s_atan)
+                                                 : fdlibm_atan2f_fast(gy, gx);
+          }
+          if (g_atan_table == 2)
+          {
+            // gx == +-0 (flat rows: common, but then usually for whole waves)
+            // takes atan2f's special values; skipped when no lane needs them
+            const uint32_t anyx = min(min(__float_as_uint(gxs[0]) << 1,
+                                          __float_as_uint(gxs[1]) << 1),
+                                      min(__float_as_uint(gxs[2]) << 1,
+                                          __float_as_uint(gxs[3]) << 1));
+            if (__ballot(anyx == 0u) != 0ull)
+            {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                if ((__float_as_uint(gxs[c]) << 1) == 0u)
+                  res[2 * c + 1] = atan2f_zero_x(gys[c], gxs[c]);
+            }
+          }
+          if (g_atan_table == 2)
+          {
+            // the short square root is exact for 0 and from 2^-102 up to
+            // FLT_MAX; anything else (never seen on image data) sends the
+            // whole wave through sqrtf()
+            const int emin = min(min(sqrt_short_exponent(ss[0]), sqrt_short_exponent(ss[1])),
+                                 min(sqrt_short_exponent(ss[2]), sqrt_short_exponent(ss[3])));
+            const float smax = fmaxf(fmaxf(ss[0], ss[1]), fmaxf(ss[2], ss[3]));
+            const bool odd = emin < kSqrtShortMinExponent ||
+                             !(smax < __builtin_inff());
+            if (__builtin_expect(__ballot(odd) != 0ull, 0))
+            {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                res[2 * c] = 2 * sqrtf(ss[c]);
+            }
+            else
+            {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                res[2 * c] = 2 * sqrt_rn_short(ss[c]);
+            }
+          }
+          else
+          {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              res[2 * c] = 2 * sqrtf(ss[c]);
           }
           if (col_ok)
           {
@@ -1723,6 +1794,50 @@ namespace sara_hip {
     hipLaunchKernelGGL(descriptor_kernel, grid, dim3(256), 0, stream, grad, cand,
                        ori, features, scale_octave, descriptors,
                        with_descriptors, root_sift, g_xcd_run, g_desc_row_shift);
+  }
+
+  // ------------------------------------------------------------------------ //
+  // Exhaustive self-check of the short device forms (device_math.hpp) against
+  // the IEEE ones the rest of the parity chain was established with: every
+  // non-negative float through the atanf reduction (look-up table + short
+  // division vs select chains + IEEE division) and through the square root as
+  // the gradient kernel uses it.  out[0], out[1] = mismatch counts.
+  // ------------------------------------------------------------------------ //
+  __global__ __launch_bounds__(256) void device_math_selfcheck_kernel(
+      unsigned long long* __restrict__ out)
+  {
+    __shared__ __attribute__((aligned(16))) float s_lut[kAtanLutFloats];
+    fill_atan_lut(s_lut, threadIdx.x, 256);
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;  // 2^24 threads
+    unsigned bad_atan = 0, bad_sqrt = 0;
+    for (uint32_t hi = 0; hi < 128; ++hi)
+    {
+      const uint32_t bits = hi * (1u << 24) + i;
+      if (bits > 0x7f800000u)
+        continue;
+      const float x = __uint_as_float(bits);
+      if (bits < 0x7f800000u)
+      {
+        const float a = atanf_nonneg_select(x);
+        const float b = atanf_nonneg_lut(x, s_lut);
+        bad_atan += __float_as_uint(a) != __float_as_uint(b);
+      }
+      const bool odd = sqrt_short_exponent(x) < kSqrtShortMinExponent ||
+                       !(x < __builtin_inff());
+      const float r = odd ? sqrtf(x) : sqrt_rn_short(x);
+      bad_sqrt += __float_as_uint(r) != __float_as_uint(sqrtf(x));
+    }
+    if (bad_atan)
+      atomicAdd(out, (unsigned long long) bad_atan);
+    if (bad_sqrt)
+      atomicAdd(out + 1, (unsigned long long) bad_sqrt);
+  }
+
+  void launch_device_math_selfcheck(unsigned long long* out, hipStream_t stream)
+  {
+    hipLaunchKernelGGL(device_math_selfcheck_kernel, dim3((1u << 24) / 256),
+                       dim3(256), 0, stream, out);
   }
 
   // ------------------------------------------------------------------------ //

@@ -1877,10 +1877,39 @@ void sara_hip_selfcheck_atan2f(const float* y, const float* x, float* out,
     // both restatements the kernels use must agree; a mismatch is reported
     // as NaN so that the comparison with libm fails
     static const float tab[sara_hip::kAtanTableFloats] = SARA_ATAN_TABLE_INIT;
+    static const std::vector<float> lut = [] {
+      std::vector<float> l(sara_hip::kAtanLutFloats);
+      for (int j = 0; j < sara_hip::kAtanLutRows; ++j)
+        for (int q = 0; q < 8; ++q)
+          l[size_t(8 * j + q)] = tab[8 * sara_hip::atan_lut_source_row(j) + q];
+      return l;
+    }();
     const float a = sara_hip::fdlibm_atan2f_fast(y[i], x[i]);
     const float b = sara_hip::fdlibm_atan2f_table(y[i], x[i], tab);
-    out[i] = std::memcmp(&a, &b, sizeof(float)) == 0 ? a : std::nanf("");
+    const float c = sara_hip::fdlibm_atan2f_lut(y[i], x[i], lut.data());
+    const bool same = std::memcmp(&a, &b, sizeof(float)) == 0 &&
+                      std::memcmp(&a, &c, sizeof(float)) == 0;
+    out[i] = same ? a : std::nanf("");
   }
+}
+
+sara_hip_status sara_hip_selfcheck_device_math(unsigned long long* mismatches,
+                                               int device)
+{
+  if (!mismatches)
+    return fail(SARA_HIP_INVALID_PARAMS, "null pointer");
+  const sara_hip_status st = select_device(device);
+  if (st != SARA_HIP_OK)
+    return st;
+  DeviceScratch sc;
+  unsigned long long* d = nullptr;
+  HIP_TRY(sc.get(d, 2));
+  HIP_TRY(hipMemset(d, 0, 2 * sizeof(unsigned long long)));
+  launch_device_math_selfcheck(d, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(mismatches, d, 2 * sizeof(unsigned long long),
+                    hipMemcpyDeviceToHost));
+  return SARA_HIP_OK;
 }
 
 }  // extern "C"

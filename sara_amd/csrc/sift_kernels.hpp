@@ -231,6 +231,7 @@ namespace sara_hip {
                           float* descriptors, int with_descriptors,
                           int root_sift, hipStream_t stream);
   void launch_root_sift(float* desc, int n, int dim, hipStream_t stream);
+  void launch_device_math_selfcheck(unsigned long long* out, hipStream_t stream);
 
   //! Sorted extrema (before orientation assignment) as OERegion + site.
   void launch_gather_extrema(const CandidateLists& cand, const int* ex_offset,

@@ -210,3 +210,14 @@ def test_rgb8_sunflower_matches_golden_gray():
     g = np.load(common.GOLDEN + "/sunflower_full.npz")
     rgb = np.array(Image.open(common.GOLDEN + "/sunflower_rgb8.png"))
     assert common.sha(sara_amd.from_rgb8_to_gray32f(rgb)) == str(g["gray_sha256"])
+
+
+def test_short_device_math_is_exact_on_every_float():
+    """The gradient kernel's short sqrt / division sequences and the look-up
+    form of the atanf range reduction against the IEEE / select forms, on the
+    device, for every non-negative float (sara_hip_selfcheck_device_math)."""
+    import ctypes as C
+    from sara_amd import capi
+    bad = (C.c_ulonglong * 2)(1, 1)
+    capi.check(capi.load().sara_hip_selfcheck_device_math(bad, 0))
+    assert (bad[0], bad[1]) == (0, 0)

@@ -102,3 +102,26 @@ def test_keypoint_text_round_trip(tmp_path):
     back = sara_amd.read_keypoints(path)
     assert np.allclose(back.regions["shape_matrix"][0],
                        [0.25, 123457.0, 1.5e-7, -2], rtol=1e-6)
+
+
+def test_atan2f_extreme_exponent_gaps_and_signed_zeros():
+    """The look-up form drops fdlibm's |y/x| > 2^60 and < 2^-60 shortcuts (the
+    general path returns the same floats, device_math.hpp): exponent gaps on
+    both sides of 60, every sign combination, +-0 operands."""
+    rng = np.random.default_rng(2024)
+    for mode in range(4):
+        n = 20000
+        ey = rng.integers(-149, 128, n)
+        ex = rng.integers(-149, 128, n)
+        if mode == 1:
+            ex = np.clip(ey - rng.integers(55, 70, n), -149, 127)
+        elif mode == 2:
+            ex = np.clip(ey + rng.integers(55, 70, n), -149, 127)
+        elif mode == 3:
+            ex = np.clip(ey + rng.integers(-30, 30, n), -149, 127)
+        y = (np.ldexp(rng.uniform(1, 2, n), ey) * rng.choice([-1, 1], n)).astype(np.float32)
+        x = (np.ldexp(rng.uniform(1, 2, n), ex) * rng.choice([-1, 1], n)).astype(np.float32)
+        y[::97], x[::89], y[::1013], x[::1019] = 0.0, 0.0, -0.0, -0.0
+        keep = np.isfinite(y) & np.isfinite(x)
+        y, x = y[keep], x[keep]
+        assert _same_bits(_mine(y, x), _libm(y, x))
