@@ -708,6 +708,13 @@ namespace sara_hip {
   {
     static_assert(PF == 3, "the row loop is unrolled 3x");
     __shared__ unsigned long long s_queue[128];
+    __shared__ __attribute__((aligned(16))) float s_atan[GRAD ? kAtanLutFloats : 8];
+    if (GRAD)
+    {
+      fill_atan_lut(s_atan, threadIdx.x, 64);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+    }
     int qn = 0;  // wave-uniform fill of the queue
     constexpr int NG = ND + 1;
     constexpr int NS = ND - 2;  // scanned scales = gradient planes 1..NS
@@ -813,10 +820,33 @@ namespace sara_hip {
               gy0 = (dn.x - up.x) / 2;
               gy1 = (dn.y - up.y) / 2;
             }
-            const float r0 = 2 * sqrtf(gx0 * gx0 + gy0 * gy0);
-            const float r1 = 2 * sqrtf(gx1 * gx1 + gy1 * gy1);
-            const float a0 = fdlibm_atan2f_fast(gy0, gx0);
-            const float a1 = fdlibm_atan2f_fast(gy1, gx1);
+            // the short forms of gradient_polar_march_kernel (see there)
+            const float ss0 = gx0 * gx0 + gy0 * gy0;
+            const float ss1 = gx1 * gx1 + gy1 * gy1;
+            float r0, r1;
+            const bool odd =
+                min(sqrt_short_exponent(ss0), sqrt_short_exponent(ss1)) <
+                    kSqrtShortMinExponent ||
+                !(fmaxf(ss0, ss1) < __builtin_inff());
+            if (__builtin_expect(__ballot(odd) != 0ull, 0))
+            {
+              r0 = 2 * sqrtf(ss0);
+              r1 = 2 * sqrtf(ss1);
+            }
+            else
+            {
+              r0 = 2 * sqrt_rn_short(ss0);
+              r1 = 2 * sqrt_rn_short(ss1);
+            }
+            float a0 = atan2f_lut_nonzero_x(gy0, gx0, s_atan);
+            float a1 = atan2f_lut_nonzero_x(gy1, gx1, s_atan);
+            const bool z0 = (__float_as_uint(gx0) << 1) == 0u;
+            const bool z1 = (__float_as_uint(gx1) << 1) == 0u;
+            if (__ballot(z0 || z1) != 0ull)
+            {
+              a0 = z0 ? atan2f_zero_x(gy0, gx0) : a0;
+              a1 = z1 ? atan2f_zero_x(gy1, gx1) : a1;
+            }
             float* op = grad + (size_t(t + 1) * plane + size_t(y) * w + col) * 2;
             if (gvalid0 && gvalid1)
               *reinterpret_cast<float4*>(op) = make_float4(r0, a0, r1, a1);
