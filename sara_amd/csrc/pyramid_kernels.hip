@@ -411,7 +411,10 @@ namespace sara_hip {
     constexpr int W = 256;
     // prefetch depth: the K x 4 partial-sum ring dominates the register
     // budget, keep the kernel at >= 3 waves/SIMD (<= 168 VGPRs)
-    constexpr int PF = R >= 12 ? 2 : (R >= 10 ? 3 : 4);
+#ifndef SARA_MARCH_PF
+#define SARA_MARCH_PF 4
+#endif
+    constexpr int PF = R >= 12 ? 2 : (R >= 10 ? 3 : SARA_MARCH_PF);
     const int nstrips = (w + W - 1) / W;
     // enough waves to fill 256 CUs x 3-4 waves/SIMD, segments >= 32 rows
     // segments: enough waves to fill the chip, but every segment re-filters
