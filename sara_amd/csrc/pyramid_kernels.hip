@@ -48,11 +48,16 @@ namespace sara_hip {
     const char* e = getenv("SARA_HIP_MARCH_MINROWS");
     return e ? std::max(0, atoi(e)) : 4;
   }();
-  //! Target number of waves per marching launch (tuning knobs): 2 per SIMD for
-  //! the 4-column kernel, ~3 (2880 on 1080p x 64) for the 2-column one.
+  //! Target number of waves per marching launch (tuning knobs; the launch
+  //! rounds up to whole segments).  4-column kernel (R <= 6, latency-bound:
+  //! VALU pipe 26-34 % busy): 4 per SIMD - 1080p x 64: 116 -> 111 us (R = 5),
+  //! 135 -> 128 (R = 6), 287 -> 235 (first blur) against 2 per SIMD, neutral
+  //! on 720p and 4K.  2-column kernel (R >= 8): 2048 -> 2880 waves on
+  //! 1080p x 64; 3072 is 10 % faster launch by launch on one stream but not
+  //! with the per-octave streams, which fill the same gaps.
   static const int g_march_waves = [] {
     const char* e = getenv("SARA_HIP_MARCH_WAVES");
-    return e ? std::max(64, atoi(e)) : 2048;
+    return e ? std::max(64, atoi(e)) : 4096;
   }();
   static const int g_march2_waves = [] {
     const char* e = getenv("SARA_HIP_MARCH2_WAVES");
