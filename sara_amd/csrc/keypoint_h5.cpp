@@ -121,9 +121,21 @@ namespace {
     return 0;
   }
 
+  // Failures are reported through the return value and sara_h5_last_error();
+  // HDF5's own error-stack printing is switched off for the duration of a
+  // call and the caller's handler restored afterwards.
   struct QuietErrors
   {
-    QuietErrors() { H5Eset_auto2(H5E_DEFAULT, nullptr, nullptr); }
+    H5E_auto2_t func = nullptr;
+    void* data = nullptr;
+    QuietErrors()
+    {
+      H5Eget_auto2(H5E_DEFAULT, &func, &data);
+      H5Eset_auto2(H5E_DEFAULT, nullptr, nullptr);
+    }
+    ~QuietErrors() { H5Eset_auto2(H5E_DEFAULT, func, data); }
+    QuietErrors(const QuietErrors&) = delete;
+    QuietErrors& operator=(const QuietErrors&) = delete;
   };
 
 }  // namespace
@@ -134,7 +146,7 @@ int sara_h5_write_keypoints(const char* path, int truncate, const char* group,
                             const sara_oeregion* features, int n,
                             const float* descriptors, int dim, int overwrite)
 {
-  static QuietErrors quiet;
+  QuietErrors quiet;
   if (!path || !group || n < 0 || dim < 0 || (n > 0 && (!features || !descriptors)))
     return fail("null pointer or negative size");
   hid_t fid = -1;
@@ -176,7 +188,7 @@ int sara_h5_write_keypoints(const char* path, int truncate, const char* group,
 
 int sara_h5_keypoints_sizes(const char* path, const char* group, int* n, int* dim)
 {
-  static QuietErrors quiet;
+  QuietErrors quiet;
   if (!path || !group || !n || !dim)
     return fail("null pointer");
   Handle file(H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT), H5Fclose);
@@ -197,7 +209,7 @@ int sara_h5_keypoints_sizes(const char* path, const char* group, int* n, int* di
 int sara_h5_read_keypoints(const char* path, const char* group,
                            sara_oeregion* features, float* descriptors)
 {
-  static QuietErrors quiet;
+  QuietErrors quiet;
   if (!path || !group)
     return fail("null pointer");
   Handle file(H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT), H5Fclose);
