@@ -126,6 +126,13 @@ def test_invalid_params_rejected_before_device(lib):
     assert b"4 scales per octave" in lib.sara_hip_last_error()
     with pytest.raises(RuntimeError):
         sara_amd.ComputeDoGExtrema(sara_amd.ImagePyramidParams(0, 3))
+    # argument checks of the stand-alone operators come before any device call
+    assert lib.sara_hip_root_sift(None, 4, 128, 0, 0) == capi.INVALID_PARAMS
+    buf = (C.c_float * 4)()
+    assert lib.sara_hip_root_sift(buf, 1, 0, 0, 0) == capi.INVALID_PARAMS
+    assert lib.sara_hip_root_sift(buf, 0, 4, 0, 0) == capi.OK      # nothing to do
+    assert lib.sara_hip_selfcheck_device_math(None, 0) == capi.INVALID_PARAMS
+    assert lib.sara_hip_sift_set_option(None, capi.OPT_ROOT_SIFT, 1) == capi.INVALID_PARAMS
 
 
 def test_product_does_not_reference_oracle():
