@@ -122,8 +122,8 @@ namespace sara_hip {
   __global__ __launch_bounds__(64, SARA_GRAD_WAVES_PER_EU) void gradient_polar_march_kernel(
       const float* __restrict__ src, size_t src_stride,
       float* __restrict__ dst, size_t dst_stride, int w, int h, int nscales,
-      int seg_rows, int nstrips, unsigned* __restrict__ cmax,
-      size_t cmax_stride)
+      int seg_rows, int nstrips, int nseg, int xcd_total,
+      unsigned* __restrict__ cmax, size_t cmax_stride)
   {
     constexpr int W = 256;
     const int lane = threadIdx.x;
@@ -142,9 +142,11 @@ namespace sara_hip {
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
     }
-    const int strip = blockIdx.x % nstrips;
-    const int seg = blockIdx.x / nstrips;
-    const int z = blockIdx.y;
+    int strip, seg;
+    size_t zz;
+    if (!march_work_item(nstrips, nseg, xcd_total, strip, seg, zz))
+      return;
+    const int z = int(zz);
     const size_t b = z / nscales;
     const size_t s = z - b * nscales;
     const size_t plane = size_t(w) * h;
@@ -364,10 +366,11 @@ namespace sara_hip {
       nseg = std::max(1, std::min(nseg, (h + 15) / 16));
       const int seg_rows = (h + nseg - 1) / nseg;
       nseg = (h + seg_rows - 1) / seg_rows;
-      hipLaunchKernelGGL((gradient_polar_march_kernel<4>),
-                         dim3(nstrips * nseg, planes), dim3(64), 0, stream, src,
-                         src_stride, dst, dst_stride, w, h, nscales, seg_rows,
-                         nstrips, cmax, cmax_stride);
+      const int total = xcd_map_enabled() ? nstrips * nseg * planes : 0;
+      const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(nstrips * nseg, planes);
+      hipLaunchKernelGGL((gradient_polar_march_kernel<4>), grid, dim3(64), 0,
+                         stream, src, src_stride, dst, dst_stride, w, h, nscales,
+                         seg_rows, nstrips, nseg, total, cmax, cmax_stride);
       return;
     }
     const dim3 block(64, 4);
@@ -703,8 +706,9 @@ namespace sara_hip {
   template <int ND, int PF, bool GRAD>
   __global__ __launch_bounds__(64, GRAD ? 2 : SARA_EXTREMA_WAVES_PER_EU) void extrema_march_kernel(
       OctaveView gauss, int octave, ExtremaParams p, SiteLists sites,
-      int seg_rows, int nstrips, float* __restrict__ grad,
-      size_t grad_frame_stride, unsigned* __restrict__ cmax, size_t cmax_stride)
+      int seg_rows, int nstrips, int nseg, int xcd_total,
+      float* __restrict__ grad, size_t grad_frame_stride,
+      unsigned* __restrict__ cmax, size_t cmax_stride)
   {
     static_assert(PF == 3, "the row loop is unrolled 3x");
     __shared__ unsigned long long s_queue[128];
@@ -720,9 +724,11 @@ namespace sara_hip {
     constexpr int NS = ND - 2;  // scanned scales = gradient planes 1..NS
     constexpr int STRIDE = 126;
     const int lane = threadIdx.x;
-    const int strip = blockIdx.x % nstrips;
-    const int seg = blockIdx.x / nstrips;
-    const int b = blockIdx.y;
+    int strip, seg;
+    size_t bb;
+    if (!march_work_item(nstrips, nseg, xcd_total, strip, seg, bb))
+      return;
+    const int b = int(bb);
     const int w = gauss.w, h = gauss.h;
     const int pad = p.img_padding_sz;
     const float* g = gauss.base + size_t(b) * gauss.frame_stride;
@@ -1001,16 +1007,17 @@ namespace sara_hip {
                         gauss.h >= 2 &&
                         (reinterpret_cast<uintptr_t>(grad) % 16 == 0) &&
                         (grad_frame_stride % 4 == 0);
+      const int total = xcd_map_enabled() ? nstrips * nseg * batch : 0;
+      const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(nstrips * nseg, batch);
       if (fuse)
-        hipLaunchKernelGGL((extrema_march_kernel<5, 3, true>),
-                           dim3(nstrips * nseg, batch), dim3(64), 0, stream,
-                           gauss, octave, p, sites, seg_rows, nstrips, grad,
-                           grad_frame_stride, cmax, cmax_stride);
+        hipLaunchKernelGGL((extrema_march_kernel<5, 3, true>), grid, dim3(64), 0,
+                           stream, gauss, octave, p, sites, seg_rows, nstrips,
+                           nseg, total, grad, grad_frame_stride, cmax,
+                           cmax_stride);
       else
-        hipLaunchKernelGGL((extrema_march_kernel<5, 3, false>),
-                           dim3(nstrips * nseg, batch), dim3(64), 0, stream,
-                           gauss, octave, p, sites, seg_rows, nstrips, nullptr,
-                           0, nullptr, 0);
+        hipLaunchKernelGGL((extrema_march_kernel<5, 3, false>), grid, dim3(64), 0,
+                           stream, gauss, octave, p, sites, seg_rows, nstrips,
+                           nseg, total, nullptr, 0, nullptr, 0);
       return fuse;
     }
     const dim3 block(64, 4);

@@ -266,7 +266,8 @@ namespace sara_hip {
   __global__ __launch_bounds__(64) void gaussian_blur_march_kernel(
       const float* __restrict__ src, size_t src_stride,
       float* __restrict__ dst, size_t dst_stride, float* __restrict__ dec,
-      size_t dec_stride, int w, int h, int seg_rows, int nstrips, Taps taps)
+      size_t dec_stride, int w, int h, int seg_rows, int nstrips, int nseg,
+      int xcd_total, Taps taps)
   {
     constexpr int CPL = 4;
     constexpr int K = 2 * R + 1;
@@ -278,9 +279,10 @@ namespace sara_hip {
     __shared__ __attribute__((aligned(16))) float s_row[2 * ROWF];
 
     const int lane = threadIdx.x;
-    const int strip = blockIdx.x % nstrips;
-    const int seg = blockIdx.x / nstrips;
-    const size_t b = blockIdx.y;
+    int strip, seg;
+    size_t b;
+    if (!march_work_item(nstrips, nseg, xcd_total, strip, seg, b))
+      return;
     src += b * src_stride;
     dst += b * dst_stride;
     if (DEC)
@@ -429,15 +431,18 @@ namespace sara_hip {
     nseg = std::max(1, std::min(nseg, (h + min_rows - 1) / min_rows));
     const int seg_rows = (h + nseg - 1) / nseg;
     nseg = (h + seg_rows - 1) / seg_rows;
-    const dim3 grid(nstrips * nseg, batch);
+    const int total = xcd_map_enabled() ? nstrips * nseg * batch : 0;
+    const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(nstrips * nseg, batch);
     if (dec)
       hipLaunchKernelGGL((gaussian_blur_march_kernel<R, PF, true>), grid,
                          dim3(64), 0, stream, src, src_stride, dst, dst_stride,
-                         dec, dec_stride, w, h, seg_rows, nstrips, taps);
+                         dec, dec_stride, w, h, seg_rows, nstrips, nseg, total,
+                         taps);
     else
       hipLaunchKernelGGL((gaussian_blur_march_kernel<R, PF, false>), grid,
                          dim3(64), 0, stream, src, src_stride, dst, dst_stride,
-                         dec, dec_stride, w, h, seg_rows, nstrips, taps);
+                         dec, dec_stride, w, h, seg_rows, nstrips, nseg, total,
+                         taps);
   }
 
   // ------------------------------------------------------------------------ //
@@ -539,7 +544,7 @@ namespace sara_hip {
   __global__ __launch_bounds__(64) void gaussian_blur_march2_kernel(
       const float* __restrict__ src, size_t src_stride,
       float* __restrict__ dst, size_t dst_stride, int w, int h, int seg_rows,
-      int nstrips, Taps taps)
+      int nstrips, int nseg, int xcd_total, Taps taps)
   {
     constexpr int CPL = 2;
     constexpr int K = 2 * R + 1;
@@ -551,9 +556,10 @@ namespace sara_hip {
     __shared__ __attribute__((aligned(16))) float s_row[2 * ROWF];
 
     const int lane = threadIdx.x;
-    const int strip = blockIdx.x % nstrips;
-    const int seg = blockIdx.x / nstrips;
-    const size_t b = blockIdx.y;
+    int strip, seg;
+    size_t b;
+    if (!march_work_item(nstrips, nseg, xcd_total, strip, seg, b))
+      return;
     src += b * src_stride;
     dst += b * dst_stride;
 
@@ -694,10 +700,11 @@ namespace sara_hip {
     nseg = std::max(1, std::min(nseg, (h + min_rows - 1) / min_rows));
     const int seg_rows = (h + nseg - 1) / nseg;
     nseg = (h + seg_rows - 1) / seg_rows;
-    const dim3 grid(nstrips * nseg, batch);
+    const int total = xcd_map_enabled() ? nstrips * nseg * batch : 0;
+    const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(nstrips * nseg, batch);
     hipLaunchKernelGGL((gaussian_blur_march2_kernel<R, PF>), grid, dim3(64), 0,
                        stream, src, src_stride, dst, dst_stride, w, h, seg_rows,
-                       nstrips, taps);
+                       nstrips, nseg, total, taps);
   }
 
   template <int R>

@@ -6,6 +6,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/sara_hip_sift.h"
 
@@ -253,5 +254,48 @@ namespace sara_hip {
                               float* part_d0, float* part_d1, int* part_i0,
                               sara_match* out, int capacity, int* count,
                               hipStream_t stream);
+
+#if defined(__HIPCC__)
+  //! (strip, segment, frame) of a marching workgroup.  Workgroups are handed
+  //! to the 8 XCDs round-robin in launch order and every XCD has its own L2, so
+  //! with the plain order (strip fastest) neighbouring strips - which share
+  //! their halo columns - and neighbouring segments - which share 2R halo rows
+  //! - always sit on different XCDs and every halo line is fetched once per
+  //! XCD.  With xcd_total > 0 (1-D grid of 8 * ceil(total / 8) groups) XCD k
+  //! takes the k-th contiguous eighth of the (frame, segment, strip) list, so
+  //! neighbours meet in one L2.  xcd_total == 0: plain 2-D grid.
+  __device__ inline bool march_work_item(int nstrips, int nseg, int xcd_total,
+                                         int& strip, int& seg, size_t& b)
+  {
+    if (xcd_total > 0)
+    {
+      const int per = (xcd_total + 7) >> 3;
+      const int item = int(blockIdx.x & 7u) * per + int(blockIdx.x >> 3);
+      if (item >= xcd_total)
+        return false;
+      strip = item % nstrips;
+      const int t = item / nstrips;
+      seg = t % nseg;
+      b = size_t(t / nseg);
+      return true;
+    }
+    strip = blockIdx.x % nstrips;
+    seg = blockIdx.x / nstrips;
+    b = blockIdx.y;
+    return true;
+  }
+
+#endif
+
+  //! XCD-aware placement of the marching workgroups (march_work_item);
+  //! SARA_HIP_XCD_MAP=0 restores the plain launch order.
+  inline bool xcd_map_enabled()
+  {
+    static const bool on = [] {
+      const char* e = std::getenv("SARA_HIP_XCD_MAP");
+      return !(e && e[0] == '0' && e[1] == 0);
+    }();
+    return on;
+  }
 
 }  // namespace sara_hip
