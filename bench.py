@@ -186,7 +186,13 @@ def main():
     # the kernels in flight, no extra device synchronisation per step
     count_group = None
     if world > 1 and backend == "nccl":
-        count_group = dist.new_group(backend="gloo")
+        try:
+            count_group = dist.new_group(backend="gloo")
+        except Exception as e:  # no host-side group: counts go over RCCL
+            count_group = None
+            if rank == 0:
+                print("gloo side group unavailable (%r): keypoint counts are "
+                      "exchanged on the device" % (e,), file=sys.stderr)
         # establish the RCCL communicator collectively before the first
         # point-to-point exchange
         dist.all_reduce(torch.zeros(1, device=dev))
@@ -244,7 +250,10 @@ def main():
         tensors, total = item
         if backend != "nccl":
             tensors = [t.cpu() for t in tensors]  # gloo: host staging
-        counts_all = exchange_counts(total, count_group)
+        # host-side exchange (gloo group, or the default group when that is
+        # gloo); without one gatherv_to_root all_gathers them on the device
+        host_counts = count_group is not None or backend != "nccl"
+        counts_all = exchange_counts(total, count_group) if host_counts else None
         wait_gather()
         pending[0] = gatherv_to_root(tensors, root=0, async_op=True,
                                      counts=counts_all)
