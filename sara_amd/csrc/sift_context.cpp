@@ -230,6 +230,7 @@ struct sara_hip_sift
   bool have_init_taps = false;
   Taps init_taps{};
   std::vector<Taps> taps;  // per scale s = 1..S-1
+  int* d_counters = nullptr;  // cand.count | sites.count | ori.kp_count | ori.frame_offset
   ScaleTable h_tab{};
   ScaleTable* d_tab = nullptr;
   double* d_oriw = nullptr;
@@ -465,7 +466,12 @@ namespace {
     c->cand.cap = c->cap;
     TRY_ST(c->alloc(c->cand.key, rows));
     TRY_ST(c->alloc(c->cand.data, rows));
-    TRY_ST(c->alloc(c->cand.count, max_batch));
+    // the four per-frame counters share one block: one memset per detect()
+    TRY_ST(c->alloc(c->d_counters, 4 * size_t(max_batch) + 1));
+    c->cand.count = c->d_counters;
+    c->sites.count = c->d_counters + max_batch;
+    c->ori.kp_count = c->d_counters + 2 * size_t(max_batch);
+    c->ori.frame_offset = c->d_counters + 3 * size_t(max_batch);  // max_batch + 1
     TRY_ST(c->alloc(c->cand.order, rows));
     {
       // one bucket per image row of every plane of the largest schedule
@@ -481,12 +487,9 @@ namespace {
     }
     c->sites.cap = 4 * c->cap;
     TRY_ST(c->alloc(c->sites.key, size_t(max_batch) * c->sites.cap));
-    TRY_ST(c->alloc(c->sites.count, max_batch));
     TRY_ST(c->alloc(c->ori.peak_count, rows));
     TRY_ST(c->alloc(c->ori.peak_theta, rows * kMaxPeaks));
     TRY_ST(c->alloc(c->ori.offset, rows));
-    TRY_ST(c->alloc(c->ori.kp_count, max_batch));
-    TRY_ST(c->alloc(c->ori.frame_offset, size_t(max_batch) + 1));
     TRY_ST(c->alloc(c->d_ex_offset, size_t(max_batch) + 1));
     TRY_ST(c->alloc(c->d_feat, rows));
     TRY_ST(c->alloc(c->d_so, rows * 2));
@@ -1006,11 +1009,8 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   }
 
   // ---- extrema ------------------------------------------------------------
-  HIP_TRY(hipMemsetAsync(c->cand.count, 0, sizeof(int) * batch, stream));
-  HIP_TRY(hipMemsetAsync(c->sites.count, 0, sizeof(int) * batch, stream));
-  HIP_TRY(hipMemsetAsync(c->ori.kp_count, 0, sizeof(int) * batch, stream));
-  HIP_TRY(hipMemsetAsync(c->ori.frame_offset, 0, sizeof(int) * (batch + 1),
-                         stream));
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0,
+                         sizeof(int) * (4 * size_t(c->max_batch) + 1), stream));
   if (last_stage >= SARA_HIP_STAGE_EXTREMA)
   {
     ExtremaParams ep;
