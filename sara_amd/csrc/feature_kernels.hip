@@ -1516,9 +1516,9 @@ namespace sara_hip {
   // FeatureDetectors/SIFT.cpp:92-98.
   //
   // One wave per extremum, looping over its orientations; lanes stride the
-  // patch pixels and accumulate into a 128-bin LDS histogram (one histogram
-  // per wave, ds_add_f32).  Float tolerance vs the CPU path: summation order
-  // and expf/cos/sin last-ulp differences only.
+  // patch pixels and accumulate into a 128-bin LDS histogram per wave, held
+  // as 64-bit fixed point (ds_add_u64, see below).  Float tolerance vs the CPU
+  // path: summation order and expf/cos/sin last-ulp differences only.
   // ======================================================================== //
   __device__ inline float wave_sum(float v)
   {

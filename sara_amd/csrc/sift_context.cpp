@@ -254,7 +254,7 @@ struct sara_hip_sift
   int bucket_stride = 0;
   RowBuckets row_buckets{};        // of the current schedule
   bool bucketed_rank = true;       // SARA_HIP_RANK=count restores the O(n^2) kernel
-  int* h_counts = nullptr;  // pinned, 2*(max_batch+1)
+  int* h_counts = nullptr;  // pinned, 3*max_batch+2
   // Small batches are launch-bound (about 60 launches in 0.7 ms for one 1080p
   // frame): the enqueue sequence of detect() is captured once per (size,
   // batch, stage) into a HIP graph and replayed (SARA_HIP_GRAPH=0 disables,
@@ -439,7 +439,7 @@ namespace {
     std::memset(c->h_grad, 0, sizeof(GradPyramidView));
     TRY_ST(c->alloc(c->d_grad, 1));
     TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_counts),
-                          sizeof(int) * 2 * (size_t(max_batch) + 1)));
+                          sizeof(int) * (3 * size_t(max_batch) + 2)));
 
     // ---- HBM: pyramids [frame][scale][h][w] per octave
     const int no = c->max_sched.num_octaves;
@@ -1206,8 +1206,10 @@ sara_hip_status sara_hip_sift_detect_u8(sara_hip_sift* c, const uint8_t* images,
   launch_u8_to_gray32f(src, src_stride, channels, c->d_input, px, px, batch,
                        stream);
   HIP_TRY(hipGetLastError());
+  // the caller's handle (possibly null), not the resolved stream: a null
+  // handle keeps the HIP-graph replay of small batches available
   return sara_hip_sift_detect(c, c->d_input, px, batch, width, height, 1,
-                              last_stage, stream);
+                              last_stage, hip_stream);
 }
 
 sara_hip_status sara_hip_sift_stage(sara_hip_sift* c, const void* images,
@@ -1315,12 +1317,13 @@ sara_hip_status sara_hip_sift_counts(sara_hip_sift* c, int* per_frame, int* tota
   if (st != SARA_HIP_OK)
     return st;
   HIP_TRY(hipSetDevice(c->device));
-  // both count arrays in one round trip (h_counts holds 2*(max_batch+1) ints)
-  int* h_kp = c->h_counts;
-  int* h_ex = c->h_counts + c->max_batch + 1;
-  HIP_TRY(hipMemcpyAsync(h_kp, c->ori.kp_count, sizeof(int) * c->cur_batch,
-                         hipMemcpyDeviceToHost, c->last_stream));
-  HIP_TRY(hipMemcpyAsync(h_ex, c->cand.count, sizeof(int) * c->cur_batch,
+  // cand.count | sites.count | ori.kp_count are contiguous in d_counters: one
+  // round trip brings all three (h_counts holds 3 * max_batch + 2 ints)
+  int* h_ex = c->h_counts;
+  int* h_sites = c->h_counts + c->max_batch;
+  int* h_kp = c->h_counts + 2 * size_t(c->max_batch);
+  HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counters,
+                         sizeof(int) * 3 * size_t(c->max_batch),
                          hipMemcpyDeviceToHost, c->last_stream));
   HIP_TRY(hipStreamSynchronize(c->last_stream));
   int sum = 0;
@@ -1338,11 +1341,17 @@ sara_hip_status sara_hip_sift_counts(sara_hip_sift* c, int* per_frame, int* tota
   if (overflow)
     return fail(SARA_HIP_CAPACITY_EXCEEDED,
                 "a frame produced more keypoints than max_keypoints");
-  // the extremum list can also overflow without the keypoint list doing so
+  // the extremum list and the list of classified sites can also overflow
+  // without the keypoint list doing so (keypoints would be missing silently)
   for (int b = 0; b < c->cur_batch; ++b)
+  {
     if (h_ex[b] > c->cap)
       return fail(SARA_HIP_CAPACITY_EXCEEDED,
                   "a frame produced more extrema than max_keypoints");
+    if (h_sites[b] > c->sites.cap)
+      return fail(SARA_HIP_CAPACITY_EXCEEDED,
+                  "a frame produced more classified sites than 4*max_keypoints");
+  }
   return SARA_HIP_OK;
 }
 

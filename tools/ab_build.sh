@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/../sara_amd/csrc"
 name=$1; shift
-flags="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fPIC -fvisibility=hidden $*"
+flags="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -fvisibility=hidden $*"
 mkdir -p ../lib/ab /tmp/ab_$name
 for f in pyramid_kernels.hip feature_kernels.hip match_kernels.hip; do
   /opt/rocm/bin/hipcc $flags -c -o /tmp/ab_$name/${f%.hip}.o $f &
