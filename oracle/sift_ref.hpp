@@ -18,11 +18,15 @@
 //     peak recovery, descriptor API consistency.
 //   * "parity unpinned" (the reference holds no known-answer test, and the
 //     reference itself cannot be built here: Eigen >= 3.4 is neither vendored
-//     nor installed): refine_extremum / on_edge numerics, descriptor
-//     normalisation, and everything at the last-ulp level that depends on
-//     Eigen's packet exp and vectorised reductions (make_gaussian_kernel's
-//     exp()/sum(), normalize()'s squaredNorm()).  Those are restated with libm
-//     expf and left-to-right float sums.
+//     nor installed).  Round 2 restates the PUBLISHED Eigen 3.4.0 algorithms
+//     for the two pieces that decide something: the float
+//     SelfAdjointEigenSolver<Matrix3f> behind refine_extremum's definiteness
+//     test, and the Packet4f reduction order of normalize()'s squaredNorm();
+//     both are compared with round 1's stand-ins (Sylvester minors in double,
+//     left-to-right sum) site by site / row by row, see DESIGN.md section 2.
+//     Still at the last-ulp level only: make_gaussian_kernel's packet exp()
+//     and sum() (restated with libm expf and a left-to-right sum; the
+//     reference's own test accepts 1e-5 there).
 // ========================================================================== //
 #pragma once
 
@@ -639,13 +643,240 @@ namespace sara_ref {
         (n(x, y + 1) - n(x, y - 1) - p(x, y + 1) + p(x, y - 1)) / 4.f;
   }
 
-  //! Eigenvalue signs of a symmetric 3x3 matrix, standing in for Eigen's
-  //! SelfAdjointEigenSolver<Matrix3f> at RefineExtremum.cpp:74-77.  The
-  //! reference only consumes max_i(lambda_i * type) >= 0, i.e. definiteness:
-  //!   returns +1 if all eigenvalues > 0, -1 if all < 0, 0 otherwise.
-  //! Decided in double by Sylvester's criterion on the float entries (the
-  //! float eigen-solver's own rounding near singular H is "parity unpinned").
-  inline int definiteness3(const float Hf[3][3])
+  // ------------------------------------------------------------------------ //
+  // Definiteness of the 3x3 Hessian (RefineExtremum.cpp:74-77):
+  //   SelfAdjointEigenSolver<Matrix3f> solver(D_second);
+  //   lambda = solver.eigenvalues();
+  //   if ((lambda * float(type)).maxCoeff() >= 0) -> do not refine
+  // The constructor runs compute() (the iterative solver, not computeDirect())
+  // in float.  Eigen (>= 3.4, CMakeLists.txt:94-96; the CI's distro package is
+  // 3.4.0) is absent from this image, so its PUBLISHED algorithm is restated
+  // below from Eigen 3.4.0's SelfAdjointEigenSolver.h / Tridiagonalization.h /
+  // Jacobi.h / MathFunctions.h, operation by operation, in float:
+  //   1. lower triangle copied, divided by scale = max |coefficient| (1 if 0);
+  //   2. tridiagonalization_inplace_selector<Matrix3f, 3, false>::run: one
+  //      closed-form Householder step;
+  //   3. computeFromTridiagonal_impl: deflation test, implicit symmetric QR
+  //      step with Wilkinson shift (tridiagonal_qr_step, makeGivens), at most
+  //      30 * n iterations;
+  //   4. eigenvalues * scale, sorted ascending.
+  // kDefEigen33 differs only in the deflation test (Eigen 3.3.x:
+  // |e| <= 2 eps (|d_i| + |d_i+1|)), kept to measure how much the decision
+  // depends on the solver's version.  kDefSylvesterDouble is round 1's
+  // stand-in (exact signs of the leading minors in double).
+  // PARITY: still unpinned against a real Eigen build (none here), but the
+  // three rules are compared site by site in tests/test_oracle_definiteness.py
+  // and the counts are in DESIGN.md section 2.
+  // ------------------------------------------------------------------------ //
+  enum
+  {
+    kDefEigen34 = 0,         // default: the reference's build
+    kDefEigen33 = 1,
+    kDefSylvesterDouble = 2
+  };
+  inline int& definiteness_rule()
+  {
+    static int rule = kDefEigen34;
+    return rule;
+  }
+
+  //! numext::hypot -> positive_real_hypot(abs(x), abs(y)), MathFunctions.h.
+  inline float eigen_hypot(float x, float y)
+  {
+    x = std::abs(x);
+    y = std::abs(y);
+    if (std::isinf(x) || std::isinf(y))
+      return std::numeric_limits<float>::infinity();
+    if (std::isnan(x) || std::isnan(y))
+      return std::numeric_limits<float>::quiet_NaN();
+    const float p = std::max(x, y);
+    if (p == 0.f)
+      return 0.f;
+    const float qp = std::min(y, x) / p;
+    return p * std::sqrt(1.f + qp * qp);
+  }
+
+  //! JacobiRotation<float>::makeGivens(p, q) (real case), Jacobi.h.
+  inline void eigen_make_givens(float p, float q, float& c, float& s)
+  {
+    if (q == 0.f)
+    {
+      c = p < 0.f ? -1.f : 1.f;
+      s = 0.f;
+    }
+    else if (p == 0.f)
+    {
+      c = 0.f;
+      s = q < 0.f ? 1.f : -1.f;
+    }
+    else if (std::abs(p) > std::abs(q))
+    {
+      const float t = q / p;
+      float u = std::sqrt(1.f + t * t);
+      if (p < 0.f)
+        u = -u;
+      c = 1.f / u;
+      s = -t * c;
+    }
+    else
+    {
+      const float t = p / q;
+      float u = std::sqrt(1.f + t * t);
+      if (q < 0.f)
+        u = -u;
+      s = -1.f / u;
+      c = -t * s;
+    }
+  }
+
+  //! tridiagonal_qr_step (eigenvalues only), SelfAdjointEigenSolver.h.
+  inline void eigen_tridiagonal_qr_step(float* diag, float* subdiag, int start,
+                                        int end)
+  {
+    const float td = (diag[end - 1] - diag[end]) * 0.5f;
+    const float e = subdiag[end - 1];
+    float mu = diag[end];
+    if (td == 0.f)
+      mu -= std::abs(e);
+    else if (e != 0.f)
+    {
+      const float e2 = e * e;
+      const float h = eigen_hypot(td, e);
+      if (e2 == 0.f)
+        mu -= e / ((td + (td > 0.f ? h : -h)) / e);
+      else
+        mu -= e2 / (td + (td > 0.f ? h : -h));
+    }
+    float x = diag[start] - mu;
+    float z = subdiag[start];
+    for (int k = start; k < end && z != 0.f; ++k)
+    {
+      float c, s;
+      eigen_make_givens(x, z, c, s);
+      const float sdk = s * diag[k] + c * subdiag[k];
+      const float dkp1 = s * subdiag[k] + c * diag[k + 1];
+      diag[k] = c * (c * diag[k] - s * subdiag[k]) -
+                s * (c * subdiag[k] - s * diag[k + 1]);
+      diag[k + 1] = s * sdk + c * dkp1;
+      subdiag[k] = c * sdk - s * dkp1;
+      if (k > start)
+        subdiag[k - 1] = c * subdiag[k - 1] - s * z;
+      x = subdiag[k];
+      if (k < end - 1)
+      {
+        z = -s * subdiag[k + 1];
+        subdiag[k + 1] = c * subdiag[k + 1];
+      }
+    }
+  }
+
+  //! SelfAdjointEigenSolver<Matrix3f>(H).eigenvalues(); returns false when the
+  //! iteration limit is hit (info() == NoConvergence; the reference does not
+  //! check it and uses the unsorted values).
+  inline bool eigen_selfadjoint_eigenvalues3(const float H[3][3], float lambda[3],
+                                             int rule = kDefEigen34)
+  {
+    // lower triangle, mapped to [-1, 1]
+    float m00 = H[0][0], m10 = H[1][0], m11 = H[1][1], m20 = H[2][0],
+          m21 = H[2][1], m22 = H[2][2];
+    float scale = std::max(
+        std::max(std::max(std::abs(m00), std::abs(m10)),
+                 std::max(std::abs(m11), std::abs(m20))),
+        std::max(std::abs(m21), std::abs(m22)));
+    if (scale == 0.f)
+      scale = 1.f;
+    m00 /= scale;
+    m10 /= scale;
+    m11 /= scale;
+    m20 /= scale;
+    m21 /= scale;
+    m22 /= scale;
+
+    // tridiagonalization, 3x3 real specialisation
+    float diag[3], subdiag[2];
+    const float tol = std::numeric_limits<float>::min();
+    diag[0] = m00;
+    const float v1norm2 = m20 * m20;
+    if (v1norm2 <= tol)
+    {
+      diag[1] = m11;
+      diag[2] = m22;
+      subdiag[0] = m10;
+      subdiag[1] = m21;
+    }
+    else
+    {
+      const float beta = std::sqrt(m10 * m10 + v1norm2);
+      const float inv_beta = 1.f / beta;
+      const float m01 = m10 * inv_beta;
+      const float m02 = m20 * inv_beta;
+      const float q = 2.f * m01 * m21 + m02 * (m22 - m11);
+      diag[1] = m11 + m02 * q;
+      diag[2] = m22 - m02 * q;
+      subdiag[0] = beta;
+      subdiag[1] = m21 - m01 * q;
+    }
+
+    // computeFromTridiagonal_impl
+    const int n = 3, max_iterations = 30;
+    int end = n - 1, start = 0, iter = 0;
+    const float consider_as_zero = std::numeric_limits<float>::min();
+    const float eps = std::numeric_limits<float>::epsilon();
+    const float precision_inv = 1.f / eps;
+    while (end > 0)
+    {
+      for (int i = start; i < end; ++i)
+      {
+        if (rule == kDefEigen33)
+        {
+          // isMuchSmallerThan(|e|, |d_i| + |d_i+1|, 2 eps) || |e| <= min
+          if (std::abs(subdiag[i]) <=
+                  (std::abs(diag[i]) + std::abs(diag[i + 1])) * (2.f * eps) ||
+              std::abs(subdiag[i]) <= consider_as_zero)
+            subdiag[i] = 0.f;
+        }
+        else if (std::abs(subdiag[i]) < consider_as_zero)
+          subdiag[i] = 0.f;
+        else
+        {
+          // |e| <= eps * sqrt(|d_i| + |d_i+1|), scaled against underflow
+          const float scaled_subdiag = precision_inv * subdiag[i];
+          if (scaled_subdiag * scaled_subdiag <=
+              (std::abs(diag[i]) + std::abs(diag[i + 1])))
+            subdiag[i] = 0.f;
+        }
+      }
+      while (end > 0 && subdiag[end - 1] == 0.f)
+        end--;
+      if (end <= 0)
+        break;
+      iter++;
+      if (iter > max_iterations * n)
+        break;
+      start = end - 1;
+      while (start > 0 && subdiag[start - 1] != 0.f)
+        start--;
+      eigen_tridiagonal_qr_step(diag, subdiag, start, end);
+    }
+    const bool converged = iter <= max_iterations * n;
+    if (converged)
+      for (int i = 0; i < n - 1; ++i)
+      {
+        int k = i;
+        for (int j = i + 1; j < n; ++j)
+          if (diag[j] < diag[k])
+            k = j;
+        if (k > i)
+          std::swap(diag[i], diag[k]);
+      }
+    for (int i = 0; i < 3; ++i)
+      lambda[i] = diag[i] * scale;
+    return converged;
+  }
+
+  //! Round 1's stand-in: +1 if all eigenvalues > 0, -1 if all < 0, 0 otherwise,
+  //! by Sylvester's criterion in double on the float entries.
+  inline int definiteness3_sylvester(const float Hf[3][3])
   {
     double H[3][3];
     for (int i = 0; i < 3; ++i)
@@ -661,6 +892,36 @@ namespace sara_ref {
     if (m1 < 0 && m2 > 0 && m3 < 0)
       return -1;
     return 0;
+  }
+
+  //! (lambda * float(type)).maxCoeff() >= 0, RefineExtremum.cpp:76-77.
+  inline bool not_definite_enough3(const float H[3][3], int type, int rule)
+  {
+    if (rule == kDefSylvesterDouble)
+    {
+      const int def = definiteness3_sylvester(H);
+      return type > 0 ? (def != -1) : (def != +1);
+    }
+    float lambda[3];
+    eigen_selfadjoint_eigenvalues3(H, lambda, rule);
+    const float t = float(type);
+    return std::max(std::max(lambda[0] * t, lambda[1] * t), lambda[2] * t) >= 0.f;
+  }
+
+  //! Site-by-site comparison of the three rules (filled by refine_extremum
+  //! when enabled; tests/test_oracle_definiteness.py reads it).
+  struct DefinitenessAudit
+  {
+    bool enabled = false;
+    long long sites = 0;           // Hessians examined
+    long long eigen34_vs_sylvester = 0;
+    long long eigen34_vs_eigen33 = 0;
+    long long not_converged = 0;
+  };
+  inline DefinitenessAudit& definiteness_audit()
+  {
+    static DefinitenessAudit a;
+    return a;
   }
 
   //! Cofactor (i,j) of a 3x3 matrix the way Eigen's 3x3 inverse forms it:
@@ -727,12 +988,24 @@ namespace sara_ref {
       hessian3(I, x, y, s, o, D_second);
 
       // (lambda * float(type)).maxCoeff() >= 0
-      const int def = definiteness3(D_second);
-      bool not_definite_enough;
-      if (type > 0)  // lambda * positive: max >= 0 unless negative definite
-        not_definite_enough = (def != -1);
-      else  // lambda * negative: max >= 0 unless positive definite
-        not_definite_enough = (def != +1);
+      const bool not_definite_enough =
+          not_definite_enough3(D_second, type, definiteness_rule());
+      if (definiteness_audit().enabled)
+      {
+        DefinitenessAudit& au = definiteness_audit();
+        const bool e34 = not_definite_enough3(D_second, type, kDefEigen34);
+        const bool e33 = not_definite_enough3(D_second, type, kDefEigen33);
+        const bool syl = not_definite_enough3(D_second, type, kDefSylvesterDouble);
+        float lam[3];
+        const bool conv = eigen_selfadjoint_eigenvalues3(D_second, lam);
+#pragma omp critical(sara_ref_def_audit)
+        {
+          au.sites += 1;
+          au.eigen34_vs_sylvester += (e34 != syl);
+          au.eigen34_vs_eigen33 += (e34 != e33);
+          au.not_converged += !conv;
+        }
+      }
       if (not_definite_enough)
       {
         h[0] = h[1] = h[2] = 0.f;
@@ -1053,14 +1326,53 @@ namespace sara_ref {
     }
   }
 
-  //! Eigen's Matrix::normalize(): divide by the norm when squaredNorm() > 0.
-  //! Left-to-right float sum (Eigen's vectorised reduction order is "parity
-  //! unpinned").
+  //! Matrix<float,128,1>::squaredNorm() as Eigen 3.4 evaluates it in the
+  //! reference's default build (x86-64 baseline => SSE2, Packet4f; the
+  //! -march=native line of cmake/sara_configure_cxx_compiler.cmake:37 is
+  //! commented out): cwiseAbs2().sum() goes through redux_impl<...,
+  //! LinearVectorizedTraversal, NoUnrolling> (Redux.h; 128 coefficients exceed
+  //! the unrolling limit), i.e. two Packet4f accumulators over the even / odd
+  //! packets, initialised with packets 0 and 1, then acc0 + acc1, then
+  //! predux<Packet4f> (SSE/PacketMath.h): (a0 + a2) + (a1 + a3).
+  inline float eigen_squared_norm128(const float* h)
+  {
+    float acc0[4], acc1[4];
+    for (int j = 0; j < 4; ++j)
+    {
+      acc0[j] = h[j] * h[j];
+      acc1[j] = h[4 + j] * h[4 + j];
+    }
+    for (int i = 8; i < 128; i += 8)
+      for (int j = 0; j < 4; ++j)
+      {
+        acc0[j] = acc0[j] + h[i + j] * h[i + j];
+        acc1[j] = acc1[j] + h[i + 4 + j] * h[i + 4 + j];
+      }
+    float a[4];
+    for (int j = 0; j < 4; ++j)
+      a[j] = acc0[j] + acc1[j];
+    return (a[0] + a[2]) + (a[1] + a[3]);
+  }
+
+  //! 0: Eigen's packet order (default, see above); 1: plain left-to-right sum
+  //! (round 1's stand-in, kept to measure the difference:
+  //! tests/test_oracle_definiteness.py).
+  inline int& squared_norm_order()
+  {
+    static int order = 0;
+    return order;
+  }
+
+  //! Eigen's MatrixBase::normalize() (Dot.h): z = squaredNorm(); if (z > 0)
+  //! *this /= sqrt(z) (a true division per coefficient).
   inline void l2_normalize128(float* h)
   {
     float z = 0.f;
-    for (int i = 0; i < 128; ++i)
-      z += h[i] * h[i];
+    if (squared_norm_order() == 0)
+      z = eigen_squared_norm128(h);
+    else
+      for (int i = 0; i < 128; ++i)
+        z += h[i] * h[i];
     if (z > 0.f)
     {
       const float n = std::sqrt(z);

@@ -297,6 +297,73 @@ int ref_set_detector_mode(int mode)
   return old;
 }
 
+//! Definiteness rule of refine_extremum (kDef*, sift_ref.hpp); returns the
+//! previous value.
+int ref_set_definiteness_rule(int rule)
+{
+  const int old = definiteness_rule();
+  definiteness_rule() = rule;
+  return old;
+}
+
+//! Audit of the three definiteness rules: enable (resets the counters) /
+//! read {sites, eigen34 != sylvester, eigen34 != eigen33, not converged}.
+void ref_definiteness_audit_enable(int on)
+{
+  definiteness_audit() = DefinitenessAudit{};
+  definiteness_audit().enabled = on != 0;
+}
+void ref_definiteness_audit_read(long long* out)
+{
+  const DefinitenessAudit& a = definiteness_audit();
+  out[0] = a.sites;
+  out[1] = a.eigen34_vs_sylvester;
+  out[2] = a.eigen34_vs_eigen33;
+  out[3] = a.not_converged;
+}
+
+//! Eigenvalues of `count` symmetric 3x3 float matrices (row-major 9 floats
+//! each) by the restated SelfAdjointEigenSolver<Matrix3f>; converged[i] = 0/1.
+void ref_selfadjoint_eigenvalues3(const float* mats, int count, int rule,
+                                  float* lambda, int* converged)
+{
+  for (int i = 0; i < count; ++i)
+  {
+    float H[3][3];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)
+        H[r][c] = mats[size_t(i) * 9 + r * 3 + c];
+    const bool ok = eigen_selfadjoint_eigenvalues3(H, lambda + size_t(i) * 3, rule);
+    if (converged)
+      converged[i] = ok ? 1 : 0;
+  }
+}
+
+//! not_definite_enough3 for `count` matrices: out[i] = 0/1.
+void ref_not_definite_enough3(const float* mats, int count, int type, int rule,
+                              int* out)
+{
+  for (int i = 0; i < count; ++i)
+  {
+    float H[3][3];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)
+        H[r][c] = mats[size_t(i) * 9 + r * 3 + c];
+    out[i] = not_definite_enough3(H, type, rule) ? 1 : 0;
+  }
+}
+
+//! Reduction order of normalize()'s squaredNorm() (0 Eigen packets, 1 left to
+//! right); returns the previous value.
+int ref_set_squared_norm_order(int order)
+{
+  const int old = squared_norm_order();
+  squared_norm_order() = order;
+  return old;
+}
+
+float ref_eigen_squared_norm128(const float* h) { return eigen_squared_norm128(h); }
+
 // ---- whole-pipeline handle ---------------------------------------------- //
 
 struct ref_sift

@@ -393,6 +393,94 @@ class detector_mode:
         lib().ref_set_detector_mode(self.old)
 
 
+DEF_EIGEN34, DEF_EIGEN33, DEF_SYLVESTER_DOUBLE = 0, 1, 2
+
+
+class definiteness_rule:
+    """with definiteness_rule(DEF_*): ... - which restatement of the Hessian's
+    definiteness test refine_extremum uses (default: Eigen 3.4's float
+    SelfAdjointEigenSolver)."""
+
+    def __init__(self, rule):
+        self.rule = int(rule)
+
+    def __enter__(self):
+        fn = lib().ref_set_definiteness_rule
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_int]
+        self.old = fn(self.rule)
+        return self
+
+    def __exit__(self, *exc):
+        lib().ref_set_definiteness_rule(self.old)
+
+
+class definiteness_audit:
+    """with definiteness_audit() as a: ...; a.read() -> dict of counters."""
+
+    def __enter__(self):
+        lib().ref_definiteness_audit_enable(1)
+        return self
+
+    def read(self):
+        out = (C.c_longlong * 4)()
+        lib().ref_definiteness_audit_read(out)
+        return {"sites": out[0], "eigen34_vs_sylvester": out[1],
+                "eigen34_vs_eigen33": out[2], "not_converged": out[3]}
+
+    def __exit__(self, *exc):
+        self.result = self.read()
+        lib().ref_definiteness_audit_enable(0)
+
+
+class squared_norm_order:
+    """with squared_norm_order(1): ... - left-to-right squaredNorm() instead of
+    Eigen's Packet4f order in the descriptor's normalize()."""
+
+    def __init__(self, order):
+        self.order = int(order)
+
+    def __enter__(self):
+        fn = lib().ref_set_squared_norm_order
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_int]
+        self.old = fn(self.order)
+        return self
+
+    def __exit__(self, *exc):
+        lib().ref_set_squared_norm_order(self.old)
+
+
+def eigen_squared_norm128(h):
+    h = np.ascontiguousarray(h, np.float32)
+    assert h.size == 128
+    fn = lib().ref_eigen_squared_norm128
+    fn.restype = C.c_float
+    fn.argtypes = [C.c_void_p]
+    return float(fn(h.ctypes.data))
+
+
+def selfadjoint_eigenvalues3(mats, rule=DEF_EIGEN34):
+    m = np.ascontiguousarray(mats, np.float32).reshape(-1, 9)
+    lam = np.empty((m.shape[0], 3), np.float32)
+    conv = np.empty(m.shape[0], np.int32)
+    fn = lib().ref_selfadjoint_eigenvalues3
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    fn(m.ctypes.data, m.shape[0], int(rule), lam.ctypes.data, conv.ctypes.data)
+    return lam, conv.astype(bool)
+
+
+def not_definite_enough3(mats, type_, rule=DEF_EIGEN34):
+    m = np.ascontiguousarray(mats, np.float32).reshape(-1, 9)
+    out = np.empty(m.shape[0], np.int32)
+    fn = lib().ref_not_definite_enough3
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    fn(m.ctypes.data, m.shape[0], int(type_), int(rule), out.ctypes.data)
+    return out.astype(bool)
+
+
 def root_sift(desc):
     out = np.array(desc, np.float32, order="C", copy=True).reshape(-1, np.shape(desc)[-1])
     fn = lib().ref_root_sift
