@@ -424,6 +424,13 @@ SARA_HIP_API sara_hip_status sara_hip_match_descriptors(
 SARA_HIP_API void sara_hip_selfcheck_atan2f(const float* y, const float* x,
                                            float* out, size_t count);
 
+/* Host self-check: float(sin), float(cos) of double(theta) through the short   */
+/* double-precision sequence the descriptor kernel uses for its rotation       */
+/* matrix (FeatureDescriptors/SIFT.hpp:84-89 calls std::cos / std::sin on a    */
+/* double), for theta in [-4, 4].  Not a compute path.                          */
+SARA_HIP_API void sara_hip_selfcheck_sincos(const float* theta, float* out_sin,
+                                           float* out_cos, size_t count);
+
 /* Device self-check: the polar-gradient kernel replaces the compiler's IEEE    */
 /* sqrt and one of its divisions by shorter correctly-rounded sequences and the */
 /* range selection of atanf by a table look-up.  This runs, on the GPU, every   */

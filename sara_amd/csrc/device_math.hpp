@@ -546,4 +546,73 @@ namespace sara_hip {
     return ix == 0 ? atan2f_zero_x(y, x) : r;
   }
 
+  // ------------------------------------------------------------------------ //
+  // cos / sin in double for the descriptor's rotation (SIFT.hpp:84-89 evaluates
+  // std::cos / std::sin on double(theta) and rounds to float).  theta is a
+  // refined histogram peak in (-pi, pi], so a three-term Cody-Waite reduction
+  // by pi/2 and fdlibm's kernel polynomials (__kernel_sin / __kernel_cos
+  // coefficients, error < 1 ulp of double) are enough: about 30 FMA-class
+  // double operations instead of the general-range library routines (two
+  // calls of a few hundred instructions with a Payne-Hanek branch).  Only
+  // float(result) is consumed: it differs from the correctly rounded value
+  // only when the true cosine lies within 1e-16 of a float rounding boundary
+  // (checked against libm over every float in [-4, 4] on the host,
+  // tests/test_host_math.py).  |x| > 4 is left to the caller's fallback.
+  // ------------------------------------------------------------------------ //
+  SARA_HD double fma_f64(double a, double b, double c)
+  {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fma_rn(a, b, c);
+#else
+    return __builtin_fma(a, b, c);
+#endif
+  }
+
+  SARA_HD void sincos_reduced_f64(double x, double& s, double& c)
+  {
+    // k = nearest integer to x * 2/pi, |k| <= 3
+    const double kf = __builtin_rint(x * 6.36619772367581382433e-01);
+    const int k = int(kf);
+    // r = x - k * pi/2 with pi/2 = P1 + P2 + P3 (33 + 33 + 53 bits)
+    double r = fma_f64(-kf, 1.57079632673412561417e+00, x);
+    r = fma_f64(-kf, 6.07710050630396597660e-11, r);
+    r = fma_f64(-kf, 2.02226624871116645580e-21, r);
+    r = k == 0 ? x : r;  // keeps sin(-0) = -0
+    const double z = r * r;
+    // __kernel_sin: r + r^3 (S1 + z (S2 + ... z S6))
+    double ps = fma_f64(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma_f64(z, ps, 2.75573137070700676789e-06);
+    ps = fma_f64(z, ps, -1.98412698298579493134e-04);
+    ps = fma_f64(z, ps, 8.33333333332248946124e-03);
+    ps = fma_f64(z, ps, -1.66666666666666324348e-01);
+    double sr = fma_f64(z * r, ps, r);
+    sr = z < 5.5e-17 ? r : sr;  // |r| < 2^-27: sin r = r (and keeps -0)
+    // __kernel_cos: 1 - z/2 + z^2 (C1 + z (C2 + ... z C6))
+    double pc = fma_f64(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma_f64(z, pc, -2.75573143513906633035e-07);
+    pc = fma_f64(z, pc, 2.48015872894767294178e-05);
+    pc = fma_f64(z, pc, -1.38888888888741095749e-03);
+    pc = fma_f64(z, pc, 4.16666666666666019037e-02);
+    const double cr = fma_f64(z * z, pc, fma_f64(z, -0.5, 1.0));
+    switch (k & 3)
+    {
+    case 0:
+      s = sr;
+      c = cr;
+      break;
+    case 1:
+      s = cr;
+      c = -sr;
+      break;
+    case 2:
+      s = -sr;
+      c = -cr;
+      break;
+    default:
+      s = -cr;
+      c = sr;
+      break;
+    }
+  }
+
 }  // namespace sara_hip

@@ -328,11 +328,6 @@ namespace sara_hip {
     const char* e = getenv("SARA_HIP_PERSIST_UNITS");
     return e ? std::max(1, atoi(e)) : 1;
   }();
-  //! log2 of the lanes that share one patch row in the descriptor kernel.
-  static const int g_desc_row_shift = [] {
-    const char* e = getenv("SARA_HIP_DESC_ROW_SHIFT");
-    return e ? std::min(6, std::max(2, atoi(e))) : 4;
-  }();
   //! Off by default: measured on MI355X the fused pass takes as long as the
   //! two separate kernels (3.3 ms per 64 frames either way - the gradient's
   //! exact atan2/sqrt/div sequence is VALU-bound, not bandwidth-bound).
@@ -1233,7 +1228,12 @@ namespace sara_hip {
       __syncthreads();
     }
     if (i < n)
-      cand.order[size_t(b) * cand.cap + rank] = i;
+    {
+      const size_t row = size_t(b) * cand.cap;
+      cand.order[row + rank] = i;
+      cand.skey[row + rank] = mine;
+      cand.sdata[row + rank] = cand.data[row + i];
+    }
   }
 
   void launch_rank_candidates(const CandidateLists& cand, int batch,
@@ -1345,7 +1345,10 @@ namespace sara_hip {
     int rank = lo;
     for (int q = lo; q < hi; ++q)
       rank += (keys[g[q]] < mine);
-    cand.order[size_t(b) * cand.cap + rank] = i;
+    const size_t row = size_t(b) * cand.cap;
+    cand.order[row + rank] = i;
+    cand.skey[row + rank] = mine;
+    cand.sdata[row + rank] = cand.data[row + i];
   }
 
   void launch_rank_candidates_bucketed(const CandidateLists& cand,
@@ -1422,41 +1425,131 @@ namespace sara_hip {
     return __longlong_as_double(((unsigned long long) hi << 32) | lo);
   }
 
-  __global__ __launch_bounds__(256) void orientation_kernel(
+  // Wave reductions through DPP instead of __shfl_xor: a shuffle is a
+  // ds_bpermute_b32, i.e. one LDS round trip per step, and these kernels'
+  // LDS queues are full of atomics (a dependent chain of 6 - 12 of them per
+  // reduction is what the per-keypoint phases were waiting for).
+#define SARA_DPP_F(old, v, ctrl, rmask)                                        \
+  __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old),              \
+                                             __float_as_int(v), ctrl, rmask,   \
+                                             0xf, false))
+  //! Sum over the 64 lanes, returned in every lane.
+  __device__ __forceinline__ float wave_sum_dpp(float v)
+  {
+    v += SARA_DPP_F(0.f, v, 0x111, 0xf);  // row_shr:1
+    v += SARA_DPP_F(0.f, v, 0x112, 0xf);  // row_shr:2
+    v += SARA_DPP_F(0.f, v, 0x114, 0xf);  // row_shr:4
+    v += SARA_DPP_F(0.f, v, 0x118, 0xf);  // row_shr:8
+    v += SARA_DPP_F(0.f, v, 0x142, 0xa);  // row_bcast:15
+    v += SARA_DPP_F(0.f, v, 0x143, 0xc);  // row_bcast:31
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  }
+  //! Maximum over the 64 lanes, returned in every lane.
+  __device__ __forceinline__ float wave_max_dpp(float v)
+  {
+    v = fmaxf(v, SARA_DPP_F(v, v, 0x111, 0xf));
+    v = fmaxf(v, SARA_DPP_F(v, v, 0x112, 0xf));
+    v = fmaxf(v, SARA_DPP_F(v, v, 0x114, 0xf));
+    v = fmaxf(v, SARA_DPP_F(v, v, 0x118, 0xf));
+    v = fmaxf(v, SARA_DPP_F(v, v, 0x142, 0xa));
+    v = fmaxf(v, SARA_DPP_F(v, v, 0x143, 0xc));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  }
+  __device__ __forceinline__ int wave_max_dpp(int v)
+  {
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+  }
+  //! Lane i receives lane i - 1 (lane 0 keeps its own value) / lane i + 1.
+  __device__ __forceinline__ float wave_shr1(float v)
+  {
+    return SARA_DPP_F(v, v, 0x138, 0xf);  // wave_shr:1
+  }
+  __device__ __forceinline__ float wave_shl1(float v)
+  {
+    return SARA_DPP_F(v, v, 0x130, 0xf);  // wave_shl:1
+  }
+
+  //! Waves (= keypoints in flight) per workgroup of the per-keypoint kernels.
+  //! A workgroup's LDS and wave slots are only released when its slowest wave
+  //! retires, and the work per keypoint varies (1 to 4 orientations, patch
+  //! area 1 : 2.5 between scales): with 4 waves per group the others idle.
+  //! Measured (64 x 1080p): descriptor kernel 2.67 / 2.45 / 2.36 ms with
+  //! 4 / 2 / 1 waves per group; the orientation kernel shares its weight
+  //! tables in LDS across the group and prefers 4 (1.04 against 1.17 ms).
+#ifndef SARA_ORI_WAVES
+#define SARA_ORI_WAVES 4
+#endif
+#ifndef SARA_DESC_WAVES
+#define SARA_DESC_WAVES 1
+#endif
+
+  //! Inclusive prefix sum over the 64 lanes (DPP row shifts, then the row
+  //! broadcasts of gfx9: 6 steps, no LDS).
+  __device__ __forceinline__ int wave_inclusive_scan(int v)
+  {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+    return v;
+  }
+
+  //! WLDS: the Gaussian weight tables of all scales sit in (dynamic) LDS.  From
+  //! global memory each look-up is a vector load that shares the in-order
+  //! vmcnt counter with the gathers: waiting for a weight then also waits for
+  //! every gather issued ahead of it, which defeats the prefetch ring below.
+    constexpr int kOriWaves = SARA_ORI_WAVES;
+  template <bool WLDS>
+  __global__ __launch_bounds__(64 * kOriWaves) void orientation_kernel(
       const GradPyramidView* __restrict__ gradp,
       const ScaleTable* __restrict__ tabp, const double* __restrict__ weights,
-      CandidateLists cand, OrientationLists ori, int xcd_run)
+      int n_weights, CandidateLists cand, OrientationLists ori, int xcd_run)
   {
-    __shared__ unsigned long long s_mask[4][kOriBins];
-    __shared__ double s_contrib[4][64];
+    __shared__ unsigned long long s_mask[kOriWaves][kOriBins];
+    __shared__ double s_contrib[kOriWaves][64];
+    __shared__ int s_segoff[kOriWaves][kOriBins];
+    extern __shared__ __attribute__((aligned(16))) double s_weights[];
     const GradPyramidView& grad = *gradp;
     const ScaleTable& tab = *tabp;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    if (WLDS)
+    {
+      for (int i = threadIdx.x; i < n_weights; i += 64 * kOriWaves)
+        s_weights[i] = weights[i];
+      __syncthreads();
+    }
     const int b = blockIdx.y;
     const int n = min(cand.count[b], cand.cap);
     // Persistent blocks: the grid holds one run-group of blocks per frame and
     // every block walks the frame's work items with that stride (a grid sized
     // for the list capacity launches ~3 empty waves for every useful one).
-    const int nblk = (n + 3) >> 2;
+    const int nblk = (n + kOriWaves - 1) / kOriWaves;
     const int unit = 8 * xcd_run;
     const int positions = unit * ((nblk + unit - 1) / unit);
     auto item = [&](int lb) {
-    const int idx = lb * 4 + wave;
+    const int idx = lb * kOriWaves + wave;
     if (idx >= n)
       return;
 
     const size_t row = size_t(b) * cand.cap;
-    const int slot = cand.order[row + idx];
-    const unsigned long long key = cand.key[row + slot];
-    const float4 d = cand.data[row + slot];
+    const unsigned long long key = cand.skey[row + idx];
+    const float4 d = cand.sdata[row + idx];
     const int o = key_octave(key);
     const int s = key_scale(key);
 
     const int rx = int(roundf(d.x));
     const int ry = int(roundf(d.y));
     const int R = tab.ori_radius[s];
-    const double* wt = weights + tab.ori_woff[s];
+    const int woff = tab.ori_woff[s];
     const int w = grad.w[o], h = grad.h[o];
     // explicitly a global-memory pointer: through a generic pointer these
     // gathers become flat_load, which counts on lgkmcnt as well, so waiting
@@ -1465,94 +1558,147 @@ namespace sara_hip {
         (global_float2_ptr) reinterpret_cast<const f32x2*>(
             grad.base[o] + size_t(b) * grad.frame_stride[o]) +
         size_t(s) * grad.plane[o];
+    // a pixel that is always inside the image (idle lanes gather it)
+    const size_t center = size_t(min(max(ry, 0), h - 1)) * w +
+                          size_t(min(max(rx, 0), w - 1));
 
     const int D = 2 * R + 1;
     const int npx = D * D;
     float hist = 0.f;
 
-    // (u, v) of this lane's pixel, advanced by 64 pixels per chunk.
-    int v = lane / D - R;
-    int u = lane % D - R;
     const int dv64 = 64 / D, du64 = 64 % D;
     unsigned long long* bin_mask = s_mask[wave];
     double* contrib = s_contrib[wave];
+    int* seg_off = s_segoff[wave];
 
-    auto sample = [&](int base_, int u_, int v_, float2& mo_) -> bool {
-      const int xx = rx + u_, yy = ry + v_;
-      const bool ok = (base_ + lane < npx) && xx >= 0 && xx < w && yy >= 0 &&
-                      yy < h;
-      mo_ = make_float2(0.f, 0.f);
-      if (ok)
-        mo_ = load_pair(g, size_t(yy) * w + xx);
-      return ok;
+    // The patch is fetched from HBM once and nothing else hides that latency:
+    // a ring of kOriAhead chunks (64 pixels each) of unconditional gathers runs
+    // ahead of the histogram work.  (u, v) of this lane's pixel advances by 64
+    // pixels per chunk, once on the issue side and once on the consumer side.
+    constexpr int kOriAhead = 4;
+    auto advance = [&](int& u_, int& v_) {
+      u_ += du64;
+      v_ += dv64;
+      if (u_ > R)
+      {
+        u_ -= D;
+        v_ += 1;
+      }
     };
-    float2 mo_next;
-    bool ok_next = sample(0, u, v, mo_next);
+    int iu = lane % D - R, iv = lane / D - R;  // issue side
+    auto issue = [&](int base_, float2& mo_, bool& ok_) {
+      const int xx = rx + iu, yy = ry + iv;
+      ok_ = (base_ + lane < npx) && xx >= 0 && xx < w && yy >= 0 && yy < h;
+      mo_ = load_pair(g, ok_ ? size_t(yy) * w + xx : center);
+      advance(iu, iv);
+    };
+    float2 ring[kOriAhead];
+    bool ring_ok[kOriAhead];
+#pragma unroll
+    for (int q = 0; q < kOriAhead; ++q)
+      issue(64 * q, ring[q], ring_ok[q]);
+    __builtin_amdgcn_s_waitcnt(0x0f70 | (kOriAhead - 1));  // see descriptor_kernel
+    int u = lane % D - R, v = lane / D - R;  // consumer side
 
-    for (int base = 0; base < npx; base += 64)
+    for (int base0 = 0; base0 < npx; base0 += 64 * kOriAhead)
     {
+#pragma unroll
+    for (int q = 0; q < kOriAhead; ++q)
+    {
+      // chunks beyond the patch are idle (ok is false in every lane): no break
+      // here, the compiler counts the gathers in flight only along straight
+      // control flow
+      const int base = base0 + 64 * q;
       int bin = -1;
       double c = 0.;
-      const float2 mo = mo_next;
-      const bool ok = ok_next;
+      const float2 mo = ring[q];
+      const bool ok = ring_ok[q];
       const int uc = u, vc = v;
-      // advance to the next chunk's pixel and start its gather right away
-      u += du64;
-      v += dv64;
-      if (u > R)
-      {
-        u -= D;
-        v += 1;
-      }
-      ok_next = sample(base + 64, u, v, mo_next);
+      advance(u, v);
       if (ok)
       {
         float a = mo.y;
         a = a < 0 ? a + float(2. * M_PI) : a;
         bin = int(floor(double(a / float(2 * M_PI) * kOriBins)));
         bin %= kOriBins;
-        c = wt[uc * uc + vc * vc] * double(mo.x);
+        const int wi = woff + uc * uc + vc * vc;
+        c = (WLDS ? s_weights[wi] : weights[wi]) * double(mo.x);
       }
+      // refill the slot (its pair is consumed): chunk base + 64 * kOriAhead
+      issue(base + 64 * kOriAhead, ring[q], ring_ok[q]);
       // Which lanes of this chunk fall into which bin: one 64-bit mask per
-      // bin, built with integer LDS atomics.  The owner lane of a bin then
-      // replays exactly its contributions in ascending lane (= raster) order.
+      // bin, built with integer LDS atomics.  The contributions are then
+      // sorted by (bin, lane): a sample's slot is the number of samples in
+      // smaller bins (exclusive scan of the masks' population counts over the
+      // 36 owner lanes) plus its rank inside its bin (mbcnt of the bin's mask),
+      // and the owner lane of a bin adds its contiguous segment in ascending
+      // lane (= raster) order - the rounding sequence of the CPU loop - with a
+      // plain counted loop instead of a bit scan per addition.
       if (lane < kOriBins)
         bin_mask[lane] = 0ull;
-      contrib[lane] = c;
       __builtin_amdgcn_wave_barrier();
       if (bin >= 0)
         atomicOr(&bin_mask[bin], 1ull << lane);
       __builtin_amdgcn_wave_barrier();
-      unsigned long long mine = lane < kOriBins ? bin_mask[lane] : 0ull;
-      while (__ballot(mine != 0ull) != 0ull)
+      const unsigned long long own = lane < kOriBins ? bin_mask[lane] : 0ull;
+      const int cnt = __popcll(own);
+      const int incl = wave_inclusive_scan(cnt);
+      const int seg_begin = incl - cnt;
+      if (lane < kOriBins)
+        seg_off[lane] = seg_begin;
+      __builtin_amdgcn_wave_barrier();
+      if (bin >= 0)
       {
-        if (mine != 0ull)
+        const unsigned long long m = bin_mask[bin];
+        const int r = __builtin_amdgcn_mbcnt_hi(
+            unsigned(m >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m), 0u));
+        contrib[seg_off[bin] + r] = c;
+      }
+      __builtin_amdgcn_wave_barrier();
+      {
+        int i = seg_begin;
+        const int end = lane < kOriBins ? incl : seg_begin;
+        double nxt = i < end ? contrib[i] : 0.;
+        while (__ballot(i < end) != 0ull)
         {
-          const int k = __ffsll((long long) mine) - 1;
-          hist = float(double(hist) + contrib[k]);
-          mine &= mine - 1ull;
+          const double cur = nxt;
+          if (i + 1 < end)
+            nxt = contrib[i + 1];
+          if (i < end)
+            hist = float(double(hist) + cur);
+          ++i;
         }
       }
       __builtin_amdgcn_wave_barrier();
     }
+    }
 
     // lowe_smooth_histogram: 6 circular box-blur iterations.
-    const int lp = lane < kOriBins ? (lane + kOriBins - 1) % kOriBins : lane;
-    const int ln = lane < kOriBins ? (lane + 1) % kOriBins : lane;
+    // circular neighbours of the 36 bin lanes: DPP wave shifts, the two wrap
+    // positions through readlane
+    auto ring_prev = [&](float x) {
+      const float wrap = __int_as_float(
+          __builtin_amdgcn_readlane(__float_as_int(x), kOriBins - 1));
+      const float sh = wave_shr1(x);
+      return lane == 0 ? wrap : sh;
+    };
+    auto ring_next = [&](float x) {
+      const float wrap =
+          __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
+      const float sh = wave_shl1(x);
+      return lane == kOriBins - 1 ? wrap : sh;
+    };
     for (int iter = 0; iter < 6; ++iter)
     {
-      const float prev = __shfl(hist, lp);
-      const float next = __shfl(hist, ln);
+      const float prev = ring_prev(hist);
+      const float next = ring_next(hist);
       hist = (prev + hist + next) / 3.f;
     }
 
     // find_peaks + refine_peak.
-    float mx = lane < kOriBins ? hist : -INFINITY;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-      mx = fmaxf(mx, __shfl_xor(mx, off));
-    const float y0 = __shfl(hist, lp);
-    const float y2 = __shfl(hist, ln);
+    const float mx = wave_max_dpp(lane < kOriBins ? hist : -INFINITY);
+    const float y0 = ring_prev(hist);
+    const float y2 = ring_next(hist);
     const bool is_peak =
         lane < kOriBins && hist >= 0.8f * mx && hist > y0 && hist > y2;
     const unsigned long long mask = __ballot(is_peak);
@@ -1567,9 +1713,18 @@ namespace sara_hip {
         theta -= 2.f * float(M_PI);
       const int r = __popcll(mask & ((1ull << lane) - 1ull));
       ori.peak_theta[(row + idx) * kMaxPeaks + r] = theta;
+      if (r < 8)
+        ori.record[row + idx].theta[r] = theta;
     }
     if (lane == 0)
+    {
       ori.peak_count[row + idx] = __popcll(mask);
+      KeypointRecord& rec = ori.record[row + idx];
+      rec.d = d;
+      rec.key = key;
+      rec.npeaks = __popcll(mask);
+      rec.reserved = 0;
+    }
     };
     for (int bx = blockIdx.x; bx < positions; bx += gridDim.x)
     {
@@ -1580,7 +1735,7 @@ namespace sara_hip {
   }
 
   void launch_orientations(const GradPyramidView* grad, const ScaleTable* tab,
-                           const double* ori_weights,
+                           const double* ori_weights, int n_weights,
                            const CandidateLists& cand,
                            const OrientationLists& ori, int batch,
                            hipStream_t stream)
@@ -1588,10 +1743,18 @@ namespace sara_hip {
     // xcd_local_block() spreads ceil(n/4) work items over 8 chunks, so the
     // grid has to be a multiple of 8 blocks
     const int unit = 8 * g_xcd_run;
-    const int needed = unit * (((cand.cap + 3) / 4 + unit - 1) / unit);
+    const int needed =
+        unit * (((cand.cap + kOriWaves - 1) / kOriWaves + unit - 1) / unit);
     const dim3 grid(std::min(needed, unit * g_persist_units), batch);
-    hipLaunchKernelGGL(orientation_kernel, grid, dim3(256), 0, stream, grad, tab,
-                       ori_weights, cand, ori, g_xcd_run);
+    // weight tables in LDS when they leave room for 8 blocks per CU
+    const size_t wbytes = sizeof(double) * size_t(n_weights);
+    if (n_weights > 0 && wbytes <= 14 * 1024)
+      hipLaunchKernelGGL(orientation_kernel<true>, grid, dim3(64 * kOriWaves), wbytes,
+                         stream, grad, tab, ori_weights, n_weights, cand, ori,
+                         g_xcd_run);
+    else
+      hipLaunchKernelGGL(orientation_kernel<false>, grid, dim3(64 * kOriWaves), 0, stream,
+                         grad, tab, ori_weights, n_weights, cand, ori, g_xcd_run);
   }
 
   // ------------------------------------------------------------------------ //
@@ -1671,13 +1834,7 @@ namespace sara_hip {
   // as 64-bit fixed point (ds_add_u64, see below).  Float tolerance vs the CPU
   // path: summation order and expf/cos/sin last-ulp differences only.
   // ======================================================================== //
-  __device__ inline float wave_sum(float v)
-  {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-      v += __shfl_xor(v, off);
-    return v;
-  }
+  __device__ inline float wave_sum(float v) { return wave_sum_dpp(v); }
 
   // LDS accumulation of the 128 bins.  ds_add_f32 costs ~192 clk per wave
   // instruction on gfx950 whatever the address pattern (tools/ubench/
@@ -1685,47 +1842,106 @@ namespace sara_hip {
   // 64-bit two's-complement fixed point (ds_add_u64 costs about one
   // ds_add_u32), scaled per patch (see fx_scale in the kernel): the sum is
   // order-independent, so the result is deterministic.
+  //
+  // Round 2 structure.  Round 1 walked the patch four rows at a time in
+  // lockstep: every pass paid the row set-up (60 instructions) and the exposed
+  // latency of its first gather - measured with the sample loop removed, that
+  // skeleton alone took 1.15 of the kernel's 2.4 ms.  Now the rows of a
+  // patch are cut into chunks of 16 consecutive pixels ONCE per orientation
+  // (each lane sets up one row, a wave scan numbers the chunks, the list goes
+  // to LDS) and the four 16-lane groups of the wave stream through that list,
+  // one chunk each per step: no per-row lockstep, equal work for the groups,
+  // and a software pipeline that runs across row boundaries (chunk entry read
+  // three steps ahead, gather issued two steps ahead).
 #ifndef SARA_DESC_COPIES
 #define SARA_DESC_COPIES 4
 #endif
-  constexpr int kDescCopies = SARA_DESC_COPIES;  // histogram replicas per wave
 #ifndef SARA_DESC_WAVES_PER_EU
-#define SARA_DESC_WAVES_PER_EU 8
+#define SARA_DESC_WAVES_PER_EU 6
+#endif
+#ifndef SARA_DESC_PAD
+#define SARA_DESC_PAD 1
+#endif
+  constexpr int kDescCopies = SARA_DESC_COPIES;  // histogram replicas per wave
+  // cell stride in 64-bit words; the padding moves neighbouring cells off the
+  // same LDS bank
+  constexpr int kDescCellStride = 8 * kDescCopies + SARA_DESC_PAD;
+  constexpr int kDescHistWords = 16 * kDescCellStride;
+  constexpr int kDescRowsPerBlock = 64;   // one row per lane
+  constexpr int kDescChunksPerPhase = 8;  // chunks of one row per table fill
+  constexpr int kDescTableCap = kDescRowsPerBlock * kDescChunksPerPhase;
+#ifndef SARA_DESC_AHEAD
+#define SARA_DESC_AHEAD 4
+#endif
+  constexpr int kDescAhead = SARA_DESC_AHEAD;  // gathers in flight per lane
+
+  constexpr int kDescWaves = SARA_DESC_WAVES;
+#ifdef SARA_DESC_PROF
+  // Per-phase wave cycles (s_memtime), summed over all waves: a development
+  // aid, read back through sara_hip_debug_desc_prof().
+  __device__ unsigned long long g_desc_prof[8];
+#define SARA_PROF_T(var) const long long var = clock64()
+#define SARA_PROF_ADD(slot, a, b)                                              \
+  if (lane == 0)                                                               \
+  atomicAdd(&g_desc_prof[slot], (unsigned long long) ((b) - (a)))
+#else
+#define SARA_PROF_T(var)
+#define SARA_PROF_ADD(slot, a, b)
 #endif
 
-  __global__ __launch_bounds__(256, SARA_DESC_WAVES_PER_EU) void descriptor_kernel(
-      const GradPyramidView* __restrict__ gradp, CandidateLists cand,
-      OrientationLists ori, sara_oeregion* __restrict__ features,
-      int32_t* __restrict__ scale_octave, float* __restrict__ descriptors,
-      int with_descriptors, int root_sift, int xcd_run, int row_shift)
+  __global__ __launch_bounds__(64 * kDescWaves, SARA_DESC_WAVES_PER_EU) void descriptor_kernel(
+      GradPyramidView grad, CandidateLists cand, OrientationLists ori,
+      sara_oeregion* __restrict__ features, int32_t* __restrict__ scale_octave,
+      float* __restrict__ descriptors, int with_descriptors, int root_sift,
+      int xcd_run)
   {
-    const GradPyramidView& grad = *gradp;
-    __shared__ unsigned long long s_acc[4][128 * kDescCopies];
+    __shared__ unsigned long long s_acc[kDescWaves][kDescHistWords];
+    __shared__ unsigned s_tab[kDescWaves][kDescTableCap];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, l16 = lane & 15;
     const int b = blockIdx.y;
     const int n = min(cand.count[b], cand.cap);
     // persistent blocks, see orientation_kernel
-    const int nblk = (n + 3) >> 2;
+    const int nblk = (n + kDescWaves - 1) / kDescWaves;
     const int unit = 8 * xcd_run;
     const int positions = unit * ((nblk + unit - 1) / unit);
-    auto item = [&](int lb) {
-    const int idx = lb * 4 + wave;
+    // The record of extremum idx (orientation_kernel) and its output offset
+    // (scan_peaks_kernel): lanes 0..15 fetch one dword of the record each,
+    // lane 16 the offset.  The loads of the NEXT work item are issued before
+    // the current one is processed.
+    const size_t row = size_t(b) * cand.cap;
+    const int frame_base = ori.frame_offset[b];
+    auto fetch_item = [&](int lb) -> unsigned {
+      const int idx = lb * kDescWaves + wave;
+      unsigned wv = 0u;
+      if (lb >= 0 && idx < n)
+      {
+        if (lane < 16)
+          wv = reinterpret_cast<const unsigned*>(ori.record + row + idx)[lane];
+        else if (lane == 16)
+          wv = unsigned(ori.offset[row + idx]);
+      }
+      return wv;
+    };
+    auto item = [&](int lb, unsigned wv) {
+    const int idx = lb * kDescWaves + wave;
     if (idx >= n)
       return;
 
-    const size_t row = size_t(b) * cand.cap;
-    const int npeaks = ori.peak_count[row + idx];
+    SARA_PROF_T(t_item);
+    auto word = [&](int i) { return unsigned(__builtin_amdgcn_readlane(int(wv), i)); };
+    const int npeaks = int(word(6));
     if (npeaks == 0)
       return;
-    const int slot = cand.order[row + idx];
-    const unsigned long long key = cand.key[row + slot];
-    const float4 d = cand.data[row + slot];
+    const float4 d = make_float4(__uint_as_float(word(0)), __uint_as_float(word(1)),
+                                 __uint_as_float(word(2)), __uint_as_float(word(3)));
+    const unsigned long long key =
+        (unsigned long long) word(4) | ((unsigned long long) word(5) << 32);
     const int o = key_octave(key);
     const int s = key_scale(key);
     const int is_max = int(key & 1ull);
-    const int frame_base = ori.frame_offset[b];
-    const int local0 = ori.offset[row + idx];
+    const int local0 = int(word(16));
 
     // OERegion(pos, sigma): shape = I * float(pow(double(sigma), -2)).
     const float shape = float(1.0 / (double(d.z) * double(d.z)));
@@ -1748,11 +1964,15 @@ namespace sara_hip {
         size_t(s) * grad.plane[o];
     const float factor = grad.factor[o];
     unsigned long long* hist = s_acc[wave];
+    unsigned* tab = s_tab[wave];
     const int copy = lane & (kDescCopies - 1);
 
     // rows / columns of the patch that fall inside the image
     const int v_lo = max(-rr, -ry), v_hi = min(rr, h - 1 - ry);
     const int u_min = max(-rr, -rx), u_max = min(rr, w - 1 - rx);
+    // a pixel that is always inside the image (idle lanes gather it)
+    const size_t center = size_t(min(max(ry, 0), h - 1)) * w +
+                          size_t(min(max(rx, 0), w - 1));
 
     // Fixed-point scale of the accumulation.  Every contribution is bounded by
     // |wy*wx*wo*weight*mag| < 2*2*1*1*max(mag); max(mag) over a superset of
@@ -1772,9 +1992,8 @@ namespace sara_hip {
       if (ncx > 0 && ncy > 0)
         for (int q = lane; q < ncx * ncy; q += 64)
           mxb = max(mxb, cm[size_t(cy0 + q / ncx) * grad.cw[o] + cx0 + q % ncx]);
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1)
-        mxb = max(mxb, (unsigned) __shfl_xor((int) mxb, off));
+      // magnitudes are >= 0: their bit patterns order like the floats
+      mxb = unsigned(wave_max_dpp(int(mxb)));
       const float mx = __uint_as_float(mxb);
       int e = 0;
       (void) frexpf(mx, &e);  // mx < 2^e
@@ -1784,13 +2003,17 @@ namespace sara_hip {
       fx_inv = ldexp(1., e - 25);
     }
 
+    SARA_PROF_T(t_setup);
+    SARA_PROF_ADD(0, t_item, t_setup);
     for (int k = 0; k < npeaks; ++k)
     {
+      SARA_PROF_T(t_peak);
       const int local = local0 + k;
       if (local >= cand.cap)
         break;
       const size_t out = size_t(frame_base) + local;
-      const float theta = ori.peak_theta[(row + idx) * kMaxPeaks + k];
+      const float theta = k < 8 ? __uint_as_float(word(8 + k))
+                                : ori.peak_theta[(row + idx) * kMaxPeaks + k];
 
       if (lane == 0)
       {
@@ -1817,29 +2040,99 @@ namespace sara_hip {
         continue;
 
 #pragma unroll
-      for (int q = 0; q < 2 * kDescCopies; ++q)
-        hist[q * 64 + lane] = 0ull;
-      __builtin_amdgcn_wave_barrier();
+      for (int q = 0; q < (kDescHistWords + 63) / 64; ++q)
+        if (q * 64 + lane < kDescHistWords)
+          hist[q * 64 + lane] = 0ull;
 
-      const float ct = float(cos(double(theta)));
-      const float st = float(sin(double(theta)));
+      double sd, cd;
+      if (fabsf(theta) <= 4.f)
+        sincos_reduced_f64(double(theta), sd, cd);
+      else
+      {
+        sd = sin(double(theta));
+        cd = cos(double(theta));
+      }
+      const float ct = float(cd);
+      const float st = float(sd);
       const float T00 = ct / l, T01 = st / l, T10 = (-st) / l, T11 = ct / l;
 
-      // Four patch rows per pass: each quarter wave (16 lanes) walks one row,
-      // 16 samples at a time, so that short rows do not leave most of the
-      // wave idle.  Row intervals are conservative (the exact float test
-      // below decides), hence the approximate reciprocals.
+      // Row intervals are conservative (the exact float test in the sample
+      // step decides), hence the approximate reciprocals.
       const bool t00_ok = fabsf(T00) > 1e-12f, t10_ok = fabsf(T10) > 1e-12f;
       const float inv00 = t00_ok ? 1.f / T00 : 0.f;
       const float inv10 = t10_ok ? 1.f / T10 : 0.f;
-      const int sub = lane >> row_shift, l16 = lane & ((1 << row_shift) - 1);
-      const int rows_per_pass = 64 >> row_shift, lanes_per_row = 1 << row_shift;
-      for (int vb = v_lo; vb <= v_hi; vb += rows_per_pass)
+
+      // One sample: trilinear accumulation of pixel (u, v) of the patch
+      // (SIFT.hpp:204-238).  p = T (u, v) is evaluated in the reference's
+      // operation order (the window test is a float comparison).
+      auto accumulate = [&](int u, int v, float2 mo) {
+        const float fu = float(u), fv = float(v);
+        float px = T00 * fu + T01 * fv;
+        float py = T10 * fu + T11 * fv;
+        const float nrm2 = px * px + py * py;
+        px += 1.5f;
+        py += 1.5f;
+        if (fminf(px, py) <= -1.f || fmaxf(px, py) >= 4.f)
+          return;
+        // weight * mag * 2^(25 - e), once per sample
+        const float wm = __expf(-nrm2 / (2.f * 4.f)) * (mo.x * fx_scale);
+        float a = mo.y - theta;
+        a = a < 0.f ? a + 2.f * pi : a;
+        a *= 8.f / (2.f * pi);
+        const float xif = truncf(px), yif = truncf(py), oif = truncf(a);
+        const float xfrac = px - xif, yfrac = py - yif, ofrac = a - oif;
+        const int xi = int(xif), yi = int(yif), oi = int(oif);
+        const float w1 = ofrac * wm, w0 = wm - w1;
+        // xi, yi are in 0..3 (p in (-1, 4), truncation): the dx / dy = 1
+        // neighbours exist when xi / yi < 3; otherwise their weight is zeroed
+        // and their address falls back on the dx / dy = 0 cell
+        const bool x_ok = xi < 3, y_ok = yi < 3;
+        const float wx1 = x_ok ? xfrac : 0.f, wy1 = y_ok ? yfrac : 0.f;
+        const float wy0 = 1.f - yfrac, wx0 = 1.f - xfrac;
+        const float p00 = wy0 * wx0, p01 = wy0 * wx1, p10 = wy1 * wx0,
+                    p11 = wy1 * wx1;
+        const unsigned dxo = x_ok ? unsigned(kDescCellStride) : 0u;
+        const unsigned dyo = y_ok ? unsigned(4 * kDescCellStride) : 0u;
+        const unsigned cell = unsigned(yi * 4 + xi);
+        const unsigned h0 =
+            __umul24(cell, unsigned(kDescCellStride)) + unsigned(copy);
+        const unsigned ia = h0 + unsigned((oi & 7) * kDescCopies);
+        const unsigned ib = h0 + unsigned(((oi + 1) & 7) * kDescCopies);
+        // the eight contributions, rounded to nearest (ties up) in one block
+        int c0, c1, c2, c3, c4, c5, c6, c7;
+        asm("v_cvt_rpi_i32_f32 %0, %8\n\tv_cvt_rpi_i32_f32 %1, %9\n\t"
+            "v_cvt_rpi_i32_f32 %2, %10\n\tv_cvt_rpi_i32_f32 %3, %11\n\t"
+            "v_cvt_rpi_i32_f32 %4, %12\n\tv_cvt_rpi_i32_f32 %5, %13\n\t"
+            "v_cvt_rpi_i32_f32 %6, %14\n\tv_cvt_rpi_i32_f32 %7, %15"
+            : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(c4), "=&v"(c5),
+              "=&v"(c6), "=&v"(c7)
+            : "v"(p00 * w0), "v"(p00 * w1), "v"(p01 * w0), "v"(p01 * w1),
+              "v"(p10 * w0), "v"(p10 * w1), "v"(p11 * w0), "v"(p11 * w1));
+#define SARA_DESC_ADD(i, val)                                                  \
+  atomicAdd(&hist[i], (unsigned long long) (long long) (val))
+        SARA_DESC_ADD(ia, c0);
+        SARA_DESC_ADD(ib, c1);
+        SARA_DESC_ADD(ia + dxo, c2);
+        SARA_DESC_ADD(ib + dxo, c3);
+        SARA_DESC_ADD(ia + dyo, c4);
+        SARA_DESC_ADD(ib + dyo, c5);
+        SARA_DESC_ADD(ia + dxo + dyo, c6);
+        SARA_DESC_ADD(ib + dxo + dyo, c7);
+#undef SARA_DESC_ADD
+      };
+
+      SARA_PROF_T(t_trig);
+      SARA_PROF_ADD(1, t_peak, t_trig);
+      for (int vb = v_lo; vb <= v_hi; vb += kDescRowsPerBlock)
       {
-        const int v = vb + sub;
-        const float fv = float(v);
-        float lo = float(u_min), hi = float(u_max);
+        SARA_PROF_T(t_blk);
+        // ---- this lane's row: conservative u-interval inside the window ----
+        const int v = vb + lane;
+        int u_first = 0, len = 0;
+        if (v <= v_hi)
         {
+          const float fv = float(v);
+          float lo = float(u_min), hi = float(u_max);
           const float bx_ = T01 * fv, by_ = T11 * fv;
           if (t00_ok)
           {
@@ -1857,73 +2150,112 @@ namespace sara_hip {
           }
           else if (fabsf(by_) > 2.6f)
             hi = lo - 1.f;
+          u_first = max(int(floorf(lo)), u_min);
+          const int u_last = min(int(ceilf(hi)), u_max);
+          len = max(u_last - u_first + 1, 0);
         }
-        int u = max(int(floorf(lo)), u_min) + l16;
-        int u_end = min(int(ceilf(hi)), u_max);
-        if (v > v_hi)
-          u_end = u - 1;
-        const global_float2_ptr grow = g + size_t(ry + min(v, v_hi)) * w + rx;
-        // one sample of look-ahead: the gather of the next sample is in
-        // flight while this one is accumulated
-        float2 nxt = make_float2(0.f, 0.f);
-        if (u <= u_end)
-          nxt = load_pair(grow, u);
-        for (; __ballot(u <= u_end) != 0ull; u += lanes_per_row)
+        const int nch_row = (len + 15) >> 4;
+        const int max_ch = wave_max_dpp(nch_row);
+
+        for (int ph = 0; ph * kDescChunksPerPhase < max_ch; ++ph)
         {
-          const float2 mo = nxt;
-          if (u + lanes_per_row <= u_end)
-            nxt = load_pair(grow, u + lanes_per_row);
-          if (u > u_end)
-            continue;
-          float px = T00 * float(u) + T01 * fv;
-          float py = T10 * float(u) + T11 * fv;
-          const float nrm2 = px * px + py * py;
-          px += 1.5f;
-          py += 1.5f;
-          if (fminf(px, py) <= -1.f || fmaxf(px, py) >= 4.f)
-            continue;
-          const float weight = __expf(-nrm2 / (2.f * 4.f));
-          const float mag = mo.x;
-          float a = mo.y - theta;
-          a = a < 0.f ? a + 2.f * pi : a;
-          a *= 8.f / (2.f * pi);
-          const float xif = truncf(px), yif = truncf(py), oif = truncf(a);
-          const float xfrac = px - xif, yfrac = py - yif, ofrac = a - oif;
-          const int xi = int(xif), yi = int(yif), oi = int(oif);
-          // xi, yi are in 0..3 here (p in (-1, 4), truncation): the dx/dy = 0
-          // bins always exist, the dx/dy = 1 bins exist when xi/yi < 3.
-          const int o0 = oi & 7, o1 = (oi + 1) & 7;
-          const float wo0 = 1 - ofrac, wo1 = ofrac;
-#pragma unroll
-          for (int dy = 0; dy < 2; ++dy)
+          // ---- chunk list of this (row block, phase) -> LDS -----------------
+          const int c_lo = ph * kDescChunksPerPhase;
+          const int nch = min(max(nch_row - c_lo, 0), kDescChunksPerPhase);
+          const int incl = wave_inclusive_scan(nch);
+          const int C = __builtin_amdgcn_readlane(incl, 63);
+          __builtin_amdgcn_wave_barrier();  // the previous list is consumed
+          for (int c = 0; c < nch; ++c)
           {
-            const float wy = (dy == 0) ? 1 - yfrac : yfrac;
+            const int u0rel = u_first - u_min + 16 * (c_lo + c);
+            const int last = min(15, len - 1 - 16 * (c_lo + c));
+            tab[incl - nch + c] =
+                unsigned(lane) | (unsigned(last) << 6) | (unsigned(u0rel) << 10);
+          }
+          __builtin_amdgcn_wave_barrier();
+          SARA_PROF_T(t_tab);
+          SARA_PROF_ADD(2, t_blk, t_tab);
+
+          // ---- stream the chunks: group g takes chunk 4 * step + g ----------
+          // kDescAhead stages in flight per lane.  A stage holds the chunk
+          // entry it is working on, the gathered pair, and the entry fetched
+          // for its next use; the loop is unrolled over the stages so that
+          // nothing is copied (a copy would wait for the gather).
+          auto fetch = [&](int step) -> unsigned {
+            const int j = 4 * step + grp;
+            return j < C ? tab[j] : 0x3c0u;  // idle: last = 15 never matches
+          };
+          auto gather = [&](int step, unsigned e) -> float2 {
+            const int j = 4 * step + grp;
+            const int last = int((e >> 6) & 15u);
+            const int vv = vb + int(e & 63u);
+            const int uu = u_min + int(e >> 10) + l16;
+            const bool act = (j < C) && (l16 <= last);
+            // Unconditional gather (idle lanes read the keypoint's own pixel):
+            // with the load under a branch the compiler cannot count it and
+            // waits for vmcnt(0), i.e. also for the gathers it has just issued.
+            return load_pair(g, act ? size_t(ry + vv) * w + size_t(rx + uu)
+                                    : center);
+          };
+          const int nsteps = (C + 3) >> 2;
+          unsigned ent[kDescAhead], ent_next[kDescAhead];
+          float2 data[kDescAhead];
 #pragma unroll
-            for (int dx = 0; dx < 2; ++dx)
+          for (int q = 0; q < kDescAhead; ++q)
+          {
+            ent[q] = fetch(q);
+            ent_next[q] = fetch(q + kDescAhead);
+          }
+#pragma unroll
+          for (int q = 0; q < kDescAhead; ++q)
+            data[q] = gather(q, ent[q]);
+          // everything older than these gathers has landed: the compiler's
+          // wait-count bookkeeping enters the loop with exactly kDescAhead
+          // loads pending and can wait for vmcnt(kDescAhead - 1) per step
+          // (without this it drains the queue once per unrolled round)
+          __builtin_amdgcn_s_waitcnt(0x0f70 | (kDescAhead - 1));
+          for (int step0 = 0; step0 < nsteps; step0 += kDescAhead)
+          {
+#pragma unroll
+            for (int q = 0; q < kDescAhead; ++q)
             {
-              const float wx = (dx == 0) ? 1 - xfrac : xfrac;
-              if ((dy == 1 && yi >= 3) || (dx == 1 && xi >= 3))
-                continue;
-              const int sb = (32 * (yi + dy) + 8 * (xi + dx)) * kDescCopies + copy;
-              const float c0 = wy * wx * wo0 * weight * mag;
-              const float c1 = wy * wx * wo1 * weight * mag;
-              atomicAdd(&hist[sb + o0 * kDescCopies],
-                        (unsigned long long) (long long) __float2int_rn(c0 * fx_scale));
-              atomicAdd(&hist[sb + o1 * kDescCopies],
-                        (unsigned long long) (long long) __float2int_rn(c1 * fx_scale));
+              const int step = step0 + q;  // steps >= nsteps find idle entries
+              const unsigned e = ent[q];
+              const int last = int((e >> 6) & 15u);
+              if (4 * step + grp < C && l16 <= last)
+                accumulate(u_min + int(e >> 10) + l16, vb + int(e & 63u), data[q]);
+              ent[q] = ent_next[q];
+              data[q] = gather(step + kDescAhead, ent[q]);
+              ent_next[q] = fetch(step + 2 * kDescAhead);
             }
           }
+          SARA_PROF_T(t_steps);
+          SARA_PROF_ADD(3, t_tab, t_steps);
+#ifdef SARA_DESC_PROF
+          if (lane == 0)
+          {
+            atomicAdd(&g_desc_prof[5], (unsigned long long) nsteps);
+            atomicAdd(&g_desc_prof[6], 1ull);
+          }
+#endif
         }
       }
+      SARA_PROF_T(t_rows);
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
 
       double a0 = 0., a1 = 0.;
-#pragma unroll
-      for (int c = 0; c < kDescCopies; ++c)
       {
-        a0 += double((long long) hist[lane * kDescCopies + c]) * fx_inv;
-        a1 += double((long long) hist[(lane + 64) * kDescCopies + c]) * fx_inv;
+        // bin = (y * 4 + x) * 8 + o of the reference's layout
+        const unsigned long long* q0 =
+            hist + (lane >> 3) * kDescCellStride + (lane & 7) * kDescCopies;
+        const unsigned long long* q1 = q0 + 8 * kDescCellStride;
+#pragma unroll
+        for (int c = 0; c < kDescCopies; ++c)
+        {
+          a0 += double((long long) q0[c]) * fx_inv;
+          a1 += double((long long) q1[c]) * fx_inv;
+        }
       }
       float h0 = float(a0), h1 = float(a1);
       // normalize(): L2, clamp at 0.2, L2; then x512, clamp at 255.
@@ -1959,17 +2291,30 @@ namespace sara_hip {
       descriptors[out * 128 + lane] = h0;
       descriptors[out * 128 + 64 + lane] = h1;
       __builtin_amdgcn_wave_barrier();
+      SARA_PROF_T(t_fin);
+      SARA_PROF_ADD(4, t_rows, t_fin);
     }
+    SARA_PROF_T(t_end);
+    SARA_PROF_ADD(7, t_item, t_end);
     };
-    for (int bx = blockIdx.x; bx < positions; bx += gridDim.x)
+    int bx = blockIdx.x;
+    int lb = bx < positions ? xcd_local_block(bx, b, nblk, xcd_run) : -1;
+    unsigned wv = fetch_item(lb);
+    while (bx < positions)
     {
-      const int lb = xcd_local_block(bx, b, nblk, xcd_run);
+      const int bx_next = bx + gridDim.x;
+      const int lb_next =
+          bx_next < positions ? xcd_local_block(bx_next, b, nblk, xcd_run) : -1;
+      const unsigned wv_next = fetch_item(lb_next);
       if (lb >= 0)
-        item(lb);
+        item(lb, wv);
+      bx = bx_next;
+      lb = lb_next;
+      wv = wv_next;
     }
   }
 
-  void launch_descriptors(const GradPyramidView* grad,
+  void launch_descriptors(const GradPyramidView& grad,
                           const CandidateLists& cand,
                           const OrientationLists& ori, int batch,
                           sara_oeregion* features, int32_t* scale_octave,
@@ -1977,11 +2322,12 @@ namespace sara_hip {
                           int root_sift, hipStream_t stream)
   {
     const int unit = 8 * g_xcd_run;
-    const int needed = unit * (((cand.cap + 3) / 4 + unit - 1) / unit);
+    const int needed =
+        unit * (((cand.cap + kDescWaves - 1) / kDescWaves + unit - 1) / unit);
     const dim3 grid(std::min(needed, unit * g_persist_units), batch);
-    hipLaunchKernelGGL(descriptor_kernel, grid, dim3(256), 0, stream, grad, cand,
+    hipLaunchKernelGGL(descriptor_kernel, grid, dim3(64 * kDescWaves), 0, stream, grad, cand,
                        ori, features, scale_octave, descriptors,
-                       with_descriptors, root_sift, g_xcd_run, g_desc_row_shift);
+                       with_descriptors, root_sift, g_xcd_run);
   }
 
   // ------------------------------------------------------------------------ //
@@ -2050,6 +2396,19 @@ namespace sara_hip {
     for (int i = lane; i < dim; i += 64)
       h[i] = copysignf(sqrtf(fabsf(h[i]) / l1), h[i]);
   }
+
+#ifdef SARA_DESC_PROF
+  extern "C" __attribute__((visibility("default"))) int sara_hip_debug_desc_prof(
+      unsigned long long* out, int reset)
+  {
+    unsigned long long z[8] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_desc_prof), sizeof(z)) != hipSuccess)
+      return -1;
+    if (reset)
+      (void) hipMemcpyToSymbol(HIP_SYMBOL(g_desc_prof), z, sizeof(z));
+    return 0;
+  }
+#endif
 
   void launch_root_sift(float* desc, int n, int dim, hipStream_t stream)
   {

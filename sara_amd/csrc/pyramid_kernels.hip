@@ -263,7 +263,7 @@ namespace sara_hip {
   //! int(x * (w / (w/2))) == 2x for every x < w/2), i.e. the first plane of
   //! the next octave, without a separate pass over HBM.
   template <int R, int PF, bool DEC>
-  __global__ __launch_bounds__(64) void gaussian_blur_march_kernel(
+  __global__ __launch_bounds__(64, R <= 6 ? 4 : 1) void gaussian_blur_march_kernel(
       const float* __restrict__ src, size_t src_stride,
       float* __restrict__ dst, size_t dst_stride, float* __restrict__ dec,
       size_t dec_stride, int w, int h, int seg_rows, int nstrips, int nseg,
@@ -289,7 +289,10 @@ namespace sara_hip {
       dec += b * dec_stride;
     const int dw = w / 2, dh = h / 2;
 
-    const int x0 = strip * W;
+    // the last strip is moved left so that it is full: its first columns are
+    // computed twice (two waves store identical values) instead of leaving
+    // lanes idle and taking the replicated-column path below
+    const int x0 = (w >= W) ? min(strip * W, w - W) : strip * W;
     const int y0 = seg * seg_rows;
     const int y1 = min(h, y0 + seg_rows);
     const int col = x0 + CPL * lane;
@@ -326,9 +329,9 @@ namespace sara_hip {
       for (int i = 0; i < K; ++i)
       {
         const int n = n0 + i;
+        if (n >= T)
+          return;  // wave-uniform: the last round of K steps is rarely full
         const int yy = y0 - R + n;
-        constexpr int dummy = 0;
-        (void) dummy;
         // stage source row n (loaded PF steps ago) and refill its slot
         float* rowbuf = s_row + (n & 1) * ROWF;
         *reinterpret_cast<float4*>(rowbuf + RP + CPL * lane) = pm[i % PF];
@@ -421,7 +424,7 @@ namespace sara_hip {
 #ifndef SARA_MARCH_PF
 #define SARA_MARCH_PF 4
 #endif
-    constexpr int PF = R >= 12 ? 2 : (R >= 10 ? 3 : SARA_MARCH_PF);
+    constexpr int PF = R >= 12 ? 2 : ((R >= 10 || R == 6) ? 3 : SARA_MARCH_PF);
     const int nstrips = (w + W - 1) / W;
     // enough waves to fill 256 CUs x 3-4 waves/SIMD, segments >= 32 rows
     // segments: enough waves to fill the chip, but every segment re-filters
@@ -563,7 +566,7 @@ namespace sara_hip {
     src += b * src_stride;
     dst += b * dst_stride;
 
-    const int x0 = strip * W;
+    const int x0 = (w >= W) ? min(strip * W, w - W) : strip * W;  // see above
     const int y0 = seg * seg_rows;
     const int y1 = min(h, y0 + seg_rows);
     const int col = x0 + CPL * lane;
@@ -608,6 +611,8 @@ namespace sara_hip {
       for (int i = 0; i < K; ++i)
       {
         const int n = n0 + i;
+        if (n >= T)
+          return;  // wave-uniform: the last round of K steps is rarely full
         const int yy = y0 - R + n;
         float* rowbuf = s_row + (n & 1) * ROWF;
         *reinterpret_cast<float2*>(rowbuf + RP + CPL * lane) = pm[i % PF];

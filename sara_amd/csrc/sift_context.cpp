@@ -234,6 +234,7 @@ struct sara_hip_sift
   ScaleTable h_tab{};
   ScaleTable* d_tab = nullptr;
   double* d_oriw = nullptr;
+  int n_oriw = 0;
   GradPyramidView* h_grad = nullptr;  // pinned
   GradPyramidView* d_grad = nullptr;
 
@@ -431,6 +432,7 @@ namespace {
     TRY_HIP(hipMemcpy(c->d_tab, &c->h_tab, sizeof(ScaleTable),
                       hipMemcpyHostToDevice));
     TRY_ST(c->alloc(c->d_oriw, oriw.size()));
+    c->n_oriw = int(oriw.size());
     if (!oriw.empty())
       TRY_HIP(hipMemcpy(c->d_oriw, oriw.data(), sizeof(double) * oriw.size(),
                         hipMemcpyHostToDevice));
@@ -473,6 +475,8 @@ namespace {
     c->ori.kp_count = c->d_counters + 2 * size_t(max_batch);
     c->ori.frame_offset = c->d_counters + 3 * size_t(max_batch);  // max_batch + 1
     TRY_ST(c->alloc(c->cand.order, rows));
+    TRY_ST(c->alloc(c->cand.skey, rows));
+    TRY_ST(c->alloc(c->cand.sdata, rows));
     {
       // one bucket per image row of every plane of the largest schedule
       int total = 0;
@@ -490,6 +494,7 @@ namespace {
     TRY_ST(c->alloc(c->ori.peak_count, rows));
     TRY_ST(c->alloc(c->ori.peak_theta, rows * kMaxPeaks));
     TRY_ST(c->alloc(c->ori.offset, rows));
+    TRY_ST(c->alloc(c->ori.record, rows));
     TRY_ST(c->alloc(c->d_ex_offset, size_t(max_batch) + 1));
     TRY_ST(c->alloc(c->d_feat, rows));
     TRY_ST(c->alloc(c->d_so, rows * 2));
@@ -1082,15 +1087,15 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   // ---- orientations -------------------------------------------------------
   if (last_stage >= SARA_HIP_STAGE_ORIENTATION)
   {
-    launch_orientations(c->d_grad, c->d_tab, c->d_oriw, c->cand, c->ori, batch,
-                        stream);
+    launch_orientations(c->d_grad, c->d_tab, c->d_oriw, c->n_oriw, c->cand,
+                        c->ori, batch, stream);
     launch_scan_peaks(c->cand, c->ori, batch, stream);
   }
   HIP_TRY(mark(5));
 
   // ---- descriptors --------------------------------------------------------
   if (last_stage >= SARA_HIP_STAGE_ORIENTATION)
-    launch_descriptors(c->d_grad, c->cand, c->ori, batch, c->d_feat, c->d_so,
+    launch_descriptors(*c->h_grad, c->cand, c->ori, batch, c->d_feat, c->d_so,
                        c->d_desc, last_stage >= SARA_HIP_STAGE_DESCRIPTOR ? 1 : 0,
                        c->root_sift ? 1 : 0, stream);
   HIP_TRY(mark(6));
@@ -1899,6 +1904,18 @@ void sara_hip_selfcheck_atan2f(const float* y, const float* x, float* out,
     const bool same = std::memcmp(&a, &b, sizeof(float)) == 0 &&
                       std::memcmp(&a, &c, sizeof(float)) == 0;
     out[i] = same ? a : std::nanf("");
+  }
+}
+
+void sara_hip_selfcheck_sincos(const float* theta, float* out_sin, float* out_cos,
+                               size_t count)
+{
+  for (size_t i = 0; i < count; ++i)
+  {
+    double s, c;
+    sara_hip::sincos_reduced_f64(double(theta[i]), s, c);
+    out_sin[i] = float(s);
+    out_cos[i] = float(c);
   }
 }
 

@@ -61,8 +61,25 @@ namespace sara_hip {
     float4* data;            // [frame][cap]  (x, y, sigma, value) refined
     int* count;              // [frame]       number appended (may exceed cap)
     int* order;              // [frame][cap]  slot of the rank-th candidate
+    // copies in rank (= reference) order, written with `order`: the
+    // per-keypoint kernels read them without the indirection
+    unsigned long long* skey;  // [frame][cap]
+    float4* sdata;             // [frame][cap]
     int cap;
   };
+
+  //! Everything the descriptor kernel needs to know about one extremum, in
+  //! rank order, written by the orientation kernel: one 64-byte load instead
+  //! of a chain of dependent ones (count -> slot -> key / data -> angles).
+  struct alignas(16) KeypointRecord
+  {
+    float4 d;                // (x, y, sigma, value), octave coordinates
+    unsigned long long key;  // (octave, scale, y, x | type)
+    int npeaks;
+    int reserved;
+    float theta[8];          // first 8 peak angles (the rest: peak_theta)
+  };
+  static_assert(sizeof(KeypointRecord) == 64, "record layout");
 
   //! Buckets of the counting sort that orders a frame's extrema: one per image
   //! row of every (octave, scale) plane.  base[o * kMaxScales + s] = first
@@ -103,6 +120,7 @@ namespace sara_hip {
     int* offset;       // [frame][cap] exclusive prefix of peak_count
     int* kp_count;     // [frame] keypoints of the frame (may exceed cap)
     int* frame_offset; // [batch+1] exclusive prefix of min(kp_count, cap)
+    KeypointRecord* record;  // [frame][cap]
   };
 
   inline unsigned long long make_key(int o, int s, int y, int x, int is_max)
@@ -216,7 +234,7 @@ namespace sara_hip {
   //! grad / tab are device pointers (indexed per wave, so they live in HBM
   //! rather than in the kernel argument segment).
   void launch_orientations(const GradPyramidView* grad, const ScaleTable* tab,
-                           const double* ori_weights,
+                           const double* ori_weights, int n_weights,
                            const CandidateLists& cand,
                            const OrientationLists& ori, int batch,
                            hipStream_t stream);
@@ -225,7 +243,7 @@ namespace sara_hip {
   void launch_scan_peaks(const CandidateLists& cand, const OrientationLists& ori,
                          int batch, hipStream_t stream);
 
-  void launch_descriptors(const GradPyramidView* grad,
+  void launch_descriptors(const GradPyramidView& grad,
                           const CandidateLists& cand,
                           const OrientationLists& ori, int batch,
                           sara_oeregion* features, int32_t* scale_octave,

@@ -1,16 +1,28 @@
 #!/bin/bash
 # Build a variant of the library for A/B timing on one GPU box:
-#   tools/ab_build.sh <name> "<extra hipcc flags>"  ->  sara_amd/lib/ab/lib_<name>.so
+#   tools/ab_build.sh <name> "<extra hipcc flags>" [file.hip ...]
+#     -> sara_amd/lib/ab/lib_<name>.so
 # then  SARA_HIP_SIFT_LIB=sara_amd/lib/ab/lib_<name>.so python bench.py ...
+# Only the listed sources are recompiled with the extra flags (default: all);
+# the other objects come from the regular build (run `make` first).
 set -e
 cd "$(dirname "$0")/../sara_amd/csrc"
-name=$1; shift
-flags="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -fvisibility=hidden $*"
+name=$1; extra=$2; shift; shift
+files="$*"
+[ -z "$files" ] && files="pyramid_kernels.hip feature_kernels.hip match_kernels.hip sift_context.cpp"
+flags="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -fvisibility=hidden $extra"
 mkdir -p ../lib/ab /tmp/ab_$name
-for f in pyramid_kernels.hip feature_kernels.hip match_kernels.hip; do
-  /opt/rocm/bin/hipcc $flags -c -o /tmp/ab_$name/${f%.hip}.o $f &
+objs=""
+for f in pyramid_kernels.hip feature_kernels.hip match_kernels.hip sift_context.cpp; do
+  o=${f%.*}.o
+  if echo " $files " | grep -q " $f "; then
+    x=""; [ "$f" = match_kernels.hip ] && x="-fno-slp-vectorize"
+    /opt/rocm/bin/hipcc $flags $x -c -o /tmp/ab_$name/$o $f &
+    objs="$objs /tmp/ab_$name/$o"
+  else
+    objs="$objs $o"
+  fi
 done
-/opt/rocm/bin/hipcc $flags -c -o /tmp/ab_$name/sift_context.o sift_context.cpp &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/ab/lib_$name.so /tmp/ab_$name/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/ab/lib_$name.so $objs
 echo built sara_amd/lib/ab/lib_$name.so
