@@ -30,6 +30,7 @@
 #  include <sara_keypoint_h5.h>
 #endif
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -42,6 +43,7 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 #ifdef SARA_HIP_WITH_SARA_HEADERS
@@ -456,6 +458,56 @@ namespace DO::Sara {
     };
     using Context = std::unique_ptr<sara_hip_sift, Deleter>;
 
+    //! compute_sift_keypoints() is a free function that callers invoke once
+    //! per video frame (OdometryPipeline::detect_keypoints,
+    //! SfM/Odometry/OdometryPipeline.cpp:82-90).  Creating a context costs tens
+    //! of milliseconds (pyramid, gradient and list buffers in HBM) against
+    //! less than one for the detection itself, so every thread keeps the few
+    //! contexts it used last, keyed by everything a context is built from.
+    struct ContextKey
+    {
+      sara_sift_params params;
+      int width, height, device;
+      bool operator==(const ContextKey& o) const
+      {
+        // field-wise: the C struct may have padding
+        const sara_pyramid_params &a = params.pyramid, &b = o.params.pyramid;
+        return a.first_octave_index == b.first_octave_index &&
+               a.scale_count_per_octave == b.scale_count_per_octave &&
+               a.scale_geometric_factor == b.scale_geometric_factor &&
+               a.image_padding_size == b.image_padding_size &&
+               a.scale_camera == b.scale_camera &&
+               a.scale_initial == b.scale_initial &&
+               a.num_octaves_max == b.num_octaves_max &&
+               params.gauss_truncate == o.params.gauss_truncate &&
+               params.extremum_thres == o.params.extremum_thres &&
+               params.edge_ratio_thres == o.params.edge_ratio_thres &&
+               params.extremum_refinement_iter ==
+                   o.params.extremum_refinement_iter &&
+               width == o.width && height == o.height && device == o.device;
+      }
+    };
+
+    inline sara_hip_sift* cached_context(const ContextKey& key)
+    {
+      constexpr std::size_t kMaxCached = 4;
+      thread_local std::vector<std::pair<ContextKey, Context>> cache;
+      for (std::size_t i = 0; i < cache.size(); ++i)
+        if (cache[i].first == key)
+        {
+          if (i != 0)
+            std::rotate(cache.begin(), cache.begin() + i, cache.begin() + i + 1);
+          return cache.front().second.get();
+        }
+      sara_hip_sift* raw = nullptr;
+      check(sara_hip_sift_create(&key.params, key.width, key.height, 1, 0,
+                                 key.device, &raw));
+      if (cache.size() >= kMaxCached)
+        cache.pop_back();
+      cache.emplace(cache.begin(), key, Context{raw});
+      return raw;
+    }
+
   }  // namespace hip_detail
 
   static_assert(sizeof(Rgb8) == 3, "Rgb8 must be three packed bytes");
@@ -489,22 +541,29 @@ namespace DO::Sara {
     p.extremum_thres = extremum_thres;
     p.edge_ratio_thres = edge_ratio_thres;
     p.extremum_refinement_iter = extremum_refinement_iter;
-    sara_hip_sift* raw = nullptr;
-    hip_detail::check(sara_hip_sift_create(&p, image.width(), image.height(), 1,
-                                           0, device, &raw));
-    hip_detail::Context ctx{raw};
-    hip_detail::check(sara_hip_sift_detect(ctx.get(), image.data(), 0, 1,
+    // the context (and all its HBM buffers) is reused across calls
+    sara_hip_sift* ctx = hip_detail::cached_context(
+        hip_detail::ContextKey{p, image.width(), image.height(), device});
+    // submit / collect: upload, kernels, and the read-back into pinned memory
+    // owned by the context; one copy from there into the returned containers
+    int ticket = -1;
+    hip_detail::check(sara_hip_sift_submit(ctx, image.data(), 0, 0, 1,
                                            image.width(), image.height(), 0,
-                                           SARA_HIP_STAGE_DESCRIPTOR, nullptr));
+                                           SARA_HIP_STAGE_DESCRIPTOR, &ticket));
+    const sara_oeregion* f = nullptr;
+    const float* d = nullptr;
     int total = 0;
-    hip_detail::check(sara_hip_sift_counts(ctx.get(), nullptr, &total));
+    hip_detail::check(
+        sara_hip_sift_collect(ctx, ticket, &f, &d, nullptr, nullptr, &total));
     auto feats = std::vector<OERegion>(size_t(total));
     auto desc = Tensor_<float, 2>{};
     desc.resize(total, 128);
     if (total > 0)
-      hip_detail::check(sara_hip_sift_fetch(
-          ctx.get(), reinterpret_cast<sara_oeregion*>(feats.data()),
-          desc.data(), nullptr, 0));
+    {
+      std::memcpy(static_cast<void*>(feats.data()), f,
+                  sizeof(sara_oeregion) * size_t(total));
+      std::memcpy(desc.data(), d, sizeof(float) * 128 * size_t(total));
+    }
     return {std::move(feats), std::move(desc)};
   }
 

@@ -417,6 +417,31 @@ SARA_HIP_API sara_hip_status sara_hip_match_descriptors(
     float sift_ratio_thres, int on_device, sara_match* matches, int capacity,
     int* count, int device);
 
+/* -------------------------------------------------------------------------- */
+/* Pipelined host-to-host operation (the metric of SURVEY.md section 8d: frames */
+/* in host memory -> OERegion[] + descriptors in host memory, as               */
+/* compute_sift_keypoints returns them, FeatureDetectors/SIFT.cpp:27-33,107).   */
+/* Up to two batches are in flight: submit(i + 1) may be called before          */
+/* collect(i); the upload of batch i + 1 (copy stream), its kernels and the     */
+/* read-back of batch i (a third stream) then overlap.                          */
+/*   channels: 0 = float32 gray frames (frame_stride in floats), 1 = gray8,     */
+/*             3 = interleaved RGB8 (frame_stride in bytes); 0 -> densely packed*/
+/* collect() blocks until the batch of `ticket` is in pinned host memory owned  */
+/* by the context and returns pointers into it; they stay valid until the       */
+/* second submit() after this ticket's.  frame_offsets has batch + 1 entries    */
+/* (frame b = [frame_offsets[b], frame_offsets[b + 1])).  Pass descriptors =    */
+/* NULL to skip their read-back.  SARA_HIP_CAPACITY_EXCEEDED is reported by     */
+/* collect() (the truncated lists are still delivered).                         */
+/* -------------------------------------------------------------------------- */
+SARA_HIP_API sara_hip_status sara_hip_sift_submit(
+    sara_hip_sift* ctx, const void* images, size_t frame_stride, int channels,
+    int batch, int width, int height, int images_on_device,
+    sara_hip_stage last_stage, int* ticket);
+SARA_HIP_API sara_hip_status sara_hip_sift_collect(
+    sara_hip_sift* ctx, int ticket, const sara_oeregion** features,
+    const float** descriptors, const int32_t** scale_octave,
+    const int32_t** frame_offsets, int* total);
+
 /* Host self-check: evaluates, on the CPU, the float atan2 sequence the polar-  */
 /* gradient kernels execute on the GPU (a restatement of glibc 2.35's          */
 /* atan2f), so that tests can prove it bit-identical to the host libm the CPU  */

@@ -260,6 +260,75 @@ class SiftContext:
     def synchronize(self):
         capi.check(capi.load().sara_hip_sift_synchronize(self._h))
 
+    # -- pipelined host-to-host operation ------------------------------------- #
+    def submit(self, images, last_stage=STAGE_DESCRIPTOR):
+        """Enqueue one batch (float32 B x H x W, uint8 B x H x W, or uint8 B x H
+        x W x 3, host arrays) and return its ticket at once.  Up to two batches
+        may be in flight: call submit(i + 1) before collect(i) to overlap the
+        upload and kernels of one batch with the read-back of the other."""
+        a = np.ascontiguousarray(images)
+        if a.dtype == np.uint8:
+            if a.ndim == 2 or (a.ndim == 3 and a.shape[-1] == 3):
+                a = a[None]
+            channels = 3 if a.ndim == 4 else 1
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            if a.ndim == 2:
+                a = a[None]
+            channels = 0
+        b, h, w = a.shape[:3]
+        ticket = C.c_int(-1)
+        capi.check(capi.load().sara_hip_sift_submit(
+            self._h, a.ctypes.data, 0, channels, b, w, h, 0, int(last_stage),
+            C.byref(ticket)))
+        self._inflight = getattr(self, "_inflight", {})
+        self._inflight[ticket.value] = (a, b)
+        return ticket.value
+
+    def submit_device(self, ptr, batch, width, height, channels=0,
+                      frame_stride=0, last_stage=STAGE_DESCRIPTOR):
+        """submit() for frames already resident in HBM (raw device pointer)."""
+        ticket = C.c_int(-1)
+        capi.check(capi.load().sara_hip_sift_submit(
+            self._h, ptr, frame_stride, channels, batch, width, height, 1,
+            int(last_stage), C.byref(ticket)))
+        self._inflight = getattr(self, "_inflight", {})
+        self._inflight[ticket.value] = (None, batch)
+        return ticket.value
+
+    def collect(self, ticket, with_descriptors=True, copy=False):
+        """-> (frame_offsets[B+1], regions[N], descriptors[N,128] or None,
+        scale_octave[N,2]) of the batch of ``ticket``: views of pinned host
+        memory owned by the context (valid until the second submit() after
+        this ticket's) unless ``copy``."""
+        _, batch = getattr(self, "_inflight", {}).pop(ticket, (None, 0))
+        f, d, s, o = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        total = C.c_int(0)
+        st = capi.load().sara_hip_sift_collect(
+            self._h, ticket, C.byref(f),
+            C.byref(d) if with_descriptors else None, C.byref(s), C.byref(o),
+            C.byref(total))
+        capi.check(st)
+        n = total.value
+
+        def view(ptr, count, dtype, shape):
+            if count == 0 or not ptr.value:
+                return np.zeros(shape, dtype)
+            nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            buf = (C.c_char * nbytes).from_address(ptr.value)
+            raw = np.frombuffer(buf, dtype=np.uint8)
+            if copy:
+                # byte-wise: a field-wise copy of the padded OERegion dtype
+                # would leave the padding bytes undefined
+                raw = raw.copy()
+            return raw.view(dtype).reshape(shape)
+
+        offsets = view(o, batch + 1, np.int32, (batch + 1,))
+        regions = view(f, n, OEREGION_DTYPE, (n,))
+        so = view(s, n, np.int32, (n, 2))
+        desc = view(d, n, np.float32, (n, 128)) if with_descriptors else None
+        return offsets, regions, desc, so
+
     def counts(self):
         c = np.zeros(self.batch, np.int32)
         tot = C.c_int32()
@@ -374,11 +443,46 @@ def compute_sift_keypoints(image, pyramid_params=None, gauss_truncate=4.0,
         raise ValueError("image must be a 2-D float32 array")
     h, w = img.shape
     params = pyramid_params or ImagePyramidParams()
-    with SiftContext(w, h, 1, params, gauss_truncate, extremum_thres,
-                     edge_ratio_thres, extremum_refinement_iter,
-                     device=device) as ctx:
-        ctx.detect(img)
-        return ctx.keypoint_lists()[0]
+    ctx = _cached_context(w, h, params, gauss_truncate, extremum_thres,
+                          edge_ratio_thres, extremum_refinement_iter, device)
+    ticket = ctx.submit(img)
+    _, regions, desc, so = ctx.collect(ticket, copy=True)
+    return KeypointList(regions, desc, so)
+
+
+#: contexts of compute_sift_keypoints(), most recently used first.  Creating a
+#: context allocates the pyramid / gradient / list buffers in HBM (tens of
+#: milliseconds); a detection takes less than one.
+_CONTEXT_CACHE = []
+_CONTEXT_CACHE_MAX = 4
+
+
+def _cached_context(w, h, params, gauss_truncate, extremum_thres,
+                    edge_ratio_thres, extremum_refinement_iter, device):
+    import threading
+    s = params._s
+    key = (threading.get_ident(), w, h, device, s.first_octave_index,
+           s.scale_count_per_octave, s.scale_geometric_factor,
+           s.image_padding_size, s.scale_camera, s.scale_initial,
+           s.num_octaves_max, float(gauss_truncate), float(extremum_thres),
+           float(edge_ratio_thres), int(extremum_refinement_iter))
+    for i, (k, ctx) in enumerate(_CONTEXT_CACHE):
+        if k == key:
+            if i:
+                _CONTEXT_CACHE.insert(0, _CONTEXT_CACHE.pop(i))
+            return ctx
+    ctx = SiftContext(w, h, 1, params, gauss_truncate, extremum_thres,
+                      edge_ratio_thres, extremum_refinement_iter, device=device)
+    _CONTEXT_CACHE.insert(0, (key, ctx))
+    while len(_CONTEXT_CACHE) > _CONTEXT_CACHE_MAX:
+        _CONTEXT_CACHE.pop()[1].close()
+    return ctx
+
+
+def clear_context_cache():
+    """Release the contexts compute_sift_keypoints() keeps."""
+    while _CONTEXT_CACHE:
+        _CONTEXT_CACHE.pop()[1].close()
 
 
 class ComputeDoGExtrema:

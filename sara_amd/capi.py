@@ -87,6 +87,7 @@ EXPORTS = [
     "sara_hip_from_gray8_to_gray32f", "sara_hip_match_descriptors",
     "sara_hip_sift_stage", "sara_hip_sift_detect_staged", "sara_hip_root_sift",
     "sara_hip_selfcheck_device_math", "sara_hip_selfcheck_sincos",
+    "sara_hip_sift_submit", "sara_hip_sift_collect",
 ]
 
 _f32p = C.POINTER(C.c_float)
@@ -173,6 +174,12 @@ def _declare(lib):
     lib.sara_hip_selfcheck_atan2f.restype = None
     lib.sara_hip_selfcheck_device_math.argtypes = [
         C.POINTER(C.c_ulonglong), C.c_int]
+    lib.sara_hip_sift_submit.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(C.c_int)]
+    lib.sara_hip_sift_collect.argtypes = [_vp, C.c_int, C.POINTER(_vp),
+                                          C.POINTER(_vp), C.POINTER(_vp),
+                                          C.POINTER(_vp), C.POINTER(C.c_int)]
     lib.sara_hip_selfcheck_sincos.argtypes = [_f32p, _f32p, _f32p, C.c_size_t]
     lib.sara_hip_selfcheck_sincos.restype = None
     return lib

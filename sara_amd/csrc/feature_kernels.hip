@@ -2017,24 +2017,17 @@ namespace sara_hip {
 
       if (lane == 0)
       {
-        sara_oeregion f;
-        f.coords[0] = d.x * factor;
-        f.coords[1] = d.y * factor;
-        f._pad0[0] = f._pad0[1] = 0.f;
+        // the 48 bytes of sara_oeregion as three 16-byte stores: every byte
+        // (padding included) is written, so the records are reproducible
+        // whatever the buffer held before
         const float f2 = factor * factor;
-        f.shape_matrix[0] = shape / f2;
-        f.shape_matrix[1] = 0.f / f2;
-        f.shape_matrix[2] = 0.f / f2;
-        f.shape_matrix[3] = shape / f2;
-        f.orientation = theta;
-        f.extremum_value = d.w;
-        f.type = 11;
-        f.extremum_type = is_max ? 1 : -1;
-        for (int q = 0; q < 6; ++q)
-          f._pad1[q] = 0;
-        features[out] = f;
-        scale_octave[2 * out + 0] = s;
-        scale_octave[2 * out + 1] = o;
+        float4* rec = reinterpret_cast<float4*>(features + out);
+        rec[0] = make_float4(d.x * factor, d.y * factor, 0.f, 0.f);
+        rec[1] = make_float4(shape / f2, 0.f / f2, 0.f / f2, shape / f2);
+        // type = 11 (uint8 @40), extremum_type = +1 / -1 (int8 @41), padding
+        const unsigned tail = 11u | ((is_max ? 0x01u : 0xffu) << 8);
+        rec[2] = make_float4(theta, d.w, __uint_as_float(tail), 0.f);
+        *reinterpret_cast<int2*>(scale_octave + 2 * out) = make_int2(s, o);
       }
       if (!with_descriptors)
         continue;

@@ -242,9 +242,31 @@ struct sara_hip_sift
   SiteLists sites{};
   OrientationLists ori{};
   int* d_ex_offset = nullptr;
+  // Result buffers of the current detect().  detect()/fetch() always use slot
+  // 0; the pipelined submit()/collect() pair alternates between two slots so
+  // that batch i can be copied out while batch i + 1 is computed (slot 1 is
+  // allocated on the first submit()).
   sara_oeregion* d_feat = nullptr;
   int32_t* d_so = nullptr;
   float* d_desc = nullptr;
+  sara_oeregion* d_feat_s[2] = {nullptr, nullptr};
+  int32_t* d_so_s[2] = {nullptr, nullptr};
+  float* d_desc_s[2] = {nullptr, nullptr};
+  int write_slot = 0;
+  struct RingSlot
+  {
+    int ticket = -1;
+    bool pending = false;
+    int batch = 0;
+    hipEvent_t done = nullptr;   // counters of the batch are in h_counters
+    int* h_counters = nullptr;   // pinned copy of d_counters (4 * max_batch + 1)
+    sara_oeregion* h_feat = nullptr;  // pinned result arrays, grown on demand
+    float* h_desc = nullptr;
+    int32_t* h_so = nullptr;
+    size_t h_cap = 0;            // keypoints the pinned arrays hold
+  } ring[2];
+  hipStream_t d2h_stream = nullptr;
+  int next_ticket = 0;
   sara_oeregion* d_ex_regions = nullptr;
   int32_t* d_ex_xyso = nullptr;
 
@@ -262,9 +284,12 @@ struct sara_hip_sift
   // SARA_HIP_GRAPH_MAX_BATCH, default 8, bounds the batch sizes that use it).
   bool use_graph = true;
   int graph_max_batch = 8;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
-  int graph_w = 0, graph_h = 0, graph_batch = 0, graph_stage = -1;
+  // one captured graph per result slot (the result pointers are kernel
+  // arguments baked into the capture)
+  hipGraph_t graph_s[2] = {nullptr, nullptr};
+  hipGraphExec_t graph_exec_s[2] = {nullptr, nullptr};
+  int graph_w_s[2] = {0, 0}, graph_h_s[2] = {0, 0}, graph_batch_s[2] = {0, 0},
+      graph_stage_s[2] = {-1, -1};
   bool graph_broken = false;  // a capture failed once: stay on plain launches
   hipEvent_t ev[SARA_HIP_TIME_COUNT + 1] = {};
   bool ev_recorded[SARA_HIP_TIME_COUNT + 1] = {};
@@ -496,9 +521,12 @@ namespace {
     TRY_ST(c->alloc(c->ori.offset, rows));
     TRY_ST(c->alloc(c->ori.record, rows));
     TRY_ST(c->alloc(c->d_ex_offset, size_t(max_batch) + 1));
-    TRY_ST(c->alloc(c->d_feat, rows));
-    TRY_ST(c->alloc(c->d_so, rows * 2));
-    TRY_ST(c->alloc(c->d_desc, rows * 128));
+    TRY_ST(c->alloc(c->d_feat_s[0], rows));
+    TRY_ST(c->alloc(c->d_so_s[0], rows * 2));
+    TRY_ST(c->alloc(c->d_desc_s[0], rows * 128));
+    c->d_feat = c->d_feat_s[0];
+    c->d_so = c->d_so_s[0];
+    c->d_desc = c->d_desc_s[0];
     TRY_ST(c->alloc(c->d_ex_regions, rows));
     TRY_ST(c->alloc(c->d_ex_xyso, rows * 5));
 #undef TRY_ST
@@ -702,10 +730,29 @@ sara_hip_status sara_hip_sift_destroy(sara_hip_sift* c)
     (void) hipStreamSynchronize(c->copy_stream);
     (void) hipStreamDestroy(c->copy_stream);
   }
-  if (c->graph_exec)
-    (void) hipGraphExecDestroy(c->graph_exec);
-  if (c->graph)
-    (void) hipGraphDestroy(c->graph);
+  for (int k = 0; k < 2; ++k)
+  {
+    if (c->graph_exec_s[k])
+      (void) hipGraphExecDestroy(c->graph_exec_s[k]);
+    if (c->graph_s[k])
+      (void) hipGraphDestroy(c->graph_s[k]);
+    sara_hip_sift::RingSlot& r = c->ring[k];
+    if (r.done)
+      (void) hipEventDestroy(r.done);
+    if (r.h_counters)
+      (void) hipHostFree(r.h_counters);
+    if (r.h_feat)
+      (void) hipHostFree(r.h_feat);
+    if (r.h_desc)
+      (void) hipHostFree(r.h_desc);
+    if (r.h_so)
+      (void) hipHostFree(r.h_so);
+  }
+  if (c->d2h_stream)
+  {
+    (void) hipStreamSynchronize(c->d2h_stream);
+    (void) hipStreamDestroy(c->d2h_stream);
+  }
   if (c->aux_stream)
   {
     (void) hipStreamSynchronize(c->aux_stream);
@@ -729,18 +776,18 @@ sara_hip_status sara_hip_sift_set_option(sara_hip_sift* c, int option, int value
   {
   case SARA_HIP_OPT_ALL_GRADIENT_SCALES:
     c->all_gradient_scales = value != 0;
-    c->graph_stage = -1;  // the captured launch sequence depends on it
+    c->graph_stage_s[0] = c->graph_stage_s[1] = -1;  // the captured launch sequence depends on it
     return SARA_HIP_OK;
   case SARA_HIP_OPT_STAGE_TIMERS:
     c->timers = value != 0;
     return SARA_HIP_OK;
   case SARA_HIP_OPT_ROOT_SIFT:
     c->root_sift = value != 0;
-    c->graph_stage = -1;
+    c->graph_stage_s[0] = c->graph_stage_s[1] = -1;
     return SARA_HIP_OK;
   case SARA_HIP_OPT_SIGNED_EXTREMUM_TYPE:
     c->signed_type = value != 0;
-    c->graph_stage = -1;
+    c->graph_stage_s[0] = c->graph_stage_s[1] = -1;
     return SARA_HIP_OK;
   case SARA_HIP_OPT_DOWNSCALE_AT_DOUBLE_SIGMA:
   {
@@ -753,7 +800,7 @@ sara_hip_status sara_hip_sift_set_option(sara_hip_sift* c, int option, int value
       HIP_TRY(hipStreamSynchronize(c->last_stream));
     c->downscale_at_double_sigma = on;
     c->cur_w = c->cur_h = -1;  // rebuild the schedule on the next detect
-    c->graph_stage = -1;
+    c->graph_stage_s[0] = c->graph_stage_s[1] = -1;
     return SARA_HIP_OK;
   }
   default:
@@ -1111,36 +1158,40 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     c->has_result = true;
     return SARA_HIP_OK;
   }
-  const bool cached = c->graph_exec && c->graph_w == width &&
-                      c->graph_h == height && c->graph_batch == batch &&
-                      c->graph_stage == int(last_stage);
+  const int gs = c->write_slot;
+  hipGraph_t& graph = c->graph_s[gs];
+  hipGraphExec_t& graph_exec = c->graph_exec_s[gs];
+  const bool cached = graph_exec && c->graph_w_s[gs] == width &&
+                      c->graph_h_s[gs] == height &&
+                      c->graph_batch_s[gs] == batch &&
+                      c->graph_stage_s[gs] == int(last_stage);
   if (!cached)
   {
-    if (c->graph_exec)
-      (void) hipGraphExecDestroy(c->graph_exec);
-    if (c->graph)
-      (void) hipGraphDestroy(c->graph);
-    c->graph_exec = nullptr;
-    c->graph = nullptr;
+    if (graph_exec)
+      (void) hipGraphExecDestroy(graph_exec);
+    if (graph)
+      (void) hipGraphDestroy(graph);
+    graph_exec = nullptr;
+    graph = nullptr;
     bool ok = hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed) ==
               hipSuccess;
     if (ok)
     {
       const sara_hip_status est = enqueue();
-      const hipError_t ee = hipStreamEndCapture(stream, &c->graph);
-      ok = est == SARA_HIP_OK && ee == hipSuccess && c->graph != nullptr;
+      const hipError_t ee = hipStreamEndCapture(stream, &graph);
+      ok = est == SARA_HIP_OK && ee == hipSuccess && graph != nullptr;
     }
     if (ok)
-      ok = hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0) ==
+      ok = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0) ==
            hipSuccess;
     if (!ok)
     {
       // fall back to plain launches for good; clear the sticky error
       (void) hipGetLastError();
-      if (c->graph)
-        (void) hipGraphDestroy(c->graph);
-      c->graph = nullptr;
-      c->graph_exec = nullptr;
+      if (graph)
+        (void) hipGraphDestroy(graph);
+      graph = nullptr;
+      graph_exec = nullptr;
       c->graph_broken = true;
       const sara_hip_status est = enqueue();
       if (est != SARA_HIP_OK)
@@ -1148,12 +1199,12 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       c->has_result = true;
       return SARA_HIP_OK;
     }
-    c->graph_w = width;
-    c->graph_h = height;
-    c->graph_batch = batch;
-    c->graph_stage = int(last_stage);
+    c->graph_w_s[gs] = width;
+    c->graph_h_s[gs] = height;
+    c->graph_batch_s[gs] = batch;
+    c->graph_stage_s[gs] = int(last_stage);
   }
-  HIP_TRY(hipGraphLaunch(c->graph_exec, stream));
+  HIP_TRY(hipGraphLaunch(graph_exec, stream));
   if (c->timers)
   {
     c->ev_recorded[SARA_HIP_TIME_TOTAL] = true;
@@ -1304,6 +1355,166 @@ sara_hip_status sara_hip_sift_detect_staged(sara_hip_sift* c,
   HIP_TRY(hipEventRecord(c->stage_free[k], stream));
   c->stage_used[k] = true;
   return SARA_HIP_OK;
+}
+
+namespace {
+  //! Points the pipeline's outputs at result slot `slot` (allocating slot 1 on
+  //! first use).
+  sara_hip_status select_result_slot(sara_hip_sift* c, int slot)
+  {
+    if (!c->d_feat_s[slot])
+    {
+      const size_t rows = size_t(c->max_batch) * c->cap;
+      sara_hip_status st = c->alloc(c->d_feat_s[slot], rows);
+      if (st == SARA_HIP_OK)
+        st = c->alloc(c->d_so_s[slot], rows * 2);
+      if (st == SARA_HIP_OK)
+        st = c->alloc(c->d_desc_s[slot], rows * 128);
+      if (st != SARA_HIP_OK)
+        return st;
+    }
+    c->write_slot = slot;
+    c->d_feat = c->d_feat_s[slot];
+    c->d_so = c->d_so_s[slot];
+    c->d_desc = c->d_desc_s[slot];
+    return SARA_HIP_OK;
+  }
+}  // namespace
+
+sara_hip_status sara_hip_sift_submit(sara_hip_sift* c, const void* images,
+                                     size_t frame_stride, int channels,
+                                     int batch, int width, int height,
+                                     int images_on_device,
+                                     sara_hip_stage last_stage, int* ticket)
+{
+  if (!c || !images || !ticket)
+    return fail(SARA_HIP_INVALID_PARAMS, "null context, images or ticket");
+  if (last_stage < SARA_HIP_STAGE_ORIENTATION)
+    return fail(SARA_HIP_INVALID_PARAMS,
+                "submit() delivers keypoints: last_stage must be >= ORIENTATION");
+  if (channels != 0 && channels != 1 && channels != 3)
+    return fail(SARA_HIP_INVALID_PARAMS,
+                "channels must be 0 (float), 1 (gray8) or 3 (RGB8)");
+  HIP_TRY(hipSetDevice(c->device));
+  const int slot = c->next_ticket & 1;
+  sara_hip_sift::RingSlot& r = c->ring[slot];
+  if (r.pending)
+    return fail(SARA_HIP_NOT_READY,
+                "two batches are in flight: collect() the older ticket first");
+  if (!r.done)
+  {
+    HIP_TRY(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r.h_counters),
+                          sizeof(int) * (4 * size_t(c->max_batch) + 1)));
+  }
+  if (!c->d2h_stream)
+    HIP_TRY(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+  sara_hip_status st = select_result_slot(c, slot);
+  if (st != SARA_HIP_OK)
+    return st;
+  if (!images_on_device)
+  {
+    // upload on the copy stream (double-buffered staging), then the pipeline
+    st = sara_hip_sift_stage(c, images, frame_stride, channels, batch, width,
+                             height);
+    if (st == SARA_HIP_OK)
+      st = sara_hip_sift_detect_staged(c, last_stage, nullptr);
+  }
+  else if (channels == 0)
+    st = sara_hip_sift_detect(c, static_cast<const float*>(images), frame_stride,
+                              batch, width, height, 1, last_stage, nullptr);
+  else
+    st = sara_hip_sift_detect_u8(c, static_cast<const uint8_t*>(images),
+                                 frame_stride, channels, batch, width, height, 1,
+                                 last_stage, nullptr);
+  if (st != SARA_HIP_OK)
+    return st;
+  // the counters of this batch travel to pinned memory in stream order: the
+  // next batch may reset them before collect() looks
+  HIP_TRY(hipMemcpyAsync(r.h_counters, c->d_counters,
+                         sizeof(int) * (4 * size_t(c->max_batch) + 1),
+                         hipMemcpyDeviceToHost, c->last_stream));
+  HIP_TRY(hipEventRecord(r.done, c->last_stream));
+  r.ticket = c->next_ticket;
+  r.pending = true;
+  r.batch = batch;
+  *ticket = c->next_ticket++;
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_sift_collect(sara_hip_sift* c, int ticket,
+                                      const sara_oeregion** features,
+                                      const float** descriptors,
+                                      const int32_t** scale_octave,
+                                      const int32_t** frame_offsets, int* total)
+{
+  if (!c)
+    return fail(SARA_HIP_INVALID_PARAMS, "null context");
+  sara_hip_sift::RingSlot& r = c->ring[ticket & 1];
+  if (ticket < 0 || !r.pending || r.ticket != ticket)
+    return fail(SARA_HIP_NOT_READY, "unknown or already collected ticket");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventSynchronize(r.done));
+  const int mb = c->max_batch;
+  const int* h_ex = r.h_counters;
+  const int* h_sites = r.h_counters + mb;
+  const int* h_kp = r.h_counters + 2 * size_t(mb);
+  const int* h_off = r.h_counters + 3 * size_t(mb);
+  const int n = h_off[r.batch];
+  sara_hip_status status = SARA_HIP_OK;
+  for (int b = 0; b < r.batch && status == SARA_HIP_OK; ++b)
+    if (h_kp[b] > c->cap || h_ex[b] > c->cap || h_sites[b] > c->sites.cap)
+      status = fail(SARA_HIP_CAPACITY_EXCEEDED,
+                    "a frame produced more extrema / keypoints than "
+                    "max_keypoints: the lists are truncated");
+  if (size_t(n) > r.h_cap)
+  {
+    if (r.h_feat)
+      (void) hipHostFree(r.h_feat);
+    if (r.h_desc)
+      (void) hipHostFree(r.h_desc);
+    if (r.h_so)
+      (void) hipHostFree(r.h_so);
+    r.h_feat = nullptr;
+    r.h_desc = nullptr;
+    r.h_so = nullptr;
+    r.h_cap = 0;
+    const size_t want = std::min(size_t(mb) * c->cap, size_t(n) + size_t(n) / 2 + 1024);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r.h_feat),
+                          sizeof(sara_oeregion) * want));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r.h_desc),
+                          sizeof(float) * 128 * want));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r.h_so),
+                          sizeof(int32_t) * 2 * want));
+    r.h_cap = want;
+  }
+  const int slot = ticket & 1;
+  if (n > 0)
+  {
+    // the batch is complete (event): the copies need no further ordering and
+    // run beside the next batch's kernels
+    HIP_TRY(hipMemcpyAsync(r.h_feat, c->d_feat_s[slot], sizeof(sara_oeregion) * n,
+                           hipMemcpyDeviceToHost, c->d2h_stream));
+    HIP_TRY(hipMemcpyAsync(r.h_so, c->d_so_s[slot], sizeof(int32_t) * 2 * n,
+                           hipMemcpyDeviceToHost, c->d2h_stream));
+    if (descriptors)
+      HIP_TRY(hipMemcpyAsync(r.h_desc, c->d_desc_s[slot],
+                             sizeof(float) * 128 * size_t(n),
+                             hipMemcpyDeviceToHost, c->d2h_stream));
+    HIP_TRY(hipStreamSynchronize(c->d2h_stream));
+  }
+  r.pending = false;
+  if (features)
+    *features = r.h_feat;
+  if (descriptors)
+    *descriptors = r.h_desc;
+  if (scale_octave)
+    *scale_octave = r.h_so;
+  if (frame_offsets)
+    *frame_offsets = h_off;
+  if (total)
+    *total = n;
+  return status;
 }
 
 sara_hip_status sara_hip_sift_synchronize(sara_hip_sift* c)

@@ -522,3 +522,76 @@ def test_downscale_option_rejected_when_out_of_range():
     with sara_amd.SiftContext(128, 128, 1, p) as ctx:
         with pytest.raises(sara_amd.SaraHipError):
             ctx.set_option(sara_amd.capi.OPT_DOWNSCALE_AT_DOUBLE_SIGMA, 1)
+
+
+def test_submit_collect_pipeline(oracle):
+    """submit() / collect(): two batches in flight (upload and kernels of one,
+    read-back of the other); results byte-identical to detect() + fetch(), for
+    float and 8-bit frames; the third submit() without a collect() is refused."""
+    batches = [synth_batch(160, 120, 3, first_index=10 * i) for i in range(5)]
+    u8 = (batches[2] * 255).astype(np.uint8)
+    with sara_amd.SiftContext(160, 120, 3, hip_params(0, 3)) as ctx:
+        want = []
+        for b in batches:
+            ctx.detect(b)
+            want.append(ctx.fetch())
+        ctx.detect_u8(u8)
+        want_u8 = ctx.fetch()
+
+        def same(w, got):
+            counts, regions, desc, so = w
+            offsets, g_regions, g_desc, g_so = got
+            assert np.array_equal(np.diff(offsets), counts)
+            assert regions.tobytes() == g_regions.tobytes()
+            assert np.array_equal(desc, g_desc) and np.array_equal(so, g_so)
+
+        t0 = ctx.submit(batches[0])
+        for i in range(len(batches)):
+            t1 = ctx.submit(batches[i + 1]) if i + 1 < len(batches) else None
+            if t1 is not None and i + 2 < len(batches):
+                with pytest.raises(sara_amd.SaraHipError):
+                    ctx.submit(batches[i + 2])   # two batches already in flight
+            same(want[i], ctx.collect(t0, copy=True))
+            t0 = t1
+        same(want_u8, ctx.collect(ctx.submit(u8)))
+        # plain detect() / fetch() keep working on the same context
+        ctx.detect(batches[1])
+        for x, y in zip(want[1], ctx.fetch()):
+            assert x.tobytes() == y.tobytes()
+        with pytest.raises(sara_amd.SaraHipError):
+            ctx.collect(12345)
+
+
+def test_compute_sift_keypoints_keeps_its_context(oracle):
+    """The free function reuses the context of the previous call with the same
+    parameters and size (one per thread): same results, no re-allocation."""
+    import time
+    sara_amd.clear_context_cache()
+    p = hip_params(0, 3)
+    a = synth(320, 240, 77)
+    b = synth(320, 240, 78)
+    t = time.perf_counter()
+    ka = sara_amd.compute_sift_keypoints(a, p)
+    first = time.perf_counter() - t
+    assert len(sara_amd._CONTEXT_CACHE) == 1
+    ctx_id = id(sara_amd._CONTEXT_CACHE[0][1])
+    t = time.perf_counter()
+    kb = sara_amd.compute_sift_keypoints(b, p)
+    ka2 = sara_amd.compute_sift_keypoints(a, p)
+    later = (time.perf_counter() - t) / 2
+    assert len(sara_amd._CONTEXT_CACHE) == 1
+    assert id(sara_amd._CONTEXT_CACHE[0][1]) == ctx_id
+    assert ka.regions.tobytes() == ka2.regions.tobytes()
+    assert np.array_equal(ka.descriptor_matrix, ka2.descriptor_matrix)
+    assert len(kb) > 0 and kb.regions.tobytes() != ka.regions.tobytes()
+    assert later < first
+    with sara_amd.SiftContext(320, 240, 1, p) as ctx:
+        ctx.detect(a)
+        _, regions, desc, _ = ctx.fetch()
+    assert regions.tobytes() == ka.regions.tobytes()
+    assert np.array_equal(desc, ka.descriptor_matrix)
+    # a different size gets its own context, the cache stays bounded
+    for w in (200, 208, 216, 224, 232):
+        sara_amd.compute_sift_keypoints(synth(w, 160, 3), p)
+    assert len(sara_amd._CONTEXT_CACHE) <= sara_amd._CONTEXT_CACHE_MAX
+    sara_amd.clear_context_cache()
