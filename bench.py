@@ -38,9 +38,13 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--octaves", type=int, default=4)
-    ap.add_argument("--unique-frames", type=int, default=4,
-                    help="distinct synthetic frames generated per rank (the "
-                         "rest are their flips)")
+    ap.add_argument("--unique-frames", type=int, default=0,
+                    help="distinct synthetic frames generated per rank (0 = "
+                         "every frame has its own seed, 1234 + global index; "
+                         "k > 0: k frames and their flips)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements (host-to-host rate, "
+                         "single-image config 2, 4K config 5)")
     ap.add_argument("--cpu-frames", type=int, default=24,
                     help="frames of the cpu_baseline sample, about 10 s of CPU work "
                          "(0 = skip)")
@@ -114,10 +118,13 @@ def cpu_baseline(args, frames):
     n = min(args.cpu_frames, len(frames))
     kp = 0
     stage = {}
+    results = []
     t0 = time.perf_counter()
     for i in range(n):
         r = rb.RefSift(frames[i], params, parallel=True)
-        kp += len(r.keypoints()[0])
+        res = r.keypoints()
+        results.append(res)
+        kp += len(res[0])
         for k, v in r.times().items():
             stage[k] = stage.get(k, 0.0) + v / n
     dt = time.perf_counter() - t0
@@ -135,7 +142,7 @@ def cpu_baseline(args, frames):
                 break
     except OSError:
         pass
-    return {
+    return results, {
         "value": kp / dt, "unit": "keypoints/s", "cores": cores, "kind": "port",
         "cpu_model": model,
         "value_single_thread": kp1 / dt1,
@@ -145,6 +152,159 @@ def cpu_baseline(args, frames):
         "ms_per_frame": 1e3 * dt / n,
         "stage_ms_per_frame": {k: round(v, 2) for k, v in stage.items()},
     }
+
+
+def check_parity(gpu, oracle_results):
+    """The benchmarked batch against the oracle, frame by frame (outside the
+    timed region): keypoint count, order, (s, o) pairs exact; coordinates and
+    extremum values exact; shape rel 1e-6; orientation 1e-6 rad; descriptors
+    max-abs 2e-3 on 0..255 - the bars of tests/test_gpu_pipeline.py.  Raises on
+    the first mismatch; returns the number of frames checked."""
+    counts, regions, desc, so = gpu
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    worst = 0.0
+    for i, (rreg, rso, rdesc) in enumerate(oracle_results):
+        sl = slice(int(off[i]), int(off[i + 1]))
+        if int(counts[i]) != len(rreg):
+            raise SystemExit("parity: frame %d has %d keypoints, oracle %d" %
+                             (i, int(counts[i]), len(rreg)))
+        g = regions[sl]
+        ok = (np.array_equal(so[sl], rso) and
+              np.array_equal(g["coords"], rreg["coords"]) and
+              np.array_equal(g["extremum_value"], rreg["extremum_value"]) and
+              np.array_equal(g["extremum_type"], rreg["extremum_type"]) and
+              np.allclose(g["shape_matrix"], rreg["shape_matrix"], rtol=1e-6,
+                          atol=0) and
+              np.allclose(g["orientation"], rreg["orientation"], rtol=0,
+                          atol=1e-6))
+        err = float(np.max(np.abs(desc[sl] - rdesc))) if len(rreg) else 0.0
+        worst = max(worst, err)
+        if not ok or err > 2e-3:
+            raise SystemExit("parity: frame %d differs from the oracle "
+                             "(descriptor max-abs %.3g)" % (i, err))
+    return len(oracle_results), worst
+
+
+def timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    return (time.perf_counter() - t0) / max(steps, 1)
+
+
+def host_to_host(ctx, frames_host, args, torch):
+    """SURVEY.md 8d's metric: frames in pinned host memory -> OERegion[] +
+    descriptors in (pinned) host memory, two batches in flight (submit /
+    collect).  Returns keypoints/s for float32 and for gray8 frames."""
+    import sara_amd
+    B, H, W = frames_host.shape
+    out = {}
+    for name, arr, ch in (
+            ("float32", frames_host, 0),
+            ("gray8", np.round(frames_host * 255.0).astype(np.uint8), 1)):
+        pinned = torch.from_numpy(np.ascontiguousarray(arr)).pin_memory()
+        ptr = pinned.data_ptr()
+        state = {"ticket": None, "kp": 0}
+
+        def step():
+            t = ctx.submit_raw(ptr, ch, B, W, H, on_device=False)
+            if state["ticket"] is not None:
+                off, _, _, _ = ctx.collect(state["ticket"])
+                state["kp"] += int(off[-1])
+            state["ticket"] = t
+
+        for _ in range(4):  # grows the pinned result buffers of both slots
+            step()
+        ctx.collect(state["ticket"])
+        state.update(ticket=None, kp=0)
+        steps = max(args.steps, 8)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        off, _, _, _ = ctx.collect(state["ticket"])
+        state["kp"] += int(off[-1])
+        dt = time.perf_counter() - t0
+        out[name] = {"keypoints_per_s": state["kp"] / dt,
+                     "ms_per_step": 1e3 * dt / steps}
+        del pinned
+    return out
+
+
+def secondary_configs(args, torch, dev):
+    """BASELINE.json configs 2 and 5 as secondary measurements (rank 0, N = 1):
+    config 2 = ONE 1920x1080 frame, pyramid + DoG + extrema only, against the
+    128*P algorithmic bytes of SURVEY.md 8d; the same frame through the full
+    pipeline (the drop-in's per-call operating point); config 5 = 16 frames of
+    3840x2160, 5 octaves, Gaussian-pyramid stage against 48*P."""
+    import sara_amd
+    from sara_amd.synth import synth_batch
+    out = {}
+    # ---- config 2 / single image
+    W, H = 1920, 1080
+    one = synth_batch(W, H, 1)
+    d_one = torch.from_numpy(one).to(dev)
+    p4 = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=4)
+    P = sum((W >> o) * (H >> o) for o in range(4))
+    with sara_amd.SiftContext(W, H, 1, p4, device=dev.index or 0) as c1:
+        def run(stage):
+            c1.detect_device(d_one.data_ptr(), 1, W, H, last_stage=stage)
+            c1.synchronize()
+        t2 = timed(lambda: run(2), 200, 20)
+        t5 = timed(lambda: run(5), 200, 20)
+        c1.set_option(sara_amd.capi.OPT_STAGE_TIMERS, 1)
+        h2h = timed(lambda: c1.collect(c1.submit(one)), 100, 10)
+        u8 = np.round(one * 255.0).astype(np.uint8)
+        h2h8 = timed(lambda: c1.collect(c1.submit(u8)), 100, 10)
+        n1 = int(c1.collect(c1.submit(one))[0][-1])
+    out["config2"] = {
+        "workload": "1 x 1920x1080, pyramid + DoG + extrema only (stage 2), "
+                    "frame resident in HBM, HIP-graph replay",
+        "ms": 1e3 * t2,
+        "algorithmic_bytes": 128 * P,
+        "achieved_GBs": 128 * P / 1e9 / t2,
+        "frac_of_hbm_peak": 128 * P / 1e9 / t2 / HBM_PEAK_GBS,
+    }
+    out["single_image"] = {
+        "workload": "1 x 1920x1080 full SIFT per call (the reference's "
+                    "compute_sift_keypoints call pattern)",
+        "keypoints": n1,
+        "ms_hbm_resident": 1e3 * t5,
+        "ms_host_float32_to_host": 1e3 * h2h,
+        "ms_host_gray8_to_host": 1e3 * h2h8,
+        "keypoints_per_s_host_to_host": n1 / h2h,
+    }
+    # ---- config 5: 4K, 5 octaves
+    W4, H4, B4 = 3840, 2160, 16
+    f4 = synth_batch(W4, H4, B4, unique=4)
+    d4 = torch.from_numpy(f4).to(dev)
+    p5 = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=5)
+    P4 = sum((W4 >> o) * (H4 >> o) for o in range(5))
+    with sara_amd.SiftContext(W4, H4, B4, p5, device=dev.index or 0) as c4:
+        pyr, tot, kp = [], [], 0
+        for i in range(8):
+            c4.detect_device(d4.data_ptr(), B4, W4, H4)
+            _, kp = c4.counts()
+            if i >= 2:
+                st = c4.stage_times()
+                pyr.append(st["pyramid"])
+                tot.append(st["total"])
+        pyr_ms = float(np.mean(pyr))
+        tot_ms = float(np.mean(tot))
+    out["config5"] = {
+        "workload": "16 x 3840x2160, 5 octaves x 3 scales/octave, full SIFT; "
+                    "pyramid stage from HIP events",
+        "pyramid_ms": pyr_ms,
+        "pyramid_achieved_GBs": 48 * P4 * B4 / 1e9 / (pyr_ms / 1e3),
+        "pyramid_frac_of_hbm_peak":
+            48 * P4 * B4 / 1e9 / (pyr_ms / 1e3) / HBM_PEAK_GBS,
+        "ms_per_step": tot_ms,
+        "keypoints_per_s": kp / (tot_ms / 1e3),
+        "keypoints_per_frame": kp / B4,
+    }
+    del d_one, d4
+    return out
 
 
 def main():
@@ -200,12 +360,19 @@ def main():
 
     B, W, H = args.frames_per_gpu, args.width, args.height
     frames_host = synth_batch(W, H, B, first_index=rank * B,
-                              unique=args.unique_frames)
+                              unique=args.unique_frames or None)
     frames = torch.from_numpy(frames_host).to(dev)  # resident in HBM
     torch.cuda.synchronize()
 
     params = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=args.octaves)
     ctx = sara_amd.SiftContext(W, H, B, params, device=local_rank)
+    # An explicit (non-default) stream: the handle of torch's default stream is
+    # NULL, which detect() would read as "use the context's own stream", and
+    # the RCCL transfers torch posts would then not be ordered after the
+    # device-to-device copies of fetch().
+    bench_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    if bench_stream is not None:
+        torch.cuda.set_stream(bench_stream)
     stream = torch.cuda.current_stream(dev)
 
     # Keypoint arrays are gathered on rank 0.  Step i stages its results in
@@ -337,6 +504,9 @@ def main():
                             (B, W, H, args.octaves),
                 "frames_per_gpu": B,
                 "global_frames": B * world,
+                "distinct_frames_per_gpu": args.unique_frames or B,
+                "frame_seeds": "1234 + global frame index (SplitMix64, "
+                               "include/sara_synth.h)",
                 "keypoints_per_frame": kp_total / (steps * B * world),
                 "frames_per_s": steps * B * world / elapsed,
                 "parallelism": "frames sharded %d/GPU, RCCL gatherv of "
@@ -364,9 +534,32 @@ def main():
             },
         }
         if world == 1 and args.cpu_frames > 0:
-            out["cpu_baseline"] = cpu_baseline(args, frames_host)
+            oracle_results, out["cpu_baseline"] = cpu_baseline(args, frames_host)
             out["config"]["gpu_over_cpu"] = out["value"] / max(
                 out["cpu_baseline"]["value"], 1e-9)
+            if args.stage >= 5:
+                # the benchmarked batch itself (same launch geometry) against
+                # the oracle frames just computed - outside the timed region
+                ctx.detect_device(frames.data_ptr(), B, W, H, last_stage=5)
+                n_ok, worst = check_parity(ctx.fetch(), oracle_results)
+                out["parity_checked_frames"] = n_ok
+                out["config"]["parity"] = (
+                    "frames 0..%d of the benchmarked %d-frame batch equal the "
+                    "CPU oracle: counts, order, (s,o), coordinates exact, "
+                    "orientation 1e-6 rad, descriptors max-abs %.2g (bar 2e-3)"
+                    % (n_ok - 1, B, worst))
+        if world == 1 and not args.no_extras and args.stage >= 5:
+            h2h = host_to_host(ctx, frames_host, args, torch)
+            out["config"]["host_to_host_keypoints_per_s"] = \
+                h2h["gray8"]["keypoints_per_s"]
+            out["config"]["host_to_host"] = {
+                "definition": "SURVEY.md 8d: frames in pinned host memory -> "
+                              "OERegion[] + descriptors in pinned host memory, "
+                              "two batches in flight (submit/collect); `value` "
+                              "above is the HBM-resident rate",
+                "gray8": h2h["gray8"], "float32": h2h["float32"]}
+            ctx.close()
+            out["config"].update(secondary_configs(args, torch, dev))
         print(json.dumps(out))
     ctx.close()
     if world > 1:

@@ -170,7 +170,10 @@ class SiftContext:
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
-            capi.load().sara_hip_sift_destroy(self._h)
+            try:
+                capi.load().sara_hip_sift_destroy(self._h)
+            except (AttributeError, TypeError):
+                pass  # interpreter shutdown: the modules are already gone
             self._h = C.c_void_p()
 
     __del__ = close
@@ -285,13 +288,15 @@ class SiftContext:
         self._inflight[ticket.value] = (a, b)
         return ticket.value
 
-    def submit_device(self, ptr, batch, width, height, channels=0,
-                      frame_stride=0, last_stage=STAGE_DESCRIPTOR):
-        """submit() for frames already resident in HBM (raw device pointer)."""
+    def submit_raw(self, ptr, channels, batch, width, height, on_device=False,
+                   frame_stride=0, last_stage=STAGE_DESCRIPTOR):
+        """submit() from a raw pointer: pinned / pageable host memory, or HBM
+        when ``on_device``.  channels: 0 float32, 1 gray8, 3 RGB8.  The caller
+        keeps the memory alive until the ticket is collected."""
         ticket = C.c_int(-1)
         capi.check(capi.load().sara_hip_sift_submit(
-            self._h, ptr, frame_stride, channels, batch, width, height, 1,
-            int(last_stage), C.byref(ticket)))
+            self._h, ptr, frame_stride, channels, batch, width, height,
+            1 if on_device else 0, int(last_stage), C.byref(ticket)))
         self._inflight = getattr(self, "_inflight", {})
         self._inflight[ticket.value] = (None, batch)
         return ticket.value

@@ -149,3 +149,30 @@ def test_default_small_launch_threshold(oracle, tmp_path):
     common.assert_regions_equal(kreg, rk, rtol_shape=1e-6, atol_theta=1e-6)
     assert np.array_equal(got["kso"][off:off + len(rk)], rso)
     assert np.max(np.abs(got["kdesc"][off:off + len(rk)] - rdesc)) <= 2e-3
+
+
+def test_benchmark_batch_geometry_against_oracle(oracle):
+    """The benchmarked launch geometry itself - 64 distinct 1080p frames in one
+    batch (segments per strip, XCD work-item map and persistent-block walk all
+    depend on the batch size) - with the first, a middle and the last frame
+    compared against the oracle at the bars of test_gpu_pipeline.py."""
+    B = 64
+    frames = synth_batch(1920, 1080, B)           # seeds 1234 .. 1234 + 63
+    assert not np.array_equal(frames[0], frames[1])
+    rp = oracle.PyramidParams(0, 6, None, 1, 0.5, 1.6, 4)
+    with sara_amd.SiftContext(1920, 1080, B, params(4)) as ctx:
+        ctx.detect(frames)
+        kc, kreg, kdesc, kso = ctx.fetch()
+        planes = {i: ctx.gaussian(5, 0, i) for i in (0, 31, 63)}
+    off = np.concatenate([[0], np.cumsum(kc)]).astype(np.int64)
+    assert len(set(int(c) for c in kc)) > B // 2   # distinct frames, distinct counts
+    for i in (0, 31, 63):
+        ref = oracle.RefSift(frames[i], rp, parallel=True)
+        rk, rso, rdesc = ref.keypoints()
+        sl = slice(int(off[i]), int(off[i + 1]))
+        assert int(kc[i]) == len(rk) and len(rk) > 3000
+        assert np.array_equal(planes[i], ref.gaussian(5, 0))
+        assert np.array_equal(kso[sl], rso)
+        common.assert_regions_equal(kreg[sl], rk, rtol_shape=1e-6,
+                                    atol_theta=1e-6)
+        assert np.max(np.abs(kdesc[sl] - rdesc)) <= 2e-3

@@ -5,7 +5,7 @@
 cd $GRAFT_REPO_ROOT
 for cfg in "$@"; do
   echo "== $cfg"
-  env $cfg timeout 300 python bench.py --steps 10 --warmup 3 --cpu-frames 0 --unique-frames 16 $BENCH_ARGS 2>/dev/null | python -c "
+  env $cfg timeout 300 python bench.py --steps 10 --warmup 3 --cpu-frames 0 --no-extras --unique-frames 16 $BENCH_ARGS 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     l=l.strip()

@@ -7,10 +7,10 @@ D=$R/gpurun_out/prof
 mkdir -p $D
 cd $R
 python bench.py > $D/${TAG}_bench.json 2> $D/${TAG}_bench.err
-SARA_HIP_STREAMS=1 SARA_HIP_SIDE_GRADIENT=0 python bench.py --cpu-frames 0 > $D/${TAG}_bench_single_stream.json 2>> $D/${TAG}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $D -o ${TAG}_ms -- python bench.py --steps 5 --warmup 2 --cpu-frames 0 > $D/${TAG}_ms.log 2>&1
-SARA_HIP_STREAMS=1 SARA_HIP_SIDE_GRADIENT=0 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o ${TAG}_ss -- python bench.py --steps 5 --warmup 2 --cpu-frames 0 > $D/${TAG}_ss.log 2>&1
-SARA_HIP_STREAMS=1 SARA_HIP_SIDE_GRADIENT=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $D -o f -- python bench.py --steps 5 --warmup 2 --cpu-frames 0 > $D/f.log 2>&1
-SARA_HIP_STREAMS=1 SARA_HIP_SIDE_GRADIENT=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $D -o w -- python bench.py --steps 5 --warmup 2 --cpu-frames 0 > $D/w.log 2>&1
+SARA_HIP_STREAMS=1 SARA_HIP_SIDE_GRADIENT=0 python bench.py --cpu-frames 0 --no-extras > $D/${TAG}_bench_single_stream.json 2>> $D/${TAG}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $D -o ${TAG}_ms -- python bench.py --steps 5 --warmup 2 --cpu-frames 0 --no-extras > $D/${TAG}_ms.log 2>&1
+SARA_HIP_STREAMS=1 SARA_HIP_SIDE_GRADIENT=0 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o ${TAG}_ss -- python bench.py --steps 5 --warmup 2 --cpu-frames 0 --no-extras > $D/${TAG}_ss.log 2>&1
+SARA_HIP_STREAMS=1 SARA_HIP_SIDE_GRADIENT=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $D -o f -- python bench.py --steps 5 --warmup 2 --cpu-frames 0 --no-extras > $D/f.log 2>&1
+SARA_HIP_STREAMS=1 SARA_HIP_SIDE_GRADIENT=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $D -o w -- python bench.py --steps 5 --warmup 2 --cpu-frames 0 --no-extras > $D/w.log 2>&1
 python tools/pmc_traffic.py $D 7 $D/pyramid_traffic.json
 ls $D

@@ -1,6 +1,6 @@
 # BASELINE.json config 5: 3840x2160, 5 octaves - sweep of the blur work decomposition
 # (strip segment height = "tile size" of the marching kernels; 64x32 LDS tiles of the tiled kernel).
-run() { echo "== $*"; env "$@" python bench.py --width 3840 --height 2160 --octaves 5 --frames-per-gpu 16 --steps 8 --warmup 2 --cpu-frames 0 --stage 1 2>/dev/null | python -c "
+run() { echo "== $*"; env "$@" python bench.py --width 3840 --height 2160 --octaves 5 --frames-per-gpu 16 --steps 8 --warmup 2 --cpu-frames 0 --no-extras --stage 1 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     l=l.strip()
