@@ -327,81 +327,114 @@ def main():
     from sara_amd.distributed import exchange_counts, gatherv_to_root
 
     ndev = capi.require_gpu()
-    # SARA_BENCH_BACKEND=gloo lets the multi-process path be exercised on a box
-    # with fewer GPUs than ranks (ranks then share devices and the gather is
-    # staged through host memory); the real runs use nccl (= RCCL).
+    # Gather of the keypoint arrays on rank 0 (N > 1):
+    #   SARA_BENCH_GATHER=rccl (default): the library's own RCCL gatherv
+    #     (sara_hip_comm_*: counts by ncclAllGather, grouped ncclSend/ncclRecv);
+    #     torch.distributed (gloo) only ships the 128-byte communicator id and
+    #     the final timing reduction - it is not on the data path.
+    #   SARA_BENCH_GATHER=torch: the torch.distributed variant of
+    #     sara_amd/distributed.py (backend SARA_BENCH_BACKEND, default nccl;
+    #     gloo lets two ranks share one GPU on a test box).
+    gather_mode = os.environ.get("SARA_BENCH_GATHER", "rccl")
     backend = os.environ.get("SARA_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = local_rank % ndev
+    if world > ndev:
+        local_rank = local_rank % ndev  # test boxes: ranks share devices
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    B, W, H = args.frames_per_gpu, args.width, args.height
+    params = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=args.octaves)
+    ctx = sara_amd.SiftContext(W, H, B, params, device=local_rank)
+
+    comm = None
+    count_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
+        if gather_mode == "rccl":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            from sara_amd.distributed import Comm
+            ident = [Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0)
+            ok = 1
+            try:
+                comm = Comm(ctx, ident[0], world, rank, device=local_rank)
+            except Exception as e:  # e.g. two ranks on one GPU of a test box
+                ok = 0
+                print("rank %d: native RCCL gather unavailable (%s)" % (rank, e),
+                      file=sys.stderr)
+            flag = torch.tensor([ok])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                comm = None
+                gather_mode, backend = "torch", "gloo"
+                if rank == 0:
+                    print("falling back to the torch.distributed gather over "
+                          "gloo", file=sys.stderr)
+        elif backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=dev)
+            # keypoint counts travel through host tensors on a gloo group
+            try:
+                count_group = dist.new_group(backend="gloo")
+            except Exception:
+                count_group = None
+            dist.all_reduce(torch.zeros(1, device=dev))
+            torch.cuda.synchronize()
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    # keypoint counts travel through host tensors on a gloo group: no wait for
-    # the kernels in flight, no extra device synchronisation per step
-    count_group = None
-    if world > 1 and backend == "nccl":
-        try:
-            count_group = dist.new_group(backend="gloo")
-        except Exception as e:  # no host-side group: counts go over RCCL
-            count_group = None
-            if rank == 0:
-                print("gloo side group unavailable (%r): keypoint counts are "
-                      "exchanged on the device" % (e,), file=sys.stderr)
-        # establish the RCCL communicator collectively before the first
-        # point-to-point exchange
-        dist.all_reduce(torch.zeros(1, device=dev))
-        torch.cuda.synchronize()
 
-    B, W, H = args.frames_per_gpu, args.width, args.height
     frames_host = synth_batch(W, H, B, first_index=rank * B,
                               unique=args.unique_frames or None)
     frames = torch.from_numpy(frames_host).to(dev)  # resident in HBM
     torch.cuda.synchronize()
 
-    params = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=args.octaves)
-    ctx = sara_amd.SiftContext(W, H, B, params, device=local_rank)
-    # An explicit (non-default) stream: the handle of torch's default stream is
-    # NULL, which detect() would read as "use the context's own stream", and
-    # the RCCL transfers torch posts would then not be ordered after the
-    # device-to-device copies of fetch().
-    bench_stream = torch.cuda.Stream(device=dev) if world > 1 else None
-    if bench_stream is not None:
+    legacy = world > 1 and comm is None
+    # legacy path: an explicit (non-default) torch stream - the handle of
+    # torch's default stream is NULL, which detect() reads as "use the
+    # context's own stream", and the transfers torch posts would then not be
+    # ordered after the device-to-device copies of fetch()
+    stream_handle = None
+    if legacy:
+        bench_stream = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(bench_stream)
-    stream = torch.cuda.current_stream(dev)
-
-    # Keypoint arrays are gathered on rank 0.  Step i stages its results in
-    # fresh device tensors (one device-to-device copy on the detect stream);
-    # their exchange is posted right after the kernels of step i+1 have been
-    # enqueued, so the GPU never waits for the host-side part of the gather
-    # and the transfers overlap the next step's compute.
+        stream_handle = bench_stream.cuda_stream
     feat_buf = desc_buf = so_buf = None
-    pending = [None]   # point-to-point transfers in flight
-    staged = [None]    # results staged on the device, exchange not posted yet
+    pending = [None]   # legacy: point-to-point transfers in flight
+    staged = [None]    # legacy: results staged on the device, not posted yet
+    inflight = [None]  # native: ticket whose gather has not been done yet
+    gathered = [0]     # native: keypoints that reached rank 0 in the timed region
 
     def step():
         """One pass over the batch; returns this rank's keypoint count."""
+        if comm is not None:
+            # batch i + 1 is enqueued, then batch i is gathered while it runs
+            t = ctx.submit_raw(frames.data_ptr(), 0, B, W, H, on_device=True,
+                               last_stage=args.stage)
+            n = 0
+            if inflight[0] is not None:
+                res = comm.gather(inflight[0], root=0)
+                n = res.counts[rank]
+                gathered[0] += res.total if rank == 0 else 0
+            inflight[0] = t
+            return n
         ctx.detect_device(frames.data_ptr(), B, W, H, last_stage=args.stage,
-                          stream=stream.cuda_stream)
-        if world > 1 and staged[0] is not None:
+                          stream=stream_handle)
+        if legacy and staged[0] is not None:
             post_gather(staged[0])
             staged[0] = None
         if args.stage < 4:
             c, _, _ = ctx.extrema() if args.stage >= 2 else (np.zeros(B), 0, 0)
             return int(np.sum(c))
         counts, total = ctx.counts()
-        if world > 1:
+        if legacy:
             staged[0] = stage_results(total)
         return total
 
     def stage_results(total):
-        """OERegion[ ] (48 B), descriptors (512 B) and (s,o) pairs of this step
-        copied out of the context's buffers (which the next detect() reuses)."""
+        """Legacy: OERegion[ ] (48 B), descriptors (512 B) and (s,o) pairs of
+        this step copied out of the context's buffers (which the next detect()
+        reuses)."""
         mine_f = torch.empty((total, 48), dtype=torch.uint8, device=dev)
         mine_d = torch.empty((total, 128), dtype=torch.float32, device=dev)
         mine_s = torch.empty((total, 2), dtype=torch.int32, device=dev)
@@ -412,13 +445,10 @@ def main():
         return [mine_f, mine_d, mine_s], total
 
     def post_gather(item):
-        """gatherv to rank 0 (sara_amd/distributed.py).  RCCL orders the
-        transfers after everything already enqueued on the detect stream."""
+        """Legacy gatherv to rank 0 (sara_amd/distributed.py)."""
         tensors, total = item
         if backend != "nccl":
             tensors = [t.cpu() for t in tensors]  # gloo: host staging
-        # host-side exchange (gloo group, or the default group when that is
-        # gloo); without one gatherv_to_root all_gathers them on the device
         host_counts = count_group is not None or backend != "nccl"
         counts_all = exchange_counts(total, count_group) if host_counts else None
         wait_gather()
@@ -434,7 +464,15 @@ def main():
                 feat_buf, desc_buf, so_buf = outs
 
     def sync():
-        if world > 1:
+        """Drains the pipeline; returns this rank's keypoints of the drained
+        batch (native path)."""
+        n = 0
+        if comm is not None and inflight[0] is not None:
+            res = comm.gather(inflight[0], root=0)
+            n = res.counts[rank]
+            gathered[0] += res.total if rank == 0 else 0
+            inflight[0] = None
+        if legacy:
             if staged[0] is not None:
                 post_gather(staged[0])
                 staged[0] = None
@@ -444,22 +482,25 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+        return n
 
     for _ in range(args.warmup):
         step()
     sync()
+    gathered[0] = 0
     stage_ms = {}
     kp_local = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         kp_local += step()
-        if ctx is not None and args.stage >= 1:
+        if args.stage >= 1:
             for k, v in ctx.stage_times().items():
                 stage_ms[k] = stage_ms.get(k, 0.0) + v
-    sync()
+    kp_local += sync()
     elapsed = time.perf_counter() - t0
 
-    rdev = dev if backend == "nccl" else torch.device("cpu")
+    on_dev = world > 1 and legacy and backend == "nccl"
+    rdev = dev if on_dev else torch.device("cpu")
     el = torch.tensor([elapsed], device=rdev, dtype=torch.float64)
     kp = torch.tensor([kp_local], device=rdev, dtype=torch.int64)
     if world > 1:
@@ -467,6 +508,9 @@ def main():
         dist.all_reduce(kp, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
     kp_total = int(kp.item())
+    if comm is not None and rank == 0 and gathered[0] != kp_total:
+        raise SystemExit("gather: %d keypoints reached rank 0, the ranks "
+                         "produced %d" % (gathered[0], kp_total))
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -509,9 +553,13 @@ def main():
                                "include/sara_synth.h)",
                 "keypoints_per_frame": kp_total / (steps * B * world),
                 "frames_per_s": steps * B * world / elapsed,
-                "parallelism": "frames sharded %d/GPU, RCCL gatherv of "
-                               "keypoints to rank 0" % B if world > 1
-                               else "single GPU",
+                "parallelism": ("frames sharded %d/GPU, gatherv of keypoints to "
+                                "rank 0: %s" % (B, "library RCCL (ncclAllGather "
+                                "of counts + grouped ncclSend/ncclRecv), "
+                                "pipelined under the next batch"
+                                if comm is not None else
+                                "torch.distributed/" + backend))
+                               if world > 1 else "single GPU",
                 "last_stage": args.stage,
             },
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
@@ -561,6 +609,8 @@ def main():
             ctx.close()
             out["config"].update(secondary_configs(args, torch, dev))
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     ctx.close()
     if world > 1:
         dist.barrier()

@@ -51,7 +51,8 @@ typedef enum sara_hip_status
   SARA_HIP_CAPACITY_EXCEEDED = 4, /* image/batch/keypoints above the ctx capacity */
   SARA_HIP_RUNTIME_ERROR = 5,     /* a HIP call failed, message has the detail    */
   SARA_HIP_NO_DEVICE = 6,
-  SARA_HIP_NOT_READY = 7          /* results requested before any detect()        */
+  SARA_HIP_NOT_READY = 7,         /* results requested before any detect()        */
+  SARA_HIP_RCCL_ERROR = 8         /* librccl missing or a collective call failed  */
 } sara_hip_status;
 
 /* ImagePyramidParams — ImageProcessing/ImagePyramid.hpp:29-52 (same member   */
@@ -441,6 +442,82 @@ SARA_HIP_API sara_hip_status sara_hip_sift_collect(
     sara_hip_sift* ctx, int ticket, const sara_oeregion** features,
     const float** descriptors, const int32_t** scale_octave,
     const int32_t** frame_offsets, int* total);
+
+/* -------------------------------------------------------------------------- */
+/* Multi-GPU.  Frames are independent                    */
+/* (compute_sift_keypoints is a pure function of one image,                     */
+/* FeatureDetectors/SIFT.cpp:27-108): they are sharded in contiguous blocks,    */
+/* one context per GPU, and the only exchange is the gather of the              */
+/* variable-length keypoint arrays to a root device over RCCL: counts through   */
+/* one ncclAllGather, then one group of ncclSend / ncclRecv at the global       */
+/* offsets, so that the root holds the keypoints in (frame, octave, scale, y,   */
+/* x, bin) order.  librccl is loaded on first use.                              */
+/* -------------------------------------------------------------------------- */
+
+/* Contiguous block [*lo, *hi) of `n_frames` frames owned by `rank`.  Host-only. */
+SARA_HIP_API void sara_hip_shard_range(int n_frames, int world_size, int rank,
+                                      int* lo, int* hi);
+
+/* Blocking copy of `bytes` from HBM of `device` to host memory: lets a caller   */
+/* without a HIP toolchain (ctypes, cgo ...) read the gathered arrays.          */
+SARA_HIP_API sara_hip_status sara_hip_copy_to_host(void* dst,
+                                                  const void* src_device,
+                                                  size_t bytes, int device);
+
+/* --- one process per GPU --------------------------------------------------- */
+#define SARA_HIP_COMM_ID_BYTES 128
+typedef struct sara_hip_comm sara_hip_comm; /* one rank of a gather group */
+
+/* Rank 0 makes the id; the caller ships its 128 bytes to the other ranks by    */
+/* whatever transport it has (a file, MPI, a torch.distributed store ...).       */
+SARA_HIP_API sara_hip_status sara_hip_comm_unique_id(unsigned char* id);
+/* Collective over the `nranks` processes: joins rank `rank` (context `ctx`,    */
+/* HIP device `device`) to the communicator of `id` (ncclCommInitRank).         */
+SARA_HIP_API sara_hip_status sara_hip_comm_create(sara_hip_sift* ctx,
+                                                 const unsigned char* id,
+                                                 int nranks, int rank,
+                                                 int device,
+                                                 sara_hip_comm** out);
+/* Collective: gathers the keypoints of every rank's submit() ticket on `root`  */
+/* (rank order = global frame order when the shards are contiguous).  Blocks    */
+/* until this rank's part of the exchange is complete; the exchange runs on its */
+/* own stream, beside the kernels of a batch submitted after `ticket`.  The      */
+/* ticket is consumed (do not collect() it as well).  counts_per_rank: nranks    */
+/* entries, filled on every rank.  On the root the three device pointers address */
+/* arrays owned by the communicator (valid until the next gather); elsewhere    */
+/* they are set to NULL.                                                         */
+SARA_HIP_API sara_hip_status sara_hip_comm_gather(
+    sara_hip_comm* comm, int ticket, int root, int with_descriptors,
+    int* counts_per_rank, const sara_oeregion** d_features,
+    const float** d_descriptors, const int32_t** d_scale_octave, int* total);
+SARA_HIP_API sara_hip_status sara_hip_comm_destroy(sara_hip_comm* comm);
+
+/* --- one process, one host thread per GPU ---------------------------------- */
+typedef struct sara_hip_sift_group sara_hip_sift_group;
+
+/* n_dev contexts (devices[i], or 0..n_dev-1 when NULL) sized like              */
+/* sara_hip_sift_create(), and their communicator (ncclCommInitAll).            */
+SARA_HIP_API sara_hip_status sara_hip_sift_group_create(
+    const sara_sift_params* params, int max_width, int max_height,
+    int max_batch_per_device, int max_keypoints, int n_dev, const int* devices,
+    sara_hip_sift_group** out);
+SARA_HIP_API int sara_hip_sift_group_size(const sara_hip_sift_group* group);
+SARA_HIP_API sara_hip_status sara_hip_sift_group_context(
+    sara_hip_sift_group* group, int index, sara_hip_sift** ctx);
+/* Device i runs sara_hip_sift_submit() on shard_images[i] (shard_batch[i]      */
+/* frames; same frame_stride / channels / on-device meaning), all devices at    */
+/* once.  Returns when everything is enqueued.                                  */
+SARA_HIP_API sara_hip_status sara_hip_sift_group_detect(
+    sara_hip_sift_group* group, const void* const* shard_images,
+    const int* shard_batch, size_t frame_stride, int channels, int width,
+    int height, int images_on_device, sara_hip_stage last_stage);
+/* Gathers the results of the last group_detect() on device `root` (index into  */
+/* the group); outputs as for sara_hip_comm_gather on the root.                 */
+SARA_HIP_API sara_hip_status sara_hip_sift_group_gather(
+    sara_hip_sift_group* group, int root, int with_descriptors,
+    int* counts_per_device, const sara_oeregion** d_features,
+    const float** d_descriptors, const int32_t** d_scale_octave, int* total);
+SARA_HIP_API sara_hip_status sara_hip_sift_group_destroy(sara_hip_sift_group* group);
 
 /* Host self-check: evaluates, on the CPU, the float atan2 sequence the polar-  */
 /* gradient kernels execute on the GPU (a restatement of glibc 2.35's          */

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("SARA_HIP_SIFT_LIB") or os.path.join(
 
 # status codes (sara_hip_status)
 OK, INVALID_PARAMS, SIZE_MISMATCH, OUT_OF_RANGE, CAPACITY_EXCEEDED, \
-    RUNTIME_ERROR, NO_DEVICE, NOT_READY = range(8)
+    RUNTIME_ERROR, NO_DEVICE, NOT_READY, RCCL_ERROR = range(9)
 
 # stages (sara_hip_stage)
 STAGE_PYRAMID, STAGE_EXTREMA, STAGE_GRADIENT, STAGE_ORIENTATION, \
@@ -88,6 +88,11 @@ EXPORTS = [
     "sara_hip_sift_stage", "sara_hip_sift_detect_staged", "sara_hip_root_sift",
     "sara_hip_selfcheck_device_math", "sara_hip_selfcheck_sincos",
     "sara_hip_sift_submit", "sara_hip_sift_collect",
+    "sara_hip_shard_range", "sara_hip_copy_to_host", "sara_hip_comm_unique_id", "sara_hip_comm_create",
+    "sara_hip_comm_gather", "sara_hip_comm_destroy",
+    "sara_hip_sift_group_create", "sara_hip_sift_group_size",
+    "sara_hip_sift_group_context", "sara_hip_sift_group_detect",
+    "sara_hip_sift_group_gather", "sara_hip_sift_group_destroy",
 ]
 
 _f32p = C.POINTER(C.c_float)
@@ -180,6 +185,28 @@ def _declare(lib):
     lib.sara_hip_sift_collect.argtypes = [_vp, C.c_int, C.POINTER(_vp),
                                           C.POINTER(_vp), C.POINTER(_vp),
                                           C.POINTER(_vp), C.POINTER(C.c_int)]
+    lib.sara_hip_shard_range.argtypes = [C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.sara_hip_shard_range.restype = None
+    lib.sara_hip_copy_to_host.argtypes = [_vp, _vp, C.c_size_t, C.c_int]
+    lib.sara_hip_comm_unique_id.argtypes = [_vp]
+    lib.sara_hip_comm_create.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(_vp)]
+    lib.sara_hip_comm_gather.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp,
+                                         C.POINTER(_vp), C.POINTER(_vp),
+                                         C.POINTER(_vp), C.POINTER(C.c_int)]
+    lib.sara_hip_comm_destroy.argtypes = [_vp]
+    lib.sara_hip_sift_group_create.argtypes = [_vp, C.c_int, C.c_int, C.c_int,
+                                               C.c_int, C.c_int, _vp,
+                                               C.POINTER(_vp)]
+    lib.sara_hip_sift_group_size.argtypes = [_vp]
+    lib.sara_hip_sift_group_context.argtypes = [_vp, C.c_int, C.POINTER(_vp)]
+    lib.sara_hip_sift_group_detect.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int,
+                                               C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.sara_hip_sift_group_gather.argtypes = [_vp, C.c_int, C.c_int, _vp,
+                                               C.POINTER(_vp), C.POINTER(_vp),
+                                               C.POINTER(_vp), C.POINTER(C.c_int)]
+    lib.sara_hip_sift_group_destroy.argtypes = [_vp]
     lib.sara_hip_selfcheck_sincos.argtypes = [_f32p, _f32p, _f32p, C.c_size_t]
     lib.sara_hip_selfcheck_sincos.restype = None
     return lib

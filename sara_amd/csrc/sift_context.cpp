@@ -1517,6 +1517,52 @@ sara_hip_status sara_hip_sift_collect(sara_hip_sift* c, int ticket,
   return status;
 }
 
+}  // extern "C"
+
+namespace sara_hip {
+  sara_hip_status set_error(sara_hip_status code, const char* msg)
+  {
+    return fail(code, msg);
+  }
+
+  sara_hip_status ticket_results(sara_hip_sift* c, int ticket, TicketResults* out)
+  {
+    if (!c || !out)
+      return fail(SARA_HIP_INVALID_PARAMS, "null context");
+    sara_hip_sift::RingSlot& r = c->ring[ticket & 1];
+    if (ticket < 0 || !r.pending || r.ticket != ticket)
+      return fail(SARA_HIP_NOT_READY, "unknown or already collected ticket");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(r.done));
+    const int mb = c->max_batch;
+    const int* h_off = r.h_counters + 3 * size_t(mb);
+    out->device = c->device;
+    out->batch = r.batch;
+    out->total = h_off[r.batch];
+    out->h_offsets = h_off;
+    out->d_feat = c->d_feat_s[ticket & 1];
+    out->d_desc = c->d_desc_s[ticket & 1];
+    out->d_so = c->d_so_s[ticket & 1];
+    out->capacity_exceeded = false;
+    for (int b = 0; b < r.batch; ++b)
+      if (r.h_counters[2 * size_t(mb) + b] > c->cap || r.h_counters[b] > c->cap ||
+          r.h_counters[mb + b] > c->sites.cap)
+        out->capacity_exceeded = true;
+    return SARA_HIP_OK;
+  }
+
+  void ticket_release(sara_hip_sift* c, int ticket)
+  {
+    if (!c || ticket < 0)
+      return;
+    sara_hip_sift::RingSlot& r = c->ring[ticket & 1];
+    if (r.pending && r.ticket == ticket)
+      r.pending = false;
+  }
+}  // namespace sara_hip
+
+extern "C" {
+
 sara_hip_status sara_hip_sift_synchronize(sara_hip_sift* c)
 {
   if (!c)

@@ -273,6 +273,26 @@ namespace sara_hip {
                               sara_match* out, int capacity, int* count,
                               hipStream_t stream);
 
+  // ---- hand-off between the context and the RCCL gather (sift_comm.cpp) ------
+  //! Device-resident results of one submit() ticket.
+  struct TicketResults
+  {
+    int device = 0;
+    int batch = 0;
+    int total = 0;                 // keypoints of the batch
+    const int* h_offsets = nullptr;  // batch + 1, pinned host memory
+    const sara_oeregion* d_feat = nullptr;
+    const float* d_desc = nullptr;
+    const int32_t* d_so = nullptr;
+    bool capacity_exceeded = false;
+  };
+  //! Waits for the batch of `ticket` and describes where its results are in
+  //! HBM; the ticket stays pending until ticket_release().
+  sara_hip_status ticket_results(sara_hip_sift* ctx, int ticket, TicketResults* out);
+  void ticket_release(sara_hip_sift* ctx, int ticket);
+  //! Records the error message sara_hip_last_error() returns on this thread.
+  sara_hip_status set_error(sara_hip_status code, const char* msg);
+
 #if defined(__HIPCC__)
   //! (strip, segment, frame) of a marching workgroup.  Workgroups are handed
   //! to the 8 XCDs round-robin in launch order and every XCD has its own L2, so

@@ -7,8 +7,17 @@ which RCCL does not provide natively.  On the GPU boxes the backend is "nccl"
 (= RCCL over xGMI: every peer reaches the root over its own link); the same
 code runs over "gloo" on CPU tensors in the tests.
 """
-import torch
-import torch.distributed as dist
+import ctypes as C
+
+import numpy as np
+
+try:  # torch only serves the gloo / torch.distributed variant below
+    import torch
+    import torch.distributed as dist
+except ImportError:  # pragma: no cover
+    torch = dist = None
+
+from . import capi
 
 
 def shard_range(n_frames, world_size, rank):
@@ -104,3 +113,147 @@ def gatherv_to_root(arrays, root=0, group=None, async_op=False, counts=None):
     for req in reqs:
         req.wait()
     return None, counts
+
+
+# --------------------------------------------------------------------------- #
+# Native gather: RCCL inside the library (include/sara_hip_sift.h, "Multi-GPU").
+# torch is not involved in the data path; a process-per-GPU launcher only has
+# to ship the 128-byte communicator id between its processes.
+# --------------------------------------------------------------------------- #
+def shard_range_native(n_frames, world_size, rank):
+    lo, hi = C.c_int(), C.c_int()
+    capi.load().sara_hip_shard_range(n_frames, world_size, rank, C.byref(lo),
+                                     C.byref(hi))
+    return lo.value, hi.value
+
+
+def _read_device(ptr, count, dtype, shape, device):
+    out = np.zeros(shape, dtype)
+    if count and ptr:
+        capi.check(capi.load().sara_hip_copy_to_host(
+            out.ctypes.data, ptr, out.nbytes, device))
+    return out
+
+
+class GatherResult:
+    """Keypoints of the whole job on the root device (device pointers owned by
+    the communicator) with the per-rank counts; host() copies them out."""
+
+    def __init__(self, counts, d_feat, d_desc, d_so, total, device):
+        self.counts, self.total, self.device = counts, total, device
+        self.d_features, self.d_descriptors, self.d_scale_octave = d_feat, d_desc, d_so
+
+    def host(self):
+        from . import OEREGION_DTYPE
+        n = self.total
+        return (_read_device(self.d_features, n, OEREGION_DTYPE, (n,), self.device),
+                _read_device(self.d_descriptors, n, np.float32, (n, 128), self.device),
+                _read_device(self.d_scale_octave, n, np.int32, (n, 2), self.device))
+
+
+class Comm:
+    """One rank of a process-per-GPU gather group (sara_hip_comm_*)."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * Comm.ID_BYTES)()
+        capi.check(capi.load().sara_hip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, ctx, comm_id, world_size, rank, device=None):
+        self.ctx, self.world_size, self.rank = ctx, world_size, rank
+        self.device = ctx.device if device is None else device
+        self._h = C.c_void_p()
+        buf = (C.c_ubyte * Comm.ID_BYTES).from_buffer_copy(comm_id)
+        capi.check(capi.load().sara_hip_comm_create(
+            ctx._h, buf, world_size, rank, self.device, C.byref(self._h)))
+
+    def gather(self, ticket, root=0, with_descriptors=True):
+        counts = (C.c_int * self.world_size)()
+        f, d, s = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        total = C.c_int(0)
+        capi.check(capi.load().sara_hip_comm_gather(
+            self._h, ticket, root, 1 if with_descriptors else 0, counts,
+            C.byref(f), C.byref(d), C.byref(s), C.byref(total)))
+        getattr(self.ctx, "_inflight", {}).pop(ticket, None)
+        return GatherResult(list(counts), f.value, d.value, s.value, total.value,
+                            self.device)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            try:
+                capi.load().sara_hip_comm_destroy(self._h)
+            except (AttributeError, TypeError):
+                pass
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+class SiftGroup:
+    """One process, one host thread per GPU (sara_hip_sift_group_*): the call
+    pattern of a C++ consumer.  Frames are sharded in contiguous blocks."""
+
+    def __init__(self, max_width, max_height, max_batch_per_device,
+                 pyramid_params=None, gauss_truncate=4.0, extremum_thres=0.01,
+                 edge_ratio_thres=10.0, extremum_refinement_iter=5,
+                 max_keypoints=0, n_dev=1, devices=None):
+        from . import ImagePyramidParams
+        lib = capi.load()
+        capi.require_gpu()
+        self.params = pyramid_params or ImagePyramidParams()
+        sp = capi.SiftParamsStruct(self.params._s, gauss_truncate, extremum_thres,
+                                   edge_ratio_thres, int(extremum_refinement_iter))
+        devs = (C.c_int * n_dev)(*devices) if devices is not None else None
+        self.devices = list(devices) if devices is not None else list(range(n_dev))
+        self.n_dev = n_dev
+        self._h = C.c_void_p()
+        capi.check(lib.sara_hip_sift_group_create(
+            C.byref(sp), max_width, max_height, max_batch_per_device,
+            max_keypoints, n_dev, devs, C.byref(self._h)))
+
+    def detect(self, frames, last_stage=capi.STAGE_DESCRIPTOR):
+        """frames: float32 [N, H, W] or uint8 [N, H, W] / [N, H, W, 3] host
+        array; device i gets the i-th contiguous block."""
+        a = np.ascontiguousarray(frames)
+        if a.dtype == np.uint8:
+            channels = 3 if a.ndim == 4 else 1
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            channels = 0
+        n, h, w = a.shape[:3]
+        ptrs = (C.c_void_p * self.n_dev)()
+        batch = (C.c_int * self.n_dev)()
+        frame_bytes = a[0].nbytes
+        self.shards = []
+        for i in range(self.n_dev):
+            lo, hi = shard_range_native(n, self.n_dev, i)
+            self.shards.append((lo, hi))
+            ptrs[i] = a.ctypes.data + lo * frame_bytes
+            batch[i] = hi - lo
+        self._keepalive = a
+        capi.check(capi.load().sara_hip_sift_group_detect(
+            self._h, ptrs, batch, 0, channels, w, h, 0, int(last_stage)))
+        return self
+
+    def gather(self, root=0, with_descriptors=True):
+        counts = (C.c_int * self.n_dev)()
+        f, d, s = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        total = C.c_int(0)
+        capi.check(capi.load().sara_hip_sift_group_gather(
+            self._h, root, 1 if with_descriptors else 0, counts, C.byref(f),
+            C.byref(d), C.byref(s), C.byref(total)))
+        return GatherResult(list(counts), f.value, d.value, s.value, total.value,
+                            self.devices[root])
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            try:
+                capi.load().sara_hip_sift_group_destroy(self._h)
+            except (AttributeError, TypeError):
+                pass
+            self._h = C.c_void_p()
+
+    __del__ = close

@@ -145,3 +145,33 @@ def test_product_does_not_reference_oracle():
                 if re.search(r"refbind|sift_ref|libsift_ref|oracle/", txt):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_shard_ranges_cover_the_frames_in_order():
+    """sara_hip_shard_range: contiguous blocks, frame f on rank floor(f * W / N),
+    empty shards when there are fewer frames than ranks - the same split as
+    sara_amd.distributed.shard_range (the torch.distributed variant)."""
+    from sara_amd import distributed as sd
+    for n, w in ((512, 8), (64, 1), (10, 4), (3, 8), (0, 4), (7, 7), (1000, 6)):
+        at = 0
+        for r in range(w):
+            lo, hi = sd.shard_range_native(n, w, r)
+            assert (lo, hi) == sd.shard_range(n, w, r)
+            assert lo == at and hi >= lo
+            for f in range(lo, hi):
+                assert (f * w) // n == r
+            at = hi
+        assert at == n
+
+
+def test_multi_gpu_entry_points_fail_loudly_without_a_gpu():
+    from sara_amd import capi
+    import ctypes as C
+    lib = capi.load()
+    if lib.sara_hip_device_count() > 0:
+        return
+    sp = capi.SiftParamsStruct()
+    lib.sara_hip_default_sift_params(C.byref(sp))
+    g = C.c_void_p()
+    st = lib.sara_hip_sift_group_create(C.byref(sp), 64, 64, 1, 0, 1, None, C.byref(g))
+    assert st in (capi.NO_DEVICE, capi.RCCL_ERROR) and not g.value

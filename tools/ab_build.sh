@@ -13,7 +13,7 @@ files="$*"
 flags="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -fvisibility=hidden $extra"
 mkdir -p ../lib/ab /tmp/ab_$name
 objs=""
-for f in pyramid_kernels.hip feature_kernels.hip match_kernels.hip sift_context.cpp; do
+for f in pyramid_kernels.hip feature_kernels.hip match_kernels.hip sift_context.cpp sift_comm.cpp; do
   o=${f%.*}.o
   if echo " $files " | grep -q " $f "; then
     x=""; [ "$f" = match_kernels.hip ] && x="-fno-slp-vectorize"
@@ -24,5 +24,5 @@ for f in pyramid_kernels.hip feature_kernels.hip match_kernels.hip sift_context.
   fi
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/ab/lib_$name.so $objs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/ab/lib_$name.so $objs -ldl -lpthread
 echo built sara_amd/lib/ab/lib_$name.so
