@@ -358,8 +358,12 @@ SARA_HIP_API sara_hip_status sara_hip_gradient_polar_coordinates(
     const float* src, int width, int height, float* mag_ori, int device);
 
 /* Extremum map of DoG layers (a = s-1, b = s, c = s+1): +1 max, -1 min, 0,    */
-/* including the 0.8*thres and edge tests, RefineExtremum.cpp:407-437          */
-/* (seam: shakti_scale_space_dog_extremum_32f_cpu, LocalExtremum.cpp:23-37).   */
+/* including the 0.8*thres and edge tests.  img_padding_sz >= 1: the rules of  */
+/* the default build, RefineExtremum.cpp:407-437 (sites inside the padding     */
+/* only).  img_padding_sz == 0: the seam itself,                               */
+/* shakti_scale_space_dog_extremum_32f_cpu (LocalExtremum.cpp:23-37) =          */
+/* is_dog_extremum of Shakti/Halide/Components/DoGExtremum.hpp:59-78 on        */
+/* repeat_edge inputs: every pixel, strict contrast test, Halide's hessian.    */
 SARA_HIP_API sara_hip_status sara_hip_scale_space_dog_extremum_map(
     const float* a, const float* b, const float* c, int width, int height,
     float edge_ratio_thres, float extremum_thres, int img_padding_sz,

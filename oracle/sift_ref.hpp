@@ -52,8 +52,9 @@ namespace sara_ref {
   //!    (RefineExtremum.cpp:226-361): the map is int8, so minima reach
   //!    refine_extremum as type -1 and are refined like maxima (quirk Q2 gone),
   //!    and a refined scale outside (sigma(s) / 4, 4 sigma(s)) rejects the
-  //!    site (:307-325).  The map itself is still classified by the default
-  //!    rules: the Halide-generated classifier cannot be built here.
+  //!    site (:307-325).  The map comes from the restated Halide classifier
+  //!    (halide_is_dog_extremum below): every pixel, replicated borders, strict
+  //!    contrast test, Halide's own hessian.
   //!  * kModeDownscaleAtDoubleSigma: octave o + 1 is sub-sampled from the
   //!    scale whose sigma is 2 sigma_0, round(log 2 / log k), instead of
   //!    floor(...) which float rounding of k turns into one scale lower
@@ -597,6 +598,80 @@ namespace sara_ref {
            compare_with_neighborhood3(val, x, y, I(s + 1, o), true, cmp);
   }
 
+  // ------------------------------------------------------------------------ //
+  // The classifier of the reference's DO_SARA_USE_HALIDE build:
+  // scale_space_dog_extremum_map() (ImageProcessing/LocalExtremum.cpp:23-37)
+  // calls the AOT function shakti_scale_space_dog_extremum_32f_cpu, generated
+  // from v2::LocalScaleSpaceExtremum
+  // (Shakti/Halide/Generators/LocalExtremumGeneratorsV2.cpp:103-220) =
+  // is_dog_extremum(prev, curr, next, ...) of
+  // Shakti/Halide/Components/DoGExtremum.hpp:59-78 on repeat_edge() inputs:
+  //   * EVERY pixel is classified, neighbours outside the image replicate the
+  //     border (no img_padding_sz);
+  //   * extremum = value equals the maximum / minimum of the 3 x 3 x 3 block
+  //     (LocalExtremum.hpp:42-52), i.e. non-strict like the default build;
+  //     a flat block is a maximum (the select tries is_max first);
+  //   * contrast: abs(curr) > 0.8f * extremum_thres - STRICT, where the
+  //     default build keeps abs >= 0.8 thres (RefineExtremum.cpp:426);
+  //   * on_edge (DoGExtremum.hpp:29-36) through the Halide hessian
+  //     (Components/Differential.hpp:33-49): dxx = in(x+1) + in(x-1) - 2 in(x)
+  //     (another operation order than Differential.hpp of Sara), and
+  //     dxy = (in(x+1,y+1) - in(x-1,y-1) - in(x+1,y-1) + in(x-1,y-1)) / 4 -
+  //     the second term reads (x-1, y-1) where the formula wants (x-1, y+1);
+  //     restated as written.  pow(., 2) with a constant integer exponent is
+  //     expanded by Halide into a product (IROperator.cpp,
+  //     raise_to_integer_power).
+  // PARITY UNPINNED: Halide cannot be built here, and whether its x86 code
+  // generator contracts a*b+c is not knowable from the sources; plain IEEE
+  // operations in the written order are assumed.
+  // ------------------------------------------------------------------------ //
+  inline float clamped(const Image& I, int x, int y)
+  {
+    x = x < 0 ? 0 : (x > I.w - 1 ? I.w - 1 : x);
+    y = y < 0 ? 0 : (y > I.h - 1 ? I.h - 1 : y);
+    return I(x, y);
+  }
+
+  inline bool halide_on_edge(const Image& in, int x, int y, float edge_ratio)
+  {
+    const float c = clamped(in, x, y);
+    const float dxx = clamped(in, x + 1, y) + clamped(in, x - 1, y) - 2 * c;
+    const float dyy = clamped(in, x, y + 1) + clamped(in, x, y - 1) - 2 * c;
+    const float dxy = (clamped(in, x + 1, y + 1) - clamped(in, x - 1, y - 1) -
+                       clamped(in, x + 1, y - 1) + clamped(in, x - 1, y - 1)) /
+                      4;
+    const float tr = dxx + dyy;
+    const float det = dxx * dyy - dxy * dxy;
+    return (tr * tr) * edge_ratio >=
+           ((1 + edge_ratio) * (1 + edge_ratio)) * std::abs(det);
+  }
+
+  //! is_dog_extremum(prev, curr, next, edge_ratio, extremum_thres, x, y) -> int8.
+  inline int halide_is_dog_extremum(const Image& prev, const Image& curr,
+                                    const Image& next, int x, int y,
+                                    float edge_ratio, float extremum_thres)
+  {
+    const float v = curr(x, y);
+    float mx = v, mn = v;
+    for (int dv = -1; dv <= 1; ++dv)
+      for (int du = -1; du <= 1; ++du)
+      {
+        const float a = clamped(prev, x + du, y + dv);
+        const float b = clamped(curr, x + du, y + dv);
+        const float c = clamped(next, x + du, y + dv);
+        mx = std::max(mx, std::max(a, std::max(b, c)));
+        mn = std::min(mn, std::min(a, std::min(b, c)));
+      }
+    const bool is_max = mx == v, is_min = mn == v;
+    const bool is_strong = std::abs(v) > 0.8f * extremum_thres;
+    const bool is_not_on_edge = !halide_on_edge(curr, x, y, edge_ratio);
+    if (is_max && is_strong && is_not_on_edge)
+      return 1;
+    if (is_min && is_strong && is_not_on_edge)
+      return -1;
+    return 0;
+  }
+
   //! FeatureDetectors/RefineExtremum.cpp:24-30.
   inline bool on_edge(const Image& I, int x, int y, float edge_ratio)
   {
@@ -1064,12 +1139,22 @@ namespace sara_ref {
     const int wh = w * h;
 
     std::vector<std::uint8_t> map(size_t(wh), 0);
+    const bool halide_map = (detector_mode() & kModeSignedExtremumType) != 0;
 
 #pragma omp parallel for
     for (int xy = 0; xy < wh; ++xy)
     {
       const int y = xy / w;
       const int x = xy - y * w;
+      if (halide_map)
+      {
+        // RefineExtremum.cpp:246-262: the whole map comes from the Halide
+        // classifier (int8: -1 stays -1)
+        map[xy] = static_cast<std::uint8_t>(static_cast<std::int8_t>(
+            halide_is_dog_extremum(I(s - 1, o), I(s, o), I(s + 1, o), x, y,
+                                   edge_ratio_thres, extremum_thres)));
+        continue;
+      }
       const bool in_domain = img_padding_sz <= x && x < w - img_padding_sz &&
                              img_padding_sz <= y && y < h - img_padding_sz;
       if (!in_domain)

@@ -364,6 +364,21 @@ int ref_set_squared_norm_order(int order)
 
 float ref_eigen_squared_norm128(const float* h) { return eigen_squared_norm128(h); }
 
+//! The Halide build's classifier on three w x h layers -> int8 map.
+void ref_halide_dog_extremum_map(const float* a, const float* b, const float* c,
+                                 int w, int h, float edge_ratio,
+                                 float extremum_thres, signed char* out)
+{
+  Image A(w, h), B(w, h), Cc(w, h);
+  std::copy(a, a + size_t(w) * h, A.d.begin());
+  std::copy(b, b + size_t(w) * h, B.d.begin());
+  std::copy(c, c + size_t(w) * h, Cc.d.begin());
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x)
+      out[size_t(y) * w + x] = static_cast<signed char>(
+          halide_is_dog_extremum(A, B, Cc, x, y, edge_ratio, extremum_thres));
+}
+
 // ---- whole-pipeline handle ---------------------------------------------- //
 
 struct ref_sift

@@ -397,7 +397,53 @@ namespace sara_hip {
       const size_t i = size_t(s) * plane + size_t(y) * w + x;
       return base[i + plane] - base[i];
     }
+    //! BoundaryConditions::repeat_edge of the Halide classifier.
+    __device__ float at_clamped(int x, int y, int s) const
+    {
+      x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+      y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+      return at(x, y, s);
+    }
   };
+
+  //! is_dog_extremum of the reference's DO_SARA_USE_HALIDE build
+  //! (Shakti/Halide/Components/DoGExtremum.hpp:59-78 on repeat_edge inputs,
+  //! generator v2::LocalScaleSpaceExtremum): every pixel, replicated borders,
+  //! value == max / min of the 3 x 3 x 3 block, STRICT contrast test, on_edge
+  //! through the Halide hessian (Components/Differential.hpp:33-49, whose
+  //! cross term reads (x-1, y-1) twice - restated as written).  `get(x, y, ds)`
+  //! reads layer s + ds with clamped coordinates.  -> +1 / -1 / 0.
+  template <typename Get>
+  __device__ inline int halide_is_dog_extremum(Get get, int x, int y,
+                                               float edge_ratio, float thres)
+  {
+    const float v = get(x, y, 0);
+    float mx = v, mn = v;
+#pragma unroll
+    for (int dv = -1; dv <= 1; ++dv)
+#pragma unroll
+      for (int du = -1; du <= 1; ++du)
+      {
+        const float a = get(x + du, y + dv, -1);
+        const float b = get(x + du, y + dv, 0);
+        const float c = get(x + du, y + dv, 1);
+        mx = fmaxf(mx, fmaxf(a, fmaxf(b, c)));
+        mn = fminf(mn, fminf(a, fminf(b, c)));
+      }
+    const bool is_max = mx == v, is_min = mn == v;
+    if (!(is_max || is_min) || !(fabsf(v) > 0.8f * thres))
+      return 0;
+    const float dxx = get(x + 1, y, 0) + get(x - 1, y, 0) - 2 * v;
+    const float dyy = get(x, y + 1, 0) + get(x, y - 1, 0) - 2 * v;
+    const float dxy = (get(x + 1, y + 1, 0) - get(x - 1, y - 1, 0) -
+                       get(x + 1, y - 1, 0) + get(x - 1, y - 1, 0)) /
+                      4;
+    const float tr = dxx + dyy;
+    const float det = dxx * dyy - dxy * dxy;
+    if ((tr * tr) * edge_ratio >= ((1 + edge_ratio) * (1 + edge_ratio)) * fabsf(det))
+      return 0;
+    return is_max ? 1 : -1;
+  }
 
   __device__ inline float sum3(float a0, float a1, float a2)
   {
@@ -733,16 +779,19 @@ namespace sara_hip {
                                           const CandidateLists& cand)
   {
     const float v = I.at(x, y, s);
-    const float hxx = I.at(x + 1, y, s) - 2.f * v + I.at(x - 1, y, s);
-    const float hyy = I.at(x, y + 1, s) - 2.f * v + I.at(x, y - 1, s);
-    const float hxy = (I.at(x + 1, y + 1, s) - I.at(x - 1, y + 1, s) -
-                       I.at(x + 1, y - 1, s) + I.at(x - 1, y - 1, s)) /
-                      4.f;
-    const float tr = hxx + hyy;
-    const float det = hxx * hyy - hxy * hxy;
-    const float er = p.edge_ratio_thres;
-    if ((tr * tr) * er >= ((er + 1.f) * (er + 1.f)) * fabsf(det))
-      return;
+    if (!p.signed_type)  // the Halide classifier has done its own edge test
+    {
+      const float hxx = I.at(x + 1, y, s) - 2.f * v + I.at(x - 1, y, s);
+      const float hyy = I.at(x, y + 1, s) - 2.f * v + I.at(x, y - 1, s);
+      const float hxy = (I.at(x + 1, y + 1, s) - I.at(x - 1, y + 1, s) -
+                         I.at(x + 1, y - 1, s) + I.at(x - 1, y - 1, s)) /
+                        4.f;
+      const float tr = hxx + hyy;
+      const float det = hxx * hyy - hxy * hxy;
+      const float er = p.edge_ratio_thres;
+      if ((tr * tr) * er >= ((er + 1.f) * (er + 1.f)) * fabsf(det))
+        return;
+    }
 
     float pos[3];
     float val = v;
@@ -787,11 +836,23 @@ namespace sara_hip {
     const int s = 1 + (z - b * nscan);
     const int w = gauss.w, h = gauss.h;
     const int pad = p.img_padding_sz;
+    const DogOctave I{gauss.base + size_t(b) * gauss.frame_stride, w, h,
+                      gauss.plane, gauss.scales - 1};
+    if (p.signed_type)
+    {
+      // the map of the DO_SARA_USE_HALIDE branch (RefineExtremum.cpp:246-262)
+      if (x >= w || y >= h)
+        return;
+      const int t = halide_is_dog_extremum(
+          [&](int xx, int yy, int ds) { return I.at_clamped(xx, yy, s + ds); }, x,
+          y, p.edge_ratio_thres, p.extremum_thres);
+      if (t != 0)
+        finish_candidate(I, x, y, s, t, octave, b, p, *tabp, cand);
+      return;
+    }
     if (!(pad <= x && x < w - pad && pad <= y && y < h - pad))
       return;
 
-    const DogOctave I{gauss.base + size_t(b) * gauss.frame_stride, w, h,
-                      gauss.plane, gauss.scales - 1};
     const float v = I.at(x, y, s);
     if (fabsf(v) < 0.8f * p.extremum_thres)
       return;
@@ -1142,7 +1203,9 @@ namespace sara_hip {
     const bool aligned2 = (gauss.w % 2 == 0) && gauss.w >= 4 &&
                           (gauss.plane % 2 == 0) &&
                           (reinterpret_cast<uintptr_t>(gauss.base) % 8 == 0);
-    if (aligned2 && g_use_march && gauss.scales == 6)
+    // the Halide-branch classifier (signed_type) also classifies the border
+    // pixels: it runs on the general path
+    if (aligned2 && g_use_march && gauss.scales == 6 && !p.signed_type)
     {
       const int nstrips = (gauss.w - 2 + 125) / 126;
       int nseg = (g_extrema_waves + nstrips * batch - 1) / (nstrips * batch);
@@ -1185,7 +1248,18 @@ namespace sara_hip {
       return;
     const size_t i = size_t(y) * w + x;
     int type = 0;
-    if (pad <= x && x < w - pad && pad <= y && y < h - pad)
+    if (pad == 0)
+    {
+      // the Halide seam itself (shakti_scale_space_dog_extremum_32f_cpu)
+      auto get = [&](int xx, int yy, int ds) {
+        xx = xx < 0 ? 0 : (xx > w - 1 ? w - 1 : xx);
+        yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+        const float* l = ds < 0 ? a : (ds == 0 ? b : c);
+        return l[size_t(yy) * w + xx];
+      };
+      type = halide_is_dog_extremum(get, x, y, edge_ratio, thres);
+    }
+    else if (pad <= x && x < w - pad && pad <= y && y < h - pad)
       type = classify_site(a + i, b + i, c + i, w, thres, edge_ratio);
     out[i] = int8_t(type);
   }

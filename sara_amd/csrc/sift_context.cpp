@@ -2117,8 +2117,8 @@ sara_hip_status sara_hip_scale_space_dog_extremum_map(
 {
   if (!a || !b || !c || !out || w < 3 || h < 3)
     return fail(SARA_HIP_INVALID_PARAMS, "layers must be at least 3x3");
-  if (img_padding_sz < 1)
-    return fail(SARA_HIP_INVALID_PARAMS, "img_padding_sz must be >= 1");
+  if (img_padding_sz < 0)
+    return fail(SARA_HIP_INVALID_PARAMS, "img_padding_sz must be >= 0");
   const sara_hip_status st = select_device(device);
   if (st != SARA_HIP_OK)
     return st;

@@ -481,6 +481,21 @@ def not_definite_enough3(mats, type_, rule=DEF_EIGEN34):
     return out.astype(bool)
 
 
+def halide_dog_extremum_map(a, b, c, edge_ratio=10.0, extremum_thres=0.01):
+    """int8 map of the reference's DO_SARA_USE_HALIDE classifier (restated)."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    c = np.ascontiguousarray(c, np.float32)
+    out = np.zeros(a.shape, np.int8)
+    fn = lib().ref_halide_dog_extremum_map
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                   C.c_float, C.c_float, C.c_void_p]
+    fn(a.ctypes.data, b.ctypes.data, c.ctypes.data, a.shape[1], a.shape[0],
+       float(edge_ratio), float(extremum_thres), out.ctypes.data)
+    return out
+
+
 def root_sift(desc):
     out = np.array(desc, np.float32, order="C", copy=True).reshape(-1, np.shape(desc)[-1])
     fn = lib().ref_root_sift

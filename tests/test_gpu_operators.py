@@ -221,3 +221,20 @@ def test_short_device_math_is_exact_on_every_float():
     bad = (C.c_ulonglong * 2)(1, 1)
     capi.check(capi.load().sara_hip_selfcheck_device_math(bad, 0))
     assert (bad[0], bad[1]) == (0, 0)
+
+
+def test_extremum_map_halide_seam(oracle):
+    """img_padding_sz = 0: the seam shakti_scale_space_dog_extremum_32f_cpu
+    itself - every pixel, replicated borders, strict contrast, Halide hessian -
+    against the oracle's restatement, exact."""
+    h, w = 61, 87
+    layers = (RNG.random((3, h, w), dtype=np.float32) - 0.5) * 0.2
+    layers[1, 0, 5] = 0.8
+    layers[1, h - 1, 0] = -0.8
+    layers[0, 20, 20:24] = layers[1, 20, 21]
+    layers[1, 40, 40] = np.float32(0.8) * np.float32(0.01)
+    got = sara_amd.scale_space_dog_extremum_map(layers[0], layers[1], layers[2],
+                                                10.0, 0.01, 0)
+    want = oracle.halide_dog_extremum_map(layers[0], layers[1], layers[2], 10.0, 0.01)
+    assert np.array_equal(got, want)
+    assert got[0, 5] == 1 and got[h - 1, 0] == -1 and np.count_nonzero(got) > 20

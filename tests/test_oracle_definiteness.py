@@ -122,3 +122,50 @@ def test_normalize_order_changes_descriptors_by_ulps_only(oracle):
     assert d0.shape == d1.shape and len(d0) > 300
     # measured 9.2e-5 on four full frames (values in 0..255): a few ulps
     assert float(np.abs(d0 - d1).max()) < 2.5e-4
+
+
+def test_halide_classifier_differs_where_it_should(oracle):
+    """The restated classifier of the DO_SARA_USE_HALIDE build
+    (Shakti/Halide/Components/DoGExtremum.hpp:59-78 on repeat_edge inputs)
+    against the default rules (RefineExtremum.cpp:407-437): border pixels are
+    classified, the contrast test is strict, the hessian is Halide's own."""
+    rng = np.random.default_rng(4)
+    h, w = 48, 64
+    layers = ((rng.random((3, h, w), dtype=np.float32) - 0.5) * 0.2).astype(np.float32)
+    thres = np.float32(0.01)
+    # (a) an isolated strong maximum on the border and in a corner
+    layers[1, 0, 10] = 0.9
+    layers[1, h - 1, w - 1] = -0.9
+    # (b) interior peak exactly at 0.8 * thres: kept by ">=" rules, dropped by ">"
+    eq = np.float32(0.8) * thres
+    layers[:, 19:24, 29:34] = 0
+    layers[1, 21, 31] = eq
+    # (c) a well separated interior blob: same answer from both
+    layers[:, 30:37, 40:47] = 0
+    layers[1, 33, 43] = 0.5
+    hal = oracle.halide_dog_extremum_map(layers[0], layers[1], layers[2], 10.0, thres)
+    assert hal[0, 10] == 1 and hal[h - 1, w - 1] == -1       # borders classified
+    assert hal[21, 31] == 0                                  # strict contrast
+    assert hal[33, 43] == 1
+    # default rules on the same layers (predicates of the oracle)
+    assert oracle.scale_space_extremum(layers, 31, 21, strict=False) == 1
+    assert not abs(layers[1, 21, 31]) < np.float32(0.8) * thres   # default keeps it
+    assert not oracle.on_edge(layers[1], 31, 21, 10.0)
+    assert oracle.scale_space_extremum(layers, 43, 33, strict=False) == 1
+    # interior agreement away from ties / the contrast boundary / edge cases:
+    # count how often the two maps differ inside the padding
+    want = np.zeros((h, w), np.int8)
+    for y in range(1, h - 1):
+        for x in range(1, w - 1):
+            t = oracle.scale_space_extremum(layers, x, y, strict=False)
+            if t and not abs(layers[1, y, x]) < np.float32(0.8) * thres \
+                    and not oracle.on_edge(layers[1], x, y, 10.0):
+                want[y, x] = t
+    inner = (slice(1, h - 1), slice(1, w - 1))
+    differ = np.argwhere(hal[inner] != want[inner]) + 1
+    # every interior difference is explained by the strict contrast rule or by
+    # the different hessian in the edge test - never by the extremum predicate
+    for y, x in differ:
+        assert oracle.scale_space_extremum(layers, int(x), int(y), strict=False) != 0
+    assert (21, 31) in {tuple(d) for d in differ}
+    assert np.count_nonzero(hal) > 20
