@@ -322,14 +322,16 @@ def test_corrected_mode_switches_of_the_restatement(oracle):
     sreg = signed.extrema()[0]
     smins = sreg[sreg["extremum_type"] == -1]["coords"]
     assert np.any(smins != np.round(smins))
-    # maxima are untouched by the switch, except for those whose refined scale
-    # is implausible (:307-325)
+    # Maxima: the branch classifies with the Halide rules (every pixel, strict
+    # contrast, its own hessian in the edge test - more lenient on this image),
+    # refines like the default build and drops implausible refined scales
+    # (:307-325): a default maximum that survives has the same record.
     smax, dmax = sreg[sreg["extremum_type"] == 1], reg[reg["extremum_type"] == 1]
     kept = {(c.tobytes(), m.tobytes(), float(v)) for c, m, v in
-            zip(dmax["coords"], dmax["shape_matrix"], dmax["extremum_value"])}
-    assert 0 < len(smax) <= len(dmax)
-    assert all((c.tobytes(), m.tobytes(), float(v)) in kept for c, m, v in
-               zip(smax["coords"], smax["shape_matrix"], smax["extremum_value"]))
+            zip(smax["coords"], smax["shape_matrix"], smax["extremum_value"])}
+    common_max = [(c.tobytes(), m.tobytes(), float(v)) in kept for c, m, v in
+                  zip(dmax["coords"], dmax["shape_matrix"], dmax["extremum_value"])]
+    assert len(smax) > 0 and sum(common_max) >= 0.8 * len(dmax)
     assert np.array_equal(signed.gaussian(0, 1), base.gaussian(0, 1))
     with oracle.detector_mode(oracle.MODE_DOWNSCALE_AT_DOUBLE_SIGMA):
         fixed = oracle.RefSift(img, p, stop_after=3)
