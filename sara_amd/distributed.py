@@ -62,11 +62,18 @@ def gatherv_to_root(arrays, root=0, group=None, async_op=False, counts=None):
     batch's kernels overlap the exchange.  `counts` (from exchange_counts)
     skips the all_gather of the counts on the arrays' device."""
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    rank = dist.get_rank(group)   # group-local; `root` is group-local as well
     n = int(arrays[0].shape[0])
     for a in arrays:
         assert int(a.shape[0]) == n
     dev = arrays[0].device
+
+    def peer(r):
+        """P2POp addresses peers by GLOBAL rank: translate a group-local one."""
+        if group is None:
+            return r
+        return dist.get_global_rank(group, r)
+
     if counts is None:
         n_t = torch.tensor([n], device=dev, dtype=torch.int64)
         all_n = [torch.zeros_like(n_t) for _ in range(world)]
@@ -96,7 +103,7 @@ def gatherv_to_root(arrays, root=0, group=None, async_op=False, counts=None):
                 continue
             for o in outs:
                 ops.append(dist.P2POp(dist.irecv, o[offs[r]:offs[r] + counts[r]],
-                                      r, group))
+                                      peer(r), group))
         reqs = dist.batch_isend_irecv(ops) if ops else []
         if async_op:
             return PendingGather(outs, counts, reqs, (outs, arrays))
@@ -106,7 +113,7 @@ def gatherv_to_root(arrays, root=0, group=None, async_op=False, counts=None):
     ops = []
     sends = [a.contiguous() for a in arrays]
     if n:
-        ops = [dist.P2POp(dist.isend, a, root, group) for a in sends]
+        ops = [dist.P2POp(dist.isend, a, peer(root), group) for a in sends]
     reqs = dist.batch_isend_irecv(ops) if ops else []
     if async_op:
         return PendingGather(None, counts, reqs, sends)

@@ -110,3 +110,33 @@ def test_gatherv_over_gloo(oracle, tmp_path, world, n_frames):
     assert np.array_equal(got["desc"], np.concatenate(descs))
     assert np.array_equal(got["so"], np.concatenate(sos))
     assert int(got["counts"].sum()) == len(got["regs"]) > 0
+
+
+def _subgroup_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sub = dist.new_group(ranks=[1, 2])       # group-local 0, 1 = global 1, 2
+    if rank in (1, 2):
+        local = dist.get_rank(sub)
+        n = 3 + local
+        arrays = [torch.full((n, 4), float(rank)),
+                  torch.arange(n, dtype=torch.int32).reshape(n, 1) + 100 * rank]
+        outs, counts = gatherv_to_root(arrays, root=0, group=sub)
+        assert counts == [3, 4]
+        if local == 0:                       # the root of the SUBGROUP is global 1
+            assert outs[0].shape == (7, 4)
+            assert torch.equal(outs[0][:3], torch.full((3, 4), 1.0))
+            assert torch.equal(outs[0][3:], torch.full((4, 4), 2.0))
+            assert outs[1].flatten().tolist() == [100, 101, 102, 200, 201, 202, 203]
+        else:
+            assert outs is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gatherv_in_a_subgroup():
+    """Peers of P2POp are GLOBAL ranks: a gather inside a subgroup whose ranks
+    are not 0..n-1 must translate its group-local ranks."""
+    mp.start_processes(_subgroup_worker, args=(3, _free_port()), nprocs=3,
+                       join=True, start_method="spawn")
