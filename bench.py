@@ -303,7 +303,33 @@ def secondary_configs(args, torch, dev):
         "keypoints_per_s": kp / (tot_ms / 1e3),
         "keypoints_per_frame": kp / B4,
     }
-    del d_one, d4
+    # ---- opt-in fused-multiply-add blurs (SARA_HIP_OPT_FMA_BLUR): not bit-exact,
+    # never part of `value` / `roofline`; reported for comparison only
+    Wb, Hb, Bb = 1920, 1080, 64
+    fb = synth_batch(Wb, Hb, Bb, unique=8)
+    db = torch.from_numpy(fb).to(dev)
+    Pb = sum((Wb >> o) * (Hb >> o) for o in range(4))
+    with sara_amd.SiftContext(Wb, Hb, Bb, p4, device=dev.index or 0) as cb:
+        res = {}
+        for name, on in (("exact", 0), ("fma", 1)):
+            cb.set_option(sara_amd.capi.OPT_FMA_BLUR, on)
+            pyr, tot = [], []
+            for i in range(8):
+                cb.detect_device(db.data_ptr(), Bb, Wb, Hb)
+                cb.counts()
+                if i >= 2:
+                    st = cb.stage_times()
+                    pyr.append(st["pyramid"])
+                    tot.append(st["total"])
+            res[name] = (float(np.mean(pyr)), float(np.mean(tot)))
+    out["fma_blur_option"] = {
+        "note": "SARA_HIP_OPT_FMA_BLUR = 1 (opt-in, pyramids within 3e-7 of the "
+                "range instead of bit-exact); same 64 x 1080p workload",
+        "pyramid_ms_exact": res["exact"][0], "pyramid_ms_fma": res["fma"][0],
+        "pyramid_frac_fma": 48 * Pb * Bb / 1e9 / (res["fma"][0] / 1e3) / HBM_PEAK_GBS,
+        "ms_per_step_exact": res["exact"][1], "ms_per_step_fma": res["fma"][1],
+    }
+    del d_one, d4, db
     return out
 
 

@@ -311,11 +311,18 @@ enum
                                         /* maxima, and sites whose refined      */
                                         /* scale leaves (sigma(s)/4, 4 sigma(s))*/
                                         /* are rejected (:307-325)              */
-  SARA_HIP_OPT_DOWNSCALE_AT_DOUBLE_SIGMA = 5  /* 1: octave o+1 is sub-sampled    */
+  SARA_HIP_OPT_DOWNSCALE_AT_DOUBLE_SIGMA = 5, /* 1: octave o+1 is sub-sampled    */
                                         /* from scale round(log 2 / log k), the */
                                         /* one at 2 sigma_0, instead of floor() */
                                         /* (GaussianPyramid.hpp:97-100), which   */
                                         /* is one lower for k = float(2^(1/3))  */
+  SARA_HIP_OPT_FMA_BLUR = 6             /* 1: the Gaussian blurs fuse multiply   */
+                                        /* and add (v_fma_f32): half the         */
+                                        /* arithmetic, pyramids within 3e-7 of   */
+                                        /* the range of the reference's instead  */
+                                        /* of bit-identical (the reference is    */
+                                        /* built without FMA).  Default 0; never */
+                                        /* used by the benchmark's headline line */
 };
 SARA_HIP_API sara_hip_status sara_hip_sift_set_option(sara_hip_sift* ctx,
                                                      int option, int value);

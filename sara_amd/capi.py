@@ -30,6 +30,7 @@ OPT_STAGE_TIMERS = 2
 OPT_ROOT_SIFT = 3
 OPT_SIGNED_EXTREMUM_TYPE = 4
 OPT_DOWNSCALE_AT_DOUBLE_SIGMA = 5
+OPT_FMA_BLUR = 6
 
 #: numpy view of sara_oeregion (48 bytes, Features/Feature.hpp:155-177).
 MATCH_DTYPE = np.dtype([("x_index", "<i4"), ("y_index", "<i4"), ("score", "<f4"),

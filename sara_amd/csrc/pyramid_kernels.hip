@@ -262,7 +262,10 @@ namespace sara_hip {
   //! dec(x, y) = dst(2x, 2y) - exactly downscale(dst, 2) (Resize.cpp:45-84:
   //! int(x * (w / (w/2))) == 2x for every x < w/2), i.e. the first plane of
   //! the next octave, without a separate pass over HBM.
-  template <int R, int PF, bool DEC>
+  //! FMA (opt-in, SARA_HIP_OPT_FMA_BLUR): sum = fma(v, k, sum) instead of the
+  //! reference's separately rounded multiply and add - half the arithmetic
+  //! instructions, results within 2e-7 of the range instead of bit-exact.
+  template <int R, int PF, bool DEC, bool FMA = false>
   __global__ __launch_bounds__(64, R <= 6 ? 4 : 1) void gaussian_blur_march_kernel(
       const float* __restrict__ src, size_t src_stride,
       float* __restrict__ dst, size_t dst_stride, float* __restrict__ dec,
@@ -360,7 +363,8 @@ namespace sara_hip {
             float sum = 0.f;
 #pragma unroll
             for (int j = 0; j < K; ++j)
-              sum += v[D + c + j] * taps.k[j];
+              sum = FMA ? __builtin_fmaf(v[D + c + j], taps.k[j], sum)
+                        : sum + v[D + c + j] * taps.k[j];
             t[c] = sum;
           }
         }
@@ -376,7 +380,8 @@ namespace sara_hip {
             if (j == 0)
               A[sl][c] = 0.f + t[c] * taps.k[0];
             else
-              A[sl][c] += t[c] * taps.k[j];
+              A[sl][c] = FMA ? __builtin_fmaf(t[c], taps.k[j], A[sl][c])
+                             : A[sl][c] + t[c] * taps.k[j];
           }
         }
 
@@ -416,7 +421,7 @@ namespace sara_hip {
   static void launch_blur_march(const float* src, size_t src_stride, float* dst,
                                 size_t dst_stride, float* dec, size_t dec_stride,
                                 int w, int h, int batch, const Taps& taps,
-                                hipStream_t stream)
+                                hipStream_t stream, bool fma = false)
   {
     constexpr int W = 256;
     // prefetch depth: the K x 4 partial-sum ring dominates the register
@@ -436,16 +441,20 @@ namespace sara_hip {
     nseg = (h + seg_rows - 1) / seg_rows;
     const int total = xcd_map_enabled() ? nstrips * nseg * batch : 0;
     const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(nstrips * nseg, batch);
-    if (dec)
-      hipLaunchKernelGGL((gaussian_blur_march_kernel<R, PF, true>), grid,
-                         dim3(64), 0, stream, src, src_stride, dst, dst_stride,
-                         dec, dec_stride, w, h, seg_rows, nstrips, nseg, total,
-                         taps);
+#define SARA_MARCH_LAUNCH(DEC_, FMA_)                                          \
+  hipLaunchKernelGGL((gaussian_blur_march_kernel<R, PF, DEC_, FMA_>), grid,    \
+                     dim3(64), 0, stream, src, src_stride, dst, dst_stride,    \
+                     dec, dec_stride, w, h, seg_rows, nstrips, nseg, total,    \
+                     taps)
+    if (dec && fma)
+      SARA_MARCH_LAUNCH(true, true);
+    else if (dec)
+      SARA_MARCH_LAUNCH(true, false);
+    else if (fma)
+      SARA_MARCH_LAUNCH(false, true);
     else
-      hipLaunchKernelGGL((gaussian_blur_march_kernel<R, PF, false>), grid,
-                         dim3(64), 0, stream, src, src_stride, dst, dst_stride,
-                         dec, dec_stride, w, h, seg_rows, nstrips, nseg, total,
-                         taps);
+      SARA_MARCH_LAUNCH(false, false);
+#undef SARA_MARCH_LAUNCH
   }
 
   // ------------------------------------------------------------------------ //
@@ -543,8 +552,8 @@ namespace sara_hip {
                  : "v"(t0), "v"(t1), "v"(k0), "v"(kr));
   }
 
-  template <int R, int PF>
-  __global__ __launch_bounds__(64) void gaussian_blur_march2_kernel(
+  template <int R, int PF, bool FMA = false>
+  __global__ __launch_bounds__(64, (FMA && R < 12) ? 4 : 1) void gaussian_blur_march2_kernel(
       const float* __restrict__ src, size_t src_stride,
       float* __restrict__ dst, size_t dst_stride, int w, int h, int seg_rows,
       int nstrips, int nseg, int xcd_total, Taps taps)
@@ -634,6 +643,33 @@ namespace sara_hip {
         }
         // row pass on source row n
         float t0 = 0.f, t1 = 0.f;
+        if constexpr (FMA)
+        {
+          // opt-in fused form: one v_fma per tap and output (no product is
+          // shared between outputs any more), compiler-scheduled
+#pragma unroll
+          for (int j = 0; j < K; ++j)
+          {
+            t0 = __builtin_fmaf(v[D + j], SARA_TK(j), t0);
+            t1 = __builtin_fmaf(v[D + j + 1], SARA_TK(j), t1);
+          }
+#pragma unroll
+          for (int j = 0; j < K; ++j)
+          {
+            const int sl = (i + K - 1 - j) % K;
+            if (j == 0)
+            {
+              A[sl][0] = 0.f + t0 * SARA_TK(0);
+              A[sl][1] = 0.f + t1 * SARA_TK(0);
+            }
+            else
+            {
+              A[sl][0] = __builtin_fmaf(t0, SARA_TK(j), A[sl][0]);
+              A[sl][1] = __builtin_fmaf(t1, SARA_TK(j), A[sl][1]);
+            }
+          }
+        }
+        else
         {
           constexpr int NB = K / 4;
 #pragma unroll
@@ -647,7 +683,6 @@ namespace sara_hip {
 #pragma unroll
           for (int j = 4 * NB; j < K; ++j)
             row1(t0, t1, v[D + j], v[D + j + 1], SARA_TK(j));
-        }
         // column pass: tap j goes to the output that is j steps old, and the
         // same product, as tap K-1-j, to the one that is K-1-j steps old
 #define SARA_SL(j) ((i + K - 1 - (j)) % K)
@@ -664,6 +699,7 @@ namespace sara_hip {
           col1(A[SARA_SL(R - 1)][0], A[SARA_SL(R - 1)][1], A[SARA_SL(R + 1)][0],
                A[SARA_SL(R + 1)][1], t0, t1, SARA_TK(R - 1));
 #undef SARA_SL
+        }
 
         const int o = yy - R;
         if ((o >= y0) && (o < y1) && col_ok)
@@ -695,7 +731,8 @@ namespace sara_hip {
   template <int R>
   static void launch_blur_march2(const float* src, size_t src_stride, float* dst,
                                  size_t dst_stride, int w, int h, int batch,
-                                 const Taps& taps, hipStream_t stream)
+                                 const Taps& taps, hipStream_t stream,
+                                 bool fma = false)
   {
     constexpr int W = 128;
     constexpr int PF = 4;
@@ -707,9 +744,14 @@ namespace sara_hip {
     nseg = (h + seg_rows - 1) / seg_rows;
     const int total = xcd_map_enabled() ? nstrips * nseg * batch : 0;
     const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(nstrips * nseg, batch);
-    hipLaunchKernelGGL((gaussian_blur_march2_kernel<R, PF>), grid, dim3(64), 0,
-                       stream, src, src_stride, dst, dst_stride, w, h, seg_rows,
-                       nstrips, nseg, total, taps);
+    if (fma)
+      hipLaunchKernelGGL((gaussian_blur_march2_kernel<R, PF, true>), grid,
+                         dim3(64), 0, stream, src, src_stride, dst, dst_stride, w,
+                         h, seg_rows, nstrips, nseg, total, taps);
+    else
+      hipLaunchKernelGGL((gaussian_blur_march2_kernel<R, PF, false>), grid,
+                         dim3(64), 0, stream, src, src_stride, dst, dst_stride, w,
+                         h, seg_rows, nstrips, nseg, total, taps);
   }
 
   template <int R>
@@ -726,7 +768,8 @@ namespace sara_hip {
   bool launch_gaussian_blur(const float* src, size_t src_stride, float* dst,
                             size_t dst_stride, float* dog, size_t dog_stride,
                             int w, int h, int batch, const Taps& taps,
-                            hipStream_t stream, float* dec, size_t dec_stride)
+                            hipStream_t stream, float* dec, size_t dec_stride,
+                            bool fma)
   {
     const int R = taps.size / 2;
     // fast path: strips of float4 columns need 16-byte aligned rows
@@ -753,15 +796,15 @@ namespace sara_hip {
       {
       case 8:
         launch_blur_march2<8>(src, src_stride, dst, dst_stride, w, h, batch,
-                              taps, stream);
+                              taps, stream, fma);
         return false;
       case 10:
         launch_blur_march2<10>(src, src_stride, dst, dst_stride, w, h, batch,
-                               taps, stream);
+                               taps, stream, fma);
         return false;
       case 12:
         launch_blur_march2<12>(src, src_stride, dst, dst_stride, w, h, batch,
-                               taps, stream);
+                               taps, stream, fma);
         return false;
       default:
         break;
@@ -772,7 +815,7 @@ namespace sara_hip {
 #define SARA_MARCH_CASE(r)                                                     \
   case r:                                                                      \
     launch_blur_march<r>(src, src_stride, dst, dst_stride, dec, dec_stride, w, \
-                         h, batch, taps, stream);                              \
+                         h, batch, taps, stream, fma);                         \
     return dec != nullptr;
       switch (R)
       {

@@ -205,6 +205,7 @@ struct sara_hip_sift
   bool root_sift = false;
   bool signed_type = false;
   bool downscale_at_double_sigma = false;
+  bool fma_blur = false;
   bool timers = true;
 
   // pyramids, one allocation per octave (sized for max dims / max batch).
@@ -789,6 +790,10 @@ sara_hip_status sara_hip_sift_set_option(sara_hip_sift* c, int option, int value
     c->signed_type = value != 0;
     c->graph_stage_s[0] = c->graph_stage_s[1] = -1;
     return SARA_HIP_OK;
+  case SARA_HIP_OPT_FMA_BLUR:
+    c->fma_blur = value != 0;
+    c->graph_stage_s[0] = c->graph_stage_s[1] = -1;
+    return SARA_HIP_OK;
   case SARA_HIP_OPT_DOWNSCALE_AT_DOUBLE_SIGMA:
   {
     const bool on = value != 0;
@@ -955,7 +960,8 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       if (sc.init_blur)
       {
         launch_gaussian_blur(src, src_stride, c->d_full, in_plane, nullptr, 0,
-                             width, height, batch, c->init_taps, stream);
+                             width, height, batch, c->init_taps, stream, nullptr,
+                             0, c->fma_blur);
         blurred = c->d_full;
         bstride = in_plane;
       }
@@ -965,7 +971,8 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     else if (sc.init_blur)
     {
       launch_gaussian_blur(src, src_stride, G00, g_stride0, nullptr, 0, width,
-                           height, batch, c->init_taps, stream);
+                           height, batch, c->init_taps, stream, nullptr, 0,
+                           c->fma_blur);
     }
     else
     {
@@ -1009,7 +1016,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
         }
         const bool fused = launch_gaussian_blur(
             c->G[o] + pl * (s - 1), gs, c->G[o] + pl * s, gs, nullptr, 0, w, h,
-            batch, c->taps[s], so, dec, dec_stride);
+            batch, c->taps[s], so, dec, dec_stride, c->fma_blur);
         if (dec)
           base_ready = fused;
         if (ms && s == sc.downscale_index && has_next)

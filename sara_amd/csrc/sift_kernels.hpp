@@ -138,12 +138,13 @@ namespace sara_hip {
   //! When `dec` is given and the fast path runs, the kernel also writes
   //! dec(x, y) = dst(2x, 2y) (planes of (w/2) x (h/2), frame stride
   //! dec_stride) and the function returns true; otherwise the caller has to
-  //! run launch_scale itself.
+  //! run launch_scale itself.  fma: the marching kernels fuse multiply and add
+  //! (SARA_HIP_OPT_FMA_BLUR; not bit-exact with the reference).
   bool launch_gaussian_blur(const float* src, size_t src_stride, float* dst,
                             size_t dst_stride, float* dog, size_t dog_stride,
                             int w, int h, int batch, const Taps& taps,
                             hipStream_t stream, float* dec = nullptr,
-                            size_t dec_stride = 0);
+                            size_t dec_stride = 0, bool fma = false);
 
   //! Nearest-neighbour resize (Resize.cpp:31-62).
   void launch_scale(const float* src, size_t src_stride, int sw, int sh,
