@@ -1857,7 +1857,22 @@ namespace sara_hip {
         __syncthreads();
       }
       if (i < n)
-        ori.offset[row + i] = running + s_scan[threadIdx.x] - v;
+      {
+        const int at = running + s_scan[threadIdx.x] - v;
+        ori.offset[row + i] = at;
+        // Orientation.cpp:146-161: the list is expanded in input order, one
+        // entry per dominant orientation - the descriptor kernel's work items
+        const KeypointRecord& rec = ori.record[row + i];
+        for (int k = 0; k < v && at + k < cand.cap; ++k)
+        {
+          KeypointItem it;
+          it.d = rec.d;
+          it.key = rec.key;
+          it.theta = k < 8 ? rec.theta[k] : ori.peak_theta[(row + i) * kMaxPeaks + k];
+          it.reserved = 0;
+          ori.item[row + at + k] = it;
+        }
+      }
       running += s_scan[255];
       __syncthreads();
     }
@@ -1975,27 +1990,22 @@ namespace sara_hip {
     const int wave = threadIdx.x >> 6;
     const int grp = lane >> 4, l16 = lane & 15;
     const int b = blockIdx.y;
-    const int n = min(cand.count[b], cand.cap);
+    // work items = keypoints (one dominant orientation each), in output order
+    const int n = min(ori.kp_count[b], cand.cap);
     // persistent blocks, see orientation_kernel
     const int nblk = (n + kDescWaves - 1) / kDescWaves;
     const int unit = 8 * xcd_run;
     const int positions = unit * ((nblk + unit - 1) / unit);
-    // The record of extremum idx (orientation_kernel) and its output offset
-    // (scan_peaks_kernel): lanes 0..15 fetch one dword of the record each,
-    // lane 16 the offset.  The loads of the NEXT work item are issued before
-    // the current one is processed.
+    // The item of keypoint idx (scan_peaks_kernel): lanes 0..7 fetch one dword
+    // each.  The load of the NEXT work item is issued before the current one
+    // is processed.
     const size_t row = size_t(b) * cand.cap;
     const int frame_base = ori.frame_offset[b];
     auto fetch_item = [&](int lb) -> unsigned {
       const int idx = lb * kDescWaves + wave;
       unsigned wv = 0u;
-      if (lb >= 0 && idx < n)
-      {
-        if (lane < 16)
-          wv = reinterpret_cast<const unsigned*>(ori.record + row + idx)[lane];
-        else if (lane == 16)
-          wv = unsigned(ori.offset[row + idx]);
-      }
+      if (lb >= 0 && idx < n && lane < 8)
+        wv = reinterpret_cast<const unsigned*>(ori.item + row + idx)[lane];
       return wv;
     };
     auto item = [&](int lb, unsigned wv) {
@@ -2005,17 +2015,14 @@ namespace sara_hip {
 
     SARA_PROF_T(t_item);
     auto word = [&](int i) { return unsigned(__builtin_amdgcn_readlane(int(wv), i)); };
-    const int npeaks = int(word(6));
-    if (npeaks == 0)
-      return;
     const float4 d = make_float4(__uint_as_float(word(0)), __uint_as_float(word(1)),
                                  __uint_as_float(word(2)), __uint_as_float(word(3)));
     const unsigned long long key =
         (unsigned long long) word(4) | ((unsigned long long) word(5) << 32);
+    const float theta = __uint_as_float(word(6));
     const int o = key_octave(key);
     const int s = key_scale(key);
     const int is_max = int(key & 1ull);
-    const int local0 = int(word(16));
 
     // OERegion(pos, sigma): shape = I * float(pow(double(sigma), -2)).
     const float shape = float(1.0 / (double(d.z) * double(d.z)));
@@ -2079,15 +2086,9 @@ namespace sara_hip {
 
     SARA_PROF_T(t_setup);
     SARA_PROF_ADD(0, t_item, t_setup);
-    for (int k = 0; k < npeaks; ++k)
     {
       SARA_PROF_T(t_peak);
-      const int local = local0 + k;
-      if (local >= cand.cap)
-        break;
-      const size_t out = size_t(frame_base) + local;
-      const float theta = k < 8 ? __uint_as_float(word(8 + k))
-                                : ori.peak_theta[(row + idx) * kMaxPeaks + k];
+      const size_t out = size_t(frame_base) + idx;
 
       if (lane == 0)
       {
@@ -2104,7 +2105,7 @@ namespace sara_hip {
         *reinterpret_cast<int2*>(scale_octave + 2 * out) = make_int2(s, o);
       }
       if (!with_descriptors)
-        continue;
+        return;
 
 #pragma unroll
       for (int q = 0; q < (kDescHistWords + 63) / 64; ++q)

@@ -521,6 +521,7 @@ namespace {
     TRY_ST(c->alloc(c->ori.peak_theta, rows * kMaxPeaks));
     TRY_ST(c->alloc(c->ori.offset, rows));
     TRY_ST(c->alloc(c->ori.record, rows));
+    TRY_ST(c->alloc(c->ori.item, rows));
     TRY_ST(c->alloc(c->d_ex_offset, size_t(max_batch) + 1));
     TRY_ST(c->alloc(c->d_feat_s[0], rows));
     TRY_ST(c->alloc(c->d_so_s[0], rows * 2));

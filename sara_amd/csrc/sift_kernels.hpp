@@ -81,6 +81,17 @@ namespace sara_hip {
   };
   static_assert(sizeof(KeypointRecord) == 64, "record layout");
 
+  //! One keypoint = one (extremum, dominant orientation) pair, in output order,
+  //! written by the peak scan: the work item of the descriptor kernel.
+  struct alignas(16) KeypointItem
+  {
+    float4 d;                // (x, y, sigma, value), octave coordinates
+    unsigned long long key;  // (octave, scale, y, x | type)
+    float theta;
+    int reserved;
+  };
+  static_assert(sizeof(KeypointItem) == 32, "item layout");
+
   //! Buckets of the counting sort that orders a frame's extrema: one per image
   //! row of every (octave, scale) plane.  base[o * kMaxScales + s] = first
   //! bucket of that plane; `total` buckets per frame, rows of `stride` ints
@@ -121,6 +132,7 @@ namespace sara_hip {
     int* kp_count;     // [frame] keypoints of the frame (may exceed cap)
     int* frame_offset; // [batch+1] exclusive prefix of min(kp_count, cap)
     KeypointRecord* record;  // [frame][cap]
+    KeypointItem* item;      // [frame][cap], first min(kp_count, cap) valid
   };
 
   inline unsigned long long make_key(int o, int s, int y, int x, int is_max)
