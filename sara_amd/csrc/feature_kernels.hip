@@ -300,8 +300,16 @@ namespace sara_hip {
             if ((y & 15) == 15 || y == y1 - 1)
             {
               if ((lane & 3) == 0 && col_ok)
-                atomicMax(cm + size_t(y >> 4) * cw + (col >> 4),
-                          __float_as_uint(run_max));
+              {
+                // segments of whole 16-row bands (seg_rows % 16 == 0): this
+                // lane is the only writer of its 16 x 16 block - a plain
+                // store, and the map needs no zeroing before the launch
+                unsigned* at = cm + size_t(y >> 4) * cw + (col >> 4);
+                if ((seg_rows & 15) == 0)
+                  *at = __float_as_uint(run_max);
+                else
+                  atomicMax(at, __float_as_uint(run_max));
+              }
               run_max = 0.f;
             }
           }
@@ -335,6 +343,20 @@ namespace sara_hip {
     const char* e = getenv("SARA_HIP_FUSE_GRADIENT");
     return e && std::string(e) == "1";
   }();
+  //! Segments of the marching gradient kernel made of whole 16-row bands (one
+  //! writer per entry of the coarse magnitude map, no memset); 0 = round 1's
+  //! split with atomicMax.
+  //! Default: only for small batches, where the saved memset launches count
+  //! (one 1080p frame: -20 us); with 64 frames the aligned split runs the
+  //! overlapped extrema + gradient stage 0.15 ms slower than round 1's.
+  static const int g_grad_bands_env = [] {
+    const char* e = getenv("SARA_HIP_GRAD_BANDS");
+    return e ? (std::string(e) == "0" ? 0 : 1) : -1;
+  }();
+  static inline bool grad_bands(int batch)
+  {
+    return g_grad_bands_env >= 0 ? g_grad_bands_env != 0 : batch <= 8;
+  }
   static const int g_grad_waves = [] {
     const char* e = getenv("SARA_HIP_GRAD_WAVES");
     return e ? std::max(64, atoi(e)) : 18432;
@@ -343,6 +365,18 @@ namespace sara_hip {
     const char* e = getenv("SARA_HIP_EXTREMA_WAVES");
     return e ? std::max(64, atoi(e)) : 4096;
   }();
+
+  bool gradient_polar_needs_zeroed_cmax(const float* src, size_t src_stride,
+                                        const float* dst, size_t dst_stride,
+                                        int w, int h, int batch)
+  {
+    const bool aligned4 = (w % 4 == 0) && w >= 4 && h >= 2 &&
+                          (src_stride % 4 == 0) && (dst_stride % 4 == 0) &&
+                          (reinterpret_cast<uintptr_t>(src) % 16 == 0) &&
+                          (reinterpret_cast<uintptr_t>(dst) % 16 == 0);
+    // the tiled kernel (and SARA_HIP_GRAD_BANDS=0) use atomicMax
+    return !(aligned4 && g_use_march && grad_bands(batch));
+  }
 
   void launch_gradient_polar(const float* src, size_t src_stride, float* dst,
                              size_t dst_stride, int w, int h, int nscales,
@@ -359,7 +393,10 @@ namespace sara_hip {
       const int planes = batch * nscales;
       int nseg = (g_grad_waves + nstrips * planes - 1) / (nstrips * planes);
       nseg = std::max(1, std::min(nseg, (h + 15) / 16));
-      const int seg_rows = (h + nseg - 1) / nseg;
+      // whole 16-row bands per segment: every 16 x 16 block of the coarse
+      // magnitude map has exactly one writer (gradient_polar_needs_zeroed_cmax)
+      const int seg_rows = grad_bands(batch) ? (((h + nseg - 1) / nseg) + 15) & ~15
+                                        : (h + nseg - 1) / nseg;
       nseg = (h + seg_rows - 1) / seg_rows;
       const int total = xcd_map_enabled() ? nstrips * nseg * planes : 0;
       const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(nstrips * nseg, planes);
@@ -1425,11 +1462,102 @@ namespace sara_hip {
     cand.sdata[row + rank] = cand.data[row + i];
   }
 
+  //! The four steps above in ONE launch: one 1024-thread workgroup per frame,
+  //! the row buckets in LDS (total + 1 ints: 48 KB at 1080p, 100 KB at 4K).
+  //! Saves two memsets and three kernel boundaries per step - what a
+  //! one-frame batch mostly consists of - and is no slower on big batches
+  //! (a frame has a few thousand keys).  `grouped`: [frame][cap] scratch.
+  __global__ __launch_bounds__(1024) void bucket_sort_fused_kernel(
+      CandidateLists cand, RowBuckets rb, int* __restrict__ grouped)
+  {
+    extern __shared__ int s_bucket[];  // rb.total + 1 counters, then 1024 partials
+    int* s_part = s_bucket + rb.total + 1;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = min(cand.count[b], cand.cap);
+    const size_t row = size_t(b) * cand.cap;
+    const unsigned long long* keys = cand.key + row;
+    int* g = grouped + row;
+    int* tmp = cand.order + row;  // position inside the bucket, until the end
+    for (int i = tid; i <= rb.total; i += 1024)
+      s_bucket[i] = 0;
+    __syncthreads();
+    // 1. count: position of every key inside its bucket
+    for (int i = tid; i < n; i += 1024)
+      tmp[i] = atomicAdd(&s_bucket[key_row_bucket(keys[i], rb)], 1);
+    __syncthreads();
+    // 2. exclusive scan of the bucket counts (thread t owns a run of buckets)
+    const int per = (rb.total + 1 + 1023) / 1024;
+    const int lo = min(tid * per, rb.total + 1), hi = min(lo + per, rb.total + 1);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i)
+      sum += s_bucket[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1)
+    {
+      const int t = tid >= off ? s_part[tid - off] : 0;
+      __syncthreads();
+      s_part[tid] += t;
+      __syncthreads();
+    }
+    int run = s_part[tid] - sum;
+    for (int i = lo; i < hi; ++i)
+    {
+      const int c = s_bucket[i];
+      s_bucket[i] = run;
+      run += c;
+    }
+    __syncthreads();
+    // 3. scatter: keys grouped by bucket
+    for (int i = tid; i < n; i += 1024)
+      g[s_bucket[key_row_bucket(keys[i], rb)] + tmp[i]] = i;
+    __threadfence_block();
+    __syncthreads();
+    // 4. rank inside the bucket (a handful of keys), sorted copies.  order[]
+    //    held the in-bucket positions (tmp) until the barrier above: every
+    //    thread has consumed its entries in step 3, so it can be overwritten.
+    for (int p = tid; p < n; p += 1024)
+    {
+      const int i = g[p];
+      const unsigned long long mine = keys[i];
+      const int bucket = key_row_bucket(mine, rb);
+      const int s0 = s_bucket[bucket], s1 = s_bucket[bucket + 1];
+      int rank = s0;
+      for (int q = s0; q < s1; ++q)
+        rank += (keys[g[q]] < mine);
+      cand.order[row + rank] = i;
+      cand.skey[row + rank] = mine;
+      cand.sdata[row + rank] = cand.data[row + i];
+    }
+  }
+
   void launch_rank_candidates_bucketed(const CandidateLists& cand,
                                        const RowBuckets& rb, int* hist,
                                        int* cursor, int* grouped, int batch,
                                        hipStream_t stream)
   {
+    // fused form when the buckets fit in LDS (images up to about 6000 rows
+    // per octave-0 plane set); SARA_HIP_SORT=split keeps the four launches
+    static const bool split = [] {
+      const char* e = getenv("SARA_HIP_SORT");
+      return e && std::string(e) == "split";
+    }();
+    const size_t lds = sizeof(int) * (size_t(rb.total) + 1 + 1024);
+    if (!split && lds <= 150 * 1024)
+    {
+      static size_t allowed = 64 * 1024;
+      if (lds > allowed)
+      {
+        (void) hipFuncSetAttribute(
+            reinterpret_cast<const void*>(bucket_sort_fused_kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        allowed = 160 * 1024;
+      }
+      hipLaunchKernelGGL(bucket_sort_fused_kernel, dim3(batch), dim3(1024), lds,
+                         stream, cand, rb, grouped);
+      return;
+    }
     (void) hipMemsetAsync(hist, 0, sizeof(int) * size_t(batch) * rb.stride, stream);
     const dim3 grid((cand.cap + 255) / 256, batch);
     hipLaunchKernelGGL(bucket_count_kernel, grid, dim3(256), 0, stream, cand, rb,
@@ -1835,49 +1963,74 @@ namespace sara_hip {
   // Output offsets: exclusive scan of the per-extremum peak counts in sorted
   // order (Orientation.cpp:146-161 expands the list in input order).
   // ------------------------------------------------------------------------ //
-  __global__ __launch_bounds__(256) void scan_peaks_kernel(CandidateLists cand,
-                                                           OrientationLists ori)
+  //! One 1024-thread workgroup per frame: thread t owns a run of consecutive
+  //! extrema (their counts summed locally, one block scan of the 1024
+  //! partials), writes the offsets and expands the keypoint list
+  //! (Orientation.cpp:146-161: one entry per dominant orientation, in input
+  //! order).  The workgroup that finishes last (device counter `done`, zeroed
+  //! with the other per-step counters) also writes the frame offsets, which
+  //! saves the separate single-thread launch.
+  __global__ __launch_bounds__(1024) void scan_peaks_kernel(CandidateLists cand,
+                                                            OrientationLists ori,
+                                                            int* done, int batch)
   {
-    __shared__ int s_scan[256];
+    __shared__ int s_part[1024];
+    __shared__ int s_last;
     const int b = blockIdx.x;
+    const int tid = threadIdx.x;
     const int n = min(cand.count[b], cand.cap);
     const size_t row = size_t(b) * cand.cap;
-    int running = 0;
-    for (int base = 0; base < n; base += 256)
+    const int per = (n + 1023) / 1024;
+    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i)
+      sum += ori.peak_count[row + i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1)
     {
-      const int i = base + threadIdx.x;
-      const int v = i < n ? ori.peak_count[row + i] : 0;
-      s_scan[threadIdx.x] = v;
+      const int t = tid >= off ? s_part[tid - off] : 0;
       __syncthreads();
-      for (int off = 1; off < 256; off <<= 1)
-      {
-        const int t = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
-        __syncthreads();
-        s_scan[threadIdx.x] += t;
-        __syncthreads();
-      }
-      if (i < n)
-      {
-        const int at = running + s_scan[threadIdx.x] - v;
-        ori.offset[row + i] = at;
-        // Orientation.cpp:146-161: the list is expanded in input order, one
-        // entry per dominant orientation - the descriptor kernel's work items
-        const KeypointRecord& rec = ori.record[row + i];
-        for (int k = 0; k < v && at + k < cand.cap; ++k)
-        {
-          KeypointItem it;
-          it.d = rec.d;
-          it.key = rec.key;
-          it.theta = k < 8 ? rec.theta[k] : ori.peak_theta[(row + i) * kMaxPeaks + k];
-          it.reserved = 0;
-          ori.item[row + at + k] = it;
-        }
-      }
-      running += s_scan[255];
+      s_part[tid] += t;
       __syncthreads();
     }
-    if (threadIdx.x == 0)
-      ori.kp_count[b] = running;
+    int at = s_part[tid] - sum;
+    for (int i = lo; i < hi; ++i)
+    {
+      const KeypointRecord& rec = ori.record[row + i];
+      const int v = rec.npeaks;
+      ori.offset[row + i] = at;
+      for (int k = 0; k < v && at + k < cand.cap; ++k)
+      {
+        KeypointItem it;
+        it.d = rec.d;
+        it.key = rec.key;
+        it.theta = k < 8 ? rec.theta[k] : ori.peak_theta[(row + i) * kMaxPeaks + k];
+        it.reserved = 0;
+        ori.item[row + at + k] = it;
+      }
+      at += v;
+    }
+    if (tid == 1023)
+    {
+      ori.kp_count[b] = s_part[1023];
+      __threadfence();  // the count is visible before the arrival is
+      s_last = atomicAdd(done, 1) == batch - 1;
+    }
+    __syncthreads();
+    if (s_last && tid == 0)
+    {
+      __threadfence();
+      int acc = 0;
+      for (int f = 0; f < batch; ++f)
+      {
+        ori.frame_offset[f] = acc;
+        acc += min(__hip_atomic_load(&ori.kp_count[f], __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT),
+                   cand.cap);
+      }
+      ori.frame_offset[batch] = acc;
+    }
   }
 
   __global__ void frame_offsets_kernel(const int* __restrict__ counts, int cap,
@@ -1896,12 +2049,10 @@ namespace sara_hip {
   }
 
   void launch_scan_peaks(const CandidateLists& cand, const OrientationLists& ori,
-                         int batch, hipStream_t stream)
+                         int* done_counter, int batch, hipStream_t stream)
   {
-    hipLaunchKernelGGL(scan_peaks_kernel, dim3(batch), dim3(256), 0, stream, cand,
-                       ori);
-    hipLaunchKernelGGL(frame_offsets_kernel, dim3(1), dim3(64), 0, stream,
-                       ori.kp_count, cand.cap, ori.frame_offset, batch);
+    hipLaunchKernelGGL(scan_peaks_kernel, dim3(batch), dim3(1024), 0, stream, cand,
+                       ori, done_counter, batch);
   }
 
   void launch_extrema_offsets(const CandidateLists& cand, int* ex_offset,

@@ -81,7 +81,8 @@ namespace sara_hip {
   __global__ __launch_bounds__(NT) void gaussian_blur_kernel(
       const float* __restrict__ src, size_t src_stride,
       float* __restrict__ dst, size_t dst_stride, float* __restrict__ dog,
-      size_t dog_stride, int w, int h, Taps taps)
+      size_t dog_stride, int w, int h, Taps taps, float* __restrict__ dec,
+      size_t dec_stride)
   {
     constexpr int K = 2 * R + 1;
     constexpr int IW = TX + 2 * R;
@@ -169,6 +170,11 @@ namespace sara_hip {
         dst[size_t(gy) * w + gx] = sum;
         if (dog)
           dog[size_t(gy) * w + gx] = sum - s_in[(yq * 8 + i + R) * IP + tx + R];
+        // nearest-neighbour half of the output = first plane of the next
+        // octave (Resize.cpp:45-84: int(x * (w / (w/2))) == 2x), see the
+        // marching kernel's DEC
+        if (dec && ((gx | gy) & 1) == 0 && (gx >> 1) < (w >> 1) && (gy >> 1) < (h >> 1))
+          dec[b * dec_stride + size_t(gy >> 1) * (w >> 1) + (gx >> 1)] = sum;
       }
     }
   }
@@ -758,11 +764,12 @@ namespace sara_hip {
   static void launch_blur_r(const float* src, size_t src_stride, float* dst,
                             size_t dst_stride, float* dog, size_t dog_stride,
                             int w, int h, int batch, const Taps& taps,
-                            hipStream_t stream)
+                            hipStream_t stream, float* dec, size_t dec_stride)
   {
     const dim3 grid((w + TX - 1) / TX, (h + TY - 1) / TY, batch);
     hipLaunchKernelGGL(gaussian_blur_kernel<R>, grid, dim3(NT), 0, stream, src,
-                       src_stride, dst, dst_stride, dog, dog_stride, w, h, taps);
+                       src_stride, dst, dst_stride, dog, dog_stride, w, h, taps,
+                       dec, dec_stride);
   }
 
   bool launch_gaussian_blur(const float* src, size_t src_stride, float* dst,
@@ -832,8 +839,8 @@ namespace sara_hip {
 #define SARA_BLUR_CASE(r)                                                      \
   case r:                                                                      \
     launch_blur_r<r>(src, src_stride, dst, dst_stride, dog, dog_stride, w, h,  \
-                     batch, taps, stream);                                     \
-    return false;
+                     batch, taps, stream, dec, dec_stride);                    \
+    return dec != nullptr;
     switch (R)
     {
       SARA_BLUR_CASE(1)

@@ -495,7 +495,8 @@ namespace {
     TRY_ST(c->alloc(c->cand.key, rows));
     TRY_ST(c->alloc(c->cand.data, rows));
     // the four per-frame counters share one block: one memset per detect()
-    TRY_ST(c->alloc(c->d_counters, 4 * size_t(max_batch) + 1));
+    // + 1 for frame_offset[batch], + 1 arrival counter of the peak scan
+    TRY_ST(c->alloc(c->d_counters, 4 * size_t(max_batch) + 2));
     c->cand.count = c->d_counters;
     c->sites.count = c->d_counters + max_batch;
     c->ori.kp_count = c->d_counters + 2 * size_t(max_batch);
@@ -1051,7 +1052,10 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       if (grad_fused[o])
         continue;  // written by the extremum scan
       const size_t cpl = size_t((w + 15) / 16) * ((h + 15) / 16);
-      HIP_TRY(hipMemsetAsync(c->CM[o], 0, cpl * S * batch * sizeof(unsigned), gs));
+      if (gradient_polar_needs_zeroed_cmax(c->G[o] + pl * s_lo, pl * S,
+                                           c->GR[o] + pl * 2 * s_lo, pl * 2 * S,
+                                           w, h, batch))
+        HIP_TRY(hipMemsetAsync(c->CM[o], 0, cpl * S * batch * sizeof(unsigned), gs));
       launch_gradient_polar(c->G[o] + pl * s_lo, pl * S, c->GR[o] + pl * 2 * s_lo,
                             pl * 2 * S, w, h, s_n, batch, gs,
                             c->CM[o] + cpl * s_lo, cpl * S);
@@ -1070,7 +1074,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
 
   // ---- extrema ------------------------------------------------------------
   HIP_TRY(hipMemsetAsync(c->d_counters, 0,
-                         sizeof(int) * (4 * size_t(c->max_batch) + 1), stream));
+                         sizeof(int) * (4 * size_t(c->max_batch) + 2), stream));
   if (last_stage >= SARA_HIP_STAGE_EXTREMA)
   {
     ExtremaParams ep;
@@ -1124,7 +1128,6 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
                                       stream);
     else
       launch_rank_candidates(c->cand, batch, stream);
-    launch_extrema_offsets(c->cand, c->d_ex_offset, batch, stream);
   }
   HIP_TRY(mark(3));
 
@@ -1144,7 +1147,8 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   {
     launch_orientations(c->d_grad, c->d_tab, c->d_oriw, c->n_oriw, c->cand,
                         c->ori, batch, stream);
-    launch_scan_peaks(c->cand, c->ori, batch, stream);
+    launch_scan_peaks(c->cand, c->ori, c->d_counters + 4 * size_t(c->max_batch) + 1,
+                      batch, stream);
   }
   HIP_TRY(mark(5));
 
@@ -1807,6 +1811,7 @@ sara_hip_status sara_hip_sift_fetch_extrema(sara_hip_sift* c,
     return st;
   if (total == 0)
     return st;
+  launch_extrema_offsets(c->cand, c->d_ex_offset, c->cur_batch, c->last_stream);
   launch_gather_extrema(c->cand, c->d_ex_offset, c->cur_batch, c->d_ex_regions,
                         c->d_ex_xyso, c->last_stream);
   if (regions)

@@ -187,6 +187,12 @@ namespace sara_hip {
   //! float's bits, magnitudes are >= 0) per 16x16 block, planes
   //! [frame][scale][ceil(h/16)][ceil(w/16)], frame stride cmax_stride; the
   //! kernels atomicMax into it, so it has to be zeroed before the launch.
+  //! Whether launch_gradient_polar with these operands accumulates the coarse
+  //! maxima with atomicMax (the map then has to be zeroed first) or writes
+  //! every entry exactly once (marching kernel: no memset needed).
+  bool gradient_polar_needs_zeroed_cmax(const float* src, size_t src_stride,
+                                        const float* dst, size_t dst_stride,
+                                        int w, int h, int batch);
   void launch_gradient_polar(const float* src, size_t src_stride, float* dst,
                              size_t dst_stride, int w, int h, int nscales,
                              int batch, hipStream_t stream,
@@ -252,9 +258,10 @@ namespace sara_hip {
                            const OrientationLists& ori, int batch,
                            hipStream_t stream);
 
-  //! Per-frame exclusive scan of peak counts + frame offsets.
+  //! Per-frame exclusive scan of peak counts, keypoint list, frame offsets
+  //! (done_counter: one int zeroed before the launch).
   void launch_scan_peaks(const CandidateLists& cand, const OrientationLists& ori,
-                         int batch, hipStream_t stream);
+                         int* done_counter, int batch, hipStream_t stream);
 
   void launch_descriptors(const GradPyramidView& grad,
                           const CandidateLists& cand,
