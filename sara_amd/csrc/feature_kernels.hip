@@ -99,6 +99,12 @@ namespace sara_hip {
 #ifndef SARA_GRAD_WAVES_PER_EU
 #define SARA_GRAD_WAVES_PER_EU 6
 #endif
+#ifndef SARA_GRAD_PF
+#define SARA_GRAD_PF 4
+#endif
+#ifndef SARA_GRAD_EDGE_UNCOND
+#define SARA_GRAD_EDGE_UNCOND 0
+#endif
 #ifndef SARA_ATAN_TABLE
 #define SARA_ATAN_TABLE 2
 #endif
@@ -162,14 +168,22 @@ namespace sara_hip {
     // strip-edge neighbours: lane 0 needs column x0-1, lane 63 column x0+256
     const int ecol = lane == 0 ? max(x0 - 1, 0) : min(x0 + W, w - 1);
     const bool edge_lane = (lane == 0) || (lane == 63);
+    // every lane issues the edge load (inner lanes re-read their own first
+    // column: same cache line as the float4) - no branch around a load
+    const int ecol_all = edge_lane ? ecol : mcol;
+    (void) ecol_all;
 
     auto load_row = [&](int yy, float4& m, float& e) {
       const int gy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
       const float* rowp = f + size_t(gy) * w;
       m = *reinterpret_cast<const float4*>(rowp + mcol);
+#if SARA_GRAD_EDGE_UNCOND
+      e = rowp[ecol_all];
+#else
       e = 0.f;
       if (edge_lane)
         e = rowp[ecol];
+#endif
     };
 
     // coarse 16x16 magnitude maxima: 4 lanes = 16 columns, running row max
@@ -332,10 +346,21 @@ namespace sara_hip {
   }();
   //! Run-groups (8 * SARA_HIP_XCD_RUN blocks of 4 keypoints) in the grid of the
   //! per-keypoint kernels per frame; the blocks loop over the rest.
-  static const int g_persist_units = [] {
+  static const int g_persist_units_env = [] {
     const char* e = getenv("SARA_HIP_PERSIST_UNITS");
-    return e ? std::max(1, atoi(e)) : 1;
+    return e ? std::max(1, atoi(e)) : 0;
   }();
+  //! One run-group per frame fills the chip when there are many frames; a
+  //! small batch gets as many groups as it takes to put ~8 waves on every
+  //! SIMD (one 1080p frame: 4 300 keypoints on 1 024 one-wave blocks would
+  //! walk 4 keypoints each, one after the other).
+  static inline int persist_units(int batch, int waves_per_block)
+  {
+    if (g_persist_units_env > 0)
+      return g_persist_units_env;
+    const int per_unit = 8 * g_xcd_run * waves_per_block * std::max(batch, 1);
+    return std::max(1, (8192 + per_unit - 1) / per_unit);
+  }
   //! Off by default: measured on MI355X the fused pass takes as long as the
   //! two separate kernels (3.3 ms per 64 frames either way - the gradient's
   //! exact atan2/sqrt/div sequence is VALU-bound, not bandwidth-bound).
@@ -400,7 +425,7 @@ namespace sara_hip {
       nseg = (h + seg_rows - 1) / seg_rows;
       const int total = xcd_map_enabled() ? nstrips * nseg * planes : 0;
       const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(nstrips * nseg, planes);
-      hipLaunchKernelGGL((gradient_polar_march_kernel<4>), grid, dim3(64), 0,
+      hipLaunchKernelGGL((gradient_polar_march_kernel<SARA_GRAD_PF>), grid, dim3(64), 0,
                          stream, src, src_stride, dst, dst_stride, w, h, nscales,
                          seg_rows, nstrips, nseg, total, cmax, cmax_stride);
       return;
@@ -1947,7 +1972,7 @@ namespace sara_hip {
     const int unit = 8 * g_xcd_run;
     const int needed =
         unit * (((cand.cap + kOriWaves - 1) / kOriWaves + unit - 1) / unit);
-    const dim3 grid(std::min(needed, unit * g_persist_units), batch);
+    const dim3 grid(std::min(needed, unit * persist_units(batch, kOriWaves)), batch);
     // weight tables in LDS when they leave room for 8 blocks per CU
     const size_t wbytes = sizeof(double) * size_t(n_weights);
     if (n_weights > 0 && wbytes <= 14 * 1024)
@@ -2543,7 +2568,7 @@ namespace sara_hip {
     const int unit = 8 * g_xcd_run;
     const int needed =
         unit * (((cand.cap + kDescWaves - 1) / kDescWaves + unit - 1) / unit);
-    const dim3 grid(std::min(needed, unit * g_persist_units), batch);
+    const dim3 grid(std::min(needed, unit * persist_units(batch, kDescWaves)), batch);
     hipLaunchKernelGGL(descriptor_kernel, grid, dim3(64 * kDescWaves), 0, stream, grad, cand,
                        ori, features, scale_octave, descriptors,
                        with_descriptors, root_sift, g_xcd_run);

@@ -186,6 +186,12 @@ struct sara_hip_sift
   hipStream_t oct_stream[16] = {};
   hipEvent_t oct_ready[16] = {};  // G(downscale_index, o) is complete
   hipEvent_t oct_done[16] = {};   // octave o's chain is complete
+  hipEvent_t scan_done[16] = {};  // octave o's extremum scan is complete
+  // Octave pipelining: the extremum scan and the polar gradients of octave o
+  // follow its last blur on the octave's own stream instead of waiting for
+  // the whole pyramid.  -1 = automatic (graph replay, i.e. small batches,
+  // where the dependent-launch chain is the bound), 0 / 1 = SARA_HIP_OCTAVE_PIPELINE
+  int octave_pipeline = -1;
   bool multi_stream = true;
   // The polar gradients read the Gaussian pyramid only, like the extremum
   // scan: they are enqueued first, on a side stream, so that the short
@@ -398,6 +404,7 @@ namespace {
     {
       TRY_HIP(hipEventCreateWithFlags(&c->oct_ready[o], hipEventDisableTiming));
       TRY_HIP(hipEventCreateWithFlags(&c->oct_done[o], hipEventDisableTiming));
+      TRY_HIP(hipEventCreateWithFlags(&c->scan_done[o], hipEventDisableTiming));
       if (o > 0 && o < c->max_sched.num_octaves)
         TRY_HIP(hipStreamCreateWithFlags(&c->oct_stream[o], hipStreamNonBlocking));
     }
@@ -405,6 +412,8 @@ namespace {
       c->multi_stream = std::string(e) != "1";
     if (const char* e = getenv("SARA_HIP_SIDE_GRADIENT"))
       c->side_gradient = std::string(e) != "0";
+    if (const char* e = getenv("SARA_HIP_OCTAVE_PIPELINE"))
+      c->octave_pipeline = std::string(e) != "0" ? 1 : 0;
     TRY_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     TRY_HIP(hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
     TRY_HIP(hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
@@ -720,6 +729,8 @@ sara_hip_status sara_hip_sift_destroy(sara_hip_sift* c)
       (void) hipEventDestroy(c->oct_ready[o]);
     if (c->oct_done[o])
       (void) hipEventDestroy(c->oct_done[o]);
+    if (c->scan_done[o])
+      (void) hipEventDestroy(c->scan_done[o]);
   }
   for (int k = 0; k < 2; ++k)
   {
@@ -944,6 +955,72 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
 
   auto enqueue = [&]() -> sara_hip_status {
 
+  static const bool fuse_gradient_env = [] {
+    const char* e = getenv("SARA_HIP_FUSE_GRADIENT");
+    return e && std::string(e) == "1";
+  }();
+  const bool want_gradients = last_stage >= SARA_HIP_STAGE_GRADIENT;
+  const bool side = c->side_gradient && want_gradients && !fuse_gradient_env &&
+                    !debug_sync;
+  // see SiftContext::octave_pipeline
+  const bool pipe = c->multi_stream && sc.num_octaves > 1 &&
+                    last_stage >= SARA_HIP_STAGE_EXTREMA && !fuse_gradient_env &&
+                    !debug_sync && (!want_gradients || side) &&
+                    (c->octave_pipeline < 0 ? graph_mode : c->octave_pipeline != 0);
+  bool grad_fused[16] = {};
+
+  // polar gradients of one octave (the planes the later stages read)
+  auto enqueue_gradient = [&](int o, hipStream_t gs) -> sara_hip_status {
+    const int s_lo = c->all_gradient_scales ? 0 : 1;
+    const int s_n = c->all_gradient_scales ? S : S - 3;
+    const int w = sc.oct[o].w, h = sc.oct[o].h;
+    const size_t pl = size_t(w) * h;
+    if (grad_fused[o])
+      return SARA_HIP_OK;  // written by the extremum scan
+    const size_t cpl = size_t((w + 15) / 16) * ((h + 15) / 16);
+    if (gradient_polar_needs_zeroed_cmax(c->G[o] + pl * s_lo, pl * S,
+                                         c->GR[o] + pl * 2 * s_lo, pl * 2 * S,
+                                         w, h, batch))
+      HIP_TRY(hipMemsetAsync(c->CM[o], 0, cpl * S * batch * sizeof(unsigned), gs));
+    launch_gradient_polar(c->G[o] + pl * s_lo, pl * S, c->GR[o] + pl * 2 * s_lo,
+                          pl * 2 * S, w, h, s_n, batch, gs,
+                          c->CM[o] + cpl * s_lo, cpl * S);
+    return SARA_HIP_OK;
+  };
+  ExtremaParams ep;
+  ep.extremum_thres = c->extremum_thres;
+  ep.edge_ratio_thres = c->edge_ratio;
+  ep.img_padding_sz = c->img_padding;
+  ep.refine_iters = c->refine_iters;
+  ep.scale_geometric_factor = c->pyr.scale_geometric_factor;
+  ep.signed_type = c->signed_type ? 1 : 0;
+  // extremum scan of one octave
+  auto enqueue_scan = [&](int o, hipStream_t ss) -> sara_hip_status {
+    OctaveView dv;  // the Gaussian octave; DoG layers are formed on the fly
+    dv.base = c->G[o];
+    dv.w = sc.oct[o].w;
+    dv.h = sc.oct[o].h;
+    dv.scales = S;
+    dv.plane = size_t(dv.w) * dv.h;
+    dv.frame_stride = dv.plane * S;
+    // With the gradient stage requested, the scan of the fast path also
+    // emits the polar gradients of the planes it has in registers.
+    const bool want_grad = want_gradients && !c->all_gradient_scales && !side;
+    const size_t cpl = size_t((dv.w + 15) / 16) * ((dv.h + 15) / 16);
+    grad_fused[o] = false;
+    if (want_grad)
+      HIP_TRY(hipMemsetAsync(c->CM[o], 0, cpl * S * batch * sizeof(unsigned), ss));
+    if (dv.w > 2 * c->img_padding && dv.h > 2 * c->img_padding)
+      grad_fused[o] = launch_extrema_scan(
+          dv, o, batch, ep, c->d_tab, c->cand, c->sites, ss,
+          want_grad ? c->GR[o] : nullptr, dv.plane * 2 * S,
+          want_grad ? c->CM[o] : nullptr, cpl * S);
+    return SARA_HIP_OK;
+  };
+  if (pipe)
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0,
+                           sizeof(int) * (4 * size_t(c->max_batch) + 2), stream));
+
   // ---- Gaussian pyramid + fused DoG ---------------------------------------
   if (sc.num_octaves > 0)
   {
@@ -1024,45 +1101,46 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
         if (ms && s == sc.downscale_index && has_next)
           HIP_TRY(hipEventRecord(c->oct_ready[o], so));
       }
+      if (pipe)
+      {
+        // scan, then gradients, on the octave's own stream.  (A fifth stream
+        // for octave 0's gradients would share one of the 4 hardware queues
+        // with an octave chain and hold it back.)
+        const sara_hip_status sst = enqueue_scan(o, so);
+        if (sst != SARA_HIP_OK)
+          return sst;
+        if (o > 0)
+          HIP_TRY(hipEventRecord(c->scan_done[o], so));
+        if (want_gradients)
+        {
+          const sara_hip_status gst = enqueue_gradient(o, so);
+          if (gst != SARA_HIP_OK)
+            return gst;
+        }
+      }
       if (ms && o > 0)
         HIP_TRY(hipEventRecord(c->oct_done[o], so));
     }
-    if (ms)
+    if (pipe)
+      for (int o = 1; o < sc.num_octaves; ++o)
+        HIP_TRY(hipStreamWaitEvent(stream, c->scan_done[o], 0));
+    else if (ms)
       for (int o = 1; o < sc.num_octaves; ++o)
         HIP_TRY(hipStreamWaitEvent(stream, c->oct_done[o], 0));
   }
   HIP_TRY(mark(2));
 
-  // ---- polar gradients (enqueue helper; on the side stream when enabled) ---
-  bool grad_fused[16] = {};
-  static const bool fuse_gradient_env = [] {
-    const char* e = getenv("SARA_HIP_FUSE_GRADIENT");
-    return e && std::string(e) == "1";
-  }();
-  const bool want_gradients = last_stage >= SARA_HIP_STAGE_GRADIENT;
-  const bool side = c->side_gradient && want_gradients && !fuse_gradient_env &&
-                    !debug_sync;
+  // ---- polar gradients on the side stream, next to the extrema stage --------
   auto enqueue_gradients = [&](hipStream_t gs) -> sara_hip_status {
-    const int s_lo = c->all_gradient_scales ? 0 : 1;
-    const int s_n = c->all_gradient_scales ? S : S - 3;
     for (int o = 0; o < sc.num_octaves; ++o)
     {
-      const int w = sc.oct[o].w, h = sc.oct[o].h;
-      const size_t pl = size_t(w) * h;
-      if (grad_fused[o])
-        continue;  // written by the extremum scan
-      const size_t cpl = size_t((w + 15) / 16) * ((h + 15) / 16);
-      if (gradient_polar_needs_zeroed_cmax(c->G[o] + pl * s_lo, pl * S,
-                                           c->GR[o] + pl * 2 * s_lo, pl * 2 * S,
-                                           w, h, batch))
-        HIP_TRY(hipMemsetAsync(c->CM[o], 0, cpl * S * batch * sizeof(unsigned), gs));
-      launch_gradient_polar(c->G[o] + pl * s_lo, pl * S, c->GR[o] + pl * 2 * s_lo,
-                            pl * 2 * S, w, h, s_n, batch, gs,
-                            c->CM[o] + cpl * s_lo, cpl * S);
+      const sara_hip_status gst = enqueue_gradient(o, gs);
+      if (gst != SARA_HIP_OK)
+        return gst;
     }
     return SARA_HIP_OK;
   };
-  if (side)
+  if (side && !pipe)
   {
     HIP_TRY(hipEventRecord(c->aux_fork, stream));
     HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
@@ -1073,40 +1151,18 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   }
 
   // ---- extrema ------------------------------------------------------------
-  HIP_TRY(hipMemsetAsync(c->d_counters, 0,
-                         sizeof(int) * (4 * size_t(c->max_batch) + 2), stream));
+  if (!pipe)
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0,
+                           sizeof(int) * (4 * size_t(c->max_batch) + 2), stream));
   if (last_stage >= SARA_HIP_STAGE_EXTREMA)
   {
-    ExtremaParams ep;
-    ep.extremum_thres = c->extremum_thres;
-    ep.edge_ratio_thres = c->edge_ratio;
-    ep.img_padding_sz = c->img_padding;
-    ep.refine_iters = c->refine_iters;
-    ep.scale_geometric_factor = c->pyr.scale_geometric_factor;
-    ep.signed_type = c->signed_type ? 1 : 0;
-    for (int o = 0; o < sc.num_octaves; ++o)
-    {
-      OctaveView dv;  // the Gaussian octave; DoG layers are formed on the fly
-      dv.base = c->G[o];
-      dv.w = sc.oct[o].w;
-      dv.h = sc.oct[o].h;
-      dv.scales = S;
-      dv.plane = size_t(dv.w) * dv.h;
-      dv.frame_stride = dv.plane * S;
-      // With the gradient stage requested, the scan of the fast path also
-      // emits the polar gradients of the planes it has in registers.
-      const bool want_grad = want_gradients && !c->all_gradient_scales && !side;
-      const size_t cpl = size_t((dv.w + 15) / 16) * ((dv.h + 15) / 16);
-      grad_fused[o] = false;
-      if (want_grad)
-        HIP_TRY(hipMemsetAsync(c->CM[o], 0, cpl * S * batch * sizeof(unsigned),
-                               stream));
-      if (dv.w > 2 * c->img_padding && dv.h > 2 * c->img_padding)
-        grad_fused[o] = launch_extrema_scan(
-            dv, o, batch, ep, c->d_tab, c->cand, c->sites, stream,
-            want_grad ? c->GR[o] : nullptr, dv.plane * 2 * S,
-            want_grad ? c->CM[o] : nullptr, cpl * S);
-    }
+    if (!pipe)
+      for (int o = 0; o < sc.num_octaves; ++o)
+      {
+        const sara_hip_status sst = enqueue_scan(o, stream);
+        if (sst != SARA_HIP_OK)
+          return sst;
+      }
     {
       OctavePyramidView pv{};
       pv.scales = S;
@@ -1132,7 +1188,13 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   HIP_TRY(mark(3));
 
   // ---- polar gradients ----------------------------------------------------
-  if (side)
+  if (pipe)
+  {
+    // join the octave streams (their gradients follow their scans)
+    for (int o = 1; o < sc.num_octaves; ++o)
+      HIP_TRY(hipStreamWaitEvent(stream, c->oct_done[o], 0));
+  }
+  else if (side)
     HIP_TRY(hipStreamWaitEvent(stream, c->aux_join, 0));
   else if (want_gradients)
   {
