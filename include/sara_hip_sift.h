@@ -552,6 +552,17 @@ SARA_HIP_API void sara_hip_selfcheck_sincos(const float* theta, float* out_sin,
 SARA_HIP_API sara_hip_status sara_hip_selfcheck_device_math(
     unsigned long long* mismatches, int device);
 
+/* Device self-check: the definiteness test of refine_extremum                  */
+/* (RefineExtremum.cpp:74-77: (SelfAdjointEigenSolver<Matrix3f>(H).eigenvalues()*/
+/* * float(type)).maxCoeff() >= 0) as the extrema kernels evaluate it - Eigen   */
+/* 3.4's float solver restated, skipped when Sylvester's criterion in double on */
+/* the shifted matrix already fixes the sign.  hessians = count x 9 floats      */
+/* (row-major 3 x 3, symmetric), types = 1 / 255 / -1, out[i] = 0 / 1 (host     */
+/* pointers).  Not a compute path.                                              */
+SARA_HIP_API sara_hip_status sara_hip_selfcheck_definiteness(
+    const float* hessians, const int* types, size_t count, unsigned char* out,
+    int device);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

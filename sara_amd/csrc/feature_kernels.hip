@@ -99,6 +99,9 @@ namespace sara_hip {
 #ifndef SARA_GRAD_WAVES_PER_EU
 #define SARA_GRAD_WAVES_PER_EU 6
 #endif
+#ifndef SARA_DEFINITENESS_SHORTCUT
+#define SARA_DEFINITENESS_SHORTCUT 1
+#endif
 #ifndef SARA_GRAD_PF
 #define SARA_GRAD_PF 4
 #endif
@@ -581,6 +584,24 @@ namespace sara_hip {
 
   //! (SelfAdjointEigenSolver<Matrix3f>(H).eigenvalues() * float(type))
   //! .maxCoeff() >= 0
+  //! Sylvester's criterion for the symmetric matrix sign * M + shift * I.
+  __device__ inline bool positive_definite3(double a00, double a10, double a11,
+                                            double a20, double a21, double a22,
+                                            double sign, double shift)
+  {
+    a00 = sign * a00 + shift;
+    a11 = sign * a11 + shift;
+    a22 = sign * a22 + shift;
+    a10 *= sign;
+    a20 *= sign;
+    a21 *= sign;
+    const double m2 = a00 * a11 - a10 * a10;
+    const double det = a00 * (a11 * a22 - a21 * a21) -
+                       a10 * (a10 * a22 - a21 * a20) +
+                       a20 * (a10 * a21 - a11 * a20);
+    return a00 > 0. && m2 > 0. && det > 0.;
+  }
+
   __device__ inline bool not_definite_enough3(const float H[3][3], int type)
   {
     float m00 = H[0][0], m10 = H[1][0], m11 = H[1][1], m20 = H[2][0],
@@ -590,6 +611,31 @@ namespace sara_hip {
                         fmaxf(fabsf(m21), fabsf(m22)));
     if (scale == 0.f)
       scale = 1.f;
+#if SARA_DEFINITENESS_SHORTCUT
+    // The answer is the sign of an extreme eigenvalue as the float solver
+    // computes it.  The solver is backward stable: its eigenvalues of the
+    // scaled matrix (largest |coefficient| = 1) are off by a few tens of
+    // float epsilons at most.  When the exact extreme eigenvalue is farther
+    // than delta = 2^-12 (2 048 epsilons) from zero - decided with
+    // Sylvester's criterion in double on the shifted matrix - the float
+    // solver cannot report the other sign and its iteration is skipped;
+    // otherwise (nearly singular Hessians, a handful per frame) it runs.
+    // The scale guard keeps (eigenvalue * scale) * type away from underflow.
+    if (scale > 1e-20f && scale < 1e20f)
+    {
+      const double inv = 1. / double(scale);
+      const double a00 = double(m00) * inv, a10 = double(m10) * inv,
+                   a11 = double(m11) * inv, a20 = double(m20) * inv,
+                   a21 = double(m21) * inv, a22 = double(m22) * inv;
+      constexpr double delta = 1. / 4096.;
+      // type > 0: lambda_max >= 0 ?   type < 0: lambda_min <= 0 ?
+      const double sg = type > 0 ? -1. : 1.;
+      if (positive_definite3(a00, a10, a11, a20, a21, a22, sg, -delta))
+        return false;  // every eigenvalue is beyond delta on the definite side
+      if (!positive_definite3(a00, a10, a11, a20, a21, a22, sg, delta))
+        return true;   // an eigenvalue is beyond delta on the wrong side
+    }
+#endif
     m00 /= scale;
     m10 /= scale;
     m11 /= scale;
@@ -2610,6 +2656,28 @@ namespace sara_hip {
       atomicAdd(out, (unsigned long long) bad_atan);
     if (bad_sqrt)
       atomicAdd(out + 1, (unsigned long long) bad_sqrt);
+  }
+
+  //! not_definite_enough3() of n matrices (9 floats each, row-major) -> 0 / 1.
+  __global__ void definiteness_selfcheck_kernel(const float* __restrict__ H,
+                                                const int* __restrict__ type,
+                                                int n, unsigned char* out)
+  {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+      return;
+    float m[3][3];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)
+        m[r][c] = H[9 * size_t(i) + 3 * r + c];
+    out[i] = not_definite_enough3(m, type[i]) ? 1 : 0;
+  }
+
+  void launch_definiteness_selfcheck(const float* H, const int* type, int n,
+                                     unsigned char* out, hipStream_t stream)
+  {
+    hipLaunchKernelGGL(definiteness_selfcheck_kernel, dim3((n + 255) / 256),
+                       dim3(256), 0, stream, H, type, n, out);
   }
 
   void launch_device_math_selfcheck(unsigned long long* out, hipStream_t stream)

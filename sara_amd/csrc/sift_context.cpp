@@ -2270,4 +2270,32 @@ sara_hip_status sara_hip_selfcheck_device_math(unsigned long long* mismatches,
   return SARA_HIP_OK;
 }
 
+sara_hip_status sara_hip_selfcheck_definiteness(const float* hessians,
+                                                const int* types, size_t count,
+                                                unsigned char* out, int device)
+{
+  if (!hessians || !types || !out)
+    return fail(SARA_HIP_INVALID_PARAMS, "null pointer");
+  if (count == 0)
+    return SARA_HIP_OK;
+  if (count > (size_t(1) << 28))
+    return fail(SARA_HIP_CAPACITY_EXCEEDED, "too many matrices");
+  const sara_hip_status st = select_device(device);
+  if (st != SARA_HIP_OK)
+    return st;
+  DeviceScratch sc;
+  float* dH = nullptr;
+  int* dT = nullptr;
+  unsigned char* dO = nullptr;
+  HIP_TRY(sc.get(dH, 9 * count));
+  HIP_TRY(sc.get(dT, count));
+  HIP_TRY(sc.get(dO, count));
+  HIP_TRY(hipMemcpy(dH, hessians, 9 * count * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dT, types, count * sizeof(int), hipMemcpyHostToDevice));
+  launch_definiteness_selfcheck(dH, dT, int(count), dO, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, dO, count, hipMemcpyDeviceToHost));
+  return SARA_HIP_OK;
+}
+
 }  // extern "C"

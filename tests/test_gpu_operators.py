@@ -223,6 +223,58 @@ def test_short_device_math_is_exact_on_every_float():
     assert (bad[0], bad[1]) == (0, 0)
 
 
+def _adversarial_hessians(rng, n):
+    """Symmetric 3 x 3 float matrices built as Q diag(l) Q^T with spectra that
+    are comfortably definite, indefinite, and - the interesting part - have
+    their extreme eigenvalue within 1e-2 .. 1e-9 (relative) of zero on either
+    side, at magnitudes 1e-8 .. 1e3; plus diagonal, rank-deficient and zero
+    matrices."""
+    q, _ = np.linalg.qr(rng.standard_normal((n, 3, 3)))
+    lam = -np.abs(rng.standard_normal((n, 3))) - 0.05
+    kind = rng.integers(0, 6, n)
+    tiny = 10.0 ** rng.uniform(-9, -2, n) * rng.choice([-1.0, 1.0], n)
+    lam[kind == 1, 0] = tiny[kind == 1]           # nearly singular
+    lam[kind == 2] *= -1                          # positive definite
+    lam[kind == 3, 1] *= -1                       # indefinite
+    lam[kind == 4, 0] = 0.0                       # singular
+    sel = kind == 5                               # two tiny eigenvalues
+    lam[sel, 0] = tiny[sel]
+    lam[sel, 1] = -tiny[sel] * rng.uniform(0.1, 10, sel.sum())
+    mag = 10.0 ** rng.uniform(-8, 3, n)
+    m = np.einsum("nij,nj,nkj->nik", q, lam, q) * mag[:, None, None]
+    m = (m + m.transpose(0, 2, 1)) / 2
+    m = m.astype(np.float32)
+    m[:16] = 0
+    for i in range(16, 48):                       # diagonal / axis-aligned
+        m[i] = np.diag(np.diag(m[i]))
+    return m
+
+
+def test_definiteness_on_the_device_matches_the_oracle(oracle):
+    """refine_extremum's definiteness decision as the extrema kernels take it
+    (Sylvester shortcut in double, Eigen 3.4 float solver otherwise) against
+    the oracle's restatement of the solver alone, on 600 000 matrices including
+    nearly singular ones, for the three extremum types."""
+    import ctypes as C
+    from sara_amd import capi
+    lib = capi.load()
+    rng = np.random.default_rng(2026)
+    n = 200_000
+    for t in (1, 255, -1):
+        m = _adversarial_hessians(rng, n)
+        want = oracle.not_definite_enough3(m, t)
+        types = np.full(n, t, np.int32)
+        got = np.empty(n, np.uint8)
+        capi.check(lib.sara_hip_selfcheck_definiteness(
+            m.ctypes.data_as(C.POINTER(C.c_float)),
+            types.ctypes.data_as(C.POINTER(C.c_int)), n,
+            got.ctypes.data_as(C.POINTER(C.c_ubyte)), 0))
+        assert np.array_equal(got.astype(bool), want), (
+            t, int(np.count_nonzero(got.astype(bool) != want)))
+        # both answers occur, so the comparison is not vacuous
+        assert 0 < np.count_nonzero(want) < n
+
+
 def test_extremum_map_halide_seam(oracle):
     """img_padding_sz = 0: the seam shakti_scale_space_dog_extremum_32f_cpu
     itself - every pixel, replicated borders, strict contrast, Halide hessian -

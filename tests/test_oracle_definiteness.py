@@ -169,3 +169,46 @@ def test_halide_classifier_differs_where_it_should(oracle):
         assert oracle.scale_space_extremum(layers, int(x), int(y), strict=False) != 0
     assert (21, 31) in {tuple(d) for d in differ}
     assert np.count_nonzero(hal) > 20
+
+
+def _positive_definite(a, sign, shift):
+    a00 = sign * a[:, 0, 0] + shift
+    a11 = sign * a[:, 1, 1] + shift
+    a22 = sign * a[:, 2, 2] + shift
+    a10, a20, a21 = sign * a[:, 1, 0], sign * a[:, 2, 0], sign * a[:, 2, 1]
+    m2 = a00 * a11 - a10 * a10
+    det = (a00 * (a11 * a22 - a21 * a21) - a10 * (a10 * a22 - a21 * a20) +
+           a20 * (a10 * a21 - a11 * a20))
+    return (a00 > 0) & (m2 > 0) & (det > 0)
+
+
+def test_margin_of_the_device_shortcut(oracle):
+    """The extrema kernels skip the float eigen-solver when Sylvester's
+    criterion in double, on the matrix scaled to unit largest coefficient and
+    shifted by +-2^-12, already fixes the sign of the extreme eigenvalue
+    (feature_kernels.hip, not_definite_enough3).  Restated here in numpy: on
+    matrices whose extreme eigenvalue sits 1e-9 .. 1e-2 from zero the shortcut
+    never contradicts the solver, and it does leave the close cases to it."""
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = open(os.path.join(here, "test_gpu_operators.py")).read()
+    ns = {}
+    exec(src[src.index("def _adversarial_hessians"):
+             src.index("def test_definiteness_on_the_device")], {"np": np}, ns)
+    rng = np.random.default_rng(99)
+    for t in (1, 255, -1):
+        m = ns["_adversarial_hessians"](rng, 100_000)
+        want = oracle.not_definite_enough3(m, t)
+        scale = np.abs(m).max(axis=(1, 2))
+        scale[scale == 0] = 1
+        a = m.astype(np.float64) / scale[:, None, None].astype(np.float64)
+        sg = -1.0 if t > 0 else 1.0
+        delta = 1.0 / 4096
+        sure_false = _positive_definite(a, sg, -delta)
+        sure_true = ~_positive_definite(a, sg, delta)
+        assert not np.any(sure_false & sure_true)
+        assert not np.any(sure_false & want)
+        assert not np.any(sure_true & ~want)
+        if t > 0:
+            undecided = ~(sure_false | sure_true)
+            assert 0.2 < undecided.mean() < 0.6
