@@ -170,6 +170,12 @@ namespace {
 
 }  // namespace
 
+//! Ints in d_counters (4 * max_batch + 2 used), in whole 256-byte blocks.
+static inline size_t counters_padded(int max_batch)
+{
+  return (4 * size_t(max_batch) + 2 + 8 + 63) / 64 * 64;  // >= 8 spare ints
+}
+
 struct sara_hip_sift
 {
   int device = 0;
@@ -200,6 +206,10 @@ struct sara_hip_sift
   // restores the sequential order and the separate stage times).
   bool side_gradient = true;
   hipStream_t aux_stream = nullptr;
+  // graph replay only: streams / events of the filler nodes that steer the
+  // runtime's node -> queue assignment (see the spine layout in detect)
+  hipStream_t filler_stream[3] = {};
+  hipEvent_t filler_done[3] = {};
   hipEvent_t aux_fork = nullptr, aux_join = nullptr;
 
   Schedule max_sched;
@@ -415,6 +425,11 @@ namespace {
     if (const char* e = getenv("SARA_HIP_OCTAVE_PIPELINE"))
       c->octave_pipeline = std::string(e) != "0" ? 1 : 0;
     TRY_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 3; ++k)
+    {
+      TRY_HIP(hipStreamCreateWithFlags(&c->filler_stream[k], hipStreamNonBlocking));
+      TRY_HIP(hipEventCreateWithFlags(&c->filler_done[k], hipEventDisableTiming));
+    }
     TRY_HIP(hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
     TRY_HIP(hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
     if (const char* e = getenv("SARA_HIP_GRAPH"))
@@ -505,7 +520,9 @@ namespace {
     TRY_ST(c->alloc(c->cand.data, rows));
     // the four per-frame counters share one block: one memset per detect()
     // + 1 for frame_offset[batch], + 1 arrival counter of the peak scan
-    TRY_ST(c->alloc(c->d_counters, 4 * size_t(max_batch) + 2));
+    // padded to whole 256-byte blocks: the runtime then zeroes it with one
+    // fill kernel instead of an aligned part and a tail
+    TRY_ST(c->alloc(c->d_counters, counters_padded(max_batch)));
     c->cand.count = c->d_counters;
     c->sites.count = c->d_counters + max_batch;
     c->ori.kp_count = c->d_counters + 2 * size_t(max_batch);
@@ -767,6 +784,13 @@ sara_hip_status sara_hip_sift_destroy(sara_hip_sift* c)
     (void) hipStreamSynchronize(c->d2h_stream);
     (void) hipStreamDestroy(c->d2h_stream);
   }
+  for (int k = 0; k < 3; ++k)
+  {
+    if (c->filler_stream[k])
+      (void) hipStreamDestroy(c->filler_stream[k]);
+    if (c->filler_done[k])
+      (void) hipEventDestroy(c->filler_done[k]);
+  }
   if (c->aux_stream)
   {
     (void) hipStreamSynchronize(c->aux_stream);
@@ -968,6 +992,8 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
                     !debug_sync && (!want_gradients || side) &&
                     (c->octave_pipeline < 0 ? graph_mode : c->octave_pipeline != 0);
   bool grad_fused[16] = {};
+  // the stream the extrema .. descriptor stages are enqueued on
+  hipStream_t tail = stream;
 
   // polar gradients of one octave (the planes the later stages read)
   auto enqueue_gradient = [&](int o, hipStream_t gs) -> sara_hip_status {
@@ -1017,9 +1043,9 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
           want_grad ? c->CM[o] : nullptr, cpl * S);
     return SARA_HIP_OK;
   };
-  if (pipe)
+  if (pipe)  // the scans start before the pyramid is complete
     HIP_TRY(hipMemsetAsync(c->d_counters, 0,
-                           sizeof(int) * (4 * size_t(c->max_batch) + 2), stream));
+                           sizeof(int) * counters_padded(c->max_batch), stream));
 
   // ---- Gaussian pyramid + fused DoG ---------------------------------------
   if (sc.num_octaves > 0)
@@ -1061,72 +1087,166 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     // Octave o+1 starts from G(downscale_index, o): its chain runs on its
     // own stream as soon as that plane exists and is joined at the end.
     const bool ms = c->multi_stream && sc.num_octaves > 1;
+    const int dsi = sc.downscale_index;
+    const int last = sc.num_octaves - 1;
     bool base_ready = true;  // G(0, o) already written by the previous octave
-    for (int o = 0; o < sc.num_octaves; ++o)
-    {
+    // blur G(s-1, o) -> G(s, o); the one that produces G(downscale_index, o)
+    // also emits its nearest-neighbour half, i.e. G(0, o+1), on the fast path
+    auto enqueue_blur = [&](int o, int s, hipStream_t st) {
       const int w = sc.oct[o].w, h = sc.oct[o].h;
       const size_t pl = size_t(w) * h;
       const size_t gs = pl * S;
-      hipStream_t so = (ms && o > 0) ? c->oct_stream[o] : stream;
-      const bool has_next = o + 1 < sc.num_octaves;
-      if (o > 0)
+      float* dec = nullptr;
+      size_t dec_stride = 0;
+      if (o < last && s == dsi)
+      {
+        dec = c->G[o + 1];
+        dec_stride = size_t(sc.oct[o + 1].w) * sc.oct[o + 1].h * S;
+      }
+      const bool fused = launch_gaussian_blur(
+          c->G[o] + pl * (s - 1), gs, c->G[o] + pl * s, gs, nullptr, 0, w, h,
+          batch, c->taps[s], st, dec, dec_stride, c->fma_blur);
+      if (dec)
+        base_ready = fused;
+    };
+    auto enqueue_base = [&](int o, hipStream_t st) {
+      // G(0, o) from G(downscale_index, o-1) when no blur has written it
+      if (o > 0 && !base_ready)
       {
         const int pw = sc.oct[o - 1].w, ph = sc.oct[o - 1].h;
         const size_t ppl = size_t(pw) * ph;
-        if (ms)
-          HIP_TRY(hipStreamWaitEvent(so, c->oct_ready[o - 1], 0));
-        if (!base_ready)
-          launch_scale(c->G[o - 1] + ppl * sc.downscale_index, ppl * S, pw, ph,
-                       c->G[o], gs, w, h, batch, so);
+        launch_scale(c->G[o - 1] + ppl * dsi, ppl * S, pw, ph, c->G[o],
+                     size_t(sc.oct[o].w) * sc.oct[o].h * S, sc.oct[o].w,
+                     sc.oct[o].h, batch, st);
       }
       base_ready = false;
-      if (ms && sc.downscale_index == 0 && has_next)
-        HIP_TRY(hipEventRecord(c->oct_ready[o], so));
-      for (int s = 1; s < S; ++s)
-      {
-        // the blur that produces G(downscale_index, o) also emits its
-        // nearest-neighbour half, i.e. G(0, o+1), when the fast path runs
-        float* dec = nullptr;
-        size_t dec_stride = 0;
-        if (has_next && s == sc.downscale_index)
-        {
-          dec = c->G[o + 1];
-          dec_stride = size_t(sc.oct[o + 1].w) * sc.oct[o + 1].h * S;
-        }
-        const bool fused = launch_gaussian_blur(
-            c->G[o] + pl * (s - 1), gs, c->G[o] + pl * s, gs, nullptr, 0, w, h,
-            batch, c->taps[s], so, dec, dec_stride, c->fma_blur);
-        if (dec)
-          base_ready = fused;
-        if (ms && s == sc.downscale_index && has_next)
-          HIP_TRY(hipEventRecord(c->oct_ready[o], so));
-      }
-      if (pipe)
-      {
-        // scan, then gradients, on the octave's own stream.  (A fifth stream
-        // for octave 0's gradients would share one of the 4 hardware queues
-        // with an octave chain and hold it back.)
+    };
+    if (pipe)
+    {
+      // Small batches are bound by the chain of dependent launches, and a
+      // dependency that crosses hardware queues costs ~12 us against ~0 on
+      // one queue.  The longest chain (the spine) - the blurs up to
+      // G(downscale_index, o) of every octave, the whole last octave, its
+      // scan, and then the per-keypoint stages - is enqueued on `stream`; the
+      // rest of octave o (remaining blurs, scan, gradients) forks to
+      // oct_stream[o + 1].
+      // Capture order matters under graph replay: ROCm 7.2 hands the graph's
+      // nodes to the queues in a depth-first order that follows each node's
+      // first captured successor, and puts the k-th successor on queue
+      // (queue of the node) + k - 1.  Octave 0's side chain (the heaviest) is
+      // therefore captured BEFORE the spine goes on: it keeps queue 0 and is
+      // in it by the time octave 0's third blur ends, the spine hops to queue
+      // 1 once and stays there; filler nodes (4-byte memsets of spare
+      // counters) in front of octave 1's .. side chains push each of them to
+      // a queue of its own.  With plain streams the same order simply works.
+      hipStream_t side0 = c->oct_stream[1];
+      enqueue_base(0, stream);
+      for (int s = 1; s <= dsi; ++s)
+        enqueue_blur(0, s, stream);
+      HIP_TRY(hipEventRecord(c->oct_ready[0], stream));
+      // the last octave's gradients go behind the side chain of octave last-2
+      // (done early, and not the queue finish_sites is waiting for)
+      const int grad_last_side = std::max(0, last - 2);
+      auto enqueue_side = [&](int o, hipStream_t so) -> sara_hip_status {
+        for (int s = dsi + 1; s < S; ++s)
+          enqueue_blur(o, s, so);
         const sara_hip_status sst = enqueue_scan(o, so);
         if (sst != SARA_HIP_OK)
           return sst;
-        if (o > 0)
-          HIP_TRY(hipEventRecord(c->scan_done[o], so));
+        HIP_TRY(hipEventRecord(c->scan_done[o], so));
         if (want_gradients)
         {
           const sara_hip_status gst = enqueue_gradient(o, so);
           if (gst != SARA_HIP_OK)
             return gst;
         }
+        return SARA_HIP_OK;
+      };
+      {
+        HIP_TRY(hipStreamWaitEvent(side0, c->oct_ready[0], 0));
+        const sara_hip_status st0 = enqueue_side(0, side0);
+        if (st0 != SARA_HIP_OK)
+          return st0;
       }
-      if (ms && o > 0)
+      // the spine
+      for (int o = 1; o <= last; ++o)
+      {
+        enqueue_base(o, tail);
+        const int s_hi = o == last ? S - 1 : dsi;
+        for (int s = 1; s <= s_hi; ++s)
+          enqueue_blur(o, s, tail);
+        if (o < last)
+          HIP_TRY(hipEventRecord(c->oct_ready[o], tail));
+      }
+      HIP_TRY(hipEventRecord(c->aux_fork, tail));  // the last octave's planes
+      {
+        const sara_hip_status sst = enqueue_scan(last, tail);
+        if (sst != SARA_HIP_OK)
+          return sst;
+      }
+      if (want_gradients && grad_last_side == 0)
+      {
+        HIP_TRY(hipStreamWaitEvent(side0, c->aux_fork, 0));
+        const sara_hip_status lst = enqueue_gradient(last, side0);
+        if (lst != SARA_HIP_OK)
+          return lst;
+      }
+      HIP_TRY(hipEventRecord(c->oct_done[0], side0));
+      for (int o = 1; o < last; ++o)
+      {
+        hipStream_t so = c->oct_stream[o + 1];
+        int fillers = 0;
+        if (graph_mode)
+          for (; fillers < last - 1 - o && fillers < 3; ++fillers)
+          {
+            hipStream_t fs = c->filler_stream[fillers];
+            HIP_TRY(hipStreamWaitEvent(fs, c->oct_ready[o], 0));
+            HIP_TRY(hipMemsetAsync(
+                c->d_counters + counters_padded(c->max_batch) - 1 - fillers, 0,
+                sizeof(int), fs));
+            HIP_TRY(hipEventRecord(c->filler_done[fillers], fs));
+          }
+        HIP_TRY(hipStreamWaitEvent(so, c->oct_ready[o], 0));
+        const sara_hip_status sto = enqueue_side(o, so);
+        if (sto != SARA_HIP_OK)
+          return sto;
+        if (want_gradients && o == grad_last_side)
+        {
+          HIP_TRY(hipStreamWaitEvent(so, c->aux_fork, 0));
+          const sara_hip_status lst = enqueue_gradient(last, so);
+          if (lst != SARA_HIP_OK)
+            return lst;
+        }
+        for (int k = 0; k < fillers; ++k)  // the filler streams join here
+          HIP_TRY(hipStreamWaitEvent(so, c->filler_done[k], 0));
         HIP_TRY(hipEventRecord(c->oct_done[o], so));
+      }
+      for (int o = 0; o < last; ++o)
+        HIP_TRY(hipStreamWaitEvent(tail, c->scan_done[o], 0));
     }
-    if (pipe)
-      for (int o = 1; o < sc.num_octaves; ++o)
-        HIP_TRY(hipStreamWaitEvent(stream, c->scan_done[o], 0));
-    else if (ms)
-      for (int o = 1; o < sc.num_octaves; ++o)
-        HIP_TRY(hipStreamWaitEvent(stream, c->oct_done[o], 0));
+    else
+    {
+      for (int o = 0; o <= last; ++o)
+      {
+        hipStream_t so = (ms && o > 0) ? c->oct_stream[o] : stream;
+        if (o > 0 && ms)
+          HIP_TRY(hipStreamWaitEvent(so, c->oct_ready[o - 1], 0));
+        enqueue_base(o, so);
+        if (ms && dsi == 0 && o < last)
+          HIP_TRY(hipEventRecord(c->oct_ready[o], so));
+        for (int s = 1; s < S; ++s)
+        {
+          enqueue_blur(o, s, so);
+          if (ms && s == dsi && o < last)
+            HIP_TRY(hipEventRecord(c->oct_ready[o], so));
+        }
+        if (ms && o > 0)
+          HIP_TRY(hipEventRecord(c->oct_done[o], so));
+      }
+      if (ms)
+        for (int o = 1; o <= last; ++o)
+          HIP_TRY(hipStreamWaitEvent(stream, c->oct_done[o], 0));
+    }
   }
   HIP_TRY(mark(2));
 
@@ -1153,7 +1273,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   // ---- extrema ------------------------------------------------------------
   if (!pipe)
     HIP_TRY(hipMemsetAsync(c->d_counters, 0,
-                           sizeof(int) * (4 * size_t(c->max_batch) + 2), stream));
+                           sizeof(int) * counters_padded(c->max_batch), stream));
   if (last_stage >= SARA_HIP_STAGE_EXTREMA)
   {
     if (!pipe)
@@ -1175,24 +1295,24 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
         pv.plane[o] = size_t(pv.w[o]) * pv.h[o];
         pv.frame_stride[o] = pv.plane[o] * S;
       }
-      launch_finish_sites(pv, batch, ep, c->d_tab, c->sites, c->cand, stream);
+      launch_finish_sites(pv, batch, ep, c->d_tab, c->sites, c->cand, tail);
     }
     if (c->bucketed_rank && c->row_buckets.total < c->bucket_stride &&
         sc.num_octaves <= 16)
       launch_rank_candidates_bucketed(c->cand, c->row_buckets, c->d_bucket_hist,
                                       c->d_bucket_cursor, c->d_grouped, batch,
-                                      stream);
+                                      tail);
     else
-      launch_rank_candidates(c->cand, batch, stream);
+      launch_rank_candidates(c->cand, batch, tail);
   }
   HIP_TRY(mark(3));
 
   // ---- polar gradients ----------------------------------------------------
   if (pipe)
   {
-    // join the octave streams (their gradients follow their scans)
-    for (int o = 1; o < sc.num_octaves; ++o)
-      HIP_TRY(hipStreamWaitEvent(stream, c->oct_done[o], 0));
+    // join the side chains (their gradients follow their scans)
+    for (int o = 0; o + 1 < sc.num_octaves; ++o)
+      HIP_TRY(hipStreamWaitEvent(tail, c->oct_done[o], 0));
   }
   else if (side)
     HIP_TRY(hipStreamWaitEvent(stream, c->aux_join, 0));
@@ -1208,9 +1328,9 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   if (last_stage >= SARA_HIP_STAGE_ORIENTATION)
   {
     launch_orientations(c->d_grad, c->d_tab, c->d_oriw, c->n_oriw, c->cand,
-                        c->ori, batch, stream);
+                        c->ori, batch, tail);
     launch_scan_peaks(c->cand, c->ori, c->d_counters + 4 * size_t(c->max_batch) + 1,
-                      batch, stream);
+                      batch, tail);
   }
   HIP_TRY(mark(5));
 
@@ -1218,7 +1338,13 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   if (last_stage >= SARA_HIP_STAGE_ORIENTATION)
     launch_descriptors(*c->h_grad, c->cand, c->ori, batch, c->d_feat, c->d_so,
                        c->d_desc, last_stage >= SARA_HIP_STAGE_DESCRIPTOR ? 1 : 0,
-                       c->root_sift ? 1 : 0, stream);
+                       c->root_sift ? 1 : 0, tail);
+  if (tail != stream)
+  {
+    // back to the caller's stream
+    HIP_TRY(hipEventRecord(c->aux_join, tail));
+    HIP_TRY(hipStreamWaitEvent(stream, c->aux_join, 0));
+  }
   HIP_TRY(mark(6));
   HIP_TRY(hipGetLastError());
   return SARA_HIP_OK;
@@ -1247,17 +1373,22 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       (void) hipGraphDestroy(graph);
     graph_exec = nullptr;
     graph = nullptr;
+    static const bool trace = getenv("SARA_HIP_TRACE_GRAPH") != nullptr;
     bool ok = hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed) ==
               hipSuccess;
+    if (trace) std::fprintf(stderr, "[sara_hip] capture begun: %d\n", int(ok));
     if (ok)
     {
       const sara_hip_status est = enqueue();
+      if (trace) std::fprintf(stderr, "[sara_hip] enqueued: %d\n", int(est));
       const hipError_t ee = hipStreamEndCapture(stream, &graph);
+      if (trace) std::fprintf(stderr, "[sara_hip] capture ended: %s\n", hipGetErrorString(ee));
       ok = est == SARA_HIP_OK && ee == hipSuccess && graph != nullptr;
     }
     if (ok)
       ok = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0) ==
            hipSuccess;
+    if (trace) std::fprintf(stderr, "[sara_hip] instantiated: %d\n", int(ok));
     if (!ok)
     {
       // fall back to plain launches for good; clear the sticky error
