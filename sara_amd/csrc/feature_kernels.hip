@@ -102,6 +102,12 @@ namespace sara_hip {
 #ifndef SARA_DEFINITENESS_SHORTCUT
 #define SARA_DEFINITENESS_SHORTCUT 1
 #endif
+#ifndef SARA_GRAD_EXP
+#define SARA_GRAD_EXP 0
+#endif
+#ifndef SARA_GRAD_ROLLED
+#define SARA_GRAD_ROLLED 0
+#endif
 #ifndef SARA_GRAD_PF
 #define SARA_GRAD_PF 4
 #endif
@@ -134,6 +140,14 @@ namespace sara_hip {
       int seg_rows, int nstrips, int nseg, int xcd_total,
       unsigned* __restrict__ cmax, size_t cmax_stride)
   {
+    // Round 2 layout.  A lane owns two pixel PAIRS of the 256-column strip,
+    // columns (2l, 2l+1) and (128 + 2l, 128 + 2l + 1): the two 8-byte loads
+    // and, above all, the two 16-byte stores of a row are then contiguous
+    // across the wave (1 KB each).  With 4 consecutive pixels per lane every
+    // store instruction wrote 16 of each 32 bytes, and the 1 read : 2 write
+    // stream stopped at 4.35 TB/s whatever the kernel computed (measured
+    // without any arithmetic, tools/ubench/rw12_patterns.hip); contiguous
+    // stores stream at 5.0 TB/s.
     constexpr int W = 256;
     const int lane = threadIdx.x;
     // argument-reduction table of atanf (device_math.hpp) in LDS
@@ -163,36 +177,32 @@ namespace sara_hip {
     float* o = dst + b * dst_stride + s * plane * 2;
 
     const int x0 = strip * W;
-    const int col = x0 + 4 * lane;
-    const bool col_ok = col < w;
-    const int mcol = col_ok ? col : w - 4;
+    const int colA = x0 + 2 * lane, colB = x0 + 128 + 2 * lane;
+    const bool okA = colA < w, okB = colB < w;
+    const int mcolA = okA ? colA : w - 2;
+    const int mcolB = okB ? colB : w - 2;
     const int y0 = seg * seg_rows;
     const int y1 = min(h, y0 + seg_rows);
     // strip-edge neighbours: lane 0 needs column x0-1, lane 63 column x0+256
     const int ecol = lane == 0 ? max(x0 - 1, 0) : min(x0 + W, w - 1);
     const bool edge_lane = (lane == 0) || (lane == 63);
-    // every lane issues the edge load (inner lanes re-read their own first
-    // column: same cache line as the float4) - no branch around a load
-    const int ecol_all = edge_lane ? ecol : mcol;
-    (void) ecol_all;
 
+    // one row: m = (A.x, A.y, B.x, B.y), e = the edge column of lanes 0 / 63
     auto load_row = [&](int yy, float4& m, float& e) {
       const int gy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
       const float* rowp = f + size_t(gy) * w;
-      m = *reinterpret_cast<const float4*>(rowp + mcol);
-#if SARA_GRAD_EDGE_UNCOND
-      e = rowp[ecol_all];
-#else
+      const float2 pa = *reinterpret_cast<const float2*>(rowp + mcolA);
+      const float2 pb = *reinterpret_cast<const float2*>(rowp + mcolB);
+      m = make_float4(pa.x, pa.y, pb.x, pb.y);
       e = 0.f;
       if (edge_lane)
         e = rowp[ecol];
-#endif
     };
 
-    // coarse 16x16 magnitude maxima: 4 lanes = 16 columns, running row max
+    // coarse 16x16 magnitude maxima: 8 lanes = 16 columns per pair group
     const int cw = (w + 15) / 16, ch = (h + 15) / 16;
     unsigned* cm = cmax ? cmax + b * cmax_stride + s * size_t(ch) * cw : nullptr;
-    float run_max = 0.f;
+    float run_maxA = 0.f, run_maxB = 0.f;
 
     float4 ring[3];   // source rows (n-2, n-1, n) by n % 3
     float ering[3];
@@ -221,21 +231,39 @@ namespace sara_hip {
           const float4 mid = ring[(i + 2) % 3];  // row y
           const float4 dn = ring[i % 3];         // row y+1
           const float emid = ering[(i + 2) % 3];
-          // horizontal neighbours of the 4 columns
-          float left = shift_from_prev(mid.w);
-          float right = shift_from_next(mid.x);
+          // horizontal neighbours of the two pairs
+          float leftA = shift_from_prev(mid.y);
+          float rightA = shift_from_next(mid.x);
+          float leftB = shift_from_prev(mid.w);
+          float rightB = shift_from_next(mid.z);
+          // pair A ends at column x0+127, whose right neighbour is pair B's
+          // first column (lane 0), and vice versa
+          const float firstB = __int_as_float(
+              __builtin_amdgcn_readfirstlane(__float_as_int(mid.z)));
+          const float lastA = __int_as_float(
+              __builtin_amdgcn_readlane(__float_as_int(mid.y), 63));
           if (lane == 0)
-            left = emid;
+          {
+            leftA = emid;
+            leftB = lastA;
+          }
           if (lane == 63)
-            right = emid;
+          {
+            rightA = firstB;
+            rightB = emid;
+          }
           // Differential.hpp:46-61: one-sided differences on the image border
           // = central differences with the missing neighbour replaced by the
           // pixel itself.  Rows and the left column get that from the clamped
           // loads (row -1 is row 0, column -1 is column 0); only the column
-          // after the last one (w is a multiple of 4 here) needs a select.
-          if (col + 4 >= w)
-            right = mid.w;
-          const float cx[6] = {left, mid.x, mid.y, mid.z, mid.w, right};
+          // after the last one (w is even here) needs a select.
+          if (colA + 2 >= w)
+            rightA = mid.y;
+          if (colB + 2 >= w)
+            rightB = mid.w;
+          // pixel order: A.x, A.y, B.x, B.y
+          const float cl[4] = {leftA, mid.x, leftB, mid.z};
+          const float cr[4] = {mid.y, rightA, mid.w, rightB};
           const float cu[4] = {up.x, up.y, up.z, up.w};
           const float cd[4] = {dn.x, dn.y, dn.z, dn.w};
           float res[8];
@@ -244,7 +272,7 @@ namespace sara_hip {
 #pragma unroll
           for (int c = 0; c < 4; ++c)
           {
-            const float gx = (cx[c + 2] - cx[c]) / 2;
+            const float gx = (cr[c] - cl[c]) / 2;
             const float gy = (cd[c] - cu[c]) / 2;
             gxs[c] = gx;
             gys[c] = gy;
@@ -298,36 +326,56 @@ namespace sara_hip {
             for (int c = 0; c < 4; ++c)
               res[2 * c] = 2 * sqrtf(ss[c]);
           }
-          if (col_ok)
           {
-            float4* op = reinterpret_cast<float4*>(o + (size_t(y) * w + col) * 2);
-            op[0] = make_float4(res[0], res[1], res[2], res[3]);
-            op[1] = make_float4(res[4], res[5], res[6], res[7]);
+            // lane l: 16 bytes at (x0 + 2l) and at (x0 + 128 + 2l) - contiguous
+            float4* ob = reinterpret_cast<float4*>(o + (size_t(y) * w + x0) * 2);
+            if (okA)
+              ob[lane] = make_float4(res[0], res[1], res[2], res[3]);
+            if (okB)
+              ob[64 + lane] = make_float4(res[4], res[5], res[6], res[7]);
           }
           if (cm)
           {
-            float m4 = col_ok ? fmaxf(fmaxf(res[0], res[2]), fmaxf(res[4], res[6]))
-                              : 0.f;
-            // max over the 4 lanes of a 16-column group (quad_perm DPP)
-            m4 = fmaxf(m4, __int_as_float(__builtin_amdgcn_mov_dpp(
-                               __float_as_int(m4), 0xB1, 0xf, 0xf, true)));
-            m4 = fmaxf(m4, __int_as_float(__builtin_amdgcn_mov_dpp(
-                               __float_as_int(m4), 0x4E, 0xf, 0xf, true)));
-            run_max = fmaxf(run_max, m4);
+            float mA = okA ? fmaxf(res[0], res[2]) : 0.f;
+            float mB = okB ? fmaxf(res[4], res[6]) : 0.f;
+            // max over the 8 lanes of a 16-column group: the two quad
+            // permutations, then the mirror of the 8-lane half row
+            auto max8 = [](float m) {
+              m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(
+                               __float_as_int(m), 0xB1, 0xf, 0xf, true)));
+              m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(
+                               __float_as_int(m), 0x4E, 0xf, 0xf, true)));
+              m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(
+                               __float_as_int(m), 0x141, 0xf, 0xf, true)));
+              return m;
+            };
+            run_maxA = fmaxf(run_maxA, max8(mA));
+            run_maxB = fmaxf(run_maxB, max8(mB));
             if ((y & 15) == 15 || y == y1 - 1)
             {
-              if ((lane & 3) == 0 && col_ok)
+              if ((lane & 7) == 0)
               {
                 // segments of whole 16-row bands (seg_rows % 16 == 0): this
-                // lane is the only writer of its 16 x 16 block - a plain
-                // store, and the map needs no zeroing before the launch
-                unsigned* at = cm + size_t(y >> 4) * cw + (col >> 4);
-                if ((seg_rows & 15) == 0)
-                  *at = __float_as_uint(run_max);
-                else
-                  atomicMax(at, __float_as_uint(run_max));
+                // lane is the only writer of its 16 x 16 blocks - plain
+                // stores, and the map needs no zeroing before the launch
+                unsigned* rowc = cm + size_t(y >> 4) * cw;
+                if (okA)
+                {
+                  if ((seg_rows & 15) == 0)
+                    rowc[colA >> 4] = __float_as_uint(run_maxA);
+                  else
+                    atomicMax(rowc + (colA >> 4), __float_as_uint(run_maxA));
+                }
+                if (okB)
+                {
+                  if ((seg_rows & 15) == 0)
+                    rowc[colB >> 4] = __float_as_uint(run_maxB);
+                  else
+                    atomicMax(rowc + (colB >> 4), __float_as_uint(run_maxB));
+                }
               }
-              run_max = 0.f;
+              run_maxA = 0.f;
+              run_maxB = 0.f;
             }
           }
         }

@@ -970,6 +970,49 @@ namespace sara_hip {
       dst[b * dst_stride + i] = src[b * src_stride + i];
   }
 
+  //! Byte copy by the shader cores (16 bytes per lane and iteration).  An
+  //! experiment for the result read-back into pinned host memory
+  //! (SARA_HIP_D2H=kernel): the copy engines serialise host-to-device and
+  //! device-to-host copies on this platform (measured with two streams: 9.3 ms
+  //! + 2.5 ms = 11.8 ms when both are in flight), and a kernel writing over
+  //! PCIe could run beside an upload.  Measured: float frames 12.96 -> 11.94
+  //! ms per step, but 8-bit frames 8.4 -> 11.3 ms (the copy kernel queues
+  //! behind the next batch's launches whatever its grid and stream priority),
+  //! so the copy engine stays the default.
+  __global__ __launch_bounds__(256) void blit_kernel(const uint4* __restrict__ src,
+                                                     uint4* __restrict__ dst,
+                                                     size_t n16,
+                                                     const unsigned char* src_tail,
+                                                     unsigned char* dst_tail,
+                                                     int tail)
+  {
+    const size_t stride = size_t(gridDim.x) * blockDim.x;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += stride)
+      dst[i] = src[i];
+    if (blockIdx.x == 0 && int(threadIdx.x) < tail)
+      dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+  }
+
+  void launch_blit(const void* src, void* dst, size_t bytes, hipStream_t stream)
+  {
+    if (bytes == 0)
+      return;
+    const size_t n16 = bytes / 16;
+    const int tail = int(bytes - n16 * 16);
+    const unsigned char* s = static_cast<const unsigned char*>(src);
+    unsigned char* d = static_cast<unsigned char*>(dst);
+    // a PCIe link needs few waves to stay full; a small grid leaves the CUs to
+    // the pipeline of the next batch
+    static const int max_blocks = [] {
+      const char* e = getenv("SARA_HIP_BLIT_BLOCKS");
+      return e ? std::max(1, atoi(e)) : 64;
+    }();
+    const int blocks = int(std::min<size_t>(size_t(max_blocks), (n16 + 255) / 256 + 1));
+    hipLaunchKernelGGL(blit_kernel, dim3(blocks), dim3(256), 0, stream,
+                       reinterpret_cast<const uint4*>(s), reinterpret_cast<uint4*>(d),
+                       n16, s + n16 * 16, d + n16 * 16, tail);
+  }
+
   void launch_copy_planes(const float* src, size_t src_stride, float* dst,
                           size_t dst_stride, size_t count, int batch,
                           hipStream_t stream)

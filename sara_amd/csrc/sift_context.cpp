@@ -1613,7 +1613,13 @@ sara_hip_status sara_hip_sift_submit(sara_hip_sift* c, const void* images,
                           sizeof(int) * (4 * size_t(c->max_batch) + 1)));
   }
   if (!c->d2h_stream)
-    HIP_TRY(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+  {
+    // highest priority: the read-back kernel's few workgroups should not
+    // queue behind the next batch's launches
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(hipStreamCreateWithPriority(&c->d2h_stream, hipStreamNonBlocking, hi));
+  }
   sara_hip_status st = select_result_slot(c, slot);
   if (st != SARA_HIP_OK)
     return st;
@@ -1698,14 +1704,34 @@ sara_hip_status sara_hip_sift_collect(sara_hip_sift* c, int ticket,
   {
     // the batch is complete (event): the copies need no further ordering and
     // run beside the next batch's kernels
-    HIP_TRY(hipMemcpyAsync(r.h_feat, c->d_feat_s[slot], sizeof(sara_oeregion) * n,
-                           hipMemcpyDeviceToHost, c->d2h_stream));
-    HIP_TRY(hipMemcpyAsync(r.h_so, c->d_so_s[slot], sizeof(int32_t) * 2 * n,
-                           hipMemcpyDeviceToHost, c->d2h_stream));
-    if (descriptors)
-      HIP_TRY(hipMemcpyAsync(r.h_desc, c->d_desc_s[slot],
-                             sizeof(float) * 128 * size_t(n),
+    // SARA_HIP_D2H=kernel: read-back through a copy kernel instead of the copy
+    // engine (experiment, off: see launch_blit)
+    static const bool by_kernel = [] {
+      const char* e = getenv("SARA_HIP_D2H");
+      return e && std::string(e) == "kernel";
+    }();
+    if (by_kernel)
+    {
+      launch_blit(c->d_feat_s[slot], r.h_feat, sizeof(sara_oeregion) * size_t(n),
+                  c->d2h_stream);
+      launch_blit(c->d_so_s[slot], r.h_so, sizeof(int32_t) * 2 * size_t(n),
+                  c->d2h_stream);
+      if (descriptors)
+        launch_blit(c->d_desc_s[slot], r.h_desc, sizeof(float) * 128 * size_t(n),
+                    c->d2h_stream);
+      HIP_TRY(hipGetLastError());
+    }
+    else
+    {
+      HIP_TRY(hipMemcpyAsync(r.h_feat, c->d_feat_s[slot], sizeof(sara_oeregion) * n,
                              hipMemcpyDeviceToHost, c->d2h_stream));
+      HIP_TRY(hipMemcpyAsync(r.h_so, c->d_so_s[slot], sizeof(int32_t) * 2 * n,
+                             hipMemcpyDeviceToHost, c->d2h_stream));
+      if (descriptors)
+        HIP_TRY(hipMemcpyAsync(r.h_desc, c->d_desc_s[slot],
+                               sizeof(float) * 128 * size_t(n),
+                               hipMemcpyDeviceToHost, c->d2h_stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->d2h_stream));
   }
   r.pending = false;
