@@ -18,5 +18,8 @@ bash tools/pmc_pipeline.sh ${TAG}_sq > /dev/null
 python tools/pmc_pipeline_summary.py $R/gpurun_out/pmc_pipe/${TAG}_sq_counter_collection.csv > $D/${TAG}_sq_counters.txt
 # 4K (config 5): kernel statistics of the same pipeline
 SARA_HIP_STREAMS=1 SARA_HIP_SIDE_GRADIENT=0 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o ${TAG}_4k -- python bench.py --width 3840 --height 2160 --octaves 5 --frames-per-gpu 16 --unique-frames 4 --steps 5 --warmup 2 --cpu-frames 0 --no-extras > $D/${TAG}_4k.log 2>&1
+# one 1080p frame per call: the launch timeline of a steady-state call
+rocprofv3 --kernel-trace --output-format csv -d $D -o ${TAG}_b1 -- python tools/b1_probe.py > $D/${TAG}_b1.log 2>&1
+( grep -v '^[WE]20' $D/${TAG}_b1.log; python tools/b1_timeline.py $D/${TAG}_b1_kernel_trace.csv ) > $D/${TAG}_single_frame_timeline.txt
 ls $D | head -50
 cat $D/${TAG}_spans.txt
