@@ -568,31 +568,51 @@ namespace sara_hip {
 #endif
   }
 
-  SARA_HD void sincos_reduced_f64(double x, double& s, double& c)
+  //! Constants of sincos_reduced_f64.  The device reads them through a
+  //! __constant__ copy (scalar loads at the point of use): as literals the
+  //! compiler materialises them in VGPR pairs, hoists those out of the
+  //! per-keypoint loop and - in the descriptor kernel, which is compiled for
+  //! 80 VGPRs - spills them, so that every keypoint started with a chain of
+  //! scratch reloads (23 % of the kernel's wave time, measured).
+  //! [0] 2/pi, [1..3] pi/2 = P1 + P2 + P3 (33 + 33 + 53 bits),
+  //! [4..9] S6..S1 of __kernel_sin, [10..15] C6..C1 of __kernel_cos.
+#define SARA_SINCOS_COEF_INIT                                                  \
+  {6.36619772367581382433e-01,  1.57079632673412561417e+00,                    \
+   6.07710050630396597660e-11,  2.02226624871116645580e-21,                    \
+   1.58969099521155010221e-10,  -2.50507602534068634195e-08,                   \
+   2.75573137070700676789e-06,  -1.98412698298579493134e-04,                   \
+   8.33333333332248946124e-03,  -1.66666666666666324348e-01,                   \
+   -1.13596475577881948265e-11, 2.08757232129817482790e-09,                    \
+   -2.75573143513906633035e-07, 2.48015872894767294178e-05,                    \
+   -1.38888888888741095749e-03, 4.16666666666666019037e-02}
+  constexpr int kSincosCoefCount = 16;
+
+  SARA_HD void sincos_reduced_f64(double x, double& s, double& c,
+                                  const double* __restrict__ K)
   {
     // k = nearest integer to x * 2/pi, |k| <= 3
-    const double kf = __builtin_rint(x * 6.36619772367581382433e-01);
+    const double kf = __builtin_rint(x * K[0]);
     const int k = int(kf);
     // r = x - k * pi/2 with pi/2 = P1 + P2 + P3 (33 + 33 + 53 bits)
-    double r = fma_f64(-kf, 1.57079632673412561417e+00, x);
-    r = fma_f64(-kf, 6.07710050630396597660e-11, r);
-    r = fma_f64(-kf, 2.02226624871116645580e-21, r);
+    double r = fma_f64(-kf, K[1], x);
+    r = fma_f64(-kf, K[2], r);
+    r = fma_f64(-kf, K[3], r);
     r = k == 0 ? x : r;  // keeps sin(-0) = -0
     const double z = r * r;
     // __kernel_sin: r + r^3 (S1 + z (S2 + ... z S6))
-    double ps = fma_f64(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = fma_f64(z, ps, 2.75573137070700676789e-06);
-    ps = fma_f64(z, ps, -1.98412698298579493134e-04);
-    ps = fma_f64(z, ps, 8.33333333332248946124e-03);
-    ps = fma_f64(z, ps, -1.66666666666666324348e-01);
+    double ps = fma_f64(z, K[4], K[5]);
+    ps = fma_f64(z, ps, K[6]);
+    ps = fma_f64(z, ps, K[7]);
+    ps = fma_f64(z, ps, K[8]);
+    ps = fma_f64(z, ps, K[9]);
     double sr = fma_f64(z * r, ps, r);
     sr = z < 5.5e-17 ? r : sr;  // |r| < 2^-27: sin r = r (and keeps -0)
     // __kernel_cos: 1 - z/2 + z^2 (C1 + z (C2 + ... z C6))
-    double pc = fma_f64(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = fma_f64(z, pc, -2.75573143513906633035e-07);
-    pc = fma_f64(z, pc, 2.48015872894767294178e-05);
-    pc = fma_f64(z, pc, -1.38888888888741095749e-03);
-    pc = fma_f64(z, pc, 4.16666666666666019037e-02);
+    double pc = fma_f64(z, K[10], K[11]);
+    pc = fma_f64(z, pc, K[12]);
+    pc = fma_f64(z, pc, K[13]);
+    pc = fma_f64(z, pc, K[14]);
+    pc = fma_f64(z, pc, K[15]);
     const double cr = fma_f64(z * z, pc, fma_f64(z, -0.5, 1.0));
     switch (k & 3)
     {
@@ -613,6 +633,13 @@ namespace sara_hip {
       c = sr;
       break;
     }
+  }
+
+  //! Host form (and any caller without a constant table at hand).
+  inline void sincos_reduced_f64_host(double x, double& s, double& c)
+  {
+    static const double K[kSincosCoefCount] = SARA_SINCOS_COEF_INIT;
+    sincos_reduced_f64(x, s, c, K);
   }
 
 }  // namespace sara_hip

@@ -2235,6 +2235,8 @@ namespace sara_hip {
   constexpr int kDescAhead = SARA_DESC_AHEAD;  // gathers in flight per lane
 
   constexpr int kDescWaves = SARA_DESC_WAVES;
+  //! constants of sincos_reduced_f64 (device_math.hpp), read with scalar loads
+  __constant__ double g_sincos_coef[kSincosCoefCount] = SARA_SINCOS_COEF_INIT;
 #ifdef SARA_DESC_PROF
   // Per-phase wave cycles (s_memtime), summed over all waves: a development
   // aid, read back through sara_hip_debug_desc_prof().
@@ -2382,16 +2384,26 @@ namespace sara_hip {
         if (q * 64 + lane < kDescHistWords)
           hist[q * 64 + lane] = 0ull;
 
+      SARA_PROF_T(t_zero);
+#ifdef SARA_DESC_PROF2
+      SARA_PROF_ADD(5, t_peak, t_zero);
+#endif
+      // theta is a refined histogram peak in (-pi, pi] (orientation_kernel).
+      // Anything else (never produced) is first brought back by whole turns:
+      // no general-range library call - its Payne-Hanek path and constants
+      // cost registers (spills reloaded from scratch in every item) for a
+      // branch that is never taken.
+      double td = double(theta);
+      if (!(fabsf(theta) <= 4.f))
+        td -= 6.28318530717958647692 * __builtin_rint(td * 0.15915494309189533577);
       double sd, cd;
-      if (fabsf(theta) <= 4.f)
-        sincos_reduced_f64(double(theta), sd, cd);
-      else
-      {
-        sd = sin(double(theta));
-        cd = cos(double(theta));
-      }
+      sincos_reduced_f64(td, sd, cd, g_sincos_coef);
       const float ct = float(cd);
       const float st = float(sd);
+      SARA_PROF_T(t_sc);
+#ifdef SARA_DESC_PROF2
+      SARA_PROF_ADD(6, t_zero, t_sc);
+#endif
       const float T00 = ct / l, T01 = st / l, T10 = (-st) / l, T11 = ct / l;
 
       // Row intervals are conservative (the exact float test in the sample
@@ -2569,7 +2581,7 @@ namespace sara_hip {
           }
           SARA_PROF_T(t_steps);
           SARA_PROF_ADD(3, t_tab, t_steps);
-#ifdef SARA_DESC_PROF
+#if defined(SARA_DESC_PROF) && !defined(SARA_DESC_PROF2)
           if (lane == 0)
           {
             atomicAdd(&g_desc_prof[5], (unsigned long long) nsteps);

@@ -2402,7 +2402,7 @@ void sara_hip_selfcheck_sincos(const float* theta, float* out_sin, float* out_co
   for (size_t i = 0; i < count; ++i)
   {
     double s, c;
-    sara_hip::sincos_reduced_f64(double(theta[i]), s, c);
+    sara_hip::sincos_reduced_f64_host(double(theta[i]), s, c);
     out_sin[i] = float(s);
     out_cos[i] = float(c);
   }

@@ -195,6 +195,47 @@ int main(int argc, char** argv)
                       .count() /
                   reps;
   }
+  // where a call spends its time: the same three steps through the C-ABI
+  double ms_submit = 0., ms_collect = 0., ms_fill = 0.;
+  {
+    sara_sift_params p;
+    p.pyramid = sara::hip_detail::to_c(pyr_params);
+    p.gauss_truncate = 4.f;
+    p.extremum_thres = 0.01f;
+    p.edge_ratio_thres = 10.f;
+    p.extremum_refinement_iter = 5;
+    sara_hip_sift* ctx = sara::hip_detail::cached_context(
+        sara::hip_detail::ContextKey{p, image.width(), image.height(), 0});
+    using clk = std::chrono::steady_clock;
+    const int reps = 30;
+    for (int i = 0; i < reps; ++i)
+    {
+      const auto t0 = clk::now();
+      int ticket = -1, total = 0;
+      if (sara_hip_sift_submit(ctx, image.data(), 0, 0, 1, image.width(),
+                               image.height(), 0, SARA_HIP_STAGE_DESCRIPTOR,
+                               &ticket) != SARA_HIP_OK)
+        return 16;
+      const auto t1 = clk::now();
+      const sara_oeregion* pf = nullptr;
+      const float* pd = nullptr;
+      if (sara_hip_sift_collect(ctx, ticket, &pf, &pd, nullptr, nullptr, &total) !=
+          SARA_HIP_OK)
+        return 17;
+      const auto t2 = clk::now();
+      auto feats = std::vector<sara::OERegion>(size_t(total));
+      auto desc = sara::Tensor_<float, 2>{};
+      desc.resize(total, 128);
+      std::memcpy(static_cast<void*>(feats.data()), pf, sizeof(sara_oeregion) * size_t(total));
+      std::memcpy(desc.data(), pd, sizeof(float) * 128 * size_t(total));
+      const auto t3 = clk::now();
+      ms_submit += std::chrono::duration<double, std::milli>(t1 - t0).count() / reps;
+      ms_collect += std::chrono::duration<double, std::milli>(t2 - t1).count() / reps;
+      ms_fill += std::chrono::duration<double, std::milli>(t3 - t2).count() / reps;
+    }
+  }
+  std::fprintf(stderr, "phases: submit %.3f ms, collect %.3f ms, containers %.3f ms\n",
+               ms_submit, ms_collect, ms_fill);
   std::printf("{\"keypoints\": %d, \"extrema\": %d, \"octaves\": %d, "
               "\"factor1\": %g, \"ms_per_call\": %.4f}\n",
               n, ne, G.octave_count(),

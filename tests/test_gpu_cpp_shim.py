@@ -92,5 +92,8 @@ def test_shim_per_frame_call_1080p(tmp_path):
     info = json.loads(res.stdout.strip().splitlines()[-1])
     print("C++ shim, 1 x 1080p per call: %.3f ms (%d keypoints)" %
           (info["ms_per_call"], info["keypoints"]))
+    for line in res.stderr.splitlines():
+        if line.startswith("phases:"):
+            print("C++ shim,", line)
     assert info["keypoints"] > 3000
     assert info["ms_per_call"] < 5.0
