@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 
 namespace sara_hip {
 
@@ -2224,8 +2225,19 @@ namespace sara_hip {
   constexpr int kDescCopies = SARA_DESC_COPIES;  // histogram replicas per wave
   // cell stride in 64-bit words; the padding moves neighbouring cells off the
   // same LDS bank
+#ifndef SARA_DESC_FX32
+#define SARA_DESC_FX32 1
+#endif
+  // SARA_DESC_FX32: 32-bit accumulators on a 5 x 5 cell grid.  The fifth row
+  // and column are dump cells: the dx / dy = 1 neighbours of cells 3 always
+  // exist, so the eight addresses of a sample are two registers plus
+  // immediates and the weights need no selects; the fixed-point scale is
+  // chosen per keypoint so that no bin can overflow (see fx_scale).
+  constexpr bool kDescFx32 = SARA_DESC_FX32 != 0;
+  constexpr int kDescGrid = kDescFx32 ? 5 : 4;  // cells per row of the LDS grid
   constexpr int kDescCellStride = 8 * kDescCopies + SARA_DESC_PAD;
-  constexpr int kDescHistWords = 16 * kDescCellStride;
+  constexpr int kDescHistWords = kDescGrid * kDescGrid * kDescCellStride;
+  using desc_acc_t = std::conditional_t<kDescFx32, int, unsigned long long>;
   constexpr int kDescRowsPerBlock = 64;   // one row per lane
   constexpr int kDescChunksPerPhase = 8;  // chunks of one row per table fill
   constexpr int kDescTableCap = kDescRowsPerBlock * kDescChunksPerPhase;
@@ -2256,7 +2268,7 @@ namespace sara_hip {
       float* __restrict__ descriptors, int with_descriptors, int root_sift,
       int xcd_run)
   {
-    __shared__ unsigned long long s_acc[kDescWaves][kDescHistWords];
+    __shared__ __attribute__((aligned(16))) desc_acc_t s_acc[kDescWaves][kDescHistWords + 4];
     __shared__ unsigned s_tab[kDescWaves][kDescTableCap];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -2316,7 +2328,7 @@ namespace sara_hip {
             grad.base[o] + size_t(b) * grad.frame_stride[o]) +
         size_t(s) * grad.plane[o];
     const float factor = grad.factor[o];
-    unsigned long long* hist = s_acc[wave];
+    desc_acc_t* hist = s_acc[wave];
     unsigned* tab = s_tab[wave];
     const int copy = lane & (kDescCopies - 1);
 
@@ -2330,8 +2342,9 @@ namespace sara_hip {
     // Fixed-point scale of the accumulation.  Every contribution is bounded by
     // |wy*wx*wo*weight*mag| < 2*2*1*1*max(mag); max(mag) over a superset of
     // the patch comes from the coarse 16x16 magnitude maxima written by the
-    // gradient kernel.  With max(mag) < 2^e the products scaled by 2^(25-e)
-    // stay below 2^29 and convert to int32 with one rounding of 2^-(26-e).
+    // gradient kernel.  64-bit accumulators: with max(mag) < 2^e the products
+    // scaled by 2^(25-e) stay below 2^29 and convert to int32 with one
+    // rounding of 2^-(26-e).  32-bit accumulators: see below.
     float fx_scale = 1.f;
     double fx_inv = 1.;
     if (with_descriptors)
@@ -2352,8 +2365,29 @@ namespace sara_hip {
       (void) frexpf(mx, &e);  // mx < 2^e
       if (!(mx > 0.f) || !(mx < 3.0e38f))
         e = 0;
-      fx_scale = ldexpf(1.f, 25 - e);
-      fx_inv = ldexp(1., e - 25);
+      if (kDescFx32)
+      {
+        // 32-bit accumulators: the scale is as large as the worst case allows.
+        // A bin collects the samples whose patch coordinates (px, py) lie in a
+        // 2 x 2 cell box.  Each of its four cell-sized quadrants (side l
+        // pixels) holds at most (l + 2)^2 pixels (area + perimeter / 2 + 1 of
+        // a convex region), and |wy wx| <= 4, 2, 2, 1 there (the weights
+        // exceed 1 only where modf() hands out a negative fraction, for
+        // coordinates in (-1, 0)); wo <= 1, weight <= 1, mag <= mx.  Hence
+        // sum |contribution| <= 9 (l + 2)^2 mx scale, kept below 2^31.
+        const float bound = 9.f * (l + 2.f) * (l + 2.f);
+        if (mx > 0.f && mx < 3.0e38f)
+          fx_scale = (2147483648.f * 0.999f) / (bound * mx);
+        // a scale outside the normal range (absurd magnitudes) falls back to 1
+        if (!(fx_scale > 1e-30f && fx_scale < 1e30f))
+          fx_scale = 1.f;
+        fx_inv = 1. / double(fx_scale);
+      }
+      else
+      {
+        fx_scale = ldexpf(1.f, 25 - e);
+        fx_inv = ldexp(1., e - 25);
+      }
     }
 
     SARA_PROF_T(t_setup);
@@ -2379,10 +2413,22 @@ namespace sara_hip {
       if (!with_descriptors)
         return;
 
+      if (kDescFx32)
+      {
+        // 16 bytes per lane and store (the array is padded to a multiple of 4)
+        int4* h4 = reinterpret_cast<int4*>(hist);
 #pragma unroll
-      for (int q = 0; q < (kDescHistWords + 63) / 64; ++q)
-        if (q * 64 + lane < kDescHistWords)
-          hist[q * 64 + lane] = 0ull;
+        for (int q = 0; q < (kDescHistWords + 255) / 256; ++q)
+          if (q * 64 + lane < (kDescHistWords + 3) / 4)
+            h4[q * 64 + lane] = make_int4(0, 0, 0, 0);
+      }
+      else
+      {
+#pragma unroll
+        for (int q = 0; q < (kDescHistWords + 63) / 64; ++q)
+          if (q * 64 + lane < kDescHistWords)
+            hist[q * 64 + lane] = desc_acc_t(0);
+      }
 
       SARA_PROF_T(t_zero);
 #ifdef SARA_DESC_PROF2
@@ -2436,14 +2482,14 @@ namespace sara_hip {
         // xi, yi are in 0..3 (p in (-1, 4), truncation): the dx / dy = 1
         // neighbours exist when xi / yi < 3; otherwise their weight is zeroed
         // and their address falls back on the dx / dy = 0 cell
-        const bool x_ok = xi < 3, y_ok = yi < 3;
+        const bool x_ok = kDescFx32 || xi < 3, y_ok = kDescFx32 || yi < 3;
         const float wx1 = x_ok ? xfrac : 0.f, wy1 = y_ok ? yfrac : 0.f;
         const float wy0 = 1.f - yfrac, wx0 = 1.f - xfrac;
         const float p00 = wy0 * wx0, p01 = wy0 * wx1, p10 = wy1 * wx0,
                     p11 = wy1 * wx1;
         const unsigned dxo = x_ok ? unsigned(kDescCellStride) : 0u;
-        const unsigned dyo = y_ok ? unsigned(4 * kDescCellStride) : 0u;
-        const unsigned cell = unsigned(yi * 4 + xi);
+        const unsigned dyo = y_ok ? unsigned(kDescGrid * kDescCellStride) : 0u;
+        const unsigned cell = unsigned(yi * kDescGrid + xi);
         const unsigned h0 =
             __umul24(cell, unsigned(kDescCellStride)) + unsigned(copy);
         const unsigned ia = h0 + unsigned((oi & 7) * kDescCopies);
@@ -2459,7 +2505,7 @@ namespace sara_hip {
             : "v"(p00 * w0), "v"(p00 * w1), "v"(p01 * w0), "v"(p01 * w1),
               "v"(p10 * w0), "v"(p10 * w1), "v"(p11 * w0), "v"(p11 * w1));
 #define SARA_DESC_ADD(i, val)                                                  \
-  atomicAdd(&hist[i], (unsigned long long) (long long) (val))
+  atomicAdd(&hist[i], desc_acc_t(kDescFx32 ? (long long) (val) : (long long) (val)))
         SARA_DESC_ADD(ia, c0);
         SARA_DESC_ADD(ib, c1);
         SARA_DESC_ADD(ia + dxo, c2);
@@ -2597,14 +2643,31 @@ namespace sara_hip {
       double a0 = 0., a1 = 0.;
       {
         // bin = (y * 4 + x) * 8 + o of the reference's layout
-        const unsigned long long* q0 =
-            hist + (lane >> 3) * kDescCellStride + (lane & 7) * kDescCopies;
-        const unsigned long long* q1 = q0 + 8 * kDescCellStride;
-#pragma unroll
-        for (int c = 0; c < kDescCopies; ++c)
+        // lane -> cell (lane >> 3) = y * 4 + x of the upper half, + 8 below
+        const int cy = lane >> 5, cx = (lane >> 3) & 3;
+        const desc_acc_t* q0 = hist + (cy * kDescGrid + cx) * kDescCellStride +
+                               (lane & 7) * kDescCopies;
+        const desc_acc_t* q1 = q0 + 2 * kDescGrid * kDescCellStride;
+        if (kDescFx32)
         {
-          a0 += double((long long) q0[c]) * fx_inv;
-          a1 += double((long long) q1[c]) * fx_inv;
+          long long s0 = 0, s1 = 0;
+#pragma unroll
+          for (int c = 0; c < kDescCopies; ++c)
+          {
+            s0 += (long long) (int) q0[c];
+            s1 += (long long) (int) q1[c];
+          }
+          a0 = double(s0) * fx_inv;
+          a1 = double(s1) * fx_inv;
+        }
+        else
+        {
+#pragma unroll
+          for (int c = 0; c < kDescCopies; ++c)
+          {
+            a0 += double((long long) q0[c]) * fx_inv;
+            a1 += double((long long) q1[c]) * fx_inv;
+          }
         }
       }
       float h0 = float(a0), h1 = float(a1);
