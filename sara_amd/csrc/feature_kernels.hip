@@ -1843,12 +1843,15 @@ namespace sara_hip {
     const ScaleTable& tab = *tabp;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    __shared__ float s_thr[40];
+    if (threadIdx.x < 40)
+      s_thr[threadIdx.x] = tab.ori_bin_thr[threadIdx.x];
     if (WLDS)
     {
       for (int i = threadIdx.x; i < n_weights; i += 64 * kOriWaves)
         s_weights[i] = weights[i];
-      __syncthreads();
     }
+    __syncthreads();
     const int b = blockIdx.y;
     const int n = min(cand.count[b], cand.cap);
     // Persistent blocks: the grid holds one run-group of blocks per frame and
@@ -1941,8 +1944,13 @@ namespace sara_hip {
       {
         float a = mo.y;
         a = a < 0 ? a + float(2. * M_PI) : a;
-        bin = int(floor(double(a / float(2 * M_PI) * kOriBins)));
-        bin %= kOriBins;
+        // int(floor(double(a / float(2 pi) * 36))) % 36 without the division:
+        // estimate, then one step of correction against the exact thresholds
+        int kb = int(a * float(kOriBins / (2. * M_PI)));
+        kb = min(max(kb, 0), kOriBins);
+        const float t0 = s_thr[kb], t1 = s_thr[kb + 1];
+        kb += int(a >= t1) - int(a < t0);
+        bin = kb == kOriBins ? 0 : kb;
         const int wi = woff + uc * uc + vc * vc;
         c = (WLDS ? s_weights[wi] : weights[wi]) * double(mo.x);
       }

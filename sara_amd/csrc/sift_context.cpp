@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -477,6 +478,34 @@ namespace {
       if (used)
         for (int d2 = 0; d2 <= 2 * R * R; ++d2)
           oriw.push_back(std::exp(double(float(-d2) / (2.f * sw * sw))));
+    }
+    {
+      // see ScaleTable::ori_bin_thr
+      auto bin_of = [](float a) {
+        return int(std::floor(double(a / float(2 * M_PI) * 36)));
+      };
+      for (int kk = 0; kk < 40; ++kk)
+      {
+        uint32_t lo = 0u, hi = 0x40c91000u;  // [0, a little above float(2 pi)]
+        float thr = std::numeric_limits<float>::infinity();
+        float top;
+        std::memcpy(&top, &hi, 4);
+        if (bin_of(top) >= kk)
+        {
+          while (lo < hi)  // first bit pattern (= first float >= 0) with bin >= kk
+          {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            float a;
+            std::memcpy(&a, &mid, 4);
+            if (bin_of(a) >= kk)
+              hi = mid;
+            else
+              lo = mid + 1;
+          }
+          std::memcpy(&thr, &lo, 4);
+        }
+        c->h_tab.ori_bin_thr[kk] = thr;
+      }
     }
     TRY_ST(c->alloc(c->d_tab, 1));
     TRY_HIP(hipMemcpy(c->d_tab, &c->h_tab, sizeof(ScaleTable),

@@ -42,6 +42,12 @@ namespace sara_hip {
     int ori_radius[kMaxScales];  // int_round(sigma*1.5f*3.f), Orientation.hpp:105-108
     float ori_sigma[kMaxScales]; // sigma * 1.5f
     int ori_woff[kMaxScales];    // offset of the weight table of scale s
+    // Orientation.hpp:118-119: bin = int(floor(double(ori / float(2 pi) * 36)))
+    // is non-decreasing in ori: thr[k] = smallest float >= 0 whose bin is >= k
+    // (k = 0 .. 37, +inf where no angle gets there), found by bisection on the
+    // host with the expression itself.  The kernel estimates the bin with one
+    // multiplication and corrects it by at most one against thr[].
+    float ori_bin_thr[40];
   };
 
   struct ExtremaParams
