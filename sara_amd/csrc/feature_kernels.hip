@@ -1805,7 +1805,7 @@ namespace sara_hip {
   //! 4 / 2 / 1 waves per group; the orientation kernel shares its weight
   //! tables in LDS across the group and prefers 4 (1.04 against 1.17 ms).
 #ifndef SARA_ORI_WAVES
-#define SARA_ORI_WAVES 4
+#define SARA_ORI_WAVES 2
 #endif
 #ifndef SARA_DESC_WAVES
 #define SARA_DESC_WAVES 1
@@ -1824,13 +1824,40 @@ namespace sara_hip {
     return v;
   }
 
+#if defined(SARA_DESC_PROF) || defined(SARA_ORI_PROF)
+  // Per-phase wave cycles (s_memtime), summed over all waves: a development
+  // aid, read back through sara_hip_debug_desc_prof().
+  __device__ unsigned long long g_desc_prof[8];
+#define SARA_PROF_T(var) const long long var = clock64()
+#define SARA_PROF_ADD(slot, a, b)                                              \
+  if (lane == 0)                                                               \
+  atomicAdd(&g_desc_prof[slot], (unsigned long long) ((b) - (a)))
+#else
+#define SARA_PROF_T(var)
+#define SARA_PROF_ADD(slot, a, b)
+#endif
+#ifdef SARA_ORI_PROF
+#define SARA_OPROF_T(var) const long long var = clock64()
+#define SARA_OPROF_ADD(slot, a, b)                                             \
+  if (lane == 0)                                                               \
+  atomicAdd(&g_desc_prof[slot], (unsigned long long) ((b) - (a)))
+#else
+#define SARA_OPROF_T(var)
+#define SARA_OPROF_ADD(slot, a, b)
+#endif
   //! WLDS: the Gaussian weight tables of all scales sit in (dynamic) LDS.  From
   //! global memory each look-up is a vector load that shares the in-order
   //! vmcnt counter with the gathers: waiting for a weight then also waits for
   //! every gather issued ahead of it, which defeats the prefetch ring below.
     constexpr int kOriWaves = SARA_ORI_WAVES;
+#ifndef SARA_ORI_AHEAD
+#define SARA_ORI_AHEAD 2
+#endif
+#ifndef SARA_ORI_BLOCKS_PER_EU
+#define SARA_ORI_BLOCKS_PER_EU 1
+#endif
   template <bool WLDS>
-  __global__ __launch_bounds__(64 * kOriWaves) void orientation_kernel(
+  __global__ __launch_bounds__(64 * kOriWaves, SARA_ORI_BLOCKS_PER_EU) void orientation_kernel(
       const GradPyramidView* __restrict__ gradp,
       const ScaleTable* __restrict__ tabp, const double* __restrict__ weights,
       int n_weights, CandidateLists cand, OrientationLists ori, int xcd_run)
@@ -1865,6 +1892,7 @@ namespace sara_hip {
     if (idx >= n)
       return;
 
+    SARA_OPROF_T(t_item);
     const size_t row = size_t(b) * cand.cap;
     const unsigned long long key = cand.skey[row + idx];
     const float4 d = cand.sdata[row + idx];
@@ -1900,7 +1928,7 @@ namespace sara_hip {
     // a ring of kOriAhead chunks (64 pixels each) of unconditional gathers runs
     // ahead of the histogram work.  (u, v) of this lane's pixel advances by 64
     // pixels per chunk, once on the issue side and once on the consumer side.
-    constexpr int kOriAhead = 4;
+    constexpr int kOriAhead = SARA_ORI_AHEAD;
     auto advance = [&](int& u_, int& v_) {
       u_ += du64;
       v_ += dv64;
@@ -1930,10 +1958,15 @@ namespace sara_hip {
 #pragma unroll
     for (int q = 0; q < kOriAhead; ++q)
     {
-      // chunks beyond the patch are idle (ok is false in every lane): no break
-      // here, the compiler counts the gathers in flight only along straight
-      // control flow
+      // Chunks beyond the patch are idle (ok is false in every lane): their
+      // histogram work is skipped under a wave-uniform branch, but the slot is
+      // still refilled below - the compiler counts the gathers in flight only
+      // along straight control flow, so the refill stays unconditional and
+      // there is no break.
+      SARA_OPROF_T(t_c0);
       const int base = base0 + 64 * q;
+      if (base < npx)
+      {
       int bin = -1;
       double c = 0.;
       const float2 mo = ring[q];
@@ -1954,8 +1987,6 @@ namespace sara_hip {
         const int wi = woff + uc * uc + vc * vc;
         c = (WLDS ? s_weights[wi] : weights[wi]) * double(mo.x);
       }
-      // refill the slot (its pair is consumed): chunk base + 64 * kOriAhead
-      issue(base + 64 * kOriAhead, ring[q], ring_ok[q]);
       // Which lanes of this chunk fall into which bin: one 64-bit mask per
       // bin, built with integer LDS atomics.  The contributions are then
       // sorted by (bin, lane): a sample's slot is the number of samples in
@@ -1964,6 +1995,8 @@ namespace sara_hip {
       // and the owner lane of a bin adds its contiguous segment in ascending
       // lane (= raster) order - the rounding sequence of the CPU loop - with a
       // plain counted loop instead of a bit scan per addition.
+      SARA_OPROF_T(t_c1);
+      SARA_OPROF_ADD(1, t_c0, t_c1);
       if (lane < kOriBins)
         bin_mask[lane] = 0ull;
       __builtin_amdgcn_wave_barrier();
@@ -1985,6 +2018,8 @@ namespace sara_hip {
         contrib[seg_off[bin] + r] = c;
       }
       __builtin_amdgcn_wave_barrier();
+      SARA_OPROF_T(t_c2);
+      SARA_OPROF_ADD(2, t_c1, t_c2);
       {
         int i = seg_begin;
         const int end = lane < kOriBins ? incl : seg_begin;
@@ -2000,8 +2035,14 @@ namespace sara_hip {
         }
       }
       __builtin_amdgcn_wave_barrier();
+      SARA_OPROF_T(t_c3);
+      SARA_OPROF_ADD(3, t_c2, t_c3);
+      }
+      // refill the slot (its pair is consumed): chunk base + 64 * kOriAhead
+      issue(base + 64 * kOriAhead, ring[q], ring_ok[q]);
     }
     }
+    SARA_OPROF_T(t_loop);
 
     // lowe_smooth_histogram: 6 circular box-blur iterations.
     // circular neighbours of the 36 bin lanes: DPP wave shifts, the two wrap
@@ -2055,6 +2096,9 @@ namespace sara_hip {
       rec.npeaks = __popcll(mask);
       rec.reserved = 0;
     }
+    SARA_OPROF_T(t_end);
+    SARA_OPROF_ADD(4, t_loop, t_end);
+    SARA_OPROF_ADD(7, t_item, t_end);
     };
     for (int bx = blockIdx.x; bx < positions; bx += gridDim.x)
     {
@@ -2257,18 +2301,6 @@ namespace sara_hip {
   constexpr int kDescWaves = SARA_DESC_WAVES;
   //! constants of sincos_reduced_f64 (device_math.hpp), read with scalar loads
   __constant__ double g_sincos_coef[kSincosCoefCount] = SARA_SINCOS_COEF_INIT;
-#ifdef SARA_DESC_PROF
-  // Per-phase wave cycles (s_memtime), summed over all waves: a development
-  // aid, read back through sara_hip_debug_desc_prof().
-  __device__ unsigned long long g_desc_prof[8];
-#define SARA_PROF_T(var) const long long var = clock64()
-#define SARA_PROF_ADD(slot, a, b)                                              \
-  if (lane == 0)                                                               \
-  atomicAdd(&g_desc_prof[slot], (unsigned long long) ((b) - (a)))
-#else
-#define SARA_PROF_T(var)
-#define SARA_PROF_ADD(slot, a, b)
-#endif
 
   __global__ __launch_bounds__(64 * kDescWaves, SARA_DESC_WAVES_PER_EU) void descriptor_kernel(
       GradPyramidView grad, CandidateLists cand, OrientationLists ori,
@@ -2840,7 +2872,7 @@ namespace sara_hip {
       h[i] = copysignf(sqrtf(fabsf(h[i]) / l1), h[i]);
   }
 
-#ifdef SARA_DESC_PROF
+#if defined(SARA_DESC_PROF) || defined(SARA_ORI_PROF)
   extern "C" __attribute__((visibility("default"))) int sara_hip_debug_desc_prof(
       unsigned long long* out, int reset)
   {
