@@ -1887,15 +1887,26 @@ namespace sara_hip {
     const int nblk = (n + kOriWaves - 1) / kOriWaves;
     const int unit = 8 * xcd_run;
     const int positions = unit * ((nblk + unit - 1) / unit);
-    auto item = [&](int lb) {
+    // (key, data) of a work item: loaded one item ahead (a wave walks several
+    // items, and the pair sits at the head of the item's dependent chain:
+    // key / data -> gather addresses -> first gather)
+    const size_t row = size_t(b) * cand.cap;
+    auto fetch = [&](int lb, unsigned long long& key_, float4& d_) {
+      const int idx = lb * kOriWaves + wave;
+      key_ = 0ull;
+      d_ = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lb >= 0 && idx < n)
+      {
+        key_ = cand.skey[row + idx];
+        d_ = cand.sdata[row + idx];
+      }
+    };
+    auto item = [&](int lb, unsigned long long key, float4 d) {
     const int idx = lb * kOriWaves + wave;
     if (idx >= n)
       return;
 
     SARA_OPROF_T(t_item);
-    const size_t row = size_t(b) * cand.cap;
-    const unsigned long long key = cand.skey[row + idx];
-    const float4 d = cand.sdata[row + idx];
     const int o = key_octave(key);
     const int s = key_scale(key);
 
@@ -2100,11 +2111,25 @@ namespace sara_hip {
     SARA_OPROF_ADD(4, t_loop, t_end);
     SARA_OPROF_ADD(7, t_item, t_end);
     };
-    for (int bx = blockIdx.x; bx < positions; bx += gridDim.x)
+    int bx = blockIdx.x;
+    int lb = bx < positions ? xcd_local_block(bx, b, nblk, xcd_run) : -1;
+    unsigned long long key = 0ull;
+    float4 d;
+    fetch(lb, key, d);
+    while (bx < positions)
     {
-      const int lb = xcd_local_block(bx, b, nblk, xcd_run);
+      const int bx_next = bx + gridDim.x;
+      const int lb_next =
+          bx_next < positions ? xcd_local_block(bx_next, b, nblk, xcd_run) : -1;
+      unsigned long long key_next;
+      float4 d_next;
+      fetch(lb_next, key_next, d_next);
       if (lb >= 0)
-        item(lb);
+        item(lb, key, d);
+      bx = bx_next;
+      lb = lb_next;
+      key = key_next;
+      d = d_next;
     }
   }
 
@@ -2116,19 +2141,27 @@ namespace sara_hip {
   {
     // xcd_local_block() spreads ceil(n/4) work items over 8 chunks, so the
     // grid has to be a multiple of 8 blocks
-    const int unit = 8 * g_xcd_run;
+    static const int ori_run = [] {
+      const char* e = getenv("SARA_HIP_ORI_XCD_RUN");
+      return e ? std::max(1, atoi(e)) : g_xcd_run;
+    }();
+    const int unit = 8 * ori_run;
     const int needed =
         unit * (((cand.cap + kOriWaves - 1) / kOriWaves + unit - 1) / unit);
-    const dim3 grid(std::min(needed, unit * persist_units(batch, kOriWaves)), batch);
+    const int units = g_persist_units_env > 0
+                          ? g_persist_units_env
+                          : std::max(1, (8192 + unit * kOriWaves * std::max(batch, 1) - 1) /
+                                            (unit * kOriWaves * std::max(batch, 1)));
+    const dim3 grid(std::min(needed, unit * units), batch);
     // weight tables in LDS when they leave room for 8 blocks per CU
     const size_t wbytes = sizeof(double) * size_t(n_weights);
     if (n_weights > 0 && wbytes <= 14 * 1024)
       hipLaunchKernelGGL(orientation_kernel<true>, grid, dim3(64 * kOriWaves), wbytes,
                          stream, grad, tab, ori_weights, n_weights, cand, ori,
-                         g_xcd_run);
+                         ori_run);
     else
       hipLaunchKernelGGL(orientation_kernel<false>, grid, dim3(64 * kOriWaves), 0, stream,
-                         grad, tab, ori_weights, n_weights, cand, ori, g_xcd_run);
+                         grad, tab, ori_weights, n_weights, cand, ori, ori_run);
   }
 
   // ------------------------------------------------------------------------ //
