@@ -2544,7 +2544,9 @@ namespace sara_hip {
         if (fminf(px, py) <= -1.f || fmaxf(px, py) >= 4.f)
           return;
         // weight * mag * 2^(25 - e), once per sample
-        const float wm = __expf(-nrm2 / (2.f * 4.f)) * (mo.x * fx_scale);
+        // exp(-nrm2 / 8) as one scaling into the hardware exp2
+        const float wm = __builtin_amdgcn_exp2f(nrm2 * float(-0.125 * 1.4426950408889634)) *
+                         (mo.x * fx_scale);
         float a = mo.y - theta;
         a = a < 0.f ? a + 2.f * pi : a;
         a *= 8.f / (2.f * pi);
@@ -2562,7 +2564,7 @@ namespace sara_hip {
                     p11 = wy1 * wx1;
         const unsigned dxo = x_ok ? unsigned(kDescCellStride) : 0u;
         const unsigned dyo = y_ok ? unsigned(kDescGrid * kDescCellStride) : 0u;
-        const unsigned cell = unsigned(yi * kDescGrid + xi);
+        const unsigned cell = __umul24(unsigned(yi), unsigned(kDescGrid)) + unsigned(xi);
         const unsigned h0 =
             __umul24(cell, unsigned(kDescCellStride)) + unsigned(copy);
         const unsigned ia = h0 + unsigned((oi & 7) * kDescCopies);
