@@ -1068,7 +1068,10 @@ namespace sara_hip {
 #define SARA_EXTREMA_WAVES_PER_EU 4
 #endif
   template <int ND, int PF, bool GRAD>
-  __global__ __launch_bounds__(64, GRAD ? 2 : SARA_EXTREMA_WAVES_PER_EU) void extrema_march_kernel(
+#ifndef SARA_FUSED_WAVES_PER_EU
+#define SARA_FUSED_WAVES_PER_EU 2
+#endif
+  __global__ __launch_bounds__(64, GRAD ? SARA_FUSED_WAVES_PER_EU : SARA_EXTREMA_WAVES_PER_EU) void extrema_march_kernel(
       OctaveView gauss, int octave, ExtremaParams p, SiteLists sites,
       int seg_rows, int nstrips, int nseg, int xcd_total,
       float* __restrict__ grad, size_t grad_frame_stride,
@@ -1227,7 +1230,10 @@ namespace sara_hip {
             run_max[t] = fmaxf(run_max[t], fmaxf(gvalid0 ? r0 : 0.f,
                                                  gvalid1 ? r1 : 0.f));
           }
-          if ((y & 15) == 15 || y == y1 - 1)
+#ifndef SARA_FUSED_NO_CMAX
+#define SARA_FUSED_NO_CMAX 0
+#endif
+          if (!SARA_FUSED_NO_CMAX && ((y & 15) == 15 || y == y1 - 1))
           {
             // one atomicMax per 16-column cell touched by this wave
             const int cell = col >> 4;

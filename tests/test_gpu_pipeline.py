@@ -93,6 +93,38 @@ def test_full_parity_synthetic(oracle, w, h, noct):
     assert ne > 0 and nk >= ne * 0.8
 
 
+@pytest.mark.parametrize("kind", ["binary", "blocks", "ramp_noise", "huge_range"])
+def test_descriptor_accumulator_on_extreme_magnitudes(oracle, kind):
+    """The descriptor kernel accumulates in 32-bit fixed point with a scale
+    chosen from a worst-case bound of a bin's sum (|gradient| <= the patch's
+    coarse maximum everywhere).  Images made to approach that worst case -
+    full-contrast binary noise, 8 x 8 blocks (every patch sits on strong
+    edges of one direction), a steep ramp with dots (one orientation bin takes
+    nearly everything) and magnitudes 1000 times the usual range - still
+    match the oracle at the usual bars: no bin wraps around."""
+    rng = np.random.default_rng(11)
+    w, h = 384, 288
+    if kind == "binary":
+        img = (rng.random((h, w)) > 0.5).astype(np.float32)
+    elif kind == "blocks":
+        b = (rng.random((h // 8 + 1, w // 8 + 1)) > 0.5).astype(np.float32)
+        img = np.kron(b, np.ones((8, 8), np.float32))[:h, :w].copy()
+    elif kind == "ramp_noise":
+        dots = np.kron((rng.random((h // 3 + 1, w // 3 + 1)) > 0.96).astype(np.float32),
+                       np.ones((3, 3), np.float32))[:h, :w]
+        img = (4 * np.linspace(0, 1, w, dtype=np.float32)[None, :] * np.ones((h, 1), np.float32)
+               + dots).astype(np.float32)
+    else:
+        img = synth(w, h, 77) * np.float32(1000.0)
+    thr = 10.0 if kind == "huge_range" else 0.01
+    ref = oracle.RefSift(img, ref_params(oracle, 0, 4), extremum_thres=thr)
+    with sara_amd.SiftContext(w, h, 1, hip_params(0, 4), extremum_thres=thr,
+                              max_keypoints=65536) as ctx:
+        ctx.detect(img)
+        ne, nk = compare_lists(run_lists(ctx), ref, 0)
+    assert nk > 50, (kind, nk)
+
+
 def test_sift_example_camera_scale_1(oracle):
     """sift_example.cpp:51-58 uses scale_camera = 1.0 (11-tap initial blur)."""
     img = synth(400, 300, 99)
