@@ -110,7 +110,7 @@ namespace sara_hip {
 #define SARA_GRAD_ROLLED 0
 #endif
 #ifndef SARA_GRAD_PF
-#define SARA_GRAD_PF 4
+#define SARA_GRAD_PF 2
 #endif
 #ifndef SARA_GRAD_EDGE_UNCOND
 #define SARA_GRAD_EDGE_UNCOND 0
