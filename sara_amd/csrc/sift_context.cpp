@@ -1065,7 +1065,8 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     grad_fused[o] = false;
     if (want_grad)
       HIP_TRY(hipMemsetAsync(c->CM[o], 0, cpl * S * batch * sizeof(unsigned), ss));
-    if (dv.w > 2 * c->img_padding && dv.h > 2 * c->img_padding)
+    // the Halide-branch classifier looks at every pixel, whatever the padding
+    if (c->signed_type || (dv.w > 2 * c->img_padding && dv.h > 2 * c->img_padding))
       grad_fused[o] = launch_extrema_scan(
           dv, o, batch, ep, c->d_tab, c->cand, c->sites, ss,
           want_grad ? c->GR[o] : nullptr, dv.plane * 2 * S,

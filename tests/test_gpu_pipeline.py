@@ -547,6 +547,27 @@ def test_corrected_mode_switches(oracle, bits, w, h, seed):
         assert not np.array_equal(ref.gaussian(0, 1), ref_default.gaussian(0, 1))
 
 
+def test_signed_mode_scans_octaves_smaller_than_the_padding(oracle):
+    """The Halide-branch classifier looks at every pixel of a plane, whatever
+    img_padding_sz (RefineExtremum.cpp:246-262, whole-image map).  With
+    compute_sift_keypoints' shifted arguments the padding is 5 (quirk Q1), and
+    an octave of 27 x 9 pixels - smaller than twice that - still yields its
+    border extrema (found by tools/fuzz_more.py: the scan of such an octave
+    used to be skipped as it is, rightly, in the default mode)."""
+    w, h = 216, 73
+    img = synth(w, h, 9000 + 7 * 76 + 4242)
+    img = (np.clip(img * 255.0, 0, 255).astype(np.uint8).astype(np.float32)
+           / np.float32(255))
+    kw = dict(extremum_thres=0.005, edge_ratio_thres=20.0)
+    with oracle.detector_mode(1):
+        ref = oracle.RefSift(img, ref_params(oracle, 0, 5, cam=0.8), **kw)
+    assert any(t[3] == 3 for t in ref.extrema()[1].tolist())  # the 27 x 9 octave
+    with sara_amd.SiftContext(w, h, 1, hip_params(0, 5, cam=0.8), **kw) as ctx:
+        ctx.set_option(sara_amd.capi.OPT_SIGNED_EXTREMUM_TYPE, 1)
+        ctx.detect(img)
+        compare_lists(run_lists(ctx), ref, 0)
+
+
 def test_downscale_option_rejected_when_out_of_range():
     # 4 scales, k = 1.2: log 2 / log k = 3.8 - floor() = 3 is a valid index,
     # round() = 4 is not

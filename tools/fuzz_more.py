@@ -75,5 +75,9 @@ for case in T._fuzz_cases(n, seed):
                                                  ctx.keypoint_lists()[1].descriptor_matrix, ratio))
     except Exception as e:  # noqa
         bad += 1
-        print("FAIL", case, repr(e)[:300], flush=True)
+        import traceback
+        tb = traceback.extract_tb(e.__traceback__)
+        where = "; ".join("%s:%d %s" % (os.path.basename(f.filename), f.lineno, f.name) for f in tb[-3:])
+        print("FAIL", case, "batch", batch, "u8", use_u8, "mode", mode, "root", root,
+              repr(e)[:300], "|", where, flush=True)
 print("cases", n, "failures", bad)
