@@ -671,7 +671,10 @@ def test_fma_blur_option_within_tolerance(oracle):
                 g, r = ctx.gaussian(s, o), ref.gaussian(s, o)
                 worst = max(worst, float(np.abs(g - r).max()))
                 n_diff += int(np.count_nonzero(g != r))
-        assert n_diff > 0                     # it is a different arithmetic ...
+        marching = (os.environ.get("SARA_HIP_BLUR") != "tile" and
+                    int(os.environ.get("SARA_HIP_MARCH_MIN_PIXELS", "0")) <= w * h)
+        if marching:  # the tiled fall-back kernels have no fused form
+            assert n_diff > 0                 # it is a different arithmetic ...
         # ... within 3e-7 of the [0, 1] range (measured 2.4e-7 = 4 ulp at 0.5;
         # SURVEY.md 8c's guideline for a non-exact build is 2e-7)
         assert worst <= 3e-7
