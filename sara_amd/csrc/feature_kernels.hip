@@ -2330,6 +2330,11 @@ namespace sara_hip {
   constexpr int kDescHistWords = kDescGrid * kDescGrid * kDescCellStride;
   using desc_acc_t = std::conditional_t<kDescFx32, int, unsigned long long>;
   constexpr int kDescRowsPerBlock = 64;   // one row per lane
+#ifndef SARA_DESC_CHUNK
+#define SARA_DESC_CHUNK 8
+#endif
+  constexpr int kDescChunk = SARA_DESC_CHUNK;        // pixels per chunk (16 or 8)
+  constexpr int kDescGroups = 64 / kDescChunk;       // chunks per step of a wave
   constexpr int kDescChunksPerPhase = 8;  // chunks of one row per table fill
   constexpr int kDescTableCap = kDescRowsPerBlock * kDescChunksPerPhase;
 #ifndef SARA_DESC_AHEAD
@@ -2351,7 +2356,7 @@ namespace sara_hip {
     __shared__ unsigned s_tab[kDescWaves][kDescTableCap];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int grp = lane >> 4, l16 = lane & 15;
+    const int grp = lane / kDescChunk, l16 = lane % kDescChunk;  // l16: pixel of the chunk
     const int b = blockIdx.y;
     // work items = keypoints (one dominant orientation each), in output order
     const int n = min(ori.kp_count[b], cand.cap);
@@ -2631,7 +2636,7 @@ namespace sara_hip {
           const int u_last = min(int(ceilf(hi)), u_max);
           len = max(u_last - u_first + 1, 0);
         }
-        const int nch_row = (len + 15) >> 4;
+        const int nch_row = (len + kDescChunk - 1) / kDescChunk;
         const int max_ch = wave_max_dpp(nch_row);
 
         for (int ph = 0; ph * kDescChunksPerPhase < max_ch; ++ph)
@@ -2644,8 +2649,8 @@ namespace sara_hip {
           __builtin_amdgcn_wave_barrier();  // the previous list is consumed
           for (int c = 0; c < nch; ++c)
           {
-            const int u0rel = u_first - u_min + 16 * (c_lo + c);
-            const int last = min(15, len - 1 - 16 * (c_lo + c));
+            const int u0rel = u_first - u_min + kDescChunk * (c_lo + c);
+            const int last = min(kDescChunk - 1, len - 1 - kDescChunk * (c_lo + c));
             tab[incl - nch + c] =
                 unsigned(lane) | (unsigned(last) << 6) | (unsigned(u0rel) << 10);
           }
@@ -2653,17 +2658,17 @@ namespace sara_hip {
           SARA_PROF_T(t_tab);
           SARA_PROF_ADD(2, t_blk, t_tab);
 
-          // ---- stream the chunks: group g takes chunk 4 * step + g ----------
+          // ---- stream the chunks: group g takes chunk kDescGroups * step + g --
           // kDescAhead stages in flight per lane.  A stage holds the chunk
           // entry it is working on, the gathered pair, and the entry fetched
           // for its next use; the loop is unrolled over the stages so that
           // nothing is copied (a copy would wait for the gather).
           auto fetch = [&](int step) -> unsigned {
-            const int j = 4 * step + grp;
+            const int j = kDescGroups * step + grp;
             return j < C ? tab[j] : 0x3c0u;  // idle: last = 15 never matches
           };
           auto gather = [&](int step, unsigned e) -> float2 {
-            const int j = 4 * step + grp;
+            const int j = kDescGroups * step + grp;
             const int last = int((e >> 6) & 15u);
             const int vv = vb + int(e & 63u);
             const int uu = u_min + int(e >> 10) + l16;
@@ -2674,7 +2679,7 @@ namespace sara_hip {
             return load_pair(g, act ? size_t(ry + vv) * w + size_t(rx + uu)
                                     : center);
           };
-          const int nsteps = (C + 3) >> 2;
+          const int nsteps = (C + kDescGroups - 1) / kDescGroups;
           unsigned ent[kDescAhead], ent_next[kDescAhead];
           float2 data[kDescAhead];
 #pragma unroll
@@ -2699,7 +2704,7 @@ namespace sara_hip {
               const int step = step0 + q;  // steps >= nsteps find idle entries
               const unsigned e = ent[q];
               const int last = int((e >> 6) & 15u);
-              if (4 * step + grp < C && l16 <= last)
+              if (kDescGroups * step + grp < C && l16 <= last)
                 accumulate(u_min + int(e >> 10) + l16, vb + int(e & 63u), data[q]);
               ent[q] = ent_next[q];
               data[q] = gather(step + kDescAhead, ent[q]);
