@@ -2537,7 +2537,12 @@ namespace sara_hip {
       const float T00 = ct / l, T01 = st / l, T10 = (-st) / l, T11 = ct / l;
 
       // Row intervals are conservative (the exact float test in the sample
-      // step decides), hence the approximate reciprocals.
+      // step decides), hence the approximate reciprocals: the window's edges
+      // in a row, u = (-+2.5 - T01 v) / T00, are evaluated with a few float
+      // roundings (errors ~1e-5 pixel for coordinates below 100) and widened
+      // by kDescMargin.  (Round 2a widened by a whole pixel and then rounded
+      // outwards: 3-4 idle samples per row of ~30.)
+      constexpr float kDescMargin = 0.02f;
       const bool t00_ok = fabsf(T00) > 1e-12f, t10_ok = fabsf(T10) > 1e-12f;
       const float inv00 = t00_ok ? 1.f / T00 : 0.f;
       const float inv10 = t10_ok ? 1.f / T10 : 0.f;
@@ -2619,21 +2624,22 @@ namespace sara_hip {
           if (t00_ok)
           {
             const float a = (-2.5f - bx_) * inv00, c = (2.5f - bx_) * inv00;
-            lo = fmaxf(lo, fminf(a, c) - 1.f);
-            hi = fminf(hi, fmaxf(a, c) + 1.f);
+            lo = fmaxf(lo, fminf(a, c) - kDescMargin);
+            hi = fminf(hi, fmaxf(a, c) + kDescMargin);
           }
           else if (fabsf(bx_) > 2.6f)
             hi = lo - 1.f;
           if (t10_ok)
           {
             const float a = (-2.5f - by_) * inv10, c = (2.5f - by_) * inv10;
-            lo = fmaxf(lo, fminf(a, c) - 1.f);
-            hi = fminf(hi, fmaxf(a, c) + 1.f);
+            lo = fmaxf(lo, fminf(a, c) - kDescMargin);
+            hi = fminf(hi, fmaxf(a, c) + kDescMargin);
           }
           else if (fabsf(by_) > 2.6f)
             hi = lo - 1.f;
-          u_first = max(int(floorf(lo)), u_min);
-          const int u_last = min(int(ceilf(hi)), u_max);
+          // integers of [lo, hi]: the interval already carries the margin
+          u_first = max(int(ceilf(lo)), u_min);
+          const int u_last = min(int(floorf(hi)), u_max);
           len = max(u_last - u_first + 1, 0);
         }
         const int nch_row = (len + kDescChunk - 1) / kDescChunk;
