@@ -1859,6 +1859,11 @@ namespace sara_hip {
 #ifndef SARA_ORI_AHEAD
 #define SARA_ORI_AHEAD 2
 #endif
+#ifndef SARA_ORI_GROUP
+#define SARA_ORI_GROUP 2
+#endif
+  constexpr int kOriGroup = SARA_ORI_GROUP;  // chunks sorted and replayed together
+  static_assert(SARA_ORI_GROUP % SARA_ORI_AHEAD == 0, "ring slots are static");
 #ifndef SARA_ORI_BLOCKS_PER_EU
 #define SARA_ORI_BLOCKS_PER_EU 1
 #endif
@@ -1868,9 +1873,9 @@ namespace sara_hip {
       const ScaleTable* __restrict__ tabp, const double* __restrict__ weights,
       int n_weights, CandidateLists cand, OrientationLists ori, int xcd_run)
   {
-    __shared__ unsigned long long s_mask[kOriWaves][kOriBins];
-    __shared__ double s_contrib[kOriWaves][64];
-    __shared__ int s_segoff[kOriWaves][kOriBins];
+    __shared__ unsigned long long s_mask[kOriWaves][kOriGroup * kOriBins];
+    __shared__ double s_contrib[kOriWaves][64 * kOriGroup];
+    __shared__ int s_segoff[kOriWaves][kOriGroup * kOriBins];
     extern __shared__ __attribute__((aligned(16))) double s_weights[];
     const GradPyramidView& grad = *gradp;
     const ScaleTable& tab = *tabp;
@@ -1970,70 +1975,101 @@ namespace sara_hip {
     __builtin_amdgcn_s_waitcnt(0x0f70 | (kOriAhead - 1));  // see descriptor_kernel
     int u = lane % D - R, v = lane / D - R;  // consumer side
 
-    for (int base0 = 0; base0 < npx; base0 += 64 * kOriAhead)
+    // Chunks are processed in groups of kOriGroup: the samples of a group are
+    // sorted by (bin, chunk, lane) and each bin's segment is replayed once per
+    // group.  The replay is a lock-step loop of as many steps as the fullest
+    // bin has samples; per 64-pixel chunk that is 104 steps for an average
+    // extremum of the benchmark frames, per group of four 75 (whole patch: 53)
+    // - and the scan over the bins runs once per group.
+    for (int base0 = 0; base0 < npx; base0 += 64 * kOriGroup)
     {
-#pragma unroll
-    for (int q = 0; q < kOriAhead; ++q)
-    {
-      // Chunks beyond the patch are idle (ok is false in every lane): their
-      // histogram work is skipped under a wave-uniform branch, but the slot is
-      // still refilled below - the compiler counts the gathers in flight only
-      // along straight control flow, so the refill stays unconditional and
-      // there is no break.
       SARA_OPROF_T(t_c0);
-      const int base = base0 + 64 * q;
-      if (base < npx)
+      int binq[kOriGroup];
+      double cq[kOriGroup];
+      if (lane < kOriBins)
       {
-      int bin = -1;
-      double c = 0.;
-      const float2 mo = ring[q];
-      const bool ok = ring_ok[q];
-      const int uc = u, vc = v;
-      advance(u, v);
-      if (ok)
-      {
-        float a = mo.y;
-        a = a < 0 ? a + float(2. * M_PI) : a;
-        // int(floor(double(a / float(2 pi) * 36))) % 36 without the division:
-        // estimate, then one step of correction against the exact thresholds
-        int kb = int(a * float(kOriBins / (2. * M_PI)));
-        kb = min(max(kb, 0), kOriBins);
-        const float t0 = s_thr[kb], t1 = s_thr[kb + 1];
-        kb += int(a >= t1) - int(a < t0);
-        bin = kb == kOriBins ? 0 : kb;
-        const int wi = woff + uc * uc + vc * vc;
-        c = (WLDS ? s_weights[wi] : weights[wi]) * double(mo.x);
+#pragma unroll
+        for (int q = 0; q < kOriGroup; ++q)
+          bin_mask[q * kOriBins + lane] = 0ull;
       }
-      // Which lanes of this chunk fall into which bin: one 64-bit mask per
-      // bin, built with integer LDS atomics.  The contributions are then
-      // sorted by (bin, lane): a sample's slot is the number of samples in
-      // smaller bins (exclusive scan of the masks' population counts over the
-      // 36 owner lanes) plus its rank inside its bin (mbcnt of the bin's mask),
-      // and the owner lane of a bin adds its contiguous segment in ascending
-      // lane (= raster) order - the rounding sequence of the CPU loop - with a
-      // plain counted loop instead of a bit scan per addition.
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < kOriGroup; ++q)
+      {
+        // Chunks beyond the patch are idle (ok is false in every lane): their
+        // histogram work is skipped under a wave-uniform branch, but the slot
+        // is still refilled - the compiler counts the gathers in flight only
+        // along straight control flow, so the refill stays unconditional and
+        // there is no break.
+        const int base = base0 + 64 * q;
+        binq[q] = -1;
+        cq[q] = 0.;
+        if (base < npx)
+        {
+          const float2 mo = ring[q % kOriAhead];
+          const bool ok = ring_ok[q % kOriAhead];
+          const int uc = u, vc = v;
+          advance(u, v);
+          if (ok)
+          {
+            float a = mo.y;
+            a = a < 0 ? a + float(2. * M_PI) : a;
+            // int(floor(double(a / float(2 pi) * 36))) % 36 without the
+            // division: estimate, then one step of correction against the
+            // exact thresholds
+            int kb = int(a * float(kOriBins / (2. * M_PI)));
+            kb = min(max(kb, 0), kOriBins);
+            const float t0 = s_thr[kb], t1 = s_thr[kb + 1];
+            kb += int(a >= t1) - int(a < t0);
+            binq[q] = kb == kOriBins ? 0 : kb;
+            const int wi = woff + uc * uc + vc * vc;
+            cq[q] = (WLDS ? s_weights[wi] : weights[wi]) * double(mo.x);
+            // which lanes of this chunk fall into which bin: one 64-bit mask
+            // per (chunk, bin), built with integer LDS atomics
+            atomicOr(&bin_mask[q * kOriBins + binq[q]], 1ull << lane);
+          }
+        }
+        // refill the slot (its pair is consumed): chunk base + 64 * kOriAhead
+        issue(base + 64 * kOriAhead, ring[q % kOriAhead], ring_ok[q % kOriAhead]);
+      }
+      __builtin_amdgcn_wave_barrier();
       SARA_OPROF_T(t_c1);
       SARA_OPROF_ADD(1, t_c0, t_c1);
-      if (lane < kOriBins)
-        bin_mask[lane] = 0ull;
-      __builtin_amdgcn_wave_barrier();
-      if (bin >= 0)
-        atomicOr(&bin_mask[bin], 1ull << lane);
-      __builtin_amdgcn_wave_barrier();
-      const unsigned long long own = lane < kOriBins ? bin_mask[lane] : 0ull;
-      const int cnt = __popcll(own);
+      // The contributions are sorted by (bin, chunk, lane): a sample's slot is
+      // the number of samples in smaller bins (exclusive scan of the masks'
+      // population counts over the 36 owner lanes), plus those of its bin in
+      // earlier chunks of the group, plus its rank inside its chunk's mask
+      // (mbcnt); the owner lane of a bin then adds its contiguous segment in
+      // that order - chunk by chunk, ascending lane = raster order, the
+      // rounding sequence of the CPU loop - with a plain counted loop.
+      int cnt = 0;
+      int before[kOriGroup];
+#pragma unroll
+      for (int q = 0; q < kOriGroup; ++q)
+      {
+        const unsigned long long own =
+            lane < kOriBins ? bin_mask[q * kOriBins + lane] : 0ull;
+        before[q] = cnt;
+        cnt += __popcll(own);
+      }
       const int incl = wave_inclusive_scan(cnt);
       const int seg_begin = incl - cnt;
       if (lane < kOriBins)
-        seg_off[lane] = seg_begin;
-      __builtin_amdgcn_wave_barrier();
-      if (bin >= 0)
       {
-        const unsigned long long m = bin_mask[bin];
-        const int r = __builtin_amdgcn_mbcnt_hi(
-            unsigned(m >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m), 0u));
-        contrib[seg_off[bin] + r] = c;
+#pragma unroll
+        for (int q = 0; q < kOriGroup; ++q)
+          seg_off[q * kOriBins + lane] = seg_begin + before[q];
       }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < kOriGroup; ++q)
+        if (binq[q] >= 0)
+        {
+          const unsigned long long m = bin_mask[q * kOriBins + binq[q]];
+          const int r = __builtin_amdgcn_mbcnt_hi(
+              unsigned(m >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m), 0u));
+          contrib[seg_off[q * kOriBins + binq[q]] + r] = cq[q];
+        }
       __builtin_amdgcn_wave_barrier();
       SARA_OPROF_T(t_c2);
       SARA_OPROF_ADD(2, t_c1, t_c2);
@@ -2054,10 +2090,6 @@ namespace sara_hip {
       __builtin_amdgcn_wave_barrier();
       SARA_OPROF_T(t_c3);
       SARA_OPROF_ADD(3, t_c2, t_c3);
-      }
-      // refill the slot (its pair is consumed): chunk base + 64 * kOriAhead
-      issue(base + 64 * kOriAhead, ring[q], ring_ok[q]);
-    }
     }
     SARA_OPROF_T(t_loop);
 
