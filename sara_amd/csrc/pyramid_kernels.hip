@@ -743,7 +743,13 @@ namespace sara_hip {
     constexpr int W = 128;
     constexpr int PF = 4;
     const int nstrips = (w + W - 1) / W;
-    int nseg = (g_march2_waves + nstrips * batch - 1) / (nstrips * batch);
+    // per-radius override for sweeps: SARA_HIP_MARCH2_WAVES_8 / _10 / _12
+    static const int waves_r = [] {
+      const std::string name = "SARA_HIP_MARCH2_WAVES_" + std::to_string(R);
+      const char* e = getenv(name.c_str());
+      return e ? std::max(64, atoi(e)) : g_march2_waves;
+    }();
+    int nseg = (waves_r + nstrips * batch - 1) / (nstrips * batch);
     const int min_rows = std::max(32, g_march_minrows * R);
     nseg = std::max(1, std::min(nseg, (h + min_rows - 1) / min_rows));
     const int seg_rows = (h + nseg - 1) / nseg;
