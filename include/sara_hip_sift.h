@@ -552,6 +552,14 @@ SARA_HIP_API void sara_hip_selfcheck_sincos(const float* theta, float* out_sin,
 SARA_HIP_API sara_hip_status sara_hip_selfcheck_device_math(
     unsigned long long* mismatches, int device);
 
+/* Device self-check: the orientation kernel computes a sample's histogram bin,  */
+/* int(floor(double(ori / float(2 pi) * 36))) % 36 (Orientation.hpp:118-119), by */
+/* one multiplication and at most one correction against thresholds bisected on */
+/* the host from that expression.  This runs every float of [0, float(2 pi)]    */
+/* through both forms on the GPU; *mismatches must be 0.  Not a compute path.    */
+SARA_HIP_API sara_hip_status sara_hip_selfcheck_orientation_bins(
+    unsigned long long* mismatches, int device);
+
 /* Device self-check: the definiteness test of refine_extremum                  */
 /* (RefineExtremum.cpp:74-77: (SelfAdjointEigenSolver<Matrix3f>(H).eigenvalues()*/
 /* * float(type)).maxCoeff() >= 0) as the extrema kernels evaluate it - Eigen   */

@@ -88,7 +88,7 @@ EXPORTS = [
     "sara_hip_from_gray8_to_gray32f", "sara_hip_match_descriptors",
     "sara_hip_sift_stage", "sara_hip_sift_detect_staged", "sara_hip_root_sift",
     "sara_hip_selfcheck_device_math", "sara_hip_selfcheck_sincos",
-    "sara_hip_selfcheck_definiteness",
+    "sara_hip_selfcheck_definiteness", "sara_hip_selfcheck_orientation_bins",
     "sara_hip_sift_submit", "sara_hip_sift_collect",
     "sara_hip_shard_range", "sara_hip_copy_to_host", "sara_hip_comm_unique_id", "sara_hip_comm_create",
     "sara_hip_comm_gather", "sara_hip_comm_destroy",
@@ -211,6 +211,7 @@ def _declare(lib):
     lib.sara_hip_sift_group_destroy.argtypes = [_vp]
     lib.sara_hip_selfcheck_sincos.argtypes = [_f32p, _f32p, _f32p, C.c_size_t]
     lib.sara_hip_selfcheck_sincos.restype = None
+    lib.sara_hip_selfcheck_orientation_bins.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     lib.sara_hip_selfcheck_definiteness.argtypes = [
         _f32p, C.POINTER(C.c_int), C.c_size_t, C.POINTER(C.c_ubyte), C.c_int]
     return lib

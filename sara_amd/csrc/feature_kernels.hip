@@ -2905,6 +2905,42 @@ namespace sara_hip {
       atomicAdd(out + 1, (unsigned long long) bad_sqrt);
   }
 
+  //! Every float of [0, float(2 pi)] through the orientation kernel's bin
+  //! computation (estimate + one correction against thr[]) and through the
+  //! reference expression; *bad counts the mismatches.
+  __global__ __launch_bounds__(256) void orientation_bin_selfcheck_kernel(
+      const float* __restrict__ thr, unsigned long long* __restrict__ bad)
+  {
+    __shared__ float s_thr[40];
+    if (threadIdx.x < 40)
+      s_thr[threadIdx.x] = thr[threadIdx.x];
+    __syncthreads();
+    constexpr uint32_t kEnd = 0x40c90fdbu + 1u;  // float(2 pi) inclusive
+    unsigned n_bad = 0;
+    for (uint32_t bits = blockIdx.x * 256u + threadIdx.x; bits < kEnd;
+         bits += gridDim.x * 256u)
+    {
+      const float a = __uint_as_float(bits);
+      int want = int(floor(double(a / float(2 * M_PI) * kOriBins)));
+      want %= kOriBins;
+      int kb = int(a * float(kOriBins / (2. * M_PI)));
+      kb = min(max(kb, 0), kOriBins);
+      const float t0 = s_thr[kb], t1 = s_thr[kb + 1];
+      kb += int(a >= t1) - int(a < t0);
+      const int got = kb == kOriBins ? 0 : kb;
+      n_bad += got != want;
+    }
+    if (n_bad)
+      atomicAdd(bad, (unsigned long long) n_bad);
+  }
+
+  void launch_orientation_bin_selfcheck(const float* thr, unsigned long long* bad,
+                                        hipStream_t stream)
+  {
+    hipLaunchKernelGGL(orientation_bin_selfcheck_kernel, dim3(256 * 64), dim3(256),
+                       0, stream, thr, bad);
+  }
+
   //! not_definite_enough3() of n matrices (9 floats each, row-major) -> 0 / 1.
   __global__ void definiteness_selfcheck_kernel(const float* __restrict__ H,
                                                 const int* __restrict__ type,

@@ -171,6 +171,39 @@ namespace {
 
 }  // namespace
 
+//! ScaleTable::ori_bin_thr: thr[k] = smallest float >= 0 whose histogram bin
+//! int(floor(double(a / float(2 pi) * 36))) (Orientation.hpp:118-119) is >= k,
+//! by bisection on the bit patterns with the expression itself (+inf where no
+//! angle of [0, 2 pi] gets there).
+static void orientation_bin_thresholds(float thr_out[40])
+{
+  auto bin_of = [](float a) {
+    return int(std::floor(double(a / float(2 * M_PI) * 36)));
+  };
+  for (int kk = 0; kk < 40; ++kk)
+  {
+    uint32_t lo = 0u, hi = 0x40c91000u;  // [0, a little above float(2 pi)]
+    float thr = std::numeric_limits<float>::infinity();
+    float top;
+    std::memcpy(&top, &hi, 4);
+    if (bin_of(top) >= kk)
+    {
+      while (lo < hi)  // first bit pattern (= first float >= 0) with bin >= kk
+      {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        float a;
+        std::memcpy(&a, &mid, 4);
+        if (bin_of(a) >= kk)
+          hi = mid;
+        else
+          lo = mid + 1;
+      }
+      std::memcpy(&thr, &lo, 4);
+    }
+    thr_out[kk] = thr;
+  }
+}
+
 //! Ints in d_counters (4 * max_batch + 2 used), in whole 256-byte blocks.
 static inline size_t counters_padded(int max_batch)
 {
@@ -479,34 +512,7 @@ namespace {
         for (int d2 = 0; d2 <= 2 * R * R; ++d2)
           oriw.push_back(std::exp(double(float(-d2) / (2.f * sw * sw))));
     }
-    {
-      // see ScaleTable::ori_bin_thr
-      auto bin_of = [](float a) {
-        return int(std::floor(double(a / float(2 * M_PI) * 36)));
-      };
-      for (int kk = 0; kk < 40; ++kk)
-      {
-        uint32_t lo = 0u, hi = 0x40c91000u;  // [0, a little above float(2 pi)]
-        float thr = std::numeric_limits<float>::infinity();
-        float top;
-        std::memcpy(&top, &hi, 4);
-        if (bin_of(top) >= kk)
-        {
-          while (lo < hi)  // first bit pattern (= first float >= 0) with bin >= kk
-          {
-            const uint32_t mid = lo + (hi - lo) / 2;
-            float a;
-            std::memcpy(&a, &mid, 4);
-            if (bin_of(a) >= kk)
-              hi = mid;
-            else
-              lo = mid + 1;
-          }
-          std::memcpy(&thr, &lo, 4);
-        }
-        c->h_tab.ori_bin_thr[kk] = thr;
-      }
-    }
+    orientation_bin_thresholds(c->h_tab.ori_bin_thr);
     TRY_ST(c->alloc(c->d_tab, 1));
     TRY_HIP(hipMemcpy(c->d_tab, &c->h_tab, sizeof(ScaleTable),
                       hipMemcpyHostToDevice));
@@ -2453,6 +2459,30 @@ sara_hip_status sara_hip_selfcheck_device_math(unsigned long long* mismatches,
   launch_device_math_selfcheck(d, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(mismatches, d, 2 * sizeof(unsigned long long),
+                    hipMemcpyDeviceToHost));
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_selfcheck_orientation_bins(unsigned long long* mismatches,
+                                                   int device)
+{
+  if (!mismatches)
+    return fail(SARA_HIP_INVALID_PARAMS, "null pointer");
+  const sara_hip_status st = select_device(device);
+  if (st != SARA_HIP_OK)
+    return st;
+  float thr[40];
+  orientation_bin_thresholds(thr);
+  DeviceScratch sc;
+  float* d_thr = nullptr;
+  unsigned long long* d_bad = nullptr;
+  HIP_TRY(sc.get(d_thr, 40));
+  HIP_TRY(sc.get(d_bad, 1));
+  HIP_TRY(hipMemcpy(d_thr, thr, sizeof(thr), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(d_bad, 0, sizeof(unsigned long long)));
+  launch_orientation_bin_selfcheck(d_thr, d_bad, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(mismatches, d_bad, sizeof(unsigned long long),
                     hipMemcpyDeviceToHost));
   return SARA_HIP_OK;
 }

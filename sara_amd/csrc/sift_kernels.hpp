@@ -278,6 +278,8 @@ namespace sara_hip {
                           int root_sift, hipStream_t stream);
   void launch_root_sift(float* desc, int n, int dim, hipStream_t stream);
   void launch_device_math_selfcheck(unsigned long long* out, hipStream_t stream);
+  void launch_orientation_bin_selfcheck(const float* thr, unsigned long long* bad,
+                                        hipStream_t stream);
   void launch_definiteness_selfcheck(const float* H, const int* type, int n,
                                      unsigned char* out, hipStream_t stream);
 

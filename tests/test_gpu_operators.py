@@ -223,6 +223,18 @@ def test_short_device_math_is_exact_on_every_float():
     assert (bad[0], bad[1]) == (0, 0)
 
 
+def test_orientation_bins_on_the_device_for_every_angle():
+    """The orientation kernel's estimate-and-correct bin against the reference
+    expression int(floor(double(ori / float(2 pi) * 36))) % 36, on the device,
+    for all 1 086 918 620 floats of [0, float(2 pi)]
+    (sara_hip_selfcheck_orientation_bins)."""
+    import ctypes as C
+    from sara_amd import capi
+    bad = C.c_ulonglong(1)
+    capi.check(capi.load().sara_hip_selfcheck_orientation_bins(C.byref(bad), 0))
+    assert bad.value == 0
+
+
 def _adversarial_hessians(rng, n):
     """Symmetric 3 x 3 float matrices built as Q diag(l) Q^T with spectra that
     are comfortably definite, indefinite, and - the interesting part - have
