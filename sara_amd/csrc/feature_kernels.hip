@@ -2228,19 +2228,26 @@ namespace sara_hip {
     int sum = 0;
     for (int i = lo; i < hi; ++i)
       sum += ori.peak_count[row + i];
-    s_part[tid] = sum;
+    // block scan: DPP scan inside each of the 16 waves, the 16 wave totals
+    // through LDS (two barriers instead of twenty)
+    const int lane = tid & 63, wave = tid >> 6;
+    const int incl_w = wave_inclusive_scan(sum);
+    if (lane == 63)
+      s_part[wave] = incl_w;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1)
+    int wave_base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
     {
-      const int t = tid >= off ? s_part[tid - off] : 0;
-      __syncthreads();
-      s_part[tid] += t;
-      __syncthreads();
+      const int t = s_part[k];
+      wave_base += k < wave ? t : 0;
+      total += t;
     }
-    int at = s_part[tid] - sum;
-    for (int i = lo; i < hi; ++i)
-    {
-      const KeypointRecord& rec = ori.record[row + i];
+    __syncthreads();
+    if (tid == 1023)
+      s_part[1023] = total;  // read below as the frame's keypoint count
+    int at = wave_base + incl_w - sum;
+    auto expand = [&](int i, const KeypointRecord& rec) {
       const int v = rec.npeaks;
       ori.offset[row + i] = at;
       for (int k = 0; k < v && at + k < cand.cap; ++k)
@@ -2253,7 +2260,9 @@ namespace sara_hip {
         ori.item[row + at + k] = it;
       }
       at += v;
-    }
+    };
+    for (int i = lo; i < hi; ++i)
+      expand(i, ori.record[row + i]);
     if (tid == 1023)
     {
       ori.kp_count[b] = s_part[1023];
