@@ -26,6 +26,19 @@ namespace sara_hip {
     const f32x2 v = p[i];
     return make_float2(v.x, v.y);
   }
+  //! The same with a 32-bit pixel index (a plane of one frame has far fewer
+  //! than 2^28 pixels): wave-uniform base + 32-bit byte offset, i.e. the
+  //! scalar-base form of global_load instead of 64-bit address arithmetic per
+  //! lane (v_mad_i64_i32 + v_lshl_add_u64 per sample).
+  __device__ __forceinline__ float2 load_pair32(global_float2_ptr p, unsigned i)
+  {
+    typedef const char __attribute__((address_space(1))) * global_bytes;
+    __builtin_assume(i < (1u << 28));
+    const unsigned off = i << 3;
+    const f32x2 v = *reinterpret_cast<global_float2_ptr>(
+        reinterpret_cast<global_bytes>(p) + off);
+    return make_float2(v.x, v.y);
+  }
 
   // ======================================================================== //
   // Polar gradients.  Reference: gradient_polar_coordinates,
@@ -1964,7 +1977,8 @@ namespace sara_hip {
     auto issue = [&](int base_, float2& mo_, bool& ok_) {
       const int xx = rx + iu, yy = ry + iv;
       ok_ = (base_ + lane < npx) && xx >= 0 && xx < w && yy >= 0 && yy < h;
-      mo_ = load_pair(g, ok_ ? size_t(yy) * w + xx : center);
+      mo_ = load_pair32(g, ok_ ? __umul24(unsigned(yy), unsigned(w)) + unsigned(xx)
+                                : unsigned(center));
       advance(iu, iv);
     };
     float2 ring[kOriAhead];
@@ -2723,8 +2737,10 @@ namespace sara_hip {
             // Unconditional gather (idle lanes read the keypoint's own pixel):
             // with the load under a branch the compiler cannot count it and
             // waits for vmcnt(0), i.e. also for the gathers it has just issued.
-            return load_pair(g, act ? size_t(ry + vv) * w + size_t(rx + uu)
-                                    : center);
+            // rows and widths are below 2^24: one 24-bit multiply-add
+            return load_pair32(g, act ? __umul24(unsigned(ry + vv), unsigned(w)) +
+                                            unsigned(rx + uu)
+                                      : unsigned(center));
           };
           const int nsteps = (C + kDescGroups - 1) / kDescGroups;
           unsigned ent[kDescAhead], ent_next[kDescAhead];
