@@ -271,7 +271,11 @@ namespace sara_hip {
   //! FMA (opt-in, SARA_HIP_OPT_FMA_BLUR): sum = fma(v, k, sum) instead of the
   //! reference's separately rounded multiply and add - half the arithmetic
   //! instructions, results within 2e-7 of the range instead of bit-exact.
-  template <int R, int PF, bool DEC, bool FMA = false>
+  //! U8: `src` addresses 8-bit gray frames (src_stride in bytes); every value
+  //! is converted as it is loaded, float(v) / 255.f (ChannelConversion.hpp:40-54)
+  //! - the first blur of the pyramid then reads the uploaded frame itself and
+  //! the separate conversion pass (1 B read + 4 B written per pixel) is gone.
+  template <int R, int PF, bool DEC, bool FMA = false, bool U8 = false>
   __global__ __launch_bounds__(64, R <= 6 ? 4 : 1) void gaussian_blur_march_kernel(
       const float* __restrict__ src, size_t src_stride,
       float* __restrict__ dst, size_t dst_stride, float* __restrict__ dec,
@@ -292,6 +296,8 @@ namespace sara_hip {
     size_t b;
     if (!march_work_item(nstrips, nseg, xcd_total, strip, seg, b))
       return;
+    const unsigned char* src8 =
+        reinterpret_cast<const unsigned char*>(src) + b * src_stride;
     src += b * src_stride;
     dst += b * dst_stride;
     if (DEC)
@@ -314,6 +320,19 @@ namespace sara_hip {
 
     auto load_row = [&](int yy, float4& m, float& hv) {
       const int gy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+      if (U8)
+      {
+        const unsigned char* rowp = src8 + size_t(gy) * w;
+        const uchar4 q = *reinterpret_cast<const uchar4*>(rowp + mcol);
+        m = make_float4(float(q.x) / 255.f, float(q.y) / 255.f, float(q.z) / 255.f,
+                        float(q.w) / 255.f);
+        if (!col_ok)
+          m = make_float4(m.w, m.w, m.w, m.w);
+        hv = 0.f;
+        if (lane < 2 * R)
+          hv = float(rowp[hcol]) / 255.f;
+        return;
+      }
       const float* rowp = src + size_t(gy) * w;
       m = *reinterpret_cast<const float4*>(rowp + mcol);
       if (!col_ok)
@@ -427,7 +446,8 @@ namespace sara_hip {
   static void launch_blur_march(const float* src, size_t src_stride, float* dst,
                                 size_t dst_stride, float* dec, size_t dec_stride,
                                 int w, int h, int batch, const Taps& taps,
-                                hipStream_t stream, bool fma = false)
+                                hipStream_t stream, bool fma = false,
+                                bool src_is_u8 = false)
   {
     constexpr int W = 256;
     // prefetch depth: the K x 4 partial-sum ring dominates the register
@@ -452,6 +472,16 @@ namespace sara_hip {
                      dim3(64), 0, stream, src, src_stride, dst, dst_stride,    \
                      dec, dec_stride, w, h, seg_rows, nstrips, nseg, total,    \
                      taps)
+    if (src_is_u8)
+    {
+      // gray8 source (the base blur of the first octave): exact arithmetic,
+      // no fused half-size output
+      hipLaunchKernelGGL((gaussian_blur_march_kernel<R, PF, false, false, true>),
+                         grid, dim3(64), 0, stream, src, src_stride, dst,
+                         dst_stride, dec, dec_stride, w, h, seg_rows, nstrips,
+                         nseg, total, taps);
+      return;
+    }
     if (dec && fma)
       SARA_MARCH_LAUNCH(true, true);
     else if (dec)
@@ -776,6 +806,34 @@ namespace sara_hip {
     hipLaunchKernelGGL(gaussian_blur_kernel<R>, grid, dim3(NT), 0, stream, src,
                        src_stride, dst, dst_stride, dog, dog_stride, w, h, taps,
                        dec, dec_stride);
+  }
+
+  bool launch_gaussian_blur_gray8(const unsigned char* src, size_t src_stride,
+                                  float* dst, size_t dst_stride, int w, int h,
+                                  int batch, const Taps& taps, hipStream_t stream)
+  {
+    const int R = taps.size / 2;
+    const bool big_enough = size_t(w) * h * batch >= g_march_min_pixels;
+    const bool ok = big_enough && g_use_march && (w % 4 == 0) && w >= 4 &&
+                    (src_stride % 4 == 0) && (dst_stride % 4 == 0) &&
+                    (reinterpret_cast<uintptr_t>(src) % 4 == 0) &&
+                    (reinterpret_cast<uintptr_t>(dst) % 16 == 0);
+    if (!ok)
+      return false;
+    const float* s = reinterpret_cast<const float*>(src);
+    switch (R)
+    {
+    case 5:
+      launch_blur_march<5>(s, src_stride, dst, dst_stride, nullptr, 0, w, h, batch,
+                           taps, stream, false, true);
+      return true;
+    case 6:
+      launch_blur_march<6>(s, src_stride, dst, dst_stride, nullptr, 0, w, h, batch,
+                           taps, stream, false, true);
+      return true;
+    default:
+      return false;  // other radii: the caller converts first
+    }
   }
 
   bool launch_gaussian_blur(const float* src, size_t src_stride, float* dst,

@@ -240,6 +240,10 @@ struct sara_hip_sift
   // restores the sequential order and the separate stage times).
   bool side_gradient = true;
   hipStream_t aux_stream = nullptr;
+  // set by detect_u8 for the duration of one detect(): the frames are 8-bit
+  // gray in device memory and have NOT been converted into d_input yet
+  const unsigned char* gray8_src = nullptr;
+  size_t gray8_stride = 0;
   // graph replay only: streams / events of the filler nodes that steer the
   // runtime's node -> queue assignment (see the spine layout in detect)
   hipStream_t filler_stream[3] = {};
@@ -966,6 +970,21 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   const bool graph_mode = c->use_graph && !c->graph_broken && !hip_stream &&
                           batch <= c->graph_max_batch && !debug_sync;
   const bool timing = c->timers && !graph_mode;
+  // 8-bit gray frames not converted yet (detect_u8): the first blur of the
+  // pyramid reads them directly when it is the marching blur of octave 0 and
+  // no graph is replayed (a captured graph has the float source baked in);
+  // otherwise they are converted into d_input now.
+  const unsigned char* gray8 = c->gray8_src;
+  const size_t gray8_stride = c->gray8_stride;
+  c->gray8_src = nullptr;
+  bool gray8_fused = gray8 && !graph_mode && c->pyr.first_octave_index == 0 &&
+                     sc.init_blur && images_on_device && !c->fma_blur;
+  if (gray8 && !gray8_fused)
+  {
+    launch_u8_to_gray32f(gray8, gray8_stride, 1, c->d_input, in_plane, in_plane,
+                         batch, stream);
+    HIP_TRY(hipGetLastError());
+  }
   auto mark = [&](int i) -> hipError_t {
     if (debug_sync)
     {
@@ -1111,9 +1130,19 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     }
     else if (sc.init_blur)
     {
-      launch_gaussian_blur(src, src_stride, G00, g_stride0, nullptr, 0, width,
-                           height, batch, c->init_taps, stream, nullptr, 0,
-                           c->fma_blur);
+      bool done = false;
+      if (gray8_fused)
+      {
+        done = launch_gaussian_blur_gray8(gray8, gray8_stride, G00, g_stride0, width,
+                                          height, batch, c->init_taps, stream);
+        if (!done)  // shape / radius the marching kernel does not take
+          launch_u8_to_gray32f(gray8, gray8_stride, 1, c->d_input, in_plane,
+                               in_plane, batch, stream);
+      }
+      if (!done)
+        launch_gaussian_blur(src, src_stride, G00, g_stride0, nullptr, 0, width,
+                             height, batch, c->init_taps, stream, nullptr, 0,
+                             c->fma_blur);
     }
     else
     {
@@ -1500,13 +1529,29 @@ sara_hip_status sara_hip_sift_detect_u8(sara_hip_sift* c, const uint8_t* images,
     src = c->d_u8;
     src_stride = px * channels;
   }
-  launch_u8_to_gray32f(src, src_stride, channels, c->d_input, px, px, batch,
-                       stream);
-  HIP_TRY(hipGetLastError());
+  static const bool fuse_gray8 = [] {
+    const char* e = getenv("SARA_HIP_FUSE_GRAY8");
+    return !(e && e[0] == '0' && e[1] == 0);
+  }();
+  if (channels == 1 && fuse_gray8)
+  {
+    // gray8: detect() lets the first blur read the bytes itself when it can
+    // (and converts into d_input otherwise)
+    c->gray8_src = src;
+    c->gray8_stride = src_stride;
+  }
+  else
+  {
+    launch_u8_to_gray32f(src, src_stride, channels, c->d_input, px, px, batch,
+                         stream);
+    HIP_TRY(hipGetLastError());
+  }
   // the caller's handle (possibly null), not the resolved stream: a null
   // handle keeps the HIP-graph replay of small batches available
-  return sara_hip_sift_detect(c, c->d_input, px, batch, width, height, 1,
-                              last_stage, hip_stream);
+  const sara_hip_status st = sara_hip_sift_detect(
+      c, c->d_input, px, batch, width, height, 1, last_stage, hip_stream);
+  c->gray8_src = nullptr;
+  return st;
 }
 
 sara_hip_status sara_hip_sift_stage(sara_hip_sift* c, const void* images,

@@ -164,6 +164,14 @@ namespace sara_hip {
                             hipStream_t stream, float* dec = nullptr,
                             size_t dec_stride = 0, bool fma = false);
 
+  //! The same blur reading 8-bit gray frames (src_stride in bytes), converted
+  //! on the fly as float(v) / 255.f.  Returns false (nothing launched) when the
+  //! marching kernel cannot take the shape / radius: the caller then converts
+  //! into a float plane first.
+  bool launch_gaussian_blur_gray8(const unsigned char* src, size_t src_stride,
+                                  float* dst, size_t dst_stride, int w, int h,
+                                  int batch, const Taps& taps, hipStream_t stream);
+
   //! Nearest-neighbour resize (Resize.cpp:31-62).
   void launch_scale(const float* src, size_t src_stride, int sw, int sh,
                     float* dst, size_t dst_stride, int dw, int dh, int batch,

@@ -405,6 +405,34 @@ def test_detect_u8_equals_detect_on_converted_frames(oracle):
         assert np.array_equal(want[2], got[2])
 
 
+@pytest.mark.parametrize("w,h,cam", [(160, 120, 0.5), (320, 96, 0.5), (162, 120, 0.5),
+                                     (160, 120, 1.6)])
+def test_gray8_read_by_the_first_blur(oracle, w, h, cam):
+    """Batches too large for graph replay: the base blur of octave 0 reads the
+    gray8 frames itself (float(v) / 255.f as it loads, no conversion pass).
+    Byte-identical keypoints to detect() on the converted float frames, for
+    widths the marching kernel takes, one it does not (162), and a camera
+    scale without an initial blur; also through stage() / detect_staged()."""
+    batch = 10  # > SARA_HIP_GRAPH_MAX_BATCH
+    u8 = (synth_batch(w, h, batch) * 255).astype(np.uint8)
+    f32 = u8.astype(np.float32) / np.float32(255)
+    with sara_amd.SiftContext(w, h, batch, hip_params(0, 3, cam=cam)) as ctx:
+        ctx.detect(f32)
+        want = ctx.fetch()
+        planes = [ctx.gaussian(0, 0, b) for b in (0, batch - 1)]
+        ctx.detect_u8(u8)
+        got = ctx.fetch()
+        assert np.array_equal(planes[0], ctx.gaussian(0, 0, 0))
+        assert np.array_equal(planes[1], ctx.gaussian(0, 0, batch - 1))
+        for a, b in zip(want, got):
+            assert a.tobytes() == b.tobytes()
+        assert int(np.sum(want[0])) > 0
+        ctx.stage(u8)
+        ctx.detect_staged()
+        for a, b in zip(want, ctx.fetch()):
+            assert a.tobytes() == b.tobytes()
+
+
 def _fuzz_cases(n, seed):
     rng = np.random.default_rng(seed)
     cases = []
