@@ -37,6 +37,35 @@ __global__ __launch_bounds__(64 * WPB) void march_copy(const float* __restrict__
     }
   }
 }
+// the wide blurs' pattern: 2 columns per lane (strips of 128), 8-byte loads and stores
+template <int PF>
+__global__ __launch_bounds__(64) void march_copy2(const float* __restrict__ src, float* __restrict__ dst,
+                                                  int w, int h, int seg_rows, int nstrips)
+{
+  const int lane = threadIdx.x;
+  const int wid = blockIdx.x;
+  const int strip = wid % nstrips, seg = wid / nstrips;
+  const size_t b = blockIdx.y;
+  src += b * size_t(w) * h; dst += b * size_t(w) * h;
+  const int col = strip * 128 + 2 * lane;
+  if (col >= w) return;
+  const int y0 = seg * seg_rows, y1 = min(h, y0 + seg_rows);
+  if (y0 >= h) return;
+  float2 pm[PF];
+#pragma unroll
+  for (int q = 0; q < PF; ++q) pm[q] = *reinterpret_cast<const float2*>(src + size_t(min(y0 + q, h - 1)) * w + col);
+  for (int y = y0; y < y1; y += PF)
+  {
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+    {
+      const int yy = y + i;
+      const float2 v = pm[i];
+      pm[i] = *reinterpret_cast<const float2*>(src + size_t(min(yy + PF, h - 1)) * w + col);
+      if (yy < y1) *reinterpret_cast<float2*>(dst + size_t(yy) * w + col) = v;
+    }
+  }
+}
 template <typename F> float timeit(F f, int reps = 5)
 {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -70,6 +99,14 @@ int main()
       float ms = timeit([&] { march_copy<4, 4><<<dim3((nstrips * nseg + 3) / 4, B), 256>>>(a, b, w, h, seg_rows, nstrips); });
       printf("march PF=4 WPB=4 nseg=%2d (waves %5d): %.3f ms  %.2f TB/s\n", nseg, nstrips * nseg * B, ms, gb / ms);
     }
+  }
+  for (int nseg : {2, 3, 4, 6}) {
+    const int seg_rows = (h + nseg - 1) / nseg;
+    const int ns128 = (w + 127) / 128;
+    float ms = timeit([&] { march_copy2<4><<<dim3(ns128 * nseg, B), 64>>>(a, b, w, h, seg_rows, ns128); });
+    printf("march2 (128-col strips, float2) PF=4 nseg=%2d (waves %5d): %.3f ms  %.2f TB/s\n", nseg, ns128 * nseg * B, ms, gb / ms);
+    ms = timeit([&] { march_copy2<8><<<dim3(ns128 * nseg, B), 64>>>(a, b, w, h, seg_rows, ns128); });
+    printf("march2 (128-col strips, float2) PF=8 nseg=%2d (waves %5d): %.3f ms  %.2f TB/s\n", nseg, ns128 * nseg * B, ms, gb / ms);
   }
   return 0;
 }
