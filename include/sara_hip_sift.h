@@ -438,12 +438,23 @@ SARA_HIP_API sara_hip_status sara_hip_match_descriptors(
 /* read-back of batch i (a third stream) then overlap.                          */
 /*   channels: 0 = float32 gray frames (frame_stride in floats), 1 = gray8,     */
 /*             3 = interleaved RGB8 (frame_stride in bytes); 0 -> densely packed*/
+/* Lifetime of `images` (host frames): the upload is asynchronous - with pinned  */
+/* memory submit() returns before the copy engine has read the frames - so the  */
+/* buffer must stay valid AND UNMODIFIED until collect() / collect_into() /     */
+/* gather of that ticket has returned (decode the next frames into another      */
+/* buffer; two alternating buffers suffice).  Device frames (images_on_device)  */
+/* are read by the kernels of the batch: same rule.                             */
 /* collect() blocks until the batch of `ticket` is in pinned host memory owned  */
-/* by the context and returns pointers into it; they stay valid until the       */
-/* second submit() after this ticket's.  frame_offsets has batch + 1 entries    */
-/* (frame b = [frame_offsets[b], frame_offsets[b + 1])).  Pass descriptors =    */
-/* NULL to skip their read-back.  SARA_HIP_CAPACITY_EXCEEDED is reported by     */
-/* collect() (the truncated lists are still delivered).                         */
+/* by the context and returns pointers into it.  features / descriptors /       */
+/* scale_octave AND frame_offsets all live in the ticket's ring slot: they stay */
+/* valid until the second submit() after this ticket's (the submit of ticket +  */
+/* 2 reuses the slot and overwrites all four arrays, frame_offsets included).   */
+/* frame_offsets has batch + 1 entries (frame b = [frame_offsets[b],            */
+/* frame_offsets[b + 1])).  Pass descriptors = NULL to skip their read-back;    */
+/* asking for descriptors of a ticket submitted with last_stage < DESCRIPTOR    */
+/* returns SARA_HIP_NOT_READY and leaves the ticket pending (as fetch() does).  */
+/* SARA_HIP_CAPACITY_EXCEEDED is reported by collect() (the truncated lists are */
+/* still delivered).                                                            */
 /* -------------------------------------------------------------------------- */
 SARA_HIP_API sara_hip_status sara_hip_sift_submit(
     sara_hip_sift* ctx, const void* images, size_t frame_stride, int channels,
@@ -454,6 +465,27 @@ SARA_HIP_API sara_hip_status sara_hip_sift_collect(
     const float** descriptors, const int32_t** scale_octave,
     const int32_t** frame_offsets, int* total);
 
+/* The same read-back into memory the CALLER owns (any host memory; pinned or   */
+/* sara_hip_host_register()-ed memory is copied by DMA without a bounce):       */
+/* ticket_counts() waits for the batch and reports its size (frame_offsets:     */
+/* batch + 1 entries copied out, may be NULL) and leaves the ticket pending;    */
+/* collect_into() copies total x sara_oeregion / total x 128 float / total x 2  */
+/* int32 (NULL to skip) and consumes the ticket.  This is what lets several     */
+/* processes - one per GPU - deliver their shards into ONE host array (a shared */
+/* mapping registered by every process) at their global offsets, each over its  */
+/* own PCIe link: SURVEY.md section 8d's "results in host memory on the root"   */
+/* without funnelling every byte through the root GPU's link.                   */
+SARA_HIP_API sara_hip_status sara_hip_sift_ticket_counts(
+    sara_hip_sift* ctx, int ticket, int32_t* frame_offsets, int* batch,
+    int* total);
+SARA_HIP_API sara_hip_status sara_hip_sift_collect_into(
+    sara_hip_sift* ctx, int ticket, sara_oeregion* features, float* descriptors,
+    int32_t* scale_octave);
+/* hipHostRegister / hipHostUnregister (portable: usable from every device) for */
+/* callers without a HIP toolchain.                                             */
+SARA_HIP_API sara_hip_status sara_hip_host_register(void* ptr, size_t bytes);
+SARA_HIP_API sara_hip_status sara_hip_host_unregister(void* ptr);
+
 /* -------------------------------------------------------------------------- */
 /* Multi-GPU.  Frames are independent                    */
 /* (compute_sift_keypoints is a pure function of one image,                     */
@@ -463,6 +495,16 @@ SARA_HIP_API sara_hip_status sara_hip_sift_collect(
 /* one ncclAllGather, then one group of ncclSend / ncclRecv at the global       */
 /* offsets, so that the root holds the keypoints in (frame, octave, scale, y,   */
 /* x, bin) order.  librccl is loaded on first use.                              */
+/* Failure handling: every rank takes part in every collective of a gather; a   */
+/* rank that cannot (unknown ticket, descriptors that were not computed, bad    */
+/* root) says so through the count exchange, all ranks then skip the transfers  */
+/* together and return an error - nobody is left blocked, and the ticket is     */
+/* released on every path.                                                      */
+/* Test transport: with SARA_HIP_COMM_TRANSPORT=loopback in the environment     */
+/* sara_hip_comm_unique_id() / sara_hip_sift_group_create() build communicators */
+/* whose ranks are THREADS OF ONE PROCESS (on one device or several) and whose  */
+/* AllGather / Send / Recv are device copies through a process-local mailbox:   */
+/* the N > 1 exchange then runs on a one-GPU box.  Not a production path.       */
 /* -------------------------------------------------------------------------- */
 
 /* Contiguous block [*lo, *hi) of `n_frames` frames owned by `rank`.  Host-only. */
@@ -502,6 +544,8 @@ SARA_HIP_API sara_hip_status sara_hip_comm_gather(
     int* counts_per_rank, const sara_oeregion** d_features,
     const float** d_descriptors, const int32_t** d_scale_octave, int* total);
 SARA_HIP_API sara_hip_status sara_hip_comm_destroy(sara_hip_comm* comm);
+/* "rccl" or "loopback". */
+SARA_HIP_API const char* sara_hip_comm_transport(const sara_hip_comm* comm);
 
 /* --- one process, one host thread per GPU ---------------------------------- */
 typedef struct sara_hip_sift_group sara_hip_sift_group;
@@ -517,17 +561,36 @@ SARA_HIP_API sara_hip_status sara_hip_sift_group_context(
     sara_hip_sift_group* group, int index, sara_hip_sift** ctx);
 /* Device i runs sara_hip_sift_submit() on shard_images[i] (shard_batch[i]      */
 /* frames; same frame_stride / channels / on-device meaning), all devices at    */
-/* once.  Returns when everything is enqueued.                                  */
+/* once.  Returns when everything is enqueued.  shard_batch[i] == 0 is allowed  */
+/* (fewer frames than devices): that device contributes nothing.  A batch that  */
+/* was detected but never gathered is dropped by the next group_detect().       */
 SARA_HIP_API sara_hip_status sara_hip_sift_group_detect(
     sara_hip_sift_group* group, const void* const* shard_images,
     const int* shard_batch, size_t frame_stride, int channels, int width,
     int height, int images_on_device, sara_hip_stage last_stage);
 /* Gathers the results of the last group_detect() on device `root` (index into  */
-/* the group); outputs as for sara_hip_comm_gather on the root.                 */
+/* the group); outputs as for sara_hip_comm_gather on the root.  An invalid     */
+/* `root` is rejected before anything changes (gather again with a valid one);  */
+/* every other failure releases the batch.  The per-device counts are host      */
+/* values of this one process, so no count collective runs here - only the      */
+/* grouped Send / Recv.                                                         */
 SARA_HIP_API sara_hip_status sara_hip_sift_group_gather(
     sara_hip_sift_group* group, int root, int with_descriptors,
     int* counts_per_device, const sara_oeregion** d_features,
     const float** d_descriptors, const int32_t** d_scale_octave, int* total);
+/* SURVEY.md section 8d's ending for a whole node: instead of funnelling the    */
+/* results through the root GPU (whose single PCIe link would then carry every  */
+/* device's share), every device copies its shard straight into ONE pinned      */
+/* (portable) host array owned by the group, at its global offset, over its own */
+/* PCIe link, all devices at once.  Same order as group_gather.  The pointers    */
+/* stay valid until the next collect_host() / destroy().  Consumes the batch    */
+/* (call either this or group_gather, not both).                                */
+SARA_HIP_API sara_hip_status sara_hip_sift_group_collect_host(
+    sara_hip_sift_group* group, int with_descriptors, int* counts_per_device,
+    const sara_oeregion** h_features, const float** h_descriptors,
+    const int32_t** h_scale_octave, int* total);
+SARA_HIP_API const char* sara_hip_sift_group_transport(
+    const sara_hip_sift_group* group);
 SARA_HIP_API sara_hip_status sara_hip_sift_group_destroy(sara_hip_sift_group* group);
 
 /* Host self-check: evaluates, on the CPU, the float atan2 sequence the polar-  */

@@ -11,6 +11,7 @@ point the benchmark and the multi-GPU path use.
 Everything computes on the GPU; there is no CPU path in this package.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -334,6 +335,24 @@ class SiftContext:
         desc = view(d, n, np.float32, (n, 128)) if with_descriptors else None
         return offsets, regions, desc, so
 
+    def ticket_counts(self, ticket):
+        """Waits for the batch of ``ticket``; -> (frame_offsets[B+1], total).
+        The ticket stays pending."""
+        off = np.zeros(self.max_batch + 1, np.int32)
+        b, total = C.c_int(0), C.c_int(0)
+        capi.check(capi.load().sara_hip_sift_ticket_counts(
+            self._h, ticket, off.ctypes.data, C.byref(b), C.byref(total)))
+        return off[:b.value + 1], total.value
+
+    def collect_into(self, ticket, features_ptr, descriptors_ptr, scale_octave_ptr):
+        """Read the batch of ``ticket`` back into caller-owned host memory (raw
+        addresses, 0 / None to skip an array) and consume the ticket: several
+        ranks deliver into ONE shared host array at their global offsets."""
+        getattr(self, "_inflight", {}).pop(ticket, None)
+        capi.check(capi.load().sara_hip_sift_collect_into(
+            self._h, ticket, features_ptr or None, descriptors_ptr or None,
+            scale_octave_ptr or None))
+
     def counts(self):
         c = np.zeros(self.batch, np.int32)
         tot = C.c_int32()
@@ -455,39 +474,52 @@ def compute_sift_keypoints(image, pyramid_params=None, gauss_truncate=4.0,
     return KeypointList(regions, desc, so)
 
 
-#: contexts of compute_sift_keypoints(), most recently used first.  Creating a
-#: context allocates the pyramid / gradient / list buffers in HBM (tens of
-#: milliseconds); a detection takes less than one.
-_CONTEXT_CACHE = []
+#: contexts of compute_sift_keypoints(), most recently used first, ONE LIST PER
+#: THREAD (like the thread_local cache of include/DO/Sara/HipSift.hpp): a
+#: context is not thread-safe, and a shared list would let one thread evict -
+#: and destroy - a context another thread is still inside submit()/collect()
+#: with.  Creating a context allocates the pyramid / gradient / list buffers
+#: in HBM (tens of milliseconds); a detection takes less than one.
 _CONTEXT_CACHE_MAX = 4
+
+
+class _ThreadContexts(threading.local):
+    def __init__(self):
+        # dropped with the thread; SiftContext.__del__ then frees its HBM
+        self.entries = []
+
+
+_CONTEXTS = _ThreadContexts()
 
 
 def _cached_context(w, h, params, gauss_truncate, extremum_thres,
                     edge_ratio_thres, extremum_refinement_iter, device):
-    import threading
     s = params._s
-    key = (threading.get_ident(), w, h, device, s.first_octave_index,
+    key = (w, h, device, s.first_octave_index,
            s.scale_count_per_octave, s.scale_geometric_factor,
            s.image_padding_size, s.scale_camera, s.scale_initial,
            s.num_octaves_max, float(gauss_truncate), float(extremum_thres),
            float(edge_ratio_thres), int(extremum_refinement_iter))
-    for i, (k, ctx) in enumerate(_CONTEXT_CACHE):
+    cache = _CONTEXTS.entries
+    for i, (k, ctx) in enumerate(cache):
         if k == key:
             if i:
-                _CONTEXT_CACHE.insert(0, _CONTEXT_CACHE.pop(i))
+                cache.insert(0, cache.pop(i))
             return ctx
     ctx = SiftContext(w, h, 1, params, gauss_truncate, extremum_thres,
                       edge_ratio_thres, extremum_refinement_iter, device=device)
-    _CONTEXT_CACHE.insert(0, (key, ctx))
-    while len(_CONTEXT_CACHE) > _CONTEXT_CACHE_MAX:
-        _CONTEXT_CACHE.pop()[1].close()
+    cache.insert(0, (key, ctx))
+    while len(cache) > _CONTEXT_CACHE_MAX:
+        cache.pop()[1].close()      # only ever a context of THIS thread
     return ctx
 
 
 def clear_context_cache():
-    """Release the contexts compute_sift_keypoints() keeps."""
-    while _CONTEXT_CACHE:
-        _CONTEXT_CACHE.pop()[1].close()
+    """Release the contexts compute_sift_keypoints() keeps for the calling
+    thread."""
+    cache = _CONTEXTS.entries
+    while cache:
+        cache.pop()[1].close()
 
 
 class ComputeDoGExtrema:

@@ -95,6 +95,10 @@ EXPORTS = [
     "sara_hip_sift_group_create", "sara_hip_sift_group_size",
     "sara_hip_sift_group_context", "sara_hip_sift_group_detect",
     "sara_hip_sift_group_gather", "sara_hip_sift_group_destroy",
+    "sara_hip_sift_ticket_counts", "sara_hip_sift_collect_into",
+    "sara_hip_host_register", "sara_hip_host_unregister",
+    "sara_hip_comm_transport", "sara_hip_sift_group_collect_host",
+    "sara_hip_sift_group_transport",
 ]
 
 _f32p = C.POINTER(C.c_float)
@@ -209,6 +213,19 @@ def _declare(lib):
                                                C.POINTER(_vp), C.POINTER(_vp),
                                                C.POINTER(_vp), C.POINTER(C.c_int)]
     lib.sara_hip_sift_group_destroy.argtypes = [_vp]
+    lib.sara_hip_sift_group_collect_host.argtypes = [
+        _vp, C.c_int, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
+        C.POINTER(C.c_int)]
+    lib.sara_hip_sift_group_transport.argtypes = [_vp]
+    lib.sara_hip_sift_group_transport.restype = C.c_char_p
+    lib.sara_hip_comm_transport.argtypes = [_vp]
+    lib.sara_hip_comm_transport.restype = C.c_char_p
+    lib.sara_hip_sift_ticket_counts.argtypes = [_vp, C.c_int, _vp,
+                                                C.POINTER(C.c_int),
+                                                C.POINTER(C.c_int)]
+    lib.sara_hip_sift_collect_into.argtypes = [_vp, C.c_int, _vp, _vp, _vp]
+    lib.sara_hip_host_register.argtypes = [_vp, C.c_size_t]
+    lib.sara_hip_host_unregister.argtypes = [_vp]
     lib.sara_hip_selfcheck_sincos.argtypes = [_f32p, _f32p, _f32p, C.c_size_t]
     lib.sara_hip_selfcheck_sincos.restype = None
     lib.sara_hip_selfcheck_orientation_bins.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]

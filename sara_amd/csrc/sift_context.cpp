@@ -313,6 +313,7 @@ struct sara_hip_sift
     int ticket = -1;
     bool pending = false;
     int batch = 0;
+    sara_hip_stage stage = SARA_HIP_STAGE_DESCRIPTOR;  // last_stage of the submit()
     hipEvent_t done = nullptr;   // counters of the batch are in h_counters
     int* h_counters = nullptr;   // pinned copy of d_counters (4 * max_batch + 1)
     sara_oeregion* h_feat = nullptr;  // pinned result arrays, grown on demand
@@ -1730,6 +1731,7 @@ sara_hip_status sara_hip_sift_submit(sara_hip_sift* c, const void* images,
   r.ticket = c->next_ticket;
   r.pending = true;
   r.batch = batch;
+  r.stage = last_stage;
   *ticket = c->next_ticket++;
   return SARA_HIP_OK;
 }
@@ -1753,6 +1755,10 @@ sara_hip_status sara_hip_sift_collect(sara_hip_sift* c, int ticket,
   const int* h_kp = r.h_counters + 2 * size_t(mb);
   const int* h_off = r.h_counters + 3 * size_t(mb);
   const int n = h_off[r.batch];
+  if (descriptors && r.stage < SARA_HIP_STAGE_DESCRIPTOR)
+    return fail(SARA_HIP_NOT_READY,
+                "descriptors requested, but the ticket was submitted with "
+                "last_stage < DESCRIPTOR (collect it with descriptors = NULL)");
   sara_hip_status status = SARA_HIP_OK;
   for (int b = 0; b < r.batch && status == SARA_HIP_OK; ++b)
     if (h_kp[b] > c->cap || h_ex[b] > c->cap || h_sites[b] > c->sites.cap)
@@ -1829,6 +1835,58 @@ sara_hip_status sara_hip_sift_collect(sara_hip_sift* c, int ticket,
   return status;
 }
 
+sara_hip_status sara_hip_sift_ticket_counts(sara_hip_sift* c, int ticket,
+                                           int32_t* frame_offsets, int* batch,
+                                           int* total)
+{
+  sara_hip::TicketResults res;
+  const sara_hip_status st = sara_hip::ticket_results(c, ticket, &res);
+  if (st != SARA_HIP_OK)
+    return st;
+  if (frame_offsets)
+    std::copy(res.h_offsets, res.h_offsets + res.batch + 1, frame_offsets);
+  if (batch)
+    *batch = res.batch;
+  if (total)
+    *total = res.total;
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_sift_collect_into(sara_hip_sift* c, int ticket,
+                                           sara_oeregion* features,
+                                           float* descriptors,
+                                           int32_t* scale_octave)
+{
+  sara_hip::TicketResults res;
+  const sara_hip_status st = sara_hip::ticket_results(c, ticket, &res);
+  if (st != SARA_HIP_OK)
+    return st;
+  if (descriptors && res.last_stage < SARA_HIP_STAGE_DESCRIPTOR)
+    return fail(SARA_HIP_NOT_READY,
+                "descriptors requested, but the ticket was submitted with "
+                "last_stage < DESCRIPTOR");
+  const size_t n = size_t(res.total);
+  if (n > 0)
+  {
+    if (features)
+      HIP_TRY(hipMemcpyAsync(features, res.d_feat, sizeof(sara_oeregion) * n,
+                             hipMemcpyDeviceToHost, c->d2h_stream));
+    if (scale_octave)
+      HIP_TRY(hipMemcpyAsync(scale_octave, res.d_so, sizeof(int32_t) * 2 * n,
+                             hipMemcpyDeviceToHost, c->d2h_stream));
+    if (descriptors)
+      HIP_TRY(hipMemcpyAsync(descriptors, res.d_desc, sizeof(float) * 128 * n,
+                             hipMemcpyDeviceToHost, c->d2h_stream));
+    HIP_TRY(hipStreamSynchronize(c->d2h_stream));
+  }
+  sara_hip::ticket_release(c, ticket);
+  if (res.capacity_exceeded)
+    return fail(SARA_HIP_CAPACITY_EXCEEDED,
+                "a frame produced more extrema / keypoints than "
+                "max_keypoints: the lists are truncated");
+  return SARA_HIP_OK;
+}
+
 }  // extern "C"
 
 namespace sara_hip {
@@ -1856,6 +1914,7 @@ namespace sara_hip {
     out->d_desc = c->d_desc_s[ticket & 1];
     out->d_so = c->d_so_s[ticket & 1];
     out->capacity_exceeded = false;
+    out->last_stage = r.stage;
     for (int b = 0; b < r.batch; ++b)
       if (r.h_counters[2 * size_t(mb) + b] > c->cap || r.h_counters[b] > c->cap ||
           r.h_counters[mb + b] > c->sites.cap)

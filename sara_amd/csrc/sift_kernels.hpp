@@ -324,6 +324,7 @@ namespace sara_hip {
     const float* d_desc = nullptr;
     const int32_t* d_so = nullptr;
     bool capacity_exceeded = false;
+    sara_hip_stage last_stage = SARA_HIP_STAGE_DESCRIPTOR;  // of the submit()
   };
   //! Waits for the batch of `ticket` and describes where its results are in
   //! HBM; the ticket stays pending until ticket_release().

@@ -8,6 +8,7 @@ which RCCL does not provide natively.  On the GPU boxes the backend is "nccl"
 code runs over "gloo" on CPU tensors in the tests.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -177,6 +178,10 @@ class Comm:
         capi.check(capi.load().sara_hip_comm_create(
             ctx._h, buf, world_size, rank, self.device, C.byref(self._h)))
 
+    @property
+    def transport(self):
+        return capi.load().sara_hip_comm_transport(self._h).decode()
+
     def gather(self, ticket, root=0, with_descriptors=True):
         counts = (C.c_int * self.world_size)()
         f, d, s = C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -214,7 +219,10 @@ class SiftGroup:
         sp = capi.SiftParamsStruct(self.params._s, gauss_truncate, extremum_thres,
                                    edge_ratio_thres, int(extremum_refinement_iter))
         devs = (C.c_int * n_dev)(*devices) if devices is not None else None
-        self.devices = list(devices) if devices is not None else list(range(n_dev))
+        visible = max(lib.sara_hip_device_count(), 1)
+        loop = os.environ.get("SARA_HIP_COMM_TRANSPORT") == "loopback"
+        self.devices = (list(devices) if devices is not None else
+                        [i % visible if loop else i for i in range(n_dev)])
         self.n_dev = n_dev
         self._h = C.c_void_p()
         capi.check(lib.sara_hip_sift_group_create(
@@ -238,8 +246,8 @@ class SiftGroup:
         for i in range(self.n_dev):
             lo, hi = shard_range_native(n, self.n_dev, i)
             self.shards.append((lo, hi))
-            ptrs[i] = a.ctypes.data + lo * frame_bytes
-            batch[i] = hi - lo
+            ptrs[i] = a.ctypes.data + lo * frame_bytes if hi > lo else None
+            batch[i] = hi - lo          # 0: fewer frames than devices
         self._keepalive = a
         capi.check(capi.load().sara_hip_sift_group_detect(
             self._h, ptrs, batch, 0, channels, w, h, 0, int(last_stage)))
@@ -254,6 +262,40 @@ class SiftGroup:
             C.byref(d), C.byref(s), C.byref(total)))
         return GatherResult(list(counts), f.value, d.value, s.value, total.value,
                             self.devices[root])
+
+    @property
+    def transport(self):
+        """"rccl", or "loopback" (SARA_HIP_COMM_TRANSPORT=loopback: the ranks are
+        threads of this process - the N > 1 exchange on a one-GPU box)."""
+        return capi.load().sara_hip_sift_group_transport(self._h).decode()
+
+    def collect_host(self, with_descriptors=True, copy=True):
+        """SURVEY.md section 8d's ending for a node: every device copies its
+        shard into ONE pinned host array at its global offset over its own PCIe
+        link.  -> (counts per device, regions, descriptors or None,
+        scale_octave); views of group-owned pinned memory unless ``copy``."""
+        from . import OEREGION_DTYPE
+        counts = (C.c_int * self.n_dev)()
+        f, d, s = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        total = C.c_int(0)
+        capi.check(capi.load().sara_hip_sift_group_collect_host(
+            self._h, 1 if with_descriptors else 0, counts, C.byref(f),
+            C.byref(d), C.byref(s), C.byref(total)))
+        n = total.value
+
+        def view(ptr, dtype, shape):
+            if n == 0 or not ptr.value:
+                return np.zeros(shape, dtype)
+            nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            raw = np.frombuffer((C.c_char * nbytes).from_address(ptr.value),
+                                dtype=np.uint8)
+            if copy:
+                raw = raw.copy()
+            return raw.view(dtype).reshape(shape)
+
+        return (list(counts), view(f, OEREGION_DTYPE, (n,)),
+                view(d, np.float32, (n, 128)) if with_descriptors else None,
+                view(s, np.int32, (n, 2)))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
