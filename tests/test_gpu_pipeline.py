@@ -654,14 +654,14 @@ def test_compute_sift_keypoints_keeps_its_context(oracle):
     t = time.perf_counter()
     ka = sara_amd.compute_sift_keypoints(a, p)
     first = time.perf_counter() - t
-    assert len(sara_amd._CONTEXT_CACHE) == 1
-    ctx_id = id(sara_amd._CONTEXT_CACHE[0][1])
+    assert len(sara_amd._CONTEXTS.entries) == 1
+    ctx_id = id(sara_amd._CONTEXTS.entries[0][1])
     t = time.perf_counter()
     kb = sara_amd.compute_sift_keypoints(b, p)
     ka2 = sara_amd.compute_sift_keypoints(a, p)
     later = (time.perf_counter() - t) / 2
-    assert len(sara_amd._CONTEXT_CACHE) == 1
-    assert id(sara_amd._CONTEXT_CACHE[0][1]) == ctx_id
+    assert len(sara_amd._CONTEXTS.entries) == 1
+    assert id(sara_amd._CONTEXTS.entries[0][1]) == ctx_id
     assert ka.regions.tobytes() == ka2.regions.tobytes()
     assert np.array_equal(ka.descriptor_matrix, ka2.descriptor_matrix)
     assert len(kb) > 0 and kb.regions.tobytes() != ka.regions.tobytes()
@@ -674,7 +674,35 @@ def test_compute_sift_keypoints_keeps_its_context(oracle):
     # a different size gets its own context, the cache stays bounded
     for w in (200, 208, 216, 224, 232):
         sara_amd.compute_sift_keypoints(synth(w, 160, 3), p)
-    assert len(sara_amd._CONTEXT_CACHE) <= sara_amd._CONTEXT_CACHE_MAX
+    assert len(sara_amd._CONTEXTS.entries) <= sara_amd._CONTEXT_CACHE_MAX
+    # the cache is per thread (a context is not thread-safe, and a shared list
+    # would let one thread evict - destroy - a context another one is inside):
+    # many threads with more parameter sets than the cache holds never touch
+    # each other's contexts, and all get the single-thread results
+    import threading
+    mine = [id(c) for _, c in sara_amd._CONTEXTS.entries]
+    errors, results = [], {}
+
+    def worker(k):
+        try:
+            for rep in range(3):
+                for w in (200, 208, 216, 224, 232, 240):
+                    r = sara_amd.compute_sift_keypoints(synth(w, 160, 3), p)
+                    results.setdefault(w, []).append(r.regions.tobytes())
+            assert len(sara_amd._CONTEXTS.entries) <= sara_amd._CONTEXT_CACHE_MAX
+            assert not set(id(c) for _, c in sara_amd._CONTEXTS.entries) & set(mine)
+        except Exception as e:       # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for w, blobs in results.items():
+        assert len(set(blobs)) == 1, w
+    assert [id(c) for _, c in sara_amd._CONTEXTS.entries] == mine
     sara_amd.clear_context_cache()
 
 
