@@ -12,11 +12,20 @@
 //                                   Features/KeypointList.hpp:35-96
 //
 // Two modes:
-//  * inside Sara (define SARA_HIP_WITH_SARA_HEADERS): Sara's own Image /
-//    OERegion / Tensor_ types are used; sara_oeregion is byte-compatible with
-//    OERegion (48 bytes, same member offsets), so results are memcpy'd.
 //  * standalone (default): minimal stand-ins with the same member names, no
-//    Eigen required.  This is what tests/cpp/test_shim.cpp builds.
+//    Eigen required, and the functions / classes below live in DO::Sara under
+//    the reference's own names.  This is what tests/cpp/test_shim.cpp builds.
+//  * inside Sara (define SARA_HIP_WITH_SARA_HEADERS): Sara's own Image /
+//    OERegion / Tensor_ / KeypointList / Match types are used (sara_oeregion
+//    is byte-compatible with OERegion: 48 bytes, same member offsets - checked
+//    by static_assert below - so results are memcpy'd), and because Sara
+//    already defines DO::Sara::compute_sift_keypoints, ComputeDoGExtrema,
+//    AnnMatcher, match and from_rgb8_to_gray32f, the GPU versions live in the
+//    nested namespace DO::Sara::hip with the same names and signatures:
+//    a call site switches with one `using`/qualification.
+//    tests/cpp/test_shim_in_sara.cpp compiles this branch against a MOCK of
+//    the five Sara headers it includes (tests/cpp/mock_sara/ - it proves that
+//    the branch is well-formed, not parity).
 //
 // Error convention: C status codes are re-thrown as the exception classes the
 // reference throws (std::runtime_error for the scale-count check DoG.hpp:86-89,
@@ -51,6 +60,12 @@
 #  include <DO/Sara/Core/Tensor.hpp>
 #  include <DO/Sara/Features/KeypointList.hpp>
 #  include <DO/Sara/ImageProcessing/ImagePyramid.hpp>
+#  include <DO/Sara/Match/Match.hpp>
+#  define SARA_HIP_SHIM_NS_BEGIN namespace hip {
+#  define SARA_HIP_SHIM_NS_END }
+#else
+#  define SARA_HIP_SHIM_NS_BEGIN
+#  define SARA_HIP_SHIM_NS_END
 #endif
 
 namespace DO::Sara {
@@ -246,7 +261,21 @@ namespace DO::Sara {
     std::vector<T> _d;
   };
 
-  using Point2i = std::array<int, 2>;
+  //! Core/EigenExtension.hpp:139 (Eigen::Vector2i): constructor (x, y),
+  //! operator[] / operator() / x() / y().
+  struct Point2i
+  {
+    int v[2] = {0, 0};
+    Point2i() = default;
+    Point2i(int x, int y) : v{x, y} {}
+    int& operator[](int i) { return v[i]; }
+    int operator[](int i) const { return v[i]; }
+    int& operator()(int i) { return v[i]; }
+    int operator()(int i) const { return v[i]; }
+    int x() const { return v[0]; }
+    int y() const { return v[1]; }
+    bool operator==(const Point2i& o) const { return v[0] == o.v[0] && v[1] == o.v[1]; }
+  };
 
   //! Features/KeypointList.hpp:35-96.
   template <typename F, typename T>
@@ -511,6 +540,16 @@ namespace DO::Sara {
   }  // namespace hip_detail
 
   static_assert(sizeof(Rgb8) == 3, "Rgb8 must be three packed bytes");
+  // results are memcpy'd from sara_oeregion records (also inside Sara)
+  static_assert(sizeof(OERegion) == sizeof(sara_oeregion) &&
+                    alignof(OERegion) == 16,
+                "OERegion must be the 48-byte record of the C-ABI");
+
+  // Inside Sara these names already exist in DO::Sara (FeatureDetectors/
+  // SIFT.hpp:24-33, DoG.hpp:72-165, FeatureMatching/AnnMatcher.hpp:32-86,
+  // ImageProcessing/FastColorConversion.hpp:22-23): there the GPU versions
+  // are DO::Sara::hip::<same name>.
+  SARA_HIP_SHIM_NS_BEGIN
 
   //! ImageProcessing/FastColorConversion.hpp:22-23 (.cpp:42-66): same
   //! signature, same std::domain_error on a size mismatch.
@@ -594,7 +633,8 @@ namespace DO::Sara {
     int& rank() { return _rank; }
     float score() const { return _score; }
     Direction matching_direction() const { return _matching_dir; }
-    bool operator==(const Match& m) const { return _x == m._x && _y == m._y; }
+    //! Match.hpp:161-164: equality of the two keypoints BY VALUE.
+    bool operator==(const Match& m) const { return x() == m.x() && y() == m.y(); }
 
   private:
     const OERegion* _x = nullptr;
@@ -603,9 +643,12 @@ namespace DO::Sara {
     float _score = std::numeric_limits<float>::max();
     Direction _matching_dir = Direction::SourceToTarget;
   };
+#endif  // !SARA_HIP_WITH_SARA_HEADERS (inside Sara: DO/Sara/Match/Match.hpp)
 
-  //! FeatureMatching/AnnMatcher.hpp:32-66 (two key sets): the neighbour
-  //! search runs exhaustively on the GPU with FLANN's distance arithmetic.
+  //! FeatureMatching/AnnMatcher.hpp:32-86, both constructors and their
+  //! defaults (sift_ratio_thres = 1.2f: the adaptive radius search,
+  //! AnnMatcher.cpp:133-138).  The neighbour searches run on the GPU, exact,
+  //! with FLANN's distance arithmetic; `device` is an extension, defaulted.
   class AnnMatcher
   {
   public:
@@ -620,18 +663,55 @@ namespace DO::Sara {
             "The list of keypoints are inconsistent in size!"};
     }
 
+    //! Self-matching (AnnMatcher.hpp:42-46, .cpp:199-215).
+    AnnMatcher(const KeypointList<OERegion, float>& keys,
+               float sift_ratio_thres = 1.2f,
+               float min_max_metric_dist_thres = 0.5f,
+               float pixel_dist_thres = 10.f, int device = 0)
+      : _keys1{keys}, _keys2{keys}, _ratio{sift_ratio_thres}
+      , _metric_dist_thres{min_max_metric_dist_thres}
+      , _pixel_dist_thres{pixel_dist_thres}, _self_matching{true}
+      , _device{device}
+    {
+      if (!size_consistency_predicate(_keys1))
+        throw std::runtime_error{
+            "The list of keypoints are inconsistent in size!"};
+    }
+
+    auto keys1() const -> const KeypointList<OERegion, float>& { return _keys1; }
+    auto keys2() const -> const KeypointList<OERegion, float>& { return _keys2; }
+
     auto compute_matches() -> std::vector<Match>
     {
       const auto& f1 = features(_keys1);
       const auto& f2 = features(_keys2);
       const auto& d1 = descriptors(_keys1);
       const auto& d2 = descriptors(_keys2);
-      auto raw = std::vector<sara_match>(f1.size() + f2.size() + 1);
+      // above ratio 1 a key can have several matches: retry with the count
+      // the library reports
+      auto raw = std::vector<sara_match>(2 * (f1.size() + f2.size()) + 16);
       int count = 0;
-      hip_detail::check(sara_hip_match_descriptors(
-          d1.data(), int(f1.size()), d2.data(), int(f2.size()),
-          f1.empty() ? int(d2.cols()) : int(d1.cols()), _ratio, 0, raw.data(),
-          int(raw.size()), &count, _device));
+      for (int attempt = 0; attempt < 2; ++attempt)
+      {
+        const auto st =
+            _self_matching
+                ? sara_hip_self_match_descriptors(
+                      d1.data(), reinterpret_cast<const sara_oeregion*>(f1.data()),
+                      int(f1.size()), int(d1.cols()), _ratio, _metric_dist_thres,
+                      _pixel_dist_thres, 0, raw.data(), int(raw.size()), &count,
+                      _device)
+                : sara_hip_match_descriptors(
+                      d1.data(), int(f1.size()), d2.data(), int(f2.size()),
+                      f1.empty() ? int(d2.cols()) : int(d1.cols()), _ratio, 0,
+                      raw.data(), int(raw.size()), &count, _device);
+        if (st == SARA_HIP_CAPACITY_EXCEEDED && attempt == 0)
+        {
+          raw.resize(size_t(count));
+          continue;
+        }
+        hip_detail::check(st);
+        break;
+      }
       auto matches = std::vector<Match>{};
       matches.reserve(size_t(count));
       for (int i = 0; i < count; ++i)
@@ -646,10 +726,14 @@ namespace DO::Sara {
       return matches;
     }
 
+    auto compute_self_matches() -> std::vector<Match> { return compute_matches(); }
+
   private:
     const KeypointList<OERegion, float>& _keys1;
     const KeypointList<OERegion, float>& _keys2;
     float _ratio;
+    float _metric_dist_thres = 0.5f, _pixel_dist_thres = 10.f;
+    bool _self_matching = false;
     int _device;
   };
 
@@ -661,7 +745,6 @@ namespace DO::Sara {
     AnnMatcher matcher{keys1, keys2, lowe_ratio};
     return matcher.compute_matches();
   }
-#endif  // !SARA_HIP_WITH_SARA_HEADERS (inside Sara: see INTEGRATION.md)
 
   //! FeatureDescriptors/RootSIFT.hpp:45-53 applied to the descriptor matrix of a
   //! keypoint list (ComputeRootSIFTDescriptor wraps the base operator and
@@ -729,7 +812,7 @@ namespace DO::Sara {
         const int s = xyso[5 * i + 2], o = xyso[5 * i + 3];
         _extrema[size_t(o) * nd + s].push_back(extrema[i]);
         if (scale_octave_pairs)
-          scale_octave_pairs->push_back(Point2i{{s, o}});
+          scale_octave_pairs->push_back(Point2i(s, o));
       }
       return extrema;
     }
@@ -794,4 +877,9 @@ namespace DO::Sara {
     std::vector<std::vector<OERegion>> _extrema;
   };
 
+  SARA_HIP_SHIM_NS_END
+
 }  // namespace DO::Sara
+
+#undef SARA_HIP_SHIM_NS_BEGIN
+#undef SARA_HIP_SHIM_NS_END

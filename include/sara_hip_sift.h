@@ -10,7 +10,8 @@
  *   OERegion / KeypointList             Features/Feature.hpp:40-179,
  *                                       Features/KeypointList.hpp:35-96
  *   from_rgb8_to_gray32f()              ImageProcessing/FastColorConversion.cpp:42-66
- *   AnnMatcher::compute_matches()       FeatureMatching/AnnMatcher.cpp:203-268
+ *   AnnMatcher (both constructors)      FeatureMatching/AnnMatcher.hpp:32-86,
+ *                                       AnnMatcher.cpp:59-268
  *
  * Plain C: pointers, sizes and PODs only.  No exceptions cross this boundary;
  * every entry point returns a sara_hip_status and the message is available
@@ -413,21 +414,53 @@ SARA_HIP_API sara_hip_status sara_hip_root_sift(float* desc, int n, int dim,
                                                int on_device, int device);
 
 /* match(keys1, keys2, lowe_ratio) - SfM/Helpers/KeypointMatching.cpp:19-25 ->  */
-/* AnnMatcher{keys1, keys2, ratio}.compute_matches(): nearest / second nearest  */
-/* neighbour in both directions, Lowe's ratio on SQUARED distances against      */
-/* ratio^2, duplicates (x, y) removed, sorted by score.  The neighbour search   */
-/* is exhaustive (what the reference's FLANN kd-trees approximate), with        */
-/* FLANN's squared-L2 arithmetic.  desc1: n1 x dim, desc2: n2 x dim row-major   */
-/* floats (host pointers, or device pointers when on_device != 0); dim <= 128.  */
-/* matches: host array of `capacity` records (n1 + n2 always suffices);         */
-/* *count = number of matches found; SARA_HIP_CAPACITY_EXCEEDED if it does not  */
-/* fit.  Empty key sets: SARA_HIP_RUNTIME_ERROR, like the reference's           */
-/* std::runtime_error (AnnMatcher.cpp:44-45); ratios above 1 (FLANN radius      */
-/* search, :132-136) are not supported: SARA_HIP_INVALID_PARAMS.                */
+/* AnnMatcher{keys1, keys2, ratio}.compute_matches() (FeatureMatching/          */
+/* AnnMatcher.cpp:173-268): for every key of either set FLANN's knnSearch(3)     */
+/* in the other set, score = squared-distance ratio best / second best          */
+/* (:126-130); then                                                             */
+/*   ratio^2 <= 1 : the best neighbour, if its score passes (rank 1);           */
+/*   ratio^2 >  1 : (the reference's DEFAULT, sift_ratio_thres = 1.2f,          */
+/*                  AnnMatcher.hpp:36-46) the adaptive radius search of         */
+/*                  :133-138 - every neighbour closer than d_best * ratio^2,    */
+/*                  ranks 1..K in (distance, index) order, score d_rank /       */
+/*                  d_best, until one exceeds ratio^2; a best distance of       */
+/*                  exactly 0 gives radius 0 and hence no match for that key    */
+/*                  (kept);                                                     */
+/* both directions, duplicates (x, y) removed (best score kept), sorted by      */
+/* score.  The neighbour searches are exact (what the reference's FLANN         */
+/* kd-trees approximate), with FLANN's squared-L2 arithmetic.  desc1: n1 x dim, */
+/* desc2: n2 x dim row-major floats (host pointers, or device pointers when     */
+/* on_device != 0); dim <= 128.  matches: host array of `capacity` records      */
+/* (n1 + n2 always suffices for ratio <= 1; above 1 a key can have several      */
+/* matches: on SARA_HIP_CAPACITY_EXCEEDED *count holds the number needed).      */
+/* Empty key sets: SARA_HIP_RUNTIME_ERROR, like the reference's                 */
+/* std::runtime_error (AnnMatcher.cpp:44-45).                                   */
 SARA_HIP_API sara_hip_status sara_hip_match_descriptors(
     const float* desc1, int n1, const float* desc2, int n2, int dim,
     float sift_ratio_thres, int on_device, sara_match* matches, int capacity,
     int* count, int device);
+
+/* AnnMatcher{keys, ratio, min_max_metric_dist_thres, pixel_dist_thres}         */
+/* .compute_matches() - the self-matching constructor (AnnMatcher.hpp:42-46,    */
+/* .cpp:199-215): one key set matched against itself.  Rank 0 of every search   */
+/* is taken to be the key itself (:124-125), so ranks start at the second       */
+/* entry, and a neighbour is dropped when KeyProximity finds the two keys too   */
+/* close (FeatureMatching/KeyProximity.cpp:17-30: squared pixel distance below  */
+/* pixel_dist_thres^2, or either key's shape-matrix metric below                */
+/* min_max_metric_dist_thres^2).  With ratio^2 <= 1 the reference emits nothing */
+/* in this mode (its loop runs over ranks [1, K = 1)) - kept.  Duplicates are   */
+/* removed by Match::operator==, which compares the OERegions by value          */
+/* (Match/Match.hpp:161-164).  features: host array of n sara_oeregion; desc: n */
+/* x dim floats on the host, or in HBM when desc_on_device != 0.                */
+SARA_HIP_API sara_hip_status sara_hip_self_match_descriptors(
+    const float* desc, const sara_oeregion* features, int n, int dim,
+    float sift_ratio_thres, float min_max_metric_dist_thres,
+    float pixel_dist_thres, int desc_on_device, sara_match* matches, int capacity,
+    int* count, int device);
+
+/* The matcher keeps grow-only scratch buffers per (calling thread, device)     */
+/* between calls (allocating them costs more than a search); this frees them.   */
+SARA_HIP_API sara_hip_status sara_hip_match_release_workspace(int device);
 
 /* -------------------------------------------------------------------------- */
 /* Pipelined host-to-host operation (the metric of SURVEY.md section 8d: frames */

@@ -1770,28 +1770,52 @@ namespace sara_ref {
   // ======================================================================== //
   // Descriptor matching.
   //
-  // Reference: AnnMatcher::compute_matches and append_nearest_neighbors,
-  // FeatureMatching/AnnMatcher.cpp:59-268 (two key sets, not self-matching),
-  // called by match(), SfM/Helpers/KeypointMatching.cpp:19-25.  The reference
-  // queries FLANN kd-trees (un-vendored search heuristics: 8 randomised trees,
-  // 32 checks), whose answers are *approximations* of the exact nearest
-  // neighbours and depend on FLANN's random seeds.  This restatement replaces
-  // the tree query by an exhaustive search - what FLANN converges to with
-  // unlimited checks - and keeps everything else: FLANN's squared L2 distance
-  // in its own summation order (third-party/flann/.../dist.h:150-178: groups
-  // of four, float accumulator), Lowe's ratio on squared distances with the
-  // squared threshold, both directions, sort by (x, y, score), unique on
-  // (x, y), final sort by score.  PARITY UNPINNED against the reference's FLANN
-  // results; pinned by the reference's only matcher test
-  // (test_featurematching_matching.cpp:29-62: one match, score 0).
-  // Distance ties: the lower index wins (FLANN: traversal order).
+  // Reference: AnnMatcher (both constructors), compute_matches and
+  // append_nearest_neighbors, FeatureMatching/AnnMatcher.cpp:59-268, called by
+  // match(), SfM/Helpers/KeypointMatching.cpp:19-25; KeyProximity,
+  // FeatureMatching/KeyProximity.cpp:17-30 with SquaredRefDistance,
+  // Geometry/Tools/Metric.hpp:47-50.  The reference queries FLANN kd-trees
+  // (un-vendored search heuristics: 8 randomised trees, 32 checks), whose
+  // answers are *approximations* of the exact nearest neighbours and depend on
+  // FLANN's random seeds.  This restatement replaces the tree queries by
+  // exhaustive ones - what FLANN converges to with unlimited checks - and
+  // keeps everything else:
+  //   * FLANN's squared L2 distance in its own summation order
+  //     (flann/algorithms/dist.h:150-178: groups of four, float accumulator);
+  //   * knnSearch(3) -> top1_score = d[top1] / d[top1 + 1]
+  //     (AnnMatcher.cpp:126-130), top1 = 1 when self-matching (rank 0 is taken
+  //     to be the query itself, :124-125);
+  //   * squared ratio > 1 (the DEFAULT, sift_ratio_thres = 1.2f,
+  //     AnnMatcher.hpp:36-46): the adaptive radius search of :133-138 -
+  //     radius = d[top1] * thres^2, FLANN's RadiusResultSet keeps dist < radius
+  //     (flann/util/result_set.h, strict), sorted by (dist, index); ranks
+  //     top1 .. K - 1 are emitted with score d[rank] / d[top1] until one
+  //     exceeds the threshold (:141-154); a zero best distance gives radius 0,
+  //     hence K = 0 and NO match at all - kept;
+  //   * squared ratio <= 1: K = 1, i.e. only the best neighbour - and nothing
+  //     at all when self-matching (the loop starts at rank 1) - kept;
+  //   * the boundary cases :80-120 (one candidate; two keys self-matching);
+  //   * KeyProximity on self-matches (:160-161);
+  //   * both directions, sort by (x, y, score), unique, final sort by score.
+  // Match::operator== compares the two OERegions BY VALUE (Match.hpp:161-164
+  // with Feature.hpp:140-146), so std::unique also drops consecutive matches
+  // between distinct keypoints with equal (coords, shape, orientation, type);
+  // after the (x_index, y_index) sort that can only merge equal-valued
+  // duplicates of a keypoint.  The two-set entry below has no features and
+  // compares indices; the self-matching entry compares values as the
+  // reference does.
+  // PARITY UNPINNED against the reference's FLANN results; pinned by the
+  // reference's only matcher test (test_featurematching_matching.cpp:29-62:
+  // one match, score 0 - reproduced with the default-ratio rule above only
+  // because that test passes ratio 1.0) and test_featurematching_key_proximity
+  // .cpp.  Distance ties: the lower index first (FLANN: traversal order).
   // ======================================================================== //
   struct Match
   {
     int32_t x_index;   //!< index in the first key set
     int32_t y_index;   //!< index in the second key set
-    float score;       //!< squared-distance ratio best / second best
-    int32_t rank;      //!< 1 (only the best neighbour passes a ratio <= 1)
+    float score;       //!< squared-distance ratio
+    int32_t rank;      //!< 1 = best neighbour, 2.. = further ones in the radius
     int32_t direction; //!< 0 = SourceToTarget, 1 = TargetToSource
   };
 
@@ -1814,61 +1838,119 @@ namespace sara_ref {
     return result;
   }
 
+  //! The part of an OERegion the matcher looks at (Feature.hpp:155-177).
+  struct MatchFeature
+  {
+    float x, y;
+    float m00, m10, m01, m11;  // shape matrix, column-major
+    float orientation;
+    int type;
+    bool operator==(const MatchFeature& o) const  // Feature.hpp:140-146
+    {
+      return x == o.x && y == o.y && m00 == o.m00 && m10 == o.m10 &&
+             m01 == o.m01 && m11 == o.m11 && orientation == o.orientation &&
+             type == o.type;
+    }
+  };
+
+  //! KeyProximity::operator() (KeyProximity.cpp:17-30).
+  struct KeyProximity
+  {
+    float squared_metric_dist = 0.5f * 0.5f;
+    float squared_dist_thres = 10.f * 10.f;
+    KeyProximity() = default;
+    KeyProximity(float metric_dist_thres, float pixel_dist_thres)
+      : squared_metric_dist(metric_dist_thres * metric_dist_thres)
+      , squared_dist_thres(pixel_dist_thres * pixel_dist_thres)
+    {
+    }
+    //! (b - a).dot(M (b - a)), Metric.hpp:47-50 (2 x 2 coefficient products).
+    static float metric(const MatchFeature& f, float vx, float vy)
+    {
+      const float r0 = f.m00 * vx + f.m01 * vy;
+      const float r1 = f.m10 * vx + f.m11 * vy;
+      return vx * r0 + vy * r1;
+    }
+    bool operator()(const MatchFeature& f1, const MatchFeature& f2) const
+    {
+      const float sd1 = metric(f1, f2.x - f1.x, f2.y - f1.y);
+      const float sd2 = metric(f2, f2.x - f1.x, f2.y - f1.y);
+      const float dx = f1.x - f2.x, dy = f1.y - f2.y;
+      const float squared_pixel_dist = dx * dx + dy * dy;
+      return squared_pixel_dist < squared_dist_thres ||
+             sd1 < squared_metric_dist || sd2 < squared_metric_dist;
+    }
+  };
+
   //! append_nearest_neighbors for every row of `q` against `t`
-  //! (AnnMatcher.cpp:59-170, self_matching == false, squared ratio <= 1).
+  //! (AnnMatcher.cpp:59-170).  fq / ft: features (self-matching only).
   inline void append_matches(const float* q, int nq, const float* t, int nt,
                              int dim, float squared_ratio_thres, int direction,
+                             bool self_matching, const KeyProximity& is_redundant,
+                             const MatchFeature* fq, const MatchFeature* ft,
                              std::vector<Match>& matches)
   {
     if (nt == 0)
       return;
+    auto push = [&](int i1, int i2, float score, int rank) {
+      matches.push_back(direction == 0 ? Match{i1, i2, score, rank, direction}
+                                       : Match{i2, i1, score, rank, direction});
+    };
+    std::vector<std::pair<float, int>> nn(static_cast<size_t>(nt));
     for (int i = 0; i < nq; ++i)
     {
-      if (nt == 1)
+      if (nt == 1 && !self_matching)
       {
         // AnnMatcher.cpp:87-101: a single candidate gets score 1.
         if (1.f < squared_ratio_thres)
-          matches.push_back(direction == 0 ? Match{i, 0, 1.f, 1, direction}
-                                           : Match{0, i, 1.f, 1, direction});
+          push(i, 0, 1.f, 1);
         continue;
       }
-      float d0 = std::numeric_limits<float>::max(), d1 = d0;
-      int i0 = -1;
       for (int j = 0; j < nt; ++j)
+        nn[size_t(j)] = {flann_l2(q + size_t(i) * dim, t + size_t(j) * dim, dim), j};
+      // FLANN's result sets order by (distance, index)
+      std::sort(nn.begin(), nn.end());
+      if (nt == 2 && self_matching)
       {
-        const float d = flann_l2(q + size_t(i) * dim, t + size_t(j) * dim, dim);
-        if (d < d0)
-        {
-          d1 = d0;
-          d0 = d;
-          i0 = j;
-        }
-        else if (d < d1)
-          d1 = d;
-      }
-      // AnnMatcher.cpp:126-130, 139-147.
-      const float score = d1 > 0.f ? d0 / d1 : 0.f;
-      if (score > squared_ratio_thres)
+        // AnnMatcher.cpp:103-120: the second neighbour, score 1, no proximity test
+        if (1.f < squared_ratio_thres)
+          push(i, nn[1].second, 1.f, 1);
         continue;
-      matches.push_back(direction == 0 ? Match{i, i0, score, 1, direction}
-                                       : Match{i0, i, score, 1, direction});
+      }
+      const int top1 = self_matching ? 1 : 0;
+      if (top1 + 1 >= nt)
+        continue;  // a single key self-matching: knnSearch has nothing to rank
+      const float d_top1 = nn[size_t(top1)].first;
+      const float top1_score =
+          nn[size_t(top1) + 1].first > 0.f ? d_top1 / nn[size_t(top1) + 1].first : 0.f;
+      int K = 1;
+      if (squared_ratio_thres > 1.f)
+      {
+        const float radius = d_top1 * squared_ratio_thres;
+        K = 0;
+        while (K < nt && nn[size_t(K)].first < radius)
+          ++K;
+      }
+      for (int rank = top1; rank < K; ++rank)
+      {
+        float score = 0.f;
+        if (rank == top1)
+          score = top1_score;
+        else if (d_top1)
+          score = nn[size_t(rank)].first / d_top1;
+        if (score > squared_ratio_thres)
+          break;
+        const int i2 = nn[size_t(rank)].second;
+        if (self_matching && is_redundant(fq[i], ft[i2]))
+          continue;
+        push(i, i2, score, top1 == 0 ? rank + 1 : rank);
+      }
     }
   }
 
-  inline std::vector<Match> compute_matches(const float* desc1, int n1,
-                                            const float* desc2, int n2, int dim,
-                                            float sift_ratio_thres)
+  inline void finish_matches(std::vector<Match>& matches, const MatchFeature* f1,
+                             const MatchFeature* f2)
   {
-    // create_flann_matrix, AnnMatcher.cpp:42-54.
-    if (n1 == 0 || n2 == 0)
-      throw std::runtime_error{"Error: the list of key-points is empty!"};
-    if (sift_ratio_thres > 1.f)
-      throw std::runtime_error{
-          "ratio thresholds above 1 (FLANN radius search) are not restated"};
-    const float thres2 = sift_ratio_thres * sift_ratio_thres;
-    std::vector<Match> matches;
-    append_matches(desc1, n1, desc2, n2, dim, thres2, 0, matches);
-    append_matches(desc2, n2, desc1, n1, dim, thres2, 1, matches);
     // AnnMatcher.cpp:239-258.
     std::sort(matches.begin(), matches.end(), [](const Match& a, const Match& b) {
       if (a.x_index != b.x_index)
@@ -1879,11 +1961,17 @@ namespace sara_ref {
         return a.score < b.score;
       // equal scores from the two directions (e.g. bit-identical
       // descriptors, score 0): std::sort leaves their order unspecified in
-      // the reference; SourceToTarget first is one valid outcome
-      return a.direction < b.direction;
+      // the reference; SourceToTarget first, lower rank first is one valid
+      // outcome
+      if (a.direction != b.direction)
+        return a.direction < b.direction;
+      return a.rank < b.rank;
     });
     matches.erase(std::unique(matches.begin(), matches.end(),
-                              [](const Match& a, const Match& b) {
+                              [&](const Match& a, const Match& b) {
+                                if (f1 && f2)
+                                  return f1[a.x_index] == f1[b.x_index] &&
+                                         f2[a.y_index] == f2[b.y_index];
                                 return a.x_index == b.x_index &&
                                        a.y_index == b.y_index;
                               }),
@@ -1897,6 +1985,44 @@ namespace sara_ref {
         return a.x_index < b.x_index;
       return a.y_index < b.y_index;
     });
+  }
+
+  //! AnnMatcher{keys1, keys2, ratio}.compute_matches().
+  inline std::vector<Match> compute_matches(const float* desc1, int n1,
+                                            const float* desc2, int n2, int dim,
+                                            float sift_ratio_thres)
+  {
+    // create_flann_matrix, AnnMatcher.cpp:42-54.
+    if (n1 == 0 || n2 == 0)
+      throw std::runtime_error{"Error: the list of key-points is empty!"};
+    const float thres2 = sift_ratio_thres * sift_ratio_thres;
+    std::vector<Match> matches;
+    const KeyProximity unused;
+    append_matches(desc1, n1, desc2, n2, dim, thres2, 0, false, unused, nullptr,
+                   nullptr, matches);
+    append_matches(desc2, n2, desc1, n1, dim, thres2, 1, false, unused, nullptr,
+                   nullptr, matches);
+    finish_matches(matches, nullptr, nullptr);
+    return matches;
+  }
+
+  //! AnnMatcher{keys, ratio, min_max_metric_dist_thres, pixel_dist_thres}
+  //! .compute_matches() (the self-matching constructor, AnnMatcher.cpp:199-215).
+  inline std::vector<Match> compute_self_matches(
+      const float* desc, const MatchFeature* features, int n, int dim,
+      float sift_ratio_thres, float min_max_metric_dist_thres,
+      float pixel_dist_thres)
+  {
+    if (n == 0)
+      throw std::runtime_error{"Error: the list of key-points is empty!"};
+    const float thres2 = sift_ratio_thres * sift_ratio_thres;
+    const KeyProximity too_close{min_max_metric_dist_thres, pixel_dist_thres};
+    std::vector<Match> matches;
+    append_matches(desc, n, desc, n, dim, thres2, 0, true, too_close, features,
+                   features, matches);
+    append_matches(desc, n, desc, n, dim, thres2, 1, true, too_close, features,
+                   features, matches);
+    finish_matches(matches, features, features);
     return matches;
   }
 

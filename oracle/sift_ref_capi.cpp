@@ -278,6 +278,42 @@ int ref_compute_matches(const float* desc1, int n1, const float* desc2, int n2,
   }
 }
 
+//! Self-matching constructor.  features: n x 8 floats (x, y, m00, m10, m01, m11,
+//! orientation, type).
+int ref_compute_self_matches(const float* desc, const float* features, int n,
+                             int dim, float sift_ratio_thres,
+                             float min_max_metric_dist_thres,
+                             float pixel_dist_thres, Match* out, int capacity)
+{
+  try
+  {
+    std::vector<MatchFeature> f(static_cast<size_t>(n));
+    for (int i = 0; i < n; ++i)
+    {
+      const float* r = features + size_t(i) * 8;
+      f[size_t(i)] = MatchFeature{r[0], r[1], r[2], r[3], r[4], r[5], r[6], int(r[7])};
+    }
+    const auto m = compute_self_matches(desc, f.data(), n, dim, sift_ratio_thres,
+                                        min_max_metric_dist_thres, pixel_dist_thres);
+    for (int i = 0; i < int(m.size()) && i < capacity; ++i)
+      out[i] = m[i];
+    return int(m.size());
+  }
+  catch (const std::exception& e)
+  {
+    g_last_error = e.what();
+    return -1;
+  }
+}
+
+int ref_key_proximity(const float* f1, const float* f2, float metric_dist_thres,
+                      float pixel_dist_thres)
+{
+  const MatchFeature a{f1[0], f1[1], f1[2], f1[3], f1[4], f1[5], f1[6], int(f1[7])};
+  const MatchFeature b{f2[0], f2[1], f2[2], f2[3], f2[4], f2[5], f2[6], int(f2[7])};
+  return KeyProximity{metric_dist_thres, pixel_dist_thres}(a, b) ? 1 : 0;
+}
+
 float ref_flann_l2(const float* a, const float* b, int size)
 {
   return flann_l2(a, b, size);

@@ -386,13 +386,19 @@ class SiftContext:
         off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         _, d_desc, _, _ = self.device_results()
         n1, n2 = int(counts[i]), int(counts[j])
-        cap = n1 + n2
-        out = np.zeros(max(cap, 1), MATCH_DTYPE)
-        count = C.c_int(0)
-        capi.check(capi.load().sara_hip_match_descriptors(
-            d_desc + int(off[i]) * 512, n1, d_desc + int(off[j]) * 512, n2, 128,
-            float(lowe_ratio), 1, out.ctypes.data, cap, C.byref(count),
-            self.device))
+        cap = 2 * (n1 + n2) + 16
+        for _ in range(2):
+            out = np.zeros(max(cap, 1), MATCH_DTYPE)
+            count = C.c_int(0)
+            st = capi.load().sara_hip_match_descriptors(
+                d_desc + int(off[i]) * 512, n1, d_desc + int(off[j]) * 512, n2,
+                128, float(lowe_ratio), 1, out.ctypes.data, cap, C.byref(count),
+                self.device)
+            if st == capi.CAPACITY_EXCEEDED and count.value > cap:
+                cap = count.value
+                continue
+            capi.check(st)
+            break
         return out[:count.value]
 
     def keypoint_lists(self, with_descriptors=True):
@@ -648,22 +654,50 @@ def root_sift(desc, device=0):
 
 
 class AnnMatcher:
-    """FeatureMatching/AnnMatcher.hpp:40-66 for two key sets: Lowe's ratio
-    matching in both directions on squared L2 distances, duplicates removed,
-    sorted by score.  The neighbour search is exhaustive on the GPU (the
-    reference's FLANN kd-trees approximate it).  ``compute_matches`` returns a
-    structured array (x_index, y_index, score, rank, direction)."""
+    """FeatureMatching/AnnMatcher.hpp:32-86, both constructors:
 
-    def __init__(self, keys1, keys2, sift_ratio_thres=1.2, device=0):
-        self._d1 = self._descriptors(keys1)
-        self._d2 = self._descriptors(keys2)
-        if (isinstance(keys1, KeypointList) and
-                len(keys1.regions) != len(self._d1)) or \
-           (isinstance(keys2, KeypointList) and
-                len(keys2.regions) != len(self._d2)):
-            # AnnMatcher.cpp:181-184
-            raise RuntimeError("The list of keypoints are inconsistent in size!")
-        self._ratio = float(sift_ratio_thres)
+    ``AnnMatcher(keys1, keys2, sift_ratio_thres=1.2)`` - two key sets;
+    ``AnnMatcher(keys, sift_ratio_thres=1.2, min_max_metric_dist_thres=0.5,
+    pixel_dist_thres=10.0)`` - one key set against itself, neighbours that
+    KeyProximity finds too close dropped (needs a KeypointList: the filter
+    reads the OERegions).
+
+    Lowe's ratio on squared L2 distances in both directions, duplicates
+    removed, sorted by score; a ratio above 1 (the default) is the reference's
+    adaptive radius search and yields matches of rank > 1.  The neighbour
+    searches are exact on the GPU (the reference's FLANN kd-trees approximate
+    them).  ``compute_matches`` returns a structured array (x_index, y_index,
+    score, rank, direction)."""
+
+    def __init__(self, keys1, keys2=None, *args, device=0, **kw):
+        names = ("sift_ratio_thres", "min_max_metric_dist_thres", "pixel_dist_thres")
+        self._self_matching = keys2 is None or np.isscalar(keys2)
+        if self._self_matching:
+            # AnnMatcher(keys, ratio, metric_thres, pixel_thres)
+            pos = ([] if keys2 is None else [keys2]) + list(args)
+            opt = dict(zip(names, pos))
+            opt.update(kw)
+            if not isinstance(keys1, KeypointList):
+                raise TypeError("self-matching needs a KeypointList (features "
+                                "and descriptors)")
+            self._d1 = self._d2 = self._descriptors(keys1)
+            self._regions = np.ascontiguousarray(keys1.regions)
+            if len(self._regions) != len(self._d1):
+                raise RuntimeError("The list of keypoints are inconsistent in size!")
+            self._metric = float(opt.get("min_max_metric_dist_thres", 0.5))
+            self._pixel = float(opt.get("pixel_dist_thres", 10.0))
+        else:
+            opt = dict(zip(names[:1], args))
+            opt.update(kw)
+            self._d1 = self._descriptors(keys1)
+            self._d2 = self._descriptors(keys2)
+            if (isinstance(keys1, KeypointList) and
+                    len(keys1.regions) != len(self._d1)) or \
+               (isinstance(keys2, KeypointList) and
+                    len(keys2.regions) != len(self._d2)):
+                # AnnMatcher.cpp:181-184
+                raise RuntimeError("The list of keypoints are inconsistent in size!")
+        self._ratio = float(opt.get("sift_ratio_thres", 1.2))
         self._device = device
 
     @staticmethod
@@ -678,19 +712,35 @@ class AnnMatcher:
         d1, d2 = self._d1, self._d2
         if d1.shape[0] and d2.shape[0] and d1.shape[1] != d2.shape[1]:
             raise ValueError("descriptor dimensions differ")
-        cap = d1.shape[0] + d2.shape[0]
-        out = np.zeros(max(cap, 1), MATCH_DTYPE)
-        count = C.c_int(0)
-        capi.check(capi.load().sara_hip_match_descriptors(
-            d1.ctypes.data, d1.shape[0], d2.ctypes.data, d2.shape[0],
-            d1.shape[1] if d1.shape[0] else (d2.shape[1] if d2.ndim == 2 else 0),
-            self._ratio, 0, out.ctypes.data, cap, C.byref(count), self._device))
+        dim = d1.shape[1] if d1.shape[0] else (d2.shape[1] if d2.ndim == 2 else 0)
+        lib = capi.load()
+        cap = 2 * (d1.shape[0] + d2.shape[0]) + 16
+        for _ in range(2):
+            out = np.zeros(max(cap, 1), MATCH_DTYPE)
+            count = C.c_int(0)
+            if self._self_matching:
+                st = lib.sara_hip_self_match_descriptors(
+                    d1.ctypes.data, self._regions.ctypes.data, d1.shape[0], dim,
+                    self._ratio, self._metric, self._pixel, 0, out.ctypes.data,
+                    cap, C.byref(count), self._device)
+            else:
+                st = lib.sara_hip_match_descriptors(
+                    d1.ctypes.data, d1.shape[0], d2.ctypes.data, d2.shape[0], dim,
+                    self._ratio, 0, out.ctypes.data, cap, C.byref(count),
+                    self._device)
+            if st == capi.CAPACITY_EXCEEDED and count.value > cap:
+                cap = count.value       # several matches per key: exact count
+                continue
+            capi.check(st)
+            break
         return out[:count.value]
+
+    compute_self_matches = compute_matches
 
 
 def match(keys1, keys2, lowe_ratio, device=0):
     """SfM/Helpers/KeypointMatching.cpp:19-25."""
-    return AnnMatcher(keys1, keys2, lowe_ratio, device).compute_matches()
+    return AnnMatcher(keys1, keys2, lowe_ratio, device=device).compute_matches()
 
 
 def _ostream_float(v):

@@ -98,7 +98,8 @@ EXPORTS = [
     "sara_hip_sift_ticket_counts", "sara_hip_sift_collect_into",
     "sara_hip_host_register", "sara_hip_host_unregister",
     "sara_hip_comm_transport", "sara_hip_sift_group_collect_host",
-    "sara_hip_sift_group_transport",
+    "sara_hip_sift_group_transport", "sara_hip_self_match_descriptors",
+    "sara_hip_match_release_workspace",
 ]
 
 _f32p = C.POINTER(C.c_float)
@@ -180,6 +181,10 @@ def _declare(lib):
     lib.sara_hip_match_descriptors.argtypes = [
         _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, C.c_int,
         C.POINTER(C.c_int), C.c_int]
+    lib.sara_hip_self_match_descriptors.argtypes = [
+        _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, _vp,
+        C.c_int, C.POINTER(C.c_int), C.c_int]
+    lib.sara_hip_match_release_workspace.argtypes = [C.c_int]
     lib.sara_hip_root_sift.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.sara_hip_selfcheck_atan2f.argtypes = [_f32p, _f32p, _f32p, C.c_size_t]
     lib.sara_hip_selfcheck_atan2f.restype = None

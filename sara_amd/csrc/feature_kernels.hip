@@ -8,6 +8,8 @@
 // Wave = 64 lanes everywhere; workgroups are 256 threads = 4 waves.
 #include "sift_kernels.hpp"
 
+#include <atomic>
+
 #include "device_math.hpp"
 
 #include <cmath>
@@ -1685,13 +1687,17 @@ namespace sara_hip {
     const size_t lds = sizeof(int) * (size_t(rb.total) + 1 + 1024);
     if (!split && lds <= 150 * 1024)
     {
-      static size_t allowed = 64 * 1024;
-      if (lds > allowed)
+      // the attribute is per DEVICE (one process may drive all GPUs of a
+      // node, sara_hip_sift_group_*) and several host threads may get here
+      static std::atomic<bool> allowed[64];
+      int dev = 0;
+      (void) hipGetDevice(&dev);
+      if (lds > 64 * 1024 && !allowed[dev & 63].load(std::memory_order_acquire))
       {
         (void) hipFuncSetAttribute(
             reinterpret_cast<const void*>(bucket_sort_fused_kernel),
             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        allowed = 160 * 1024;
+        allowed[dev & 63].store(true, std::memory_order_release);
       }
       hipLaunchKernelGGL(bucket_sort_fused_kernel, dim3(batch), dim3(1024), lds,
                          stream, cand, rb, grouped);

@@ -9,17 +9,25 @@
 // float accumulator, no FMA), so scores are bit-identical to an exhaustive CPU
 // search in that arithmetic (checked by tests/test_gpu_matching.py).
 //
-// nn2_kernel: one wave = 64 queries (one per lane) x one chunk of candidates.
+// What a query needs from the search (sift_match.cpp has the decision logic):
+//   * its three nearest neighbours ordered by (distance, index) = FLANN's
+//     knnSearch(3), AnnMatcher.cpp:123 (rank 0 is the query itself when a key
+//     set is matched against itself);
+//   * when the squared ratio threshold exceeds 1 (the reference's default,
+//     1.2^2): every neighbour with distance < d_top1 * threshold = FLANN's
+//     radiusSearch, :133-138.
+//
+// Exhaustive kernels (this file's first half):
+// nn3_kernel: one wave = 64 queries (one per lane) x one chunk of candidates.
 // A tile of 32 candidates is staged in LDS; per group of four dimensions the
 // lane loads its own four query values (its row stays in L1/L2 across tiles;
 // staging the 64 query rows in LDS as well would cap the CU at 3 waves) and
 // reads every candidate's four values as an LDS broadcast; 32 per-candidate
 // accumulators live in registers so that each distance is summed group by
-// group in FLANN's order.  The per-chunk
-// (best, second best) pairs are merged in chunk order by merge_kernel, which
-// also applies Lowe's ratio test on the squared distances and appends.
-// N x M x 128 subtract/multiply/add at VALU rate: exact float32 semantics,
-// which an MFMA contraction (|a|^2 + |b|^2 - 2ab) would not give.
+// group in FLANN's order.  The per-chunk top-3 lists are merged in chunk
+// order by merge3_kernel (ties keep the lower index).  radius_kernel repeats
+// the distances and appends the neighbours inside each query's radius.
+// N x M x 128 subtract/multiply/add at VALU rate: exact float32 semantics.
 #include "sift_kernels.hpp"
 
 #include <cfloat>
@@ -28,14 +36,92 @@ namespace sara_hip {
 
   constexpr int kMatchTile = 32;   // candidates per LDS tile
 
-  __global__ __launch_bounds__(64) void nn2_kernel(
+  __device__ inline void top3_insert(float d, int j, float& d0, float& d1,
+                                     float& d2, int& i0, int& i1, int& i2)
+  {
+    // strict comparisons: among equal distances the one seen first (the lower
+    // index: candidates and chunks are visited in index order) stays ahead
+    if (d < d0)
+    {
+      d2 = d1;
+      i2 = i1;
+      d1 = d0;
+      i1 = i0;
+      d0 = d;
+      i0 = j;
+    }
+    else if (d < d1)
+    {
+      d2 = d1;
+      i2 = i1;
+      d1 = d;
+      i1 = j;
+    }
+    else if (d < d2)
+    {
+      d2 = d;
+      i2 = j;
+    }
+  }
+
+  //! Stages candidates [c0, c0 + 32) in LDS and accumulates this lane's query
+  //! against each of them in FLANN's order.
+  __device__ inline void tile_distances(const float* __restrict__ t, int dim,
+                                        int dim4, int c0, int c_end,
+                                        const float* __restrict__ myq, bool vec4,
+                                        float* s_t, float (&acc)[kMatchTile])
+  {
+    const int lane = threadIdx.x;
+    const int groups = dim / 4, tail = dim - 4 * groups;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int idx = lane; idx < kMatchTile * dim4; idx += 64)
+    {
+      const int r = idx / dim4, k = idx - r * dim4;
+      float v = 0.f;
+      if (c0 + r < c_end && k < dim)
+        v = t[size_t(c0 + r) * dim + k];
+      s_t[idx] = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < kMatchTile; ++c)
+      acc[c] = 0.f;
+    for (int g = 0; g < groups; ++g)
+    {
+      float4 a;
+      if (vec4)
+        a = *reinterpret_cast<const float4*>(myq + 4 * g);
+      else
+        a = make_float4(myq[4 * g], myq[4 * g + 1], myq[4 * g + 2], myq[4 * g + 3]);
+#pragma unroll
+      for (int c = 0; c < kMatchTile; ++c)
+      {
+        const float4 b = *reinterpret_cast<const float4*>(s_t + c * dim4 + 4 * g);
+        const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+        acc[c] += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+      }
+    }
+    for (int k = 4 * groups; k < 4 * groups + tail; ++k)
+    {
+      const float a = myq[k];
+#pragma unroll
+      for (int c = 0; c < kMatchTile; ++c)
+      {
+        const float d0 = a - s_t[c * dim4 + k];
+        acc[c] += d0 * d0;
+      }
+    }
+  }
+
+  //! part_d / part_i: [3][nchunks][nq].
+  __global__ __launch_bounds__(64) void nn3_kernel(
       const float* __restrict__ q, int nq, const float* __restrict__ t, int nt,
-      int dim, int chunk, float* __restrict__ part_d0, float* __restrict__ part_d1,
-      int* __restrict__ part_i0)
+      int dim, int chunk, float* __restrict__ part_d, int* __restrict__ part_i)
   {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int dim4 = (dim + 3) & ~3;
-    float* s_t = smem;  // [kMatchTile][dim4]
     const int lane = threadIdx.x;
     const int q0 = blockIdx.x * 64;
     const int c_begin = blockIdx.y * chunk;
@@ -43,108 +129,71 @@ namespace sara_hip {
     // this lane's query row (lanes past the end re-read the last row)
     const float* myq = q + size_t(min(q0 + lane, nq - 1)) * dim;
     const bool vec4 = (dim % 4 == 0) && (reinterpret_cast<uintptr_t>(q) % 16 == 0);
-    float best0 = FLT_MAX, best1 = FLT_MAX;
-    int idx0 = -1;
-    const int groups = dim / 4, tail = dim - 4 * groups;
-
+    float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
+    int i0 = -1, i1 = -1, i2 = -1;
     for (int c0 = c_begin; c0 < c_end; c0 += kMatchTile)
     {
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
-      for (int idx = lane; idx < kMatchTile * dim4; idx += 64)
-      {
-        const int r = idx / dim4, k = idx - r * dim4;
-        float v = 0.f;
-        if (c0 + r < c_end && k < dim)
-          v = t[size_t(c0 + r) * dim + k];
-        s_t[idx] = v;
-      }
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
-
       float acc[kMatchTile];
+      tile_distances(t, dim, dim4, c0, c_end, myq, vec4, smem, acc);
 #pragma unroll
       for (int c = 0; c < kMatchTile; ++c)
-        acc[c] = 0.f;
-      for (int g = 0; g < groups; ++g)
-      {
-        float4 a;
-        if (vec4)
-          a = *reinterpret_cast<const float4*>(myq + 4 * g);
-        else
-          a = make_float4(myq[4 * g], myq[4 * g + 1], myq[4 * g + 2],
-                          myq[4 * g + 3]);
-#pragma unroll
-        for (int c = 0; c < kMatchTile; ++c)
-        {
-          const float4 b = *reinterpret_cast<const float4*>(s_t + c * dim4 + 4 * g);
-          const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z,
-                      d3 = a.w - b.w;
-          acc[c] += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-        }
-      }
-      for (int k = 4 * groups; k < 4 * groups + tail; ++k)
-      {
-        const float a = myq[k];
-#pragma unroll
-        for (int c = 0; c < kMatchTile; ++c)
-        {
-          const float d0 = a - s_t[c * dim4 + k];
-          acc[c] += d0 * d0;
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < kMatchTile; ++c)
-      {
-        const float d = acc[c];
-        const bool valid = c0 + c < c_end;
-        if (valid && d < best0)
-        {
-          best1 = best0;
-          best0 = d;
-          idx0 = c0 + c;
-        }
-        else if (valid && d < best1)
-          best1 = d;
-      }
+        if (c0 + c < c_end)
+          top3_insert(acc[c], c0 + c, b0, b1, b2, i0, i1, i2);
     }
     if (q0 + lane < nq)
     {
+      const size_t plane = size_t(gridDim.y) * nq;
       const size_t o = size_t(blockIdx.y) * nq + q0 + lane;
-      part_d0[o] = best0;
-      part_d1[o] = best1;
-      part_i0[o] = idx0;
+      part_d[o] = b0;
+      part_d[plane + o] = b1;
+      part_d[2 * plane + o] = b2;
+      part_i[o] = i0;
+      part_i[plane + o] = i1;
+      part_i[2 * plane + o] = i2;
     }
   }
 
-  //! Merges the per-chunk candidates of every query in chunk order (ties keep
-  //! the lower index), applies the ratio test of AnnMatcher.cpp:126-147 and
-  //! appends {x, y, score, rank = 1, direction}.
-  __global__ void merge_matches_kernel(const float* __restrict__ part_d0,
-                                       const float* __restrict__ part_d1,
-                                       const int* __restrict__ part_i0, int nq,
-                                       int nchunks, float squared_ratio_thres,
-                                       int direction, sara_match* __restrict__ out,
-                                       int capacity, int* __restrict__ count)
+  //! top_d / top_i: [3][nq], the knnSearch(3) answer of every query.
+  __global__ void merge3_kernel(const float* __restrict__ part_d,
+                                const int* __restrict__ part_i, int nq,
+                                int nchunks, float* __restrict__ top_d,
+                                int* __restrict__ top_i)
   {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq)
       return;
-    float d0 = FLT_MAX, d1 = FLT_MAX;
-    int i0 = -1;
+    const size_t plane = size_t(nchunks) * nq;
+    float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
+    int i0 = -1, i1 = -1, i2 = -1;
     for (int c = 0; c < nchunks; ++c)
-    {
-      const size_t o = size_t(c) * nq + i;
-      const float e0 = part_d0[o], e1 = part_d1[o];
-      if (e0 < d0)
+      for (int k = 0; k < 3; ++k)
       {
-        d1 = fminf(d0, e1);
-        d0 = e0;
-        i0 = part_i0[o];
+        const size_t o = k * plane + size_t(c) * nq + i;
+        const int j = part_i[o];
+        if (j >= 0)
+          top3_insert(part_d[o], j, b0, b1, b2, i0, i1, i2);
       }
-      else
-        d1 = fminf(d1, e0);
-    }
+    top_d[i] = b0;
+    top_d[nq + i] = b1;
+    top_d[2 * size_t(nq) + i] = b2;
+    top_i[i] = i0;
+    top_i[nq + i] = i1;
+    top_i[2 * size_t(nq) + i] = i2;
+  }
+
+  //! AnnMatcher.cpp:126-147 for squared ratio <= 1, two key sets: only the best
+  //! neighbour, score d0 / d1; appends {x, y, score, rank = 1, direction}.
+  __global__ void ratio_filter_kernel(const float* __restrict__ top_d,
+                                      const int* __restrict__ top_i, int nq,
+                                      float squared_ratio_thres, int direction,
+                                      sara_match* __restrict__ out, int capacity,
+                                      int* __restrict__ count)
+  {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq)
+      return;
+    const float d0 = top_d[i], d1 = top_d[nq + i];
+    const int i0 = top_i[i];
     const float score = d1 > 0.f ? d0 / d1 : 0.f;
     if (i0 < 0 || score > squared_ratio_thres)
       return;
@@ -160,7 +209,46 @@ namespace sara_hip {
     out[slot] = m;
   }
 
-  size_t match_partials_per_query(int nt, int* chunk, int* nchunks, int nq)
+  //! radiusSearch (AnnMatcher.cpp:133-138): every candidate with distance <
+  //! top_d[top1][query] * squared_ratio_thres is appended as (query, index,
+  //! distance); *count keeps counting past `capacity` so that the caller can
+  //! retry with room.
+  __global__ __launch_bounds__(64) void radius_kernel(
+      const float* __restrict__ q, int nq, const float* __restrict__ t, int nt,
+      int dim, int chunk, const float* __restrict__ top_d, int top1,
+      float squared_ratio_thres, MatchNeighbour* __restrict__ out, int capacity,
+      int* __restrict__ count)
+  {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int dim4 = (dim + 3) & ~3;
+    const int lane = threadIdx.x;
+    const int q0 = blockIdx.x * 64;
+    const int c_begin = blockIdx.y * chunk;
+    const int c_end = min(nt, c_begin + chunk);
+    const int me = min(q0 + lane, nq - 1);
+    const float* myq = q + size_t(me) * dim;
+    const bool vec4 = (dim % 4 == 0) && (reinterpret_cast<uintptr_t>(q) % 16 == 0);
+    // a query without a ranked neighbour (FLT_MAX) emits nothing: the product
+    // overflows to +inf only for thresholds above 1, and the caller skips
+    // those queries anyway
+    const float radius =
+        q0 + lane < nq ? top_d[size_t(top1) * nq + me] * squared_ratio_thres : 0.f;
+    for (int c0 = c_begin; c0 < c_end; c0 += kMatchTile)
+    {
+      float acc[kMatchTile];
+      tile_distances(t, dim, dim4, c0, c_end, myq, vec4, smem, acc);
+#pragma unroll
+      for (int c = 0; c < kMatchTile; ++c)
+        if (c0 + c < c_end && acc[c] < radius)
+        {
+          const int slot = atomicAdd(count, 1);
+          if (slot < capacity)
+            out[slot] = MatchNeighbour{me, c0 + c, acc[c]};
+        }
+    }
+  }
+
+  void match_chunking(int nq, int nt, int* chunk, int* nchunks)
   {
     // enough (query block, chunk) waves to fill the chip, chunks of whole tiles
     const int qblocks = (nq + 63) / 64;
@@ -169,25 +257,44 @@ namespace sara_hip {
     c = ((std::max(c, kMatchTile) + kMatchTile - 1) / kMatchTile) * kMatchTile;
     *chunk = c;
     *nchunks = (nt + c - 1) / c;
-    return size_t(*nchunks);
   }
 
-  void launch_match_direction(const float* q, int nq, const float* t, int nt,
-                              int dim, float squared_ratio_thres, int direction,
-                              float* part_d0, float* part_d1, int* part_i0,
-                              sara_match* out, int capacity, int* count,
-                              hipStream_t stream)
+  void launch_nn3_exhaustive(const float* q, int nq, const float* t, int nt,
+                             int dim, float* part_d, int* part_i, float* top_d,
+                             int* top_i, hipStream_t stream)
   {
     int chunk = 0, nchunks = 0;
-    match_partials_per_query(nt, &chunk, &nchunks, nq);
+    match_chunking(nq, nt, &chunk, &nchunks);
     const int dim4 = (dim + 3) & ~3;
     const size_t lds = size_t(kMatchTile) * dim4 * sizeof(float);
-    hipLaunchKernelGGL(nn2_kernel, dim3((nq + 63) / 64, nchunks), dim3(64), lds,
-                       stream, q, nq, t, nt, dim, chunk, part_d0, part_d1,
-                       part_i0);
-    hipLaunchKernelGGL(merge_matches_kernel, dim3((nq + 255) / 256), dim3(256), 0,
-                       stream, part_d0, part_d1, part_i0, nq, nchunks,
-                       squared_ratio_thres, direction, out, capacity, count);
+    hipLaunchKernelGGL(nn3_kernel, dim3((nq + 63) / 64, nchunks), dim3(64), lds,
+                       stream, q, nq, t, nt, dim, chunk, part_d, part_i);
+    hipLaunchKernelGGL(merge3_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream,
+                       part_d, part_i, nq, nchunks, top_d, top_i);
+  }
+
+  void launch_ratio_filter(const float* top_d, const int* top_i, int nq,
+                           float squared_ratio_thres, int direction,
+                           sara_match* out, int capacity, int* count,
+                           hipStream_t stream)
+  {
+    hipLaunchKernelGGL(ratio_filter_kernel, dim3((nq + 255) / 256), dim3(256), 0,
+                       stream, top_d, top_i, nq, squared_ratio_thres, direction,
+                       out, capacity, count);
+  }
+
+  void launch_radius_exhaustive(const float* q, int nq, const float* t, int nt,
+                                int dim, const float* top_d, int top1,
+                                float squared_ratio_thres, MatchNeighbour* out,
+                                int capacity, int* count, hipStream_t stream)
+  {
+    int chunk = 0, nchunks = 0;
+    match_chunking(nq, nt, &chunk, &nchunks);
+    const int dim4 = (dim + 3) & ~3;
+    const size_t lds = size_t(kMatchTile) * dim4 * sizeof(float);
+    hipLaunchKernelGGL(radius_kernel, dim3((nq + 63) / 64, nchunks), dim3(64), lds,
+                       stream, q, nq, t, nt, dim, chunk, top_d, top1,
+                       squared_ratio_thres, out, capacity, count);
   }
 
 }  // namespace sara_hip

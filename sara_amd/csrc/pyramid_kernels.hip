@@ -8,6 +8,8 @@
 // Wave = 64 lanes everywhere; workgroups are 256 threads = 4 waves.
 #include "sift_kernels.hpp"
 
+#include <atomic>
+
 #include "device_math.hpp"
 
 #include <cmath>
@@ -931,13 +933,16 @@ namespace sara_hip {
     const size_t lds =
         sizeof(float) * size_t(TY + 2 * R) * (size_t(TX + 2 * R) + TX);
     // radii above ~36 need more than the default 64 KB of dynamic LDS
-    static size_t lds_allowed = 64 * 1024;
-    if (lds > lds_allowed)
+    // per DEVICE, and reachable from several host threads (sara_hip_sift_group_*)
+    static std::atomic<bool> lds_allowed[64];
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    if (lds > 64 * 1024 && !lds_allowed[dev & 63].load(std::memory_order_acquire))
     {
       (void) hipFuncSetAttribute(
           reinterpret_cast<const void*>(gaussian_blur_generic_kernel),
           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      lds_allowed = 160 * 1024;
+      lds_allowed[dev & 63].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(gaussian_blur_generic_kernel, grid, dim3(NT), lds, stream,
                        src, src_stride, dst, dst_stride, dog, dog_stride, w, h,

@@ -410,6 +410,7 @@ namespace {
   sara_hip_status comm_finish_create(sara_hip_comm* c)
   {
     HIPC_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::recursive_mutex> runtime_lock(runtime_mutex());
     HIPC_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const size_t ints = size_t(kHdr) * (size_t(c->nranks) + 1);
     HIPC_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_hdr), sizeof(int) * ints));
@@ -827,6 +828,7 @@ sara_hip_status sara_hip_comm_destroy(sara_hip_comm* c)
   if (c->stream)
   {
     (void) hipStreamSynchronize(c->stream);
+    std::lock_guard<std::recursive_mutex> runtime_lock(runtime_mutex());
     (void) hipStreamDestroy(c->stream);
   }
   c->tr.reset();

@@ -15,12 +15,63 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace sara_hip;
 
+namespace sara_hip {
+  // Contexts of different host threads are independent - except inside the
+  // ROCm 7 runtime.  hipGraphLaunch keeps the streams its parallel branches
+  // run on in per-device state that is not protected against other threads
+  // creating / destroying streams, graphs and executables, or capturing and
+  // launching graphs themselves: rocgdb shows the segmentation fault in
+  // hip::Graph::UpdateStreams <- hip::GraphExec::Run <- hipGraphLaunch, with
+  // the other threads inside context creation / destruction (seen with one
+  // host thread per logical rank in sara_hip_sift_group_* and with the
+  // per-thread context caches of compute_sift_keypoints).  Captures, graph
+  // launches (host side only: tens of microseconds), and the creation /
+  // destruction of contexts, streams and graphs therefore exclude each other
+  // process-wide.  Plain kernel launches and copies take no lock.
+  std::recursive_mutex& runtime_mutex()
+  {
+    static std::recursive_mutex m;
+    return m;
+  }
+}  // namespace sara_hip
+
 namespace {
+
+  //! HIP-graph replay is reserved to ONE host thread of the process: the first
+  //! one that asks.  With graphs captured and launched from several host
+  //! threads the ROCm 7 runtime crashed in hip::Graph::UpdateStreams (under
+  //! hipGraphLaunch) even with every graph call of the process serialised by
+  //! runtime_mutex() and every graph used only by the thread that captured it
+  //! (rocgdb backtrace; tests/test_gpu_pipeline.py::
+  //! test_compute_sift_keypoints_keeps_its_context is the reproducer).  Other
+  //! threads run the same enqueue sequence as plain launches: about 0.15 ms
+  //! more per 1080p frame, same results.  SARA_HIP_GRAPH_ANY_THREAD=1 lifts it.
+  bool graph_thread_ok()
+  {
+    static const bool any = [] {
+      const char* e = getenv("SARA_HIP_GRAPH_ANY_THREAD");
+      return e && e[0] == '1';
+    }();
+    if (any)
+      return true;
+    static std::mutex m;
+    static bool claimed = false;
+    static std::thread::id owner;
+    std::lock_guard<std::mutex> lock(m);
+    if (!claimed)
+    {
+      owner = std::this_thread::get_id();
+      claimed = true;
+    }
+    return owner == std::this_thread::get_id();
+  }
 
   thread_local std::string g_error = "";
 
@@ -395,6 +446,7 @@ namespace {
     if (device < 0 || device >= ndev)
       return fail(SARA_HIP_INVALID_PARAMS, "device ordinal out of range");
     HIP_TRY(hipSetDevice(device));
+    std::lock_guard<std::recursive_mutex> runtime_lock(runtime_mutex());
 
     auto* c = new sara_hip_sift;
     c->device = device;
@@ -761,6 +813,7 @@ sara_hip_status sara_hip_sift_destroy(sara_hip_sift* c)
 {
   if (!c)
     return SARA_HIP_OK;
+  std::lock_guard<std::recursive_mutex> runtime_lock(runtime_mutex());
   (void) hipSetDevice(c->device);
   if (c->last_stream)
     (void) hipStreamSynchronize(c->last_stream);
@@ -969,6 +1022,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
 
   // Graph replay: own stream, small batch, no stage timers inside a capture.
   const bool graph_mode = c->use_graph && !c->graph_broken && !hip_stream &&
+                          graph_thread_ok() &&
                           batch <= c->graph_max_batch && !debug_sync;
   const bool timing = c->timers && !graph_mode;
   // 8-bit gray frames not converted yet (detect_u8): the first blur of the
@@ -1424,6 +1478,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     c->has_result = true;
     return SARA_HIP_OK;
   }
+  std::lock_guard<std::recursive_mutex> graph_lock(runtime_mutex());
   const int gs = c->write_slot;
   hipGraph_t& graph = c->graph_s[gs];
   hipGraphExec_t& graph_exec = c->graph_exec_s[gs];
@@ -1582,6 +1637,7 @@ sara_hip_status sara_hip_sift_stage(sara_hip_sift* c, const void* images,
   HIP_TRY(hipSetDevice(c->device));
   if (!c->copy_stream)
   {
+    std::lock_guard<std::recursive_mutex> runtime_lock(runtime_mutex());
     HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (int k = 0; k < 2; ++k)
     {
@@ -1699,6 +1755,7 @@ sara_hip_status sara_hip_sift_submit(sara_hip_sift* c, const void* images,
     // highest priority: the read-back kernel's few workgroups should not
     // queue behind the next batch's launches
     int lo = 0, hi = 0;
+    std::lock_guard<std::recursive_mutex> runtime_lock(runtime_mutex());
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIP_TRY(hipStreamCreateWithPriority(&c->d2h_stream, hipStreamNonBlocking, hi));
   }
@@ -2363,101 +2420,6 @@ sara_hip_status sara_hip_root_sift(float* desc, int n, int dim, int on_device,
     HIP_TRY(hipMemcpy(desc, d, bytes, hipMemcpyDeviceToHost));
   else
     HIP_TRY(hipStreamSynchronize(nullptr));
-  return SARA_HIP_OK;
-}
-
-sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,
-                                           const float* desc2, int n2, int dim,
-                                           float sift_ratio_thres, int on_device,
-                                           sara_match* matches, int capacity,
-                                           int* count, int device)
-{
-  if (count)
-    *count = 0;
-  if (!desc1 || !desc2 || !matches || !count || n1 < 0 || n2 < 0 || capacity < 0)
-    return fail(SARA_HIP_INVALID_PARAMS, "null pointer or negative size");
-  if (n1 == 0 || n2 == 0)
-    return fail(SARA_HIP_RUNTIME_ERROR, "Error: the list of key-points is empty!");
-  if (dim < 1 || dim > 128)
-    return fail(SARA_HIP_INVALID_PARAMS, "descriptor dimension must be in 1..128");
-  if (!(sift_ratio_thres <= 1.f))
-    return fail(SARA_HIP_INVALID_PARAMS,
-                "ratio thresholds above 1 (FLANN radius search) are not "
-                "supported");
-  const sara_hip_status st = select_device(device);
-  if (st != SARA_HIP_OK)
-    return st;
-  const float thres2 = sift_ratio_thres * sift_ratio_thres;
-  DeviceScratch sc;
-  const float *d1 = desc1, *d2 = desc2;
-  if (!on_device)
-  {
-    float *a = nullptr, *b = nullptr;
-    HIP_TRY(sc.get(a, size_t(n1) * dim));
-    HIP_TRY(sc.get(b, size_t(n2) * dim));
-    HIP_TRY(hipMemcpy(a, desc1, size_t(n1) * dim * sizeof(float),
-                      hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b, desc2, size_t(n2) * dim * sizeof(float),
-                      hipMemcpyHostToDevice));
-    d1 = a;
-    d2 = b;
-  }
-  int chunk = 0, nch12 = 0, nch21 = 0;
-  match_partials_per_query(n2, &chunk, &nch12, n1);
-  match_partials_per_query(n1, &chunk, &nch21, n2);
-  const size_t npart = std::max(size_t(nch12) * n1, size_t(nch21) * n2);
-  float *p0 = nullptr, *p1 = nullptr;
-  int *pi = nullptr, *d_count = nullptr;
-  sara_match* d_out = nullptr;
-  const int cap_dev = n1 + n2;
-  HIP_TRY(sc.get(p0, npart));
-  HIP_TRY(sc.get(p1, npart));
-  HIP_TRY(sc.get(pi, npart));
-  HIP_TRY(sc.get(d_count, 1));
-  HIP_TRY(sc.get(d_out, size_t(cap_dev)));
-  HIP_TRY(hipMemset(d_count, 0, sizeof(int)));
-  // A single candidate gets score 1 (AnnMatcher.cpp:87-101), which never
-  // passes a squared ratio <= 1: those directions contribute nothing.
-  if (n2 >= 2)
-    launch_match_direction(d1, n1, d2, n2, dim, thres2, 0, p0, p1, pi, d_out,
-                           cap_dev, d_count, nullptr);
-  if (n1 >= 2)
-    launch_match_direction(d2, n2, d1, n1, dim, thres2, 1, p0, p1, pi, d_out,
-                           cap_dev, d_count, nullptr);
-  HIP_TRY(hipGetLastError());
-  int found = 0;
-  HIP_TRY(hipMemcpy(&found, d_count, sizeof(int), hipMemcpyDeviceToHost));
-  std::vector<sara_match> m(size_t(std::max(found, 0)));
-  if (found > 0)
-    HIP_TRY(hipMemcpy(m.data(), d_out, size_t(found) * sizeof(sara_match),
-                      hipMemcpyDeviceToHost));
-  // AnnMatcher.cpp:239-258: sort by (x, y, score), unique on (x, y), sort by
-  // score (equal scores: by (x, y), one of the orders std::sort may leave).
-  std::sort(m.begin(), m.end(), [](const sara_match& a, const sara_match& b) {
-    if (a.x_index != b.x_index)
-      return a.x_index < b.x_index;
-    if (a.y_index != b.y_index)
-      return a.y_index < b.y_index;
-    if (a.score != b.score)
-      return a.score < b.score;
-    return a.direction < b.direction;
-  });
-  m.erase(std::unique(m.begin(), m.end(),
-                      [](const sara_match& a, const sara_match& b) {
-                        return a.x_index == b.x_index && a.y_index == b.y_index;
-                      }),
-          m.end());
-  std::sort(m.begin(), m.end(), [](const sara_match& a, const sara_match& b) {
-    if (a.score != b.score)
-      return a.score < b.score;
-    if (a.x_index != b.x_index)
-      return a.x_index < b.x_index;
-    return a.y_index < b.y_index;
-  });
-  *count = int(m.size());
-  if (int(m.size()) > capacity)
-    return fail(SARA_HIP_CAPACITY_EXCEEDED, "more matches than `capacity`");
-  std::copy(m.begin(), m.end(), matches);
   return SARA_HIP_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
 
 #include "../../include/sara_hip_sift.h"
 
@@ -300,17 +301,33 @@ namespace sara_hip {
   void launch_extrema_offsets(const CandidateLists& cand, int* ex_offset,
                               int batch, hipStream_t stream);
 
-  // ---- descriptor matching (match_kernels.hip) ----------------------------
-  //! Chunking of the candidates of one direction: -> number of partial
-  //! (best, second best) records per query.
-  size_t match_partials_per_query(int nt, int* chunk, int* nchunks, int nq);
-  //! Nearest and second nearest rows of `t` for every row of `q` (exhaustive,
-  //! FLANN's squared L2), ratio test, append to out[*count ...].
-  void launch_match_direction(const float* q, int nq, const float* t, int nt,
-                              int dim, float squared_ratio_thres, int direction,
-                              float* part_d0, float* part_d1, int* part_i0,
-                              sara_match* out, int capacity, int* count,
-                              hipStream_t stream);
+  // ---- descriptor matching (match_kernels.hip, sift_match.cpp) ---------------
+  //! One neighbour of a query inside its search radius.
+  struct MatchNeighbour
+  {
+    int32_t query;
+    int32_t index;
+    float distance;
+  };
+  //! (query block, candidate chunk) decomposition of an exhaustive search.
+  void match_chunking(int nq, int nt, int* chunk, int* nchunks);
+  //! knnSearch(3) of every row of `q` in `t` (exhaustive, FLANN's squared L2,
+  //! ordered by (distance, index)): top_d / top_i = [3][nq].  part_d / part_i:
+  //! scratch of 3 * nchunks * nq entries.
+  void launch_nn3_exhaustive(const float* q, int nq, const float* t, int nt,
+                             int dim, float* part_d, int* part_i, float* top_d,
+                             int* top_i, hipStream_t stream);
+  //! Ratio test for squared thresholds <= 1 on the device (best neighbour only).
+  void launch_ratio_filter(const float* top_d, const int* top_i, int nq,
+                           float squared_ratio_thres, int direction,
+                           sara_match* out, int capacity, int* count,
+                           hipStream_t stream);
+  //! radiusSearch of every query: neighbours with distance <
+  //! top_d[top1][query] * squared_ratio_thres, appended in no particular order.
+  void launch_radius_exhaustive(const float* q, int nq, const float* t, int nt,
+                                int dim, const float* top_d, int top1,
+                                float squared_ratio_thres, MatchNeighbour* out,
+                                int capacity, int* count, hipStream_t stream);
 
   // ---- hand-off between the context and the RCCL gather (sift_comm.cpp) ------
   //! Device-resident results of one submit() ticket.
@@ -330,6 +347,9 @@ namespace sara_hip {
   //! HBM; the ticket stays pending until ticket_release().
   sara_hip_status ticket_results(sara_hip_sift* ctx, int ticket, TicketResults* out);
   void ticket_release(sara_hip_sift* ctx, int ticket);
+  //! Process-wide lock around graph capture / launch and the creation /
+  //! destruction of contexts, streams and graphs (sift_context.cpp says why).
+  std::recursive_mutex& runtime_mutex();
   //! Records the error message sara_hip_last_error() returns on this thread.
   sara_hip_status set_error(sara_hip_status code, const char* msg);
 

@@ -1,0 +1,553 @@
+// Host side of descriptor matching (include/sara_hip_sift.h, "descriptor
+// matching").
+//
+// Restates AnnMatcher (FeatureMatching/AnnMatcher.hpp:32-86, .cpp:59-268) with
+// both constructors: two key sets, and one key set matched against itself with
+// the KeyProximity filter (FeatureMatching/KeyProximity.cpp:17-30).  The
+// neighbour queries - FLANN's knnSearch(3) and radiusSearch - run on the GPU
+// (match_kernels.hip: exhaustive, or an MFMA prefilter with exact re-ranking);
+// the decision logic of append_nearest_neighbors (.cpp:59-170) and the sort /
+// unique / sort of compute_matches (.cpp:239-258) run here on the few thousand
+// records that come back.
+#include "sift_kernels.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace sara_hip;
+
+namespace {
+
+#define HIPM_TRY(expr)                                                         \
+  do                                                                           \
+  {                                                                            \
+    const hipError_t e_ = (expr);                                              \
+    if (e_ != hipSuccess)                                                      \
+      return set_error(SARA_HIP_RUNTIME_ERROR,                                 \
+                       (std::string(#expr) + ": " + hipGetErrorString(e_))     \
+                           .c_str());                                          \
+  } while (0)
+
+  sara_hip_status use_device(int device)
+  {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      return set_error(SARA_HIP_NO_DEVICE,
+                       "no HIP device: the SIFT front-end has no CPU fallback");
+    if (device < 0 || device >= ndev)
+      return set_error(SARA_HIP_INVALID_PARAMS, "device ordinal out of range");
+    HIPM_TRY(hipSetDevice(device));
+    return SARA_HIP_OK;
+  }
+
+  // Grow-only scratch of the calling thread, per device: hipMalloc / hipFree
+  // per call cost more than the whole search of two 4 k key sets.
+  struct Workspace
+  {
+    enum Slot
+    {
+      kDescA,
+      kDescB,
+      kPartD,
+      kPartI,
+      kTopD,
+      kTopI,
+      kOut,
+      kRadius,
+      kAux0,
+      kAux1,
+      kAux2,
+      kAux3,
+      kSlots
+    };
+    int device = -1;
+    void* dev[kSlots] = {};
+    size_t dev_bytes[kSlots] = {};
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+
+    void release()
+    {
+      if (device < 0)
+        return;
+      (void) hipSetDevice(device);
+      for (int k = 0; k < kSlots; ++k)
+      {
+        if (dev[k])
+          (void) hipFree(dev[k]);
+        dev[k] = nullptr;
+        dev_bytes[k] = 0;
+      }
+      if (pinned)
+        (void) hipHostFree(pinned);
+      pinned = nullptr;
+      pinned_bytes = 0;
+      device = -1;
+    }
+    ~Workspace() { release(); }
+
+    template <typename T>
+    hipError_t get(Slot k, size_t count, T*& p)
+    {
+      const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+      if (bytes > dev_bytes[k])
+      {
+        if (dev[k])
+          (void) hipFree(dev[k]);
+        dev[k] = nullptr;
+        dev_bytes[k] = 0;
+        const size_t want = bytes + bytes / 4;
+        const hipError_t e = hipMalloc(&dev[k], want);
+        if (e != hipSuccess)
+          return e;
+        dev_bytes[k] = want;
+      }
+      p = static_cast<T*>(dev[k]);
+      return hipSuccess;
+    }
+    hipError_t host(size_t bytes, void*& p)
+    {
+      if (bytes > pinned_bytes)
+      {
+        if (pinned)
+          (void) hipHostFree(pinned);
+        pinned = nullptr;
+        pinned_bytes = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        const hipError_t e = hipHostMalloc(&pinned, want);
+        if (e != hipSuccess)
+          return e;
+        pinned_bytes = want;
+      }
+      p = pinned;
+      return hipSuccess;
+    }
+  };
+
+  Workspace& workspace(int device)
+  {
+    thread_local Workspace ws[2];  // the two devices a thread used last
+    for (Workspace& w : ws)
+      if (w.device == device)
+        return w;
+    for (Workspace& w : ws)
+      if (w.device < 0)
+      {
+        w.device = device;
+        return w;
+      }
+    ws[1].release();
+    ws[1].device = device;
+    return ws[1];
+  }
+
+  //! OERegion fields KeyProximity and Match::operator== read.
+  struct Feat
+  {
+    float x, y, m00, m10, m01, m11, orientation;
+    int type;
+    bool operator==(const Feat& o) const  // Feature.hpp:140-146
+    {
+      return x == o.x && y == o.y && m00 == o.m00 && m10 == o.m10 &&
+             m01 == o.m01 && m11 == o.m11 && orientation == o.orientation &&
+             type == o.type;
+    }
+  };
+
+  Feat feat_of(const sara_oeregion& r)
+  {
+    return Feat{r.coords[0],       r.coords[1],       r.shape_matrix[0],
+                r.shape_matrix[1], r.shape_matrix[2], r.shape_matrix[3],
+                r.orientation,     int(r.type)};
+  }
+
+  //! KeyProximity::operator(), KeyProximity.cpp:17-30 (SquaredRefDistance,
+  //! Geometry/Tools/Metric.hpp:47-50: (b - a).dot(M (b - a))).
+  struct KeyProximity
+  {
+    float squared_metric_dist, squared_dist_thres;
+    static float metric(const Feat& f, float vx, float vy)
+    {
+      const float r0 = f.m00 * vx + f.m01 * vy;
+      const float r1 = f.m10 * vx + f.m11 * vy;
+      return vx * r0 + vy * r1;
+    }
+    bool operator()(const Feat& f1, const Feat& f2) const
+    {
+      const float sd1 = metric(f1, f2.x - f1.x, f2.y - f1.y);
+      const float sd2 = metric(f2, f2.x - f1.x, f2.y - f1.y);
+      const float dx = f1.x - f2.x, dy = f1.y - f2.y;
+      const float squared_pixel_dist = dx * dx + dy * dy;
+      return squared_pixel_dist < squared_dist_thres || sd1 < squared_metric_dist ||
+             sd2 < squared_metric_dist;
+    }
+  };
+
+  //! What the searches of one direction returned, on the host.
+  struct Neighbours
+  {
+    int nq = 0, nt = 0;
+    std::vector<float> top_d;  // [3][nq]
+    std::vector<int> top_i;    // [3][nq]
+    std::vector<MatchNeighbour> radius;  // sorted by (query, distance, index)
+    std::vector<int> begin;              // [nq + 1] into radius
+  };
+
+  //! append_nearest_neighbors (AnnMatcher.cpp:59-170) for every query of one
+  //! direction.
+  void append_matches(const Neighbours& nb, float thres2, int direction,
+                      bool self_matching, const KeyProximity& is_redundant,
+                      const Feat* fq, const Feat* ft, std::vector<sara_match>& out)
+  {
+    const int nq = nb.nq, nt = nb.nt;
+    if (nt == 0)
+      return;
+    auto push = [&](int i1, int i2, float score, int rank) {
+      sara_match m;
+      m.x_index = direction == 0 ? i1 : i2;
+      m.y_index = direction == 0 ? i2 : i1;
+      m.score = score;
+      m.rank = rank;
+      m.direction = direction;
+      out.push_back(m);
+    };
+    for (int i = 0; i < nq; ++i)
+    {
+      if (nt == 1 && !self_matching)
+      {
+        if (1.f < thres2)  // :87-101
+          push(i, 0, 1.f, 1);
+        continue;
+      }
+      if (nt == 2 && self_matching)
+      {
+        if (1.f < thres2)  // :103-120
+          push(i, nb.top_i[size_t(nq) + i], 1.f, 1);
+        continue;
+      }
+      const int top1 = self_matching ? 1 : 0;
+      if (top1 + 1 >= nt)
+        continue;
+      const float d_top1 = nb.top_d[size_t(top1) * nq + i];
+      const float d_next = nb.top_d[size_t(top1 + 1) * nq + i];
+      const float top1_score = d_next > 0.f ? d_top1 / d_next : 0.f;
+      if (!(thres2 > 1.f))
+      {
+        // K = 1: only rank top1 = 0 is visited (nothing when self-matching)
+        if (top1 == 0 && !(top1_score > thres2))
+          push(i, nb.top_i[i], top1_score, 1);
+        continue;
+      }
+      const int lo = nb.begin[size_t(i)], K = nb.begin[size_t(i) + 1] - lo;
+      for (int rank = top1; rank < K; ++rank)
+      {
+        const MatchNeighbour& n = nb.radius[size_t(lo + rank)];
+        float score = 0.f;
+        if (rank == top1)
+          score = top1_score;
+        else if (d_top1)
+          score = n.distance / d_top1;
+        if (score > thres2)
+          break;
+        if (self_matching && is_redundant(fq[i], ft[n.index]))
+          continue;
+        push(i, n.index, score, top1 == 0 ? rank + 1 : rank);
+      }
+    }
+  }
+
+  //! compute_matches' tail, AnnMatcher.cpp:239-258.
+  void finish_matches(std::vector<sara_match>& m, const Feat* f1, const Feat* f2)
+  {
+    std::sort(m.begin(), m.end(), [](const sara_match& a, const sara_match& b) {
+      if (a.x_index != b.x_index)
+        return a.x_index < b.x_index;
+      if (a.y_index != b.y_index)
+        return a.y_index < b.y_index;
+      if (a.score != b.score)
+        return a.score < b.score;
+      if (a.direction != b.direction)
+        return a.direction < b.direction;
+      return a.rank < b.rank;
+    });
+    m.erase(std::unique(m.begin(), m.end(),
+                        [&](const sara_match& a, const sara_match& b) {
+                          if (f1 && f2)  // Match::operator== compares by value
+                            return f1[a.x_index] == f1[b.x_index] &&
+                                   f2[a.y_index] == f2[b.y_index];
+                          return a.x_index == b.x_index && a.y_index == b.y_index;
+                        }),
+            m.end());
+    std::sort(m.begin(), m.end(), [](const sara_match& a, const sara_match& b) {
+      if (a.score != b.score)
+        return a.score < b.score;
+      if (a.x_index != b.x_index)
+        return a.x_index < b.x_index;
+      return a.y_index < b.y_index;
+    });
+  }
+
+  //! knnSearch(3) (+ radiusSearch when thres2 > 1) of q in t, results on the host.
+  sara_hip_status search(Workspace& ws, const float* q, int nq, const float* t,
+                         int nt, int dim, float thres2, int top1, Neighbours* nb)
+  {
+    nb->nq = nq;
+    nb->nt = nt;
+    nb->top_d.assign(3 * size_t(nq), 0.f);
+    nb->top_i.assign(3 * size_t(nq), -1);
+    nb->radius.clear();
+    nb->begin.assign(size_t(nq) + 1, 0);
+    int chunk = 0, nchunks = 0;
+    match_chunking(nq, nt, &chunk, &nchunks);
+    float *part_d = nullptr, *top_d = nullptr;
+    int *part_i = nullptr, *top_i = nullptr;
+    HIPM_TRY(ws.get(Workspace::kPartD, 3 * size_t(nchunks) * nq, part_d));
+    HIPM_TRY(ws.get(Workspace::kPartI, 3 * size_t(nchunks) * nq, part_i));
+    HIPM_TRY(ws.get(Workspace::kTopD, 3 * size_t(nq), top_d));
+    HIPM_TRY(ws.get(Workspace::kTopI, 3 * size_t(nq), top_i));
+    launch_nn3_exhaustive(q, nq, t, nt, dim, part_d, part_i, top_d, top_i, nullptr);
+    HIPM_TRY(hipGetLastError());
+    HIPM_TRY(hipMemcpyAsync(nb->top_d.data(), top_d, sizeof(float) * 3 * nq,
+                            hipMemcpyDeviceToHost, nullptr));
+    HIPM_TRY(hipMemcpyAsync(nb->top_i.data(), top_i, sizeof(int) * 3 * nq,
+                            hipMemcpyDeviceToHost, nullptr));
+    if (thres2 > 1.f && nt > top1 + 1)
+    {
+      int* d_count = nullptr;
+      HIPM_TRY(ws.get(Workspace::kAux0, 1, d_count));
+      size_t cap = std::max<size_t>(8 * size_t(nq), 1 << 16);
+      for (int attempt = 0; attempt < 2; ++attempt)
+      {
+        MatchNeighbour* d_list = nullptr;
+        HIPM_TRY(ws.get(Workspace::kRadius, cap, d_list));
+        HIPM_TRY(hipMemsetAsync(d_count, 0, sizeof(int), nullptr));
+        launch_radius_exhaustive(q, nq, t, nt, dim, top_d, top1, thres2, d_list,
+                                 int(cap), d_count, nullptr);
+        HIPM_TRY(hipGetLastError());
+        int found = 0;
+        HIPM_TRY(hipMemcpy(&found, d_count, sizeof(int), hipMemcpyDeviceToHost));
+        if (size_t(found) > cap)
+        {
+          cap = size_t(found);  // the count is exact: the second pass fits
+          continue;
+        }
+        nb->radius.resize(size_t(found));
+        if (found > 0)
+          HIPM_TRY(hipMemcpy(nb->radius.data(), d_list,
+                             sizeof(MatchNeighbour) * size_t(found),
+                             hipMemcpyDeviceToHost));
+        break;
+      }
+      // FLANN's RadiusResultSet, sorted: by (distance, index) per query
+      std::sort(nb->radius.begin(), nb->radius.end(),
+                [](const MatchNeighbour& a, const MatchNeighbour& b) {
+                  if (a.query != b.query)
+                    return a.query < b.query;
+                  if (a.distance != b.distance)
+                    return a.distance < b.distance;
+                  return a.index < b.index;
+                });
+      for (const MatchNeighbour& n : nb->radius)
+        ++nb->begin[size_t(n.query) + 1];
+      for (int i = 0; i < nq; ++i)
+        nb->begin[size_t(i) + 1] += nb->begin[size_t(i)];
+    }
+    HIPM_TRY(hipStreamSynchronize(nullptr));
+    return SARA_HIP_OK;
+  }
+
+  sara_hip_status deliver(std::vector<sara_match>& m, sara_match* matches,
+                          int capacity, int* count)
+  {
+    *count = int(m.size());
+    if (int(m.size()) > capacity)
+      return set_error(SARA_HIP_CAPACITY_EXCEEDED,
+                       "more matches than `capacity` (*count holds the number "
+                       "needed)");
+    std::copy(m.begin(), m.end(), matches);
+    return SARA_HIP_OK;
+  }
+
+}  // namespace
+
+extern "C" {
+
+sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,
+                                           const float* desc2, int n2, int dim,
+                                           float sift_ratio_thres, int on_device,
+                                           sara_match* matches, int capacity,
+                                           int* count, int device)
+{
+  if (count)
+    *count = 0;
+  if (!desc1 || !desc2 || !matches || !count || n1 < 0 || n2 < 0 || capacity < 0)
+    return set_error(SARA_HIP_INVALID_PARAMS, "null pointer or negative size");
+  if (n1 == 0 || n2 == 0)
+    return set_error(SARA_HIP_RUNTIME_ERROR,
+                     "Error: the list of key-points is empty!");
+  if (dim < 1 || dim > 128)
+    return set_error(SARA_HIP_INVALID_PARAMS,
+                     "descriptor dimension must be in 1..128");
+  if (sift_ratio_thres != sift_ratio_thres)
+    return set_error(SARA_HIP_INVALID_PARAMS, "the ratio threshold is NaN");
+  const sara_hip_status st = use_device(device);
+  if (st != SARA_HIP_OK)
+    return st;
+  Workspace& ws = workspace(device);
+  const float thres2 = sift_ratio_thres * sift_ratio_thres;
+  const float *d1 = desc1, *d2 = desc2;
+  if (!on_device)
+  {
+    float *a = nullptr, *b = nullptr;
+    HIPM_TRY(ws.get(Workspace::kDescA, size_t(n1) * dim, a));
+    HIPM_TRY(ws.get(Workspace::kDescB, size_t(n2) * dim, b));
+    HIPM_TRY(hipMemcpyAsync(a, desc1, size_t(n1) * dim * sizeof(float),
+                            hipMemcpyHostToDevice, nullptr));
+    HIPM_TRY(hipMemcpyAsync(b, desc2, size_t(n2) * dim * sizeof(float),
+                            hipMemcpyHostToDevice, nullptr));
+    d1 = a;
+    d2 = b;
+  }
+  std::vector<sara_match> m;
+  if (!(thres2 > 1.f))
+  {
+    // Only the best neighbour can pass: the ratio test runs on the device and
+    // nothing but the matches comes back.  A single candidate gets score 1
+    // (AnnMatcher.cpp:87-101), which never passes a squared ratio <= 1.
+    struct Header
+    {
+      int count, pad[3];
+    };
+    const int cap_dev = n1 + n2;
+    unsigned char* d_out = nullptr;
+    const size_t out_bytes = sizeof(Header) + sizeof(sara_match) * size_t(cap_dev);
+    HIPM_TRY(ws.get(Workspace::kOut, out_bytes, d_out));
+    HIPM_TRY(hipMemsetAsync(d_out, 0, sizeof(Header), nullptr));
+    int* d_count = reinterpret_cast<int*>(d_out);
+    sara_match* d_m = reinterpret_cast<sara_match*>(d_out + sizeof(Header));
+    for (int dir = 0; dir < 2; ++dir)
+    {
+      const float* q = dir == 0 ? d1 : d2;
+      const float* t = dir == 0 ? d2 : d1;
+      const int nq = dir == 0 ? n1 : n2, nt = dir == 0 ? n2 : n1;
+      if (nt < 2)
+        continue;
+      int chunk = 0, nchunks = 0;
+      match_chunking(nq, nt, &chunk, &nchunks);
+      float *part_d = nullptr, *top_d = nullptr;
+      int *part_i = nullptr, *top_i = nullptr;
+      HIPM_TRY(ws.get(Workspace::kPartD, 3 * size_t(nchunks) * nq, part_d));
+      HIPM_TRY(ws.get(Workspace::kPartI, 3 * size_t(nchunks) * nq, part_i));
+      HIPM_TRY(ws.get(Workspace::kTopD, 3 * size_t(nq), top_d));
+      HIPM_TRY(ws.get(Workspace::kTopI, 3 * size_t(nq), top_i));
+      launch_nn3_exhaustive(q, nq, t, nt, dim, part_d, part_i, top_d, top_i, nullptr);
+      launch_ratio_filter(top_d, top_i, nq, thres2, dir, d_m, cap_dev, d_count,
+                          nullptr);
+    }
+    HIPM_TRY(hipGetLastError());
+    void* h = nullptr;
+    HIPM_TRY(ws.host(out_bytes, h));
+    // one read-back: the header first tells how much of the rest is valid
+    HIPM_TRY(hipMemcpyAsync(h, d_out, sizeof(Header), hipMemcpyDeviceToHost, nullptr));
+    HIPM_TRY(hipStreamSynchronize(nullptr));
+    const int found = std::min(static_cast<Header*>(h)->count, cap_dev);
+    if (found > 0)
+    {
+      HIPM_TRY(hipMemcpyAsync(static_cast<unsigned char*>(h) + sizeof(Header), d_m,
+                              sizeof(sara_match) * size_t(found),
+                              hipMemcpyDeviceToHost, nullptr));
+      HIPM_TRY(hipStreamSynchronize(nullptr));
+      const sara_match* hm = reinterpret_cast<const sara_match*>(
+          static_cast<unsigned char*>(h) + sizeof(Header));
+      m.assign(hm, hm + found);
+    }
+  }
+  else
+  {
+    const KeyProximity unused{0.f, 0.f};
+    Neighbours nb;
+    for (int dir = 0; dir < 2; ++dir)
+    {
+      const float* q = dir == 0 ? d1 : d2;
+      const float* t = dir == 0 ? d2 : d1;
+      const int nq = dir == 0 ? n1 : n2, nt = dir == 0 ? n2 : n1;
+      nb.nq = nq;
+      nb.nt = nt;
+      if (nt >= 2)
+      {
+        const sara_hip_status ss = search(ws, q, nq, t, nt, dim, thres2, 0, &nb);
+        if (ss != SARA_HIP_OK)
+          return ss;
+      }
+      append_matches(nb, thres2, dir, false, unused, nullptr, nullptr, m);
+    }
+  }
+  finish_matches(m, nullptr, nullptr);
+  return deliver(m, matches, capacity, count);
+}
+
+sara_hip_status sara_hip_self_match_descriptors(
+    const float* desc, const sara_oeregion* features, int n, int dim,
+    float sift_ratio_thres, float min_max_metric_dist_thres,
+    float pixel_dist_thres, int desc_on_device, sara_match* matches, int capacity,
+    int* count, int device)
+{
+  if (count)
+    *count = 0;
+  if (!desc || !features || !matches || !count || n < 0 || capacity < 0)
+    return set_error(SARA_HIP_INVALID_PARAMS, "null pointer or negative size");
+  if (n == 0)
+    return set_error(SARA_HIP_RUNTIME_ERROR,
+                     "Error: the list of key-points is empty!");
+  if (dim < 1 || dim > 128)
+    return set_error(SARA_HIP_INVALID_PARAMS,
+                     "descriptor dimension must be in 1..128");
+  if (sift_ratio_thres != sift_ratio_thres)
+    return set_error(SARA_HIP_INVALID_PARAMS, "the ratio threshold is NaN");
+  const sara_hip_status st = use_device(device);
+  if (st != SARA_HIP_OK)
+    return st;
+  Workspace& ws = workspace(device);
+  const float thres2 = sift_ratio_thres * sift_ratio_thres;
+  const float* d = desc;
+  if (!desc_on_device)
+  {
+    float* a = nullptr;
+    HIPM_TRY(ws.get(Workspace::kDescA, size_t(n) * dim, a));
+    HIPM_TRY(hipMemcpyAsync(a, desc, size_t(n) * dim * sizeof(float),
+                            hipMemcpyHostToDevice, nullptr));
+    d = a;
+  }
+  std::vector<Feat> f(static_cast<size_t>(n));
+  for (int i = 0; i < n; ++i)
+    f[size_t(i)] = feat_of(features[i]);
+  const KeyProximity too_close{min_max_metric_dist_thres * min_max_metric_dist_thres,
+                               pixel_dist_thres * pixel_dist_thres};
+  // both trees of compute_matches index the same descriptors
+  // (AnnMatcher.cpp:199-215): one search serves the two directions
+  Neighbours nb;
+  nb.nq = nb.nt = n;
+  if (n >= 2)
+  {
+    const sara_hip_status ss = search(ws, d, n, d, n, dim, thres2, 1, &nb);
+    if (ss != SARA_HIP_OK)
+      return ss;
+  }
+  std::vector<sara_match> m;
+  append_matches(nb, thres2, 0, true, too_close, f.data(), f.data(), m);
+  append_matches(nb, thres2, 1, true, too_close, f.data(), f.data(), m);
+  finish_matches(m, f.data(), f.data());
+  return deliver(m, matches, capacity, count);
+}
+
+sara_hip_status sara_hip_match_release_workspace(int device)
+{
+  if (use_device(device) != SARA_HIP_OK)
+    return SARA_HIP_OK;  // nothing can be held without a device
+  workspace(device).release();
+  return SARA_HIP_OK;
+}
+
+}  // extern "C"

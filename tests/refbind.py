@@ -350,17 +350,67 @@ def compute_matches(desc1, desc2, sift_ratio_thres):
     b, pb = _f(desc2)
     n1, n2 = a.shape[0], b.shape[0]
     dim = a.shape[1] if a.ndim == 2 else b.shape[1]
-    cap = n1 + n2
-    out = np.zeros(max(cap, 1), MATCH_DTYPE)
     fn = lib().ref_compute_matches
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float,
                    C.c_void_p, C.c_int]
-    n = fn(a.ctypes.data, n1, b.ctypes.data, n2, dim, sift_ratio_thres,
-           out.ctypes.data, cap)
-    if n < 0:
-        raise RuntimeError(lib().ref_last_error().decode())
-    return out[:n]
+    cap = 2 * (n1 + n2) + 16
+    while True:
+        out = np.zeros(max(cap, 1), MATCH_DTYPE)
+        n = fn(a.ctypes.data, n1, b.ctypes.data, n2, dim, sift_ratio_thres,
+               out.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError(lib().ref_last_error().decode())
+        if n <= cap:
+            return out[:n]
+        cap = n
+
+
+def match_features(regions):
+    """OERegion records -> the n x 8 float rows the oracle's matcher reads
+    (x, y, m00, m10, m01, m11, orientation, type)."""
+    r = np.asarray(regions)
+    f = np.zeros((len(r), 8), np.float32)
+    f[:, 0:2] = r["coords"]
+    f[:, 2:6] = r["shape_matrix"]
+    f[:, 6] = r["orientation"]
+    f[:, 7] = r["type"]
+    return f
+
+
+def compute_self_matches(desc, regions, sift_ratio_thres=1.2,
+                         min_max_metric_dist_thres=0.5, pixel_dist_thres=10.0):
+    """AnnMatcher{keys, ratio, metric thres, pixel thres}.compute_matches()
+    (FeatureMatching/AnnMatcher.cpp:199-268), exhaustive-search restatement."""
+    a, _ = _f(desc)
+    f = np.ascontiguousarray(match_features(regions))
+    n = a.shape[0]
+    fn = lib().ref_compute_self_matches
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
+                   C.c_float, C.c_void_p, C.c_int]
+    cap = 4 * n + 16
+    while True:
+        out = np.zeros(max(cap, 1), MATCH_DTYPE)
+        k = fn(a.ctypes.data, f.ctypes.data, n, a.shape[1], sift_ratio_thres,
+               min_max_metric_dist_thres, pixel_dist_thres, out.ctypes.data, cap)
+        if k < 0:
+            raise RuntimeError(lib().ref_last_error().decode())
+        if k <= cap:
+            return out[:k]
+        cap = k
+
+
+def key_proximity(f1, f2, metric_dist_thres=0.5, pixel_dist_thres=10.0):
+    """KeyProximity{metric, pixel}(f1, f2), KeyProximity.cpp:17-30; f = 8 floats
+    as match_features() lays them out."""
+    a = np.ascontiguousarray(f1, np.float32)
+    b = np.ascontiguousarray(f2, np.float32)
+    fn = lib().ref_key_proximity
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float]
+    return bool(fn(a.ctypes.data, b.ctypes.data, metric_dist_thres,
+                   pixel_dist_thres))
 
 
 def flann_l2(a, b):

@@ -28,6 +28,48 @@ def test_shim_compiles_against_the_c_abi():
     assert os.path.exists(exe)
 
 
+def test_in_sara_mode_compiles_against_the_mock_headers():
+    """-DSARA_HIP_WITH_SARA_HEADERS: the branch that uses Sara's own types and
+    puts the GPU functions into DO::Sara::hip, compiled against the MOCK of the
+    five Sara headers in tests/cpp/mock_sara (README there: it proves the
+    branch is well-formed and collides with nothing Sara defines - the mock
+    declares DO::Sara::compute_sift_keypoints, ComputeDoGExtrema, AnnMatcher,
+    match and from_rgb8_to_gray32f with the reference's signatures - not
+    parity)."""
+    _build()
+    exe = os.path.join(CPP, "test_shim_in_sara")
+    assert os.path.exists(exe)
+    res = subprocess.run([exe], capture_output=True, text=True)
+    assert res.returncode == 0 and "well-formed" in res.stdout
+
+
+@pytest.mark.gpu
+def test_in_sara_mode_returns_the_standalone_results(tmp_path):
+    from sara_amd.synth import synth
+    import sara_amd
+    _build()
+    exe = os.path.join(CPP, "test_shim_in_sara")
+    w, h, noct = 320, 240, 3
+    img = synth(w, h, 4321)
+    fin, fout = tmp_path / "in.f32", tmp_path / "out.bin"
+    img.tofile(fin)
+    res = subprocess.run([exe, str(fin), str(w), str(h), str(noct), str(fout)],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, (res.returncode, res.stderr)
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    keys = sara_amd.compute_sift_keypoints(
+        img, sara_amd.ImagePyramidParams(0, 6, num_octaves_max=noct))
+    raw = np.fromfile(fout, dtype=np.uint8)
+    n = int(np.frombuffer(raw[:4].tobytes(), dtype=np.int32)[0])
+    assert n == len(keys) == info["keypoints"] > 0
+    assert raw[4:4 + 48 * n].tobytes() == keys.regions.tobytes()
+    desc = np.frombuffer(raw[4 + 48 * n:4 + 560 * n].tobytes(), dtype=np.float32)
+    assert np.array_equal(desc.reshape(n, 128), keys.descriptor_matrix)
+    # the matcher calls of the C++ side agree with the Python mirror
+    assert info["matches"] == len(sara_amd.match(keys, keys, 1.0))
+    assert info["self_matches"] == len(sara_amd.AnnMatcher(keys).compute_matches())
+
+
 @pytest.mark.gpu
 def test_shim_matches_oracle(oracle, tmp_path):
     from sara_amd.synth import synth

@@ -1,7 +1,9 @@
 """-m gpu: descriptor matching through the C-ABI
-against the oracle's exhaustive-search restatement of AnnMatcher::compute_
-matches.  Bar: identical match sets and bit-identical scores (FLANN's squared
-L2 summation order is reproduced on the device)."""
+against the oracle's exhaustive-search restatement of AnnMatcher (both
+constructors; ratios below and above 1, i.e. with and without the adaptive
+radius search of AnnMatcher.cpp:133-138).  Bar: identical match lists - indices,
+ranks, directions - and bit-identical scores (FLANN's squared L2 summation
+order is reproduced on the device)."""
 import numpy as np
 import pytest
 
@@ -38,9 +40,13 @@ def test_random_descriptors_match_oracle(oracle, n1, n2, dim):
     k = min(n1, n2) // 2
     d2 = rng.random((n2, dim), dtype=np.float32)
     d2[:k] = d1[:k] + rng.normal(0, 2e-3, (k, dim)).astype(np.float32)
-    for ratio in (0.6, 0.9, 1.0):
-        assert_same(sara_amd.match(d1, d2, ratio),
-                    oracle.compute_matches(d1, d2, ratio))
+    # 1.2 is the reference's DEFAULT (AnnMatcher.hpp:36-46): the adaptive radius
+    # search of AnnMatcher.cpp:133-138, matches of rank > 1
+    for ratio in (0.6, 0.9, 1.0, 1.05, 1.2, 2.0):
+        got = sara_amd.match(d1, d2, ratio)
+        assert_same(got, oracle.compute_matches(d1, d2, ratio))
+        if ratio > 1 and min(n1, n2) > 30:
+            assert (got["rank"] > 1).any()
 
 
 def test_sift_keypoints_of_shifted_frames(oracle):
@@ -76,11 +82,90 @@ def test_error_behaviour():
     d = np.zeros((4, 128), np.float32)
     with pytest.raises(sara_amd.SaraHipError):
         sara_amd.match(np.zeros((0, 128), np.float32), d, 0.6)   # empty key set
-    with pytest.raises(sara_amd.SaraHipError):
-        sara_amd.match(d, d, 1.2)                                 # radius search
+    assert len(sara_amd.match(d, d, 1.2)) == 0    # best distance 0 -> radius 0
     with pytest.raises(sara_amd.SaraHipError):
         sara_amd.match(np.zeros((4, 200), np.float32),
                        np.zeros((4, 200), np.float32), 0.6)       # dim > 128
+
+
+def test_default_ratio_on_sift_keypoints(oracle):
+    """AnnMatcher{keys1, keys2} with the reference's default arguments
+    (sift_ratio_thres = 1.2f): radius search, ranks 1..K, scores d_rank / d_best."""
+    img = synth(360, 300, 22)
+    a = np.ascontiguousarray(img[:280, :320])
+    b = np.ascontiguousarray(img[8:288, 24:344])
+    p = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=3)
+    ka = sara_amd.compute_sift_keypoints(a, p)
+    kb = sara_amd.compute_sift_keypoints(b, p)
+    got = sara_amd.AnnMatcher(ka, kb).compute_matches()
+    want = oracle.compute_matches(ka.descriptor_matrix, kb.descriptor_matrix, 1.2)
+    assert_same(got, want)
+    assert got["rank"].max() > 1 and got["rank"].min() == 1
+    assert np.all(got["score"] <= np.float32(1.2) * np.float32(1.2))
+    # the ratio-0.6 matches are among the rank-1 matches - except those at
+    # distance exactly 0 (the shift is a whole number of pixels, so interior
+    # keypoints have bit-identical descriptors): radius = 0 * 1.44 = 0 and the
+    # reference's radius search then returns nothing for that key (kept)
+    strict = sara_amd.match(ka, kb, 0.6)
+    r1 = {(int(m["x_index"]), int(m["y_index"])) for m in got if m["rank"] == 1}
+    nz = {(int(m["x_index"]), int(m["y_index"])) for m in strict if m["score"] > 0}
+    assert nz and nz <= r1
+
+
+@pytest.mark.parametrize("ratio,metric,pixel", [(1.2, 0.5, 10.0), (1.5, 0.1, 2.0),
+                                                (2.5, 0.5, 40.0), (1.0, 0.5, 10.0),
+                                                (0.8, 0.5, 10.0)])
+def test_self_matching_constructor(oracle, ratio, metric, pixel):
+    """AnnMatcher{keys, ratio, min_max_metric_dist_thres, pixel_dist_thres}
+    (AnnMatcher.cpp:199-215): rank 0 of each search is the key itself,
+    KeyProximity (KeyProximity.cpp:17-30) drops neighbours that are too close,
+    duplicates removed by value.  With ratio <= 1 the reference emits nothing."""
+    img = synth(320, 280, 23)
+    p = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=3)
+    keys = sara_amd.compute_sift_keypoints(img, p)
+    assert len(keys) > 150
+    got = sara_amd.AnnMatcher(keys, ratio, metric, pixel).compute_matches()
+    want = oracle.compute_self_matches(keys.descriptor_matrix, keys.regions, ratio,
+                                       metric, pixel)
+    assert_same(got, want)
+    if ratio <= 1:
+        assert len(got) == 0
+        return
+    assert len(got) > 0
+    assert np.all(got["x_index"] != got["y_index"])
+    # nothing that KeyProximity calls redundant survives
+    f = oracle.match_features(keys.regions)
+    for m in got[:200]:
+        assert not oracle.key_proximity(f[m["x_index"]], f[m["y_index"]], metric, pixel)
+
+
+def test_self_matching_small_sets_and_duplicates(oracle):
+    """Boundary cases of append_nearest_neighbors in self-matching mode
+    (AnnMatcher.cpp:80-120): one key, two keys (score 1, no proximity test),
+    three keys; and exact duplicates (rank 0 is then a twin of lower index)."""
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 3, 5, 40):
+        d = (rng.random((n, 128), dtype=np.float32) * 100).astype(np.float32)
+        reg = np.zeros(n, sara_amd.OEREGION_DTYPE)
+        reg["coords"] = rng.random((n, 2), dtype=np.float32) * 300
+        reg["shape_matrix"] = np.array([0.25, 0, 0, 0.25], np.float32)
+        reg["type"] = 5
+        if n >= 5:
+            d[3] = d[1]                      # exact duplicate descriptors
+            reg["coords"][4] = reg["coords"][2] + 1   # too close in the image
+        keys = sara_amd.KeypointList(reg, d, np.zeros((n, 2), np.int32))
+        for ratio in (1.2, 3.0):
+            got = sara_amd.AnnMatcher(keys, ratio).compute_matches()
+            want = oracle.compute_self_matches(d, reg, ratio)
+            assert_same(got, want)
+
+
+def test_key_proximity_reference_case(oracle):
+    """test_featurematching_key_proximity.cpp:26-37: f1 = (0, 0), f2 = (0, 0.1)
+    with identity shape matrices are too close."""
+    f1 = np.array([0, 0, 1, 0, 0, 1, 0, 11], np.float32)
+    f2 = np.array([0, 0.1, 1 / 1.1 ** 2, 0, 0, 1 / 1.1 ** 2, 0, 11], np.float32)
+    assert oracle.key_proximity(f1, f2)
 
 
 def test_match_frames_on_device(oracle):
@@ -91,10 +176,10 @@ def test_match_frames_on_device(oracle):
     with sara_amd.SiftContext(320, 280, 3, p) as ctx:
         ctx.detect(np.ascontiguousarray(frames))
         kl = ctx.keypoint_lists()
-        for (i, j) in ((0, 1), (2, 0), (1, 1)):
-            got = ctx.match_frames(i, j, 0.6)
+        for (i, j, ratio) in ((0, 1, 0.6), (2, 0, 0.6), (1, 1, 0.6), (0, 2, 1.2)):
+            got = ctx.match_frames(i, j, ratio)
             want = oracle.compute_matches(kl[i].descriptor_matrix,
-                                          kl[j].descriptor_matrix, 0.6)
+                                          kl[j].descriptor_matrix, ratio)
             assert_same(got, want)
             assert len(got) > 0
 

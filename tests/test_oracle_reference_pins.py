@@ -288,6 +288,76 @@ def test_matching_restatement_properties(oracle):
         oracle.compute_matches(np.zeros((0, 128), np.float32), d2, 0.6)
 
 
+def test_matching_default_ratio_radius_search(oracle):
+    """AnnMatcher.cpp:133-154 with the default sift_ratio_thres = 1.2f, worked
+    by hand.  Query q0 = (0); candidates at squared distances 4, 5, 5.7, 6, 9:
+    radius = 4 * 1.44 = 5.76 -> K = 3 (strictly inside); rank 1 scores
+    d0 / d1 = 0.8, ranks 2, 3 score d / d0 = 1.25, 1.425.  A second query q1 =
+    (2.3) sits next to the candidates, so that in the other direction each of
+    them finds q1, not q0, and the (0, j) pairs come from q0's search alone."""
+    d1 = np.array([[0.0], [2.3]], np.float32)
+    d2 = np.sqrt(np.array([[4.0], [5.0], [5.7], [6.0], [9.0]])).astype(np.float32)
+    m = oracle.compute_matches(d1, d2, 1.2)
+    q0 = m[m["x_index"] == 0]
+    q0 = q0[np.argsort(q0["rank"])]
+    assert list(q0["y_index"]) == [0, 1, 2] and list(q0["rank"]) == [1, 2, 3]
+    assert list(q0["direction"]) == [0, 0, 0]
+    dd = (d2[:, 0] * d2[:, 0]).astype(np.float32)
+    assert q0["score"][0] == dd[0] / dd[1]
+    assert q0["score"][1] == dd[1] / dd[0] and q0["score"][2] == dd[2] / dd[0]
+    # q1's best neighbour is candidate 1 (found from both sides, kept once with
+    # the lower score, :239-254); every candidate's best neighbour is q1
+    q1 = m[m["x_index"] == 1]
+    assert sorted(q1["y_index"]) == [0, 1, 2, 3, 4] and np.all(q1["rank"] == 1)
+    assert np.all(np.diff(m["score"]) >= 0)
+    assert np.all(m["score"] <= np.float32(1.2) * np.float32(1.2))
+    # one candidate only: score 1 (:87-101), kept because 1 < 1.44
+    one = oracle.compute_matches(d2, d1[:1], 1.2)
+    assert len(one) == 5 and np.all(one["y_index"] == 0)
+    # ... except for the pair the lone key's own search also finds (score 0.8)
+    assert sorted(one["score"]) == [np.float32(4) / np.float32(5), 1, 1, 1, 1]
+    # a best distance of exactly 0 gives radius 0: K = 0, nothing from that side
+    z = oracle.compute_matches(np.zeros((2, 2), np.float32),
+                               np.stack([np.arange(10.0), np.arange(10.0)], 1)
+                               .astype(np.float32), 1.2)
+    assert not (z["direction"] == 0).any()
+
+
+def test_self_matching_restatement(oracle):
+    """AnnMatcher{keys, ...} (AnnMatcher.cpp:199-215): rank 0 is the key itself,
+    ranks >= 1 are emitted inside the radius unless KeyProximity
+    (KeyProximity.cpp:17-30) finds the two keys too close; nothing at all for
+    ratio <= 1 (the loop runs over [1, K = 1)).  Reference pin:
+    test_featurematching_key_proximity.cpp:26-37."""
+    f1 = np.array([0, 0, 1, 0, 0, 1, 0, 11], np.float32)
+    f2 = np.array([0, 0.1, 1 / 1.1 ** 2, 0, 0, 1 / 1.1 ** 2, 0, 11], np.float32)
+    assert oracle.key_proximity(f1, f2)
+    far = np.array([100, 0, 1, 0, 0, 1, 0, 11], np.float32)
+    assert not oracle.key_proximity(f1, far)
+    assert oracle.key_proximity(f1, far, 0.5, 101.0)        # pixel threshold
+    wide = np.array([100, 0, 1e-6, 0, 0, 1e-6, 0, 11], np.float32)
+    assert oracle.key_proximity(f1, wide)                   # its metric: 0.01 < 0.25
+    # four keys on a line, descriptors = positions: 0, 1, 2.1, 50 (squared
+    # distances from key 0: 1, 4.41, 2500), 40 px apart in the image
+    d = np.array([[0.0], [1.0], [2.1], [50.0]], np.float32)
+    reg = np.zeros(4, [("coords", "<f4", 2), ("shape_matrix", "<f4", 4),
+                       ("orientation", "<f4"), ("type", "u1")])
+    reg["coords"][:, 0] = [0, 40, 80, 120]
+    reg["shape_matrix"] = [1, 0, 0, 1]
+    m = oracle.compute_self_matches(d, reg, 3.0)            # ratio^2 = 9
+    got = {(int(a), int(b)): (float(s), int(r)) for a, b, s, r in
+           zip(m["x_index"], m["y_index"], m["score"], m["rank"])}
+    # key 0: neighbours 1 (d 1) and 2 (d 4.41 < 9): rank 1 scores 1 / 4.41
+    dd = np.float32(2.1) * np.float32(2.1)
+    assert got[(0, 1)][1] == 1 and got[(0, 1)][0] == float(np.float32(1) / dd)
+    assert (0, 2) in got and got[(0, 2)][1] == 2
+    assert all(a != b for a, b in got)                      # never a key with itself
+    assert len(oracle.compute_self_matches(d, reg, 1.0)) == 0
+    # with a 50 px pixel threshold the adjacent keys are redundant
+    m2 = oracle.compute_self_matches(d, reg, 3.0, 0.5, 50.0)
+    assert all(abs(int(a) - int(b)) > 1 for a, b in zip(m2["x_index"], m2["y_index"]))
+
+
 def test_root_sift_restatement(oracle):
     """FeatureDescriptors/RootSIFT.hpp:45-53 (dead code in the reference: Eigen 2
     API) - h /= lpNorm<1>(h); h = sqrt(h).  Known answers by hand."""
