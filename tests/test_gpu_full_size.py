@@ -104,6 +104,55 @@ def test_4k_five_octaves():
     assert np.isfinite(kdesc).all()
 
 
+def test_4k_five_octaves_against_oracle(oracle):
+    """Config 5's size against the oracle itself (not only through properties):
+    one 3840 x 2160 frame, 5 octaves, at the bars of the 1080p test - planes
+    bit-exact, extremum sites / order exact, coordinates exact, orientation
+    1e-6 rad, descriptors max-abs 2e-3.  The 100 KB bucket table of the fused
+    sort and the 15-strip marching grid only occur at this size."""
+    img = synth(3840, 2160, 4321)
+    ref = oracle.RefSift(img, oracle.PyramidParams(0, 6, None, 1, 0.5, 1.6, 5),
+                         parallel=True)
+    rk, rso, rdesc = ref.keypoints()
+    with sara_amd.SiftContext(3840, 2160, 1, params(5)) as ctx:
+        ctx.detect(img)
+        ec, ereg, exyso = ctx.extrema()
+        kc, kreg, kdesc, kso = ctx.fetch()
+        for (s, o) in ((0, 0), (5, 0), (2, 1), (3, 2), (5, 4)):
+            assert np.array_equal(ctx.gaussian(s, o), ref.gaussian(s, o)), (s, o)
+        assert np.array_equal(ctx.dog(4, 0), ref.dog(4, 0))
+        for (s, o) in ((1, 0), (3, 4)):
+            assert np.array_equal(ctx.gradient(s, o), ref.gradient(s, o)), (s, o)
+    assert np.array_equal(exyso, ref.extrema()[1])
+    assert len(kreg) == len(rk) and len(rk) > 10000
+    assert np.array_equal(kso, rso)
+    common.assert_regions_equal(kreg, rk, rtol_shape=1e-6, atol_theta=1e-6)
+    assert np.max(np.abs(kdesc - rdesc)) <= 2e-3
+
+
+def test_8k_uncapped_octaves_against_oracle(oracle):
+    """Beyond BASELINE's sizes: one 7680 x 4320 frame with the octave count left
+    to the reference's rule (GaussianPyramid.hpp:80-94 -> 9 octaves at this
+    size, the last ones smaller than the border padding), full parity."""
+    img = synth(7680, 4320, 77)
+    big = 2 ** 31 - 1
+    ref = oracle.RefSift(img, oracle.PyramidParams(0, 6, None, 1, 0.5, 1.6, big),
+                         parallel=True)
+    rk, rso, rdesc = ref.keypoints()
+    with sara_amd.SiftContext(7680, 4320, 1, params(big)) as ctx:
+        ctx.detect(img)
+        assert ctx.octave_count == ref.octave_count >= 8
+        kc, kreg, kdesc, kso = ctx.fetch()
+        ec, ereg, exyso = ctx.extrema()
+        for (s, o) in ((5, 0), (0, 3), (4, ref.octave_count - 1)):
+            assert np.array_equal(ctx.gaussian(s, o), ref.gaussian(s, o)), (s, o)
+    assert np.array_equal(exyso, ref.extrema()[1])
+    assert len(kreg) == len(rk) and len(rk) > 40000
+    assert np.array_equal(kso, rso)
+    common.assert_regions_equal(kreg, rk, rtol_shape=1e-6, atol_theta=1e-6)
+    assert np.max(np.abs(kdesc - rdesc)) <= 2e-3
+
+
 def test_default_small_launch_threshold(oracle, tmp_path):
     """conftest.py lowers SARA_HIP_MARCH_MIN_PIXELS so that small test images
     reach the marching / fused kernels; this case runs in a fresh process with
