@@ -232,6 +232,107 @@ def host_to_host(ctx, frames_host, args, torch):
     return out
 
 
+def pyramid_per_kernel(args, torch, dev, frames):
+    """Per-launch device times of the Gaussian-pyramid stage on ONE stream
+    (SARA_HIP_OPT_SINGLE_STREAM + SARA_HIP_OPT_LAUNCH_TIMERS: a hipEvent pair
+    around every launch, on the stream it is launched on), same frames and
+    batch as the timed region.  -> (per-kernel list, serial stage ms).  Each
+    blur reads and writes every pixel of its plane once: 8 B per pixel."""
+    import sara_amd
+    from sara_amd import capi
+    B, W, H = args.frames_per_gpu, args.width, args.height
+    params = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=args.octaves)
+    acc = {}
+    with sara_amd.SiftContext(W, H, B, params, device=dev.index or 0) as c:
+        c.set_option(capi.OPT_SINGLE_STREAM, 1)
+        c.set_option(capi.OPT_LAUNCH_TIMERS, 1)
+        reps = 0
+        for i in range(6):
+            c.detect_device(frames.data_ptr(), B, W, H, last_stage=1)
+            c.synchronize()
+            if i < 2:
+                continue
+            reps += 1
+            for r in c.pyramid_launches():
+                k = (int(r["octave"]), int(r["scale"]), int(r["taps"]),
+                     int(r["pixels"]))
+                acc[k] = acc.get(k, 0.0) + float(r["ms"])
+    rows, total_ms = [], 0.0
+    for (o, sc, taps, px), ms in sorted(acc.items()):
+        ms /= reps
+        total_ms += ms
+        rows.append({"octave": o, "scale": sc, "radius": taps // 2,
+                     "us": round(1e3 * ms, 2),
+                     "GBs": round(8 * px / 1e9 / (ms / 1e3), 1),
+                     "frac": round(8 * px / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4)})
+    return rows, total_ms
+
+
+def odd_width_case(torch, dev):
+    """A width that is not a multiple of 4 (1366 x 768 video): such rows cannot
+    be cut into float4 strips, so the pyramid takes another path.  Recorded so
+    that the cost of that path is a number."""
+    import sara_amd
+    from sara_amd.synth import synth_batch
+    out = {}
+    p4 = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=4)
+    for name, W, H in (("1366x768", 1366, 768), ("1368x768", 1368, 768)):
+        B = 64
+        f = torch.from_numpy(synth_batch(W, H, B, unique=8)).to(dev)
+        P = sum((W >> o) * (H >> o) for o in range(4))
+        with sara_amd.SiftContext(W, H, B, p4, device=dev.index or 0) as c:
+            pyr, tot, kp = [], [], 0
+            for i in range(6):
+                c.detect_device(f.data_ptr(), B, W, H)
+                _, kp = c.counts()
+                if i >= 2:
+                    st = c.stage_times()
+                    pyr.append(st["pyramid"])
+                    tot.append(st["total"])
+        pyr_ms, tot_ms = float(np.mean(pyr)), float(np.mean(tot))
+        out[name] = {"pyramid_ms": pyr_ms, "ms_per_step": tot_ms,
+                     "pyramid_frac_of_hbm_peak":
+                         48 * P * B / 1e9 / (pyr_ms / 1e3) / HBM_PEAK_GBS,
+                     "keypoints_per_s": kp / (tot_ms / 1e3)}
+        del f
+    out["workload"] = ("64 frames, 4 octaves, full SIFT; 1366 is not a multiple "
+                       "of 4, 1368 is the nearest width that is")
+    out["pyramid_slowdown"] = (out["1366x768"]["pyramid_ms"] /
+                               out["1368x768"]["pyramid_ms"])
+    return out
+
+
+def match_config(torch, dev):
+    """The immediate consumer: AnnMatcher / match() on the
+    keypoints of two 1080p frames, descriptors resident in HBM."""
+    import sara_amd
+    from sara_amd.synth import synth_batch
+    from sara_amd.synth import synth
+    W, H = 1920, 1080
+    p4 = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=4)
+    # two views of one scene: 1080p crops of a larger synthetic frame, shifted
+    # by (24, 8) pixels - what consecutive video frames give the matcher
+    scene = synth(W + 24, H + 8, 1234)
+    frames = np.ascontiguousarray(
+        np.stack([scene[:H, :W], scene[8:H + 8, 24:W + 24]]))
+    out = {}
+    with sara_amd.SiftContext(W, H, 2, p4, device=dev.index or 0) as c:
+        c.detect(frames)
+        counts, _ = c.counts()
+        n1, n2 = int(counts[0]), int(counts[1])
+        for name, ratio in (("ratio_0.6", 0.6), ("ratio_1.2_default", 1.2)):
+            m = c.match_frames(0, 1, ratio)
+            t = timed(lambda: c.match_frames(0, 1, ratio), 50, 5)
+            out[name] = {"ms_per_pair": 1e3 * t, "matches": int(len(m))}
+    out["workload"] = ("AnnMatcher::compute_matches on %d x %d SIFT descriptors "
+                       "(two 1080p frames), both directions, descriptors in HBM, "
+                       "match list on the host" % (n1, n2))
+    # exact arithmetic of the exhaustive search: n1*n2*128 (sub, mul, add) per
+    # direction; the prefilter path does one n1*n2*128 f32 MFMA contraction
+    out["pair_distance_terms"] = 2 * n1 * n2 * 128
+    return out
+
+
 def secondary_configs(args, torch, dev):
     """BASELINE.json configs 2 and 5 as secondary measurements (rank 0, N = 1):
     config 2 = ONE 1920x1080 frame, pyramid + DoG + extrema only, against the
@@ -331,6 +432,121 @@ def secondary_configs(args, torch, dev):
     }
     del d_one, d4, db
     return out
+
+
+def verify_gather(ctx, comm, frames, args, dist, rank, world):
+    """N > 1, outside the timed region: the BYTES that reach the root, not just
+    their count.  Every rank hashes its own results (detect + fetch of the very
+    frames it benchmarks; the pipeline is deterministic), the hashes travel
+    over gloo, and rank 0 compares them with the slices of one more RCCL
+    gather at the per-rank offsets."""
+    import hashlib
+    B, W, H = args.frames_per_gpu, args.width, args.height
+    ctx.detect_device(frames.data_ptr(), B, W, H, last_stage=5)
+    _, reg, desc, so = ctx.fetch()
+    mine = [hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+            for a in (reg, desc, so)] + [len(reg)]
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    t = ctx.submit_raw(frames.data_ptr(), 0, B, W, H, on_device=True, last_stage=5)
+    res = comm.gather(t, root=0)
+    if rank != 0:
+        return None
+    f, d, s2 = res.host()
+    at = 0
+    for r, (hf, hd, hs, n) in enumerate(everyone):
+        if res.counts[r] != n:
+            raise SystemExit("gather: rank %d sent %d keypoints, the root has %d"
+                             % (r, n, res.counts[r]))
+        got = [hashlib.sha256(np.ascontiguousarray(a[at:at + n]).tobytes())
+               .hexdigest() for a in (f, d, s2)]
+        if got != [hf, hd, hs]:
+            raise SystemExit("gather: the bytes of rank %d on the root differ "
+                             "from what it computed" % r)
+        at += n
+    return {"ranks": world, "keypoints": at,
+            "what": "sha256 of OERegion[], descriptors and (s,o) of every rank's "
+                    "shard == sha256 of the root's slice at that rank's offset"}
+
+
+def host_to_host_multi(ctx, frames_host, args, torch, dist, rank, world, kp_hint):
+    """SURVEY.md 8d's ending for N > 1: results in HOST memory, without
+    funnelling them through the root GPU (8 x 64 frames x 4.4 k keypoints x 568 B
+    = 1.27 GB per step would cross ONE PCIe link: about 23 ms against a 7 ms
+    step).  Every rank copies its shard straight into ONE host array - a shared
+    mapping every process registers with HIP - at its global offset, over its
+    own PCIe link; the counts that fix the offsets travel over gloo.  gray8
+    frames in pinned host memory in, two batches in flight per rank."""
+    from multiprocessing import shared_memory
+    from sara_amd import capi
+    B, H, W = frames_host.shape
+    cap = int(1.3 * kp_hint * world) + 4096           # keypoints of one step
+    sizes = (48 * cap, 512 * cap, 8 * cap)
+    name = [None]
+    shm = None
+    if rank == 0:
+        shm = shared_memory.SharedMemory(create=True, size=sum(sizes))
+        name[0] = shm.name
+    dist.broadcast_object_list(name, src=0)
+    if rank != 0:
+        shm = shared_memory.SharedMemory(name=name[0])
+        try:  # only the creator unlinks; keep this rank's tracker out of it
+            from multiprocessing import resource_tracker
+            resource_tracker.unregister(shm._name, "shared_memory")
+        except Exception:
+            pass
+    buf = np.frombuffer(shm.buf, dtype=np.uint8)
+    base = buf.ctypes.data
+    lib = capi.load()
+    capi.check(lib.sara_hip_host_register(base, sum(sizes)))
+    u8 = torch.from_numpy(np.round(frames_host * 255.0).astype(np.uint8)).pin_memory()
+    state = {"ticket": None, "kp": 0}
+
+    def deliver(ticket):
+        _, total = ctx.ticket_counts(ticket)
+        n_t = torch.tensor([total], dtype=torch.int64)
+        all_n = [torch.zeros_like(n_t) for _ in range(world)]
+        dist.all_gather(all_n, n_t)
+        counts = [int(t.item()) for t in all_n]
+        if sum(counts) > cap:
+            raise SystemExit("host_to_host_multi: %d keypoints exceed the shared "
+                             "array (%d)" % (sum(counts), cap))
+        at = sum(counts[:rank])
+        ctx.collect_into(ticket, base + 48 * at, base + sizes[0] + 512 * at,
+                         base + sizes[0] + sizes[1] + 8 * at)
+        return sum(counts)
+
+    def step():
+        t = ctx.submit_raw(u8.data_ptr(), 1, B, W, H, on_device=False)
+        if state["ticket"] is not None:
+            state["kp"] += deliver(state["ticket"])
+        state["ticket"] = t
+
+    for _ in range(3):
+        step()
+    deliver(state["ticket"])
+    state.update(ticket=None, kp=0)
+    steps = max(args.steps, 8)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    state["kp"] += deliver(state["ticket"])
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    capi.check(lib.sara_hip_host_unregister(base))
+    del buf
+    shm.close()
+    if rank == 0:
+        shm.unlink()
+    return {"keypoints_per_s": state["kp"] / float(dt.item()),
+            "ms_per_step": 1e3 * float(dt.item()) / steps,
+            "definition": "gray8 frames in pinned host memory on every rank -> "
+                          "ONE host array (shared, HIP-registered) holding all "
+                          "ranks' OERegion[] + descriptors + (s,o) in global "
+                          "frame order; every GPU writes its shard over its own "
+                          "PCIe link; counts over gloo"}
 
 
 def main():
@@ -537,6 +753,14 @@ def main():
     if comm is not None and rank == 0 and gathered[0] != kp_total:
         raise SystemExit("gather: %d keypoints reached rank 0, the ranks "
                          "produced %d" % (gathered[0], kp_total))
+    gather_check = h2h_multi = None
+    if comm is not None and args.stage >= 5:
+        gather_check = verify_gather(ctx, comm, frames, args, dist, rank, world)
+    if world > 1 and args.stage >= 5:
+        if not args.no_extras:
+            h2h_multi = host_to_host_multi(
+                ctx, frames_host, args, torch, dist, rank, world,
+                kp_total / max(args.steps, 1) / world)
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -566,6 +790,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "value_definition": (
+                "HBM-resident: frames in HBM when the timed region starts, "
+                "keypoint arrays in HBM%s when it ends.  SURVEY.md 8d's metric "
+                "(pinned host frames -> results in host memory) is "
+                "value_host_to_host_*" % (" of rank 0" if world > 1 else "")),
             "config": {
                 "workload": "full SIFT (pyramid+DoG, extrema+refine, polar "
                             "gradients, orientations, 128-D descriptors) on "
@@ -601,12 +830,35 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": (
+                    "profiles/pyramid_traffic.json: rocprofv3 --pmc FETCH_SIZE / "
+                    "WRITE_SIZE passes of an earlier run of this command (x2 per "
+                    "the guide, calibrated by tools/ubench/fetch_calib.hip); a "
+                    "static file, NOT measured in this run") if traffic else None,
                 "launches_per_step": pyr_launches,
                 "avg_launch_us": 1e3 * pyr_ms / max(pyr_launches, 1),
                 "algorithmic_bytes_per_step": bytes_frame * B,
                 "us_per_frame": 1e3 * pyr_ms / B,
             },
         }
+        if gather_check is not None:
+            out["config"]["gather_verified"] = gather_check
+        if h2h_multi is not None:
+            out["value_host_to_host_gray8"] = h2h_multi["keypoints_per_s"]
+            out["config"]["host_to_host"] = h2h_multi
+        if world == 1 and not args.no_extras:
+            # the same stage on ONE stream, an event pair around every launch
+            rows, serial_ms = pyramid_per_kernel(args, torch, dev, frames)
+            out["roofline"]["serial_ms"] = serial_ms
+            out["roofline"]["serial_frac"] = (
+                bytes_frame * B / 1e9 / (serial_ms / 1e3) / HBM_PEAK_GBS)
+            out["roofline"]["frac_definition"] = (
+                "frac: per-octave streams overlapped (the shipped schedule), "
+                "first launch -> all octaves joined; serial_frac: the same "
+                "launches on one stream, sum of their durations")
+            out["roofline"]["per_kernel"] = rows
+            worst = min((r for r in rows if r["radius"] > 0), key=lambda r: r["frac"])
+            out["roofline"]["worst_kernel"] = worst
         if world == 1 and args.cpu_frames > 0:
             oracle_results, out["cpu_baseline"] = cpu_baseline(args, frames_host)
             out["config"]["gpu_over_cpu"] = out["value"] / max(
@@ -624,6 +876,8 @@ def main():
                     % (n_ok - 1, B, worst))
         if world == 1 and not args.no_extras and args.stage >= 5:
             h2h = host_to_host(ctx, frames_host, args, torch)
+            out["value_host_to_host_gray8"] = h2h["gray8"]["keypoints_per_s"]
+            out["value_host_to_host_float32"] = h2h["float32"]["keypoints_per_s"]
             out["config"]["host_to_host_keypoints_per_s"] = \
                 h2h["gray8"]["keypoints_per_s"]
             out["config"]["host_to_host"] = {
@@ -634,6 +888,8 @@ def main():
                 "gray8": h2h["gray8"], "float32": h2h["float32"]}
             ctx.close()
             out["config"].update(secondary_configs(args, torch, dev))
+            out["config"]["width_not_multiple_of_4"] = odd_width_case(torch, dev)
+            out["config"]["match"] = match_config(torch, dev)
         print(json.dumps(out))
     if comm is not None:
         comm.close()

@@ -293,6 +293,24 @@ SARA_HIP_API sara_hip_status sara_hip_sift_fetch_extrema(sara_hip_sift* ctx,
 SARA_HIP_API sara_hip_status sara_hip_sift_stage_times(sara_hip_sift* ctx,
                                                       float* ms);
 
+/* Per-launch device times of the Gaussian-pyramid stage of the last detect()   */
+/* (SARA_HIP_OPT_LAUNCH_TIMERS): which plane (octave, scale; scale 0 = the base  */
+/* blur of octave 0 or a separate octave hand-over), the tap count of the blur   */
+/* (0 for a hand-over), the pixels it wrote (batch included) and its duration.   */
+/* With SARA_HIP_OPT_SINGLE_STREAM the launches do not overlap and the times     */
+/* are kernel durations; otherwise launches of different octaves overlap.        */
+/* *count = launches recorded (may exceed capacity).  Synchronises.              */
+typedef struct sara_hip_launch_time
+{
+  int32_t octave, scale, taps;
+  int32_t _pad;
+  int64_t pixels;
+  float ms;
+  float _pad2;
+} sara_hip_launch_time;
+SARA_HIP_API sara_hip_status sara_hip_sift_pyramid_launches(
+    sara_hip_sift* ctx, sara_hip_launch_time* out, int capacity, int* count);
+
 /* Options. */
 enum
 {
@@ -317,6 +335,14 @@ enum
                                         /* one at 2 sigma_0, instead of floor() */
                                         /* (GaussianPyramid.hpp:97-100), which   */
                                         /* is one lower for k = float(2^(1/3))  */
+  SARA_HIP_OPT_SINGLE_STREAM = 7,       /* 1: every launch on one stream (the     */
+                                        /* per-octave streams of the pyramid off): */
+                                        /* kernel durations then add up to the     */
+                                        /* stage times (measurement aid)           */
+  SARA_HIP_OPT_LAUNCH_TIMERS = 8,       /* 1: a hipEvent pair around every launch  */
+                                        /* of the Gaussian-pyramid stage, read by  */
+                                        /* sara_hip_sift_pyramid_launches();       */
+                                        /* ignored under HIP-graph replay          */
   SARA_HIP_OPT_FMA_BLUR = 6             /* 1: the Gaussian blurs fuse multiply   */
                                         /* and add (v_fma_f32): half the         */
                                         /* arithmetic, pyramids within 3e-7 of   */

@@ -454,6 +454,16 @@ class SiftContext:
             xyso.ctypes.data_as(C.POINTER(C.c_int32))))
         return c, regions, xyso
 
+    def pyramid_launches(self):
+        """Per-launch device times of the pyramid stage of the last detect()
+        (capi.OPT_LAUNCH_TIMERS; with capi.OPT_SINGLE_STREAM they are kernel
+        durations) -> structured array (octave, scale, taps, pixels, ms)."""
+        out = np.zeros(256, capi.LAUNCH_TIME_DTYPE)
+        n = C.c_int(0)
+        capi.check(capi.load().sara_hip_sift_pyramid_launches(
+            self._h, out.ctypes.data, len(out), C.byref(n)))
+        return out[:min(n.value, len(out))]
+
     def stage_times(self):
         ms = (C.c_float * 7)()
         capi.check(capi.load().sara_hip_sift_stage_times(self._h, ms))

@@ -31,6 +31,12 @@ OPT_ROOT_SIFT = 3
 OPT_SIGNED_EXTREMUM_TYPE = 4
 OPT_DOWNSCALE_AT_DOUBLE_SIGMA = 5
 OPT_FMA_BLUR = 6
+OPT_SINGLE_STREAM = 7
+OPT_LAUNCH_TIMERS = 8
+
+LAUNCH_TIME_DTYPE = np.dtype([("octave", "<i4"), ("scale", "<i4"), ("taps", "<i4"),
+                              ("_pad", "<i4"), ("pixels", "<i8"), ("ms", "<f4"),
+                              ("_pad2", "<f4")])
 
 #: numpy view of sara_oeregion (48 bytes, Features/Feature.hpp:155-177).
 MATCH_DTYPE = np.dtype([("x_index", "<i4"), ("y_index", "<i4"), ("score", "<f4"),
@@ -99,7 +105,7 @@ EXPORTS = [
     "sara_hip_host_register", "sara_hip_host_unregister",
     "sara_hip_comm_transport", "sara_hip_sift_group_collect_host",
     "sara_hip_sift_group_transport", "sara_hip_self_match_descriptors",
-    "sara_hip_match_release_workspace",
+    "sara_hip_match_release_workspace", "sara_hip_sift_pyramid_launches",
 ]
 
 _f32p = C.POINTER(C.c_float)
@@ -156,6 +162,8 @@ def _declare(lib):
     lib.sara_hip_sift_fetch_extrema.argtypes = [_vp, _vp, _i32p]
     lib.sara_hip_sift_stage_times.argtypes = [_vp, _f32p]
     lib.sara_hip_sift_set_option.argtypes = [_vp, C.c_int, C.c_int]
+    lib.sara_hip_sift_pyramid_launches.argtypes = [_vp, _vp, C.c_int,
+                                                   C.POINTER(C.c_int)]
     lib.sara_hip_apply_gaussian_filter.argtypes = [_f32p, _f32p, C.c_int,
                                                    C.c_int, C.c_float,
                                                    C.c_float, C.c_int]

@@ -400,6 +400,17 @@ struct sara_hip_sift
   bool graph_broken = false;  // a capture failed once: stay on plain launches
   hipEvent_t ev[SARA_HIP_TIME_COUNT + 1] = {};
   bool ev_recorded[SARA_HIP_TIME_COUNT + 1] = {};
+  // SARA_HIP_OPT_LAUNCH_TIMERS: one event pair around every launch of the
+  // pyramid stage (plain launches only), read by sara_hip_sift_pyramid_launches
+  bool launch_timers = false;
+  struct LaunchRecord
+  {
+    hipEvent_t begin = nullptr, end = nullptr;
+    int octave = 0, scale = 0, taps = 0;
+    long long pixels = 0;
+  };
+  std::vector<LaunchRecord> launch_rec;
+  int launch_count = 0;
 
   std::vector<void*> allocations;
 
@@ -499,7 +510,14 @@ namespace {
   } while (0)
 
     TRY_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    for (auto& e : c->ev)
+    for (auto& r : c->launch_rec)
+  {
+    if (r.begin)
+      (void) hipEventDestroy(r.begin);
+    if (r.end)
+      (void) hipEventDestroy(r.end);
+  }
+  for (auto& e : c->ev)
       TRY_HIP(hipEventCreate(&e));
     for (int o = 0; o < 16; ++o)
     {
@@ -912,6 +930,14 @@ sara_hip_status sara_hip_sift_set_option(sara_hip_sift* c, int option, int value
   case SARA_HIP_OPT_STAGE_TIMERS:
     c->timers = value != 0;
     return SARA_HIP_OK;
+  case SARA_HIP_OPT_SINGLE_STREAM:
+    c->multi_stream = value == 0;
+    c->graph_stage_s[0] = c->graph_stage_s[1] = -1;
+    return SARA_HIP_OK;
+  case SARA_HIP_OPT_LAUNCH_TIMERS:
+    c->launch_timers = value != 0;
+    c->launch_count = 0;
+    return SARA_HIP_OK;
   case SARA_HIP_OPT_ROOT_SIFT:
     c->root_sift = value != 0;
     c->graph_stage_s[0] = c->graph_stage_s[1] = -1;
@@ -1086,6 +1112,33 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   }
   HIP_TRY(mark(1));
 
+  // SARA_HIP_OPT_LAUNCH_TIMERS (plain launches only): an event pair per launch
+  const bool time_launches = c->launch_timers && !graph_mode;
+  c->launch_count = 0;
+  auto launch_begin = [&](int o, int s, int ntaps, size_t pixels,
+                          hipStream_t st) -> int {
+    if (!time_launches)
+      return -1;
+    if (size_t(c->launch_count) >= c->launch_rec.size())
+    {
+      sara_hip_sift::LaunchRecord r;
+      if (hipEventCreate(&r.begin) != hipSuccess || hipEventCreate(&r.end) != hipSuccess)
+        return -1;
+      c->launch_rec.push_back(r);
+    }
+    sara_hip_sift::LaunchRecord& r = c->launch_rec[size_t(c->launch_count)];
+    r.octave = o;
+    r.scale = s;
+    r.taps = ntaps;
+    r.pixels = (long long) pixels;
+    (void) hipEventRecord(r.begin, st);
+    return c->launch_count++;
+  };
+  auto launch_end = [&](int rec, hipStream_t st) {
+    if (rec >= 0)
+      (void) hipEventRecord(c->launch_rec[size_t(rec)].end, st);
+  };
+
   auto enqueue = [&]() -> sara_hip_status {
 
   static const bool fuse_gradient_env = [] {
@@ -1186,6 +1239,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     else if (sc.init_blur)
     {
       bool done = false;
+      const int rec = launch_begin(0, 0, c->init_taps.size, pl0 * batch, stream);
       if (gray8_fused)
       {
         done = launch_gaussian_blur_gray8(gray8, gray8_stride, G00, g_stride0, width,
@@ -1198,6 +1252,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
         launch_gaussian_blur(src, src_stride, G00, g_stride0, nullptr, 0, width,
                              height, batch, c->init_taps, stream, nullptr, 0,
                              c->fma_blur);
+      launch_end(rec, stream);
     }
     else
     {
@@ -1223,9 +1278,11 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
         dec = c->G[o + 1];
         dec_stride = size_t(sc.oct[o + 1].w) * sc.oct[o + 1].h * S;
       }
+      const int rec = launch_begin(o, s, c->taps[s].size, pl * batch, st);
       const bool fused = launch_gaussian_blur(
           c->G[o] + pl * (s - 1), gs, c->G[o] + pl * s, gs, nullptr, 0, w, h,
           batch, c->taps[s], st, dec, dec_stride, c->fma_blur);
+      launch_end(rec, st);
       if (dec)
         base_ready = fused;
     };
@@ -1235,9 +1292,12 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       {
         const int pw = sc.oct[o - 1].w, ph = sc.oct[o - 1].h;
         const size_t ppl = size_t(pw) * ph;
+        const int rec = launch_begin(o, 0, 0,
+                                     size_t(sc.oct[o].w) * sc.oct[o].h * batch, st);
         launch_scale(c->G[o - 1] + ppl * dsi, ppl * S, pw, ph, c->G[o],
                      size_t(sc.oct[o].w) * sc.oct[o].h * S, sc.oct[o].w,
                      sc.oct[o].h, batch, st);
+        launch_end(rec, st);
       }
       base_ready = false;
     };
@@ -2262,6 +2322,33 @@ sara_hip_status sara_hip_sift_stage_times(sara_hip_sift* c, float* ms)
   if (c->ev_recorded[0] && c->ev_recorded[SARA_HIP_TIME_TOTAL])
     HIP_TRY(hipEventElapsedTime(&ms[SARA_HIP_TIME_TOTAL], c->ev[0],
                                 c->ev[SARA_HIP_TIME_TOTAL]));
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_sift_pyramid_launches(sara_hip_sift* c,
+                                               sara_hip_launch_time* out,
+                                               int capacity, int* count)
+{
+  const sara_hip_status st = require_result(c, SARA_HIP_STAGE_PYRAMID);
+  if (st != SARA_HIP_OK)
+    return st;
+  if (!count || (capacity > 0 && !out))
+    return fail(SARA_HIP_INVALID_PARAMS, "null destination");
+  if (!c->launch_timers)
+    return fail(SARA_HIP_NOT_READY, "SARA_HIP_OPT_LAUNCH_TIMERS is off");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->last_stream));
+  *count = c->launch_count;
+  for (int i = 0; i < c->launch_count && i < capacity; ++i)
+  {
+    const sara_hip_sift::LaunchRecord& r = c->launch_rec[size_t(i)];
+    out[i].octave = r.octave;
+    out[i].scale = r.scale;
+    out[i].taps = r.taps;
+    out[i].pixels = r.pixels;
+    out[i].ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&out[i].ms, r.begin, r.end));
+  }
   return SARA_HIP_OK;
 }
 
