@@ -329,6 +329,18 @@ namespace sara_hip {
                                 float squared_ratio_thres, MatchNeighbour* out,
                                 int capacity, int* count, hipStream_t stream);
 
+  // MFMA prefilter + exact re-ranking (match_mfma.hip): the same answers as the
+  // exhaustive kernels for both directions at once.
+  size_t match_mfma_scratch_floats(int n1, int n2);
+  size_t match_mfma_scratch_ints(int n1, int n2, int cap);
+  void launch_match_mfma(const float* d1, int n1, const float* d2, int n2, int dim,
+                         float squared_ratio_thres, int top1, int with_dir1,
+                         float* fscratch, int* iscratch, int cap,
+                         float* top12_d, int* top12_i, float* top21_d, int* top21_i,
+                         MatchNeighbour* radius12, int radius12_cap, int* radius12_count,
+                         MatchNeighbour* radius21, int radius21_cap, int* radius21_count,
+                         hipStream_t stream);
+
   // ---- hand-off between the context and the RCCL gather (sift_comm.cpp) ------
   //! Device-resident results of one submit() ticket.
   struct TicketResults

@@ -289,58 +289,146 @@ namespace {
     });
   }
 
-  //! knnSearch(3) (+ radiusSearch when thres2 > 1) of q in t, results on the host.
-  sara_hip_status search(Workspace& ws, const float* q, int nq, const float* t,
-                         int nt, int dim, float thres2, int top1, Neighbours* nb)
+  //! Which producer answers the neighbour queries: "mfma" = MFMA prefilter +
+  //! exact re-ranking (match_mfma.hip), "exhaustive" = every distance in
+  //! FLANN's arithmetic (match_kernels.hip).  Same answers, entry by entry.
+  //! Default: mfma from 256 keys per set on; SARA_HIP_MATCH forces one.
+  bool use_mfma(int n1, int n2)
   {
+    static const int forced = [] {
+      const char* e = getenv("SARA_HIP_MATCH");
+      if (!e)
+        return 0;
+      return std::string(e) == "mfma" ? 1 : std::string(e) == "exhaustive" ? 2 : 0;
+    }();
+    if (forced)
+      return forced == 1;
+    return std::min(n1, n2) >= 256;
+  }
+
+  //! knnSearch(3) - and radiusSearch when thres2 > 1 - of both directions,
+  //! results in device memory of the workspace.
+  struct DeviceSearch
+  {
+    float* top_d[2] = {nullptr, nullptr};  // [3][nq] of direction 0 / 1
+    int* top_i[2] = {nullptr, nullptr};
+    MatchNeighbour* radius[2] = {nullptr, nullptr};
+    int radius_found[2] = {0, 0};
+    int nq[2] = {0, 0}, nt[2] = {0, 0};
+    bool have[2] = {false, false};
+  };
+
+  sara_hip_status device_search(Workspace& ws, const float* d1, int n1,
+                                const float* d2, int n2, int dim, float thres2,
+                                int top1, bool self_matching, DeviceSearch* out)
+  {
+    DeviceSearch& r = *out;
+    r.nq[0] = n1;
+    r.nt[0] = n2;
+    r.nq[1] = n2;
+    r.nt[1] = n1;
+    // a direction has something to rank when its target set has >= 2 keys
+    r.have[0] = n2 >= 2;
+    r.have[1] = !self_matching && n1 >= 2;
+    float* top_d = nullptr;
+    int* top_i = nullptr;
+    HIPM_TRY(ws.get(Workspace::kTopD, 3 * (size_t(n1) + n2), top_d));
+    HIPM_TRY(ws.get(Workspace::kTopI, 3 * (size_t(n1) + n2), top_i));
+    r.top_d[0] = top_d;
+    r.top_d[1] = top_d + 3 * size_t(n1);
+    r.top_i[0] = top_i;
+    r.top_i[1] = top_i + 3 * size_t(n1);
+    const bool radius_on = thres2 > 1.f;
+    int* d_count = nullptr;
+    HIPM_TRY(ws.get(Workspace::kAux0, 4, d_count));
+    const bool mfma = use_mfma(n1, n2) && r.have[0] && (self_matching || r.have[1]);
+    size_t cap[2] = {0, 0};
+    if (radius_on)
+      for (int dir = 0; dir < 2; ++dir)
+        cap[dir] = r.have[dir] ? std::max<size_t>(8 * size_t(r.nq[dir]), 1 << 15) : 1;
+    for (int attempt = 0; attempt < 2; ++attempt)
+    {
+      MatchNeighbour* list = nullptr;
+      if (radius_on)
+      {
+        HIPM_TRY(ws.get(Workspace::kRadius, cap[0] + cap[1], list));
+        HIPM_TRY(hipMemsetAsync(d_count, 0, 4 * sizeof(int), nullptr));
+      }
+      r.radius[0] = list;
+      r.radius[1] = list ? list + cap[0] : nullptr;
+      if (mfma)
+      {
+        const int slots = radius_on ? 32 : 8;
+        float* fs = nullptr;
+        int* is = nullptr;
+        HIPM_TRY(ws.get(Workspace::kAux1, match_mfma_scratch_floats(n1, n2), fs));
+        HIPM_TRY(ws.get(Workspace::kAux2, match_mfma_scratch_ints(n1, n2, slots), is));
+        launch_match_mfma(d1, n1, d2, n2, dim, thres2, top1, r.have[1] ? 1 : 0, fs,
+                          is, slots, r.top_d[0], r.top_i[0], r.top_d[1], r.top_i[1],
+                          r.radius[0], int(cap[0]), d_count, r.radius[1],
+                          int(cap[1]), d_count + 1, nullptr);
+      }
+      else
+        for (int dir = 0; dir < 2; ++dir)
+        {
+          if (!r.have[dir])
+            continue;
+          const float* q = dir == 0 ? d1 : d2;
+          const float* t = dir == 0 ? d2 : d1;
+          const int nq = r.nq[dir], nt = r.nt[dir];
+          int chunk = 0, nchunks = 0;
+          match_chunking(nq, nt, &chunk, &nchunks);
+          float* part_d = nullptr;
+          int* part_i = nullptr;
+          HIPM_TRY(ws.get(Workspace::kPartD, 3 * size_t(nchunks) * nq, part_d));
+          HIPM_TRY(ws.get(Workspace::kPartI, 3 * size_t(nchunks) * nq, part_i));
+          launch_nn3_exhaustive(q, nq, t, nt, dim, part_d, part_i, r.top_d[dir],
+                                r.top_i[dir], nullptr);
+          if (radius_on && nt > top1 + 1)
+            launch_radius_exhaustive(q, nq, t, nt, dim, r.top_d[dir], top1, thres2,
+                                     r.radius[dir], int(cap[dir]), d_count + dir,
+                                     nullptr);
+        }
+      HIPM_TRY(hipGetLastError());
+      if (!radius_on)
+        break;
+      int found[2] = {0, 0};
+      HIPM_TRY(hipMemcpy(found, d_count, 2 * sizeof(int), hipMemcpyDeviceToHost));
+      r.radius_found[0] = found[0];
+      r.radius_found[1] = found[1];
+      if (size_t(found[0]) <= cap[0] && size_t(found[1]) <= cap[1])
+        break;
+      // the counts are exact: the second pass fits
+      cap[0] = std::max(cap[0], size_t(found[0]));
+      cap[1] = std::max(cap[1], size_t(found[1]));
+    }
+    return SARA_HIP_OK;
+  }
+
+  //! One direction of a DeviceSearch on the host, radius members sorted the
+  //! way FLANN's RadiusResultSet hands them out: by (distance, index).
+  sara_hip_status to_host(const DeviceSearch& r, int dir, Neighbours* nb)
+  {
+    const int nq = r.nq[dir];
     nb->nq = nq;
-    nb->nt = nt;
+    nb->nt = r.nt[dir];
     nb->top_d.assign(3 * size_t(nq), 0.f);
     nb->top_i.assign(3 * size_t(nq), -1);
     nb->radius.clear();
     nb->begin.assign(size_t(nq) + 1, 0);
-    int chunk = 0, nchunks = 0;
-    match_chunking(nq, nt, &chunk, &nchunks);
-    float *part_d = nullptr, *top_d = nullptr;
-    int *part_i = nullptr, *top_i = nullptr;
-    HIPM_TRY(ws.get(Workspace::kPartD, 3 * size_t(nchunks) * nq, part_d));
-    HIPM_TRY(ws.get(Workspace::kPartI, 3 * size_t(nchunks) * nq, part_i));
-    HIPM_TRY(ws.get(Workspace::kTopD, 3 * size_t(nq), top_d));
-    HIPM_TRY(ws.get(Workspace::kTopI, 3 * size_t(nq), top_i));
-    launch_nn3_exhaustive(q, nq, t, nt, dim, part_d, part_i, top_d, top_i, nullptr);
-    HIPM_TRY(hipGetLastError());
-    HIPM_TRY(hipMemcpyAsync(nb->top_d.data(), top_d, sizeof(float) * 3 * nq,
-                            hipMemcpyDeviceToHost, nullptr));
-    HIPM_TRY(hipMemcpyAsync(nb->top_i.data(), top_i, sizeof(int) * 3 * nq,
-                            hipMemcpyDeviceToHost, nullptr));
-    if (thres2 > 1.f && nt > top1 + 1)
+    if (!r.have[dir])
+      return SARA_HIP_OK;
+    HIPM_TRY(hipMemcpy(nb->top_d.data(), r.top_d[dir], sizeof(float) * 3 * nq,
+                       hipMemcpyDeviceToHost));
+    HIPM_TRY(hipMemcpy(nb->top_i.data(), r.top_i[dir], sizeof(int) * 3 * nq,
+                       hipMemcpyDeviceToHost));
+    const int found = r.radius_found[dir];
+    if (found > 0)
     {
-      int* d_count = nullptr;
-      HIPM_TRY(ws.get(Workspace::kAux0, 1, d_count));
-      size_t cap = std::max<size_t>(8 * size_t(nq), 1 << 16);
-      for (int attempt = 0; attempt < 2; ++attempt)
-      {
-        MatchNeighbour* d_list = nullptr;
-        HIPM_TRY(ws.get(Workspace::kRadius, cap, d_list));
-        HIPM_TRY(hipMemsetAsync(d_count, 0, sizeof(int), nullptr));
-        launch_radius_exhaustive(q, nq, t, nt, dim, top_d, top1, thres2, d_list,
-                                 int(cap), d_count, nullptr);
-        HIPM_TRY(hipGetLastError());
-        int found = 0;
-        HIPM_TRY(hipMemcpy(&found, d_count, sizeof(int), hipMemcpyDeviceToHost));
-        if (size_t(found) > cap)
-        {
-          cap = size_t(found);  // the count is exact: the second pass fits
-          continue;
-        }
-        nb->radius.resize(size_t(found));
-        if (found > 0)
-          HIPM_TRY(hipMemcpy(nb->radius.data(), d_list,
-                             sizeof(MatchNeighbour) * size_t(found),
-                             hipMemcpyDeviceToHost));
-        break;
-      }
-      // FLANN's RadiusResultSet, sorted: by (distance, index) per query
+      nb->radius.resize(size_t(found));
+      HIPM_TRY(hipMemcpy(nb->radius.data(), r.radius[dir],
+                         sizeof(MatchNeighbour) * size_t(found),
+                         hipMemcpyDeviceToHost));
       std::sort(nb->radius.begin(), nb->radius.end(),
                 [](const MatchNeighbour& a, const MatchNeighbour& b) {
                   if (a.query != b.query)
@@ -354,7 +442,6 @@ namespace {
       for (int i = 0; i < nq; ++i)
         nb->begin[size_t(i) + 1] += nb->begin[size_t(i)];
     }
-    HIPM_TRY(hipStreamSynchronize(nullptr));
     return SARA_HIP_OK;
   }
 
@@ -411,6 +498,11 @@ sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,
     d2 = b;
   }
   std::vector<sara_match> m;
+  DeviceSearch ds;
+  const sara_hip_status ss =
+      device_search(ws, d1, n1, d2, n2, dim, thres2, 0, false, &ds);
+  if (ss != SARA_HIP_OK)
+    return ss;
   if (!(thres2 > 1.f))
   {
     // Only the best neighbour can pass: the ratio test runs on the device and
@@ -428,28 +520,13 @@ sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,
     int* d_count = reinterpret_cast<int*>(d_out);
     sara_match* d_m = reinterpret_cast<sara_match*>(d_out + sizeof(Header));
     for (int dir = 0; dir < 2; ++dir)
-    {
-      const float* q = dir == 0 ? d1 : d2;
-      const float* t = dir == 0 ? d2 : d1;
-      const int nq = dir == 0 ? n1 : n2, nt = dir == 0 ? n2 : n1;
-      if (nt < 2)
-        continue;
-      int chunk = 0, nchunks = 0;
-      match_chunking(nq, nt, &chunk, &nchunks);
-      float *part_d = nullptr, *top_d = nullptr;
-      int *part_i = nullptr, *top_i = nullptr;
-      HIPM_TRY(ws.get(Workspace::kPartD, 3 * size_t(nchunks) * nq, part_d));
-      HIPM_TRY(ws.get(Workspace::kPartI, 3 * size_t(nchunks) * nq, part_i));
-      HIPM_TRY(ws.get(Workspace::kTopD, 3 * size_t(nq), top_d));
-      HIPM_TRY(ws.get(Workspace::kTopI, 3 * size_t(nq), top_i));
-      launch_nn3_exhaustive(q, nq, t, nt, dim, part_d, part_i, top_d, top_i, nullptr);
-      launch_ratio_filter(top_d, top_i, nq, thres2, dir, d_m, cap_dev, d_count,
-                          nullptr);
-    }
+      if (ds.have[dir])
+        launch_ratio_filter(ds.top_d[dir], ds.top_i[dir], ds.nq[dir], thres2, dir,
+                            d_m, cap_dev, d_count, nullptr);
     HIPM_TRY(hipGetLastError());
     void* h = nullptr;
     HIPM_TRY(ws.host(out_bytes, h));
-    // one read-back: the header first tells how much of the rest is valid
+    // the header first tells how much of the rest is valid
     HIPM_TRY(hipMemcpyAsync(h, d_out, sizeof(Header), hipMemcpyDeviceToHost, nullptr));
     HIPM_TRY(hipStreamSynchronize(nullptr));
     const int found = std::min(static_cast<Header*>(h)->count, cap_dev);
@@ -470,17 +547,9 @@ sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,
     Neighbours nb;
     for (int dir = 0; dir < 2; ++dir)
     {
-      const float* q = dir == 0 ? d1 : d2;
-      const float* t = dir == 0 ? d2 : d1;
-      const int nq = dir == 0 ? n1 : n2, nt = dir == 0 ? n2 : n1;
-      nb.nq = nq;
-      nb.nt = nt;
-      if (nt >= 2)
-      {
-        const sara_hip_status ss = search(ws, q, nq, t, nt, dim, thres2, 0, &nb);
-        if (ss != SARA_HIP_OK)
-          return ss;
-      }
+      const sara_hip_status hs = to_host(ds, dir, &nb);
+      if (hs != SARA_HIP_OK)
+        return hs;
       append_matches(nb, thres2, dir, false, unused, nullptr, nullptr, m);
     }
   }
@@ -527,14 +596,14 @@ sara_hip_status sara_hip_self_match_descriptors(
                                pixel_dist_thres * pixel_dist_thres};
   // both trees of compute_matches index the same descriptors
   // (AnnMatcher.cpp:199-215): one search serves the two directions
+  DeviceSearch ds;
+  const sara_hip_status ss = device_search(ws, d, n, d, n, dim, thres2, 1, true, &ds);
+  if (ss != SARA_HIP_OK)
+    return ss;
   Neighbours nb;
-  nb.nq = nb.nt = n;
-  if (n >= 2)
-  {
-    const sara_hip_status ss = search(ws, d, n, d, n, dim, thres2, 1, &nb);
-    if (ss != SARA_HIP_OK)
-      return ss;
-  }
+  const sara_hip_status hs = to_host(ds, 0, &nb);
+  if (hs != SARA_HIP_OK)
+    return hs;
   std::vector<sara_match> m;
   append_matches(nb, thres2, 0, true, too_close, f.data(), f.data(), m);
   append_matches(nb, thres2, 1, true, too_close, f.data(), f.data(), m);

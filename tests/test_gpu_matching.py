@@ -49,6 +49,82 @@ def test_random_descriptors_match_oracle(oracle, n1, n2, dim):
             assert (got["rank"] > 1).any()
 
 
+@pytest.mark.parametrize("case", ["random", "clusters", "big_norms", "odd_dim"])
+def test_mfma_prefilter_equals_exhaustive_and_oracle(oracle, case, tmp_path):
+    """Key sets large enough (>= 256) for the default producer, the MFMA
+    prefilter with exact re-ranking (match_mfma.hip): the match lists must be
+    the oracle's, entry by entry - and a child process with
+    SARA_HIP_MATCH=exhaustive must return the same bytes.  Adversarial inputs:
+    `clusters` puts hundreds of keys inside the prefilter's error guard of each
+    other (slot overflow -> exhaustive fallback per query), `big_norms` has
+    components up to 1e4 (large guard), `odd_dim` is not a multiple of four."""
+    import os
+    import subprocess
+    import sys
+    rng = np.random.default_rng(len(case))
+    dim = 128
+    if case == "random":
+        d1 = (rng.random((1500, dim), dtype=np.float32) * 255).astype(np.float32)
+        d2 = (rng.random((1300, dim), dtype=np.float32) * 255).astype(np.float32)
+        d2[:600] = d1[:600] + rng.normal(0, 2.0, (600, dim)).astype(np.float32)
+        d2[600:620] = d1[700:720]                       # exact duplicates
+    elif case == "clusters":
+        centre = (rng.random((4, dim), dtype=np.float32) * 255).astype(np.float32)
+        d1 = np.repeat(centre, 100, axis=0) + \
+            rng.normal(0, 1e-3, (400, dim)).astype(np.float32)
+        d2 = np.repeat(centre[::-1], 90, axis=0) + \
+            rng.normal(0, 1e-3, (360, dim)).astype(np.float32)
+    elif case == "big_norms":
+        d1 = (rng.random((700, dim), dtype=np.float32) * 1e4).astype(np.float32)
+        d2 = d1[::-1][:650] + rng.normal(0, 5.0, (650, dim)).astype(np.float32)
+        d2 = d2.astype(np.float32)
+    else:
+        dim = 57
+        d1 = rng.random((400, dim), dtype=np.float32)
+        d2 = rng.random((300, dim), dtype=np.float32)
+        d2[:100] = d1[50:150] + rng.normal(0, 1e-2, (100, dim)).astype(np.float32)
+    np.save(tmp_path / "d1.npy", d1)
+    np.save(tmp_path / "d2.npy", d2)
+    ratios = (0.8, 1.0, 1.2)
+    got = {r: sara_amd.match(d1, d2, r) for r in ratios}
+    for r in ratios:
+        assert_same(got[r], oracle.compute_matches(d1, d2, r))
+    assert len(got[0.8]) > 0 or case == "clusters"
+    script = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import sara_amd\n"
+        "d1 = np.load(%r); d2 = np.load(%r)\n"
+        "for r in %r:\n"
+        "    np.save(%r %% r, sara_amd.match(d1, d2, r))\n"
+        % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+           str(tmp_path / "d1.npy"), str(tmp_path / "d2.npy"), ratios,
+           str(tmp_path / "ex_%s.npy")))
+    env = dict(os.environ, SARA_HIP_MATCH="exhaustive")
+    subprocess.run([sys.executable, "-c", script], check=True, env=env)
+    for r in ratios:
+        other = np.load(str(tmp_path / "ex_%s.npy") % r)
+        assert other.tobytes() == got[r].tobytes(), (case, r)
+
+
+def test_mfma_prefilter_self_matching(oracle):
+    """The self-matching constructor on a set large enough for the prefilter
+    (rank 0 = the key itself, top1 = 1)."""
+    rng = np.random.default_rng(9)
+    n = 900
+    d = (rng.random((n, 128), dtype=np.float32) * 200).astype(np.float32)
+    d[300:600] = d[:300] + rng.normal(0, 3.0, (300, 128)).astype(np.float32)
+    reg = np.zeros(n, sara_amd.OEREGION_DTYPE)
+    reg["coords"] = rng.random((n, 2), dtype=np.float32) * 2000
+    reg["shape_matrix"] = np.array([0.04, 0, 0, 0.04], np.float32)
+    reg["type"] = 5
+    keys = sara_amd.KeypointList(reg, d, np.zeros((n, 2), np.int32))
+    for ratio in (1.2, 1.6):
+        got = sara_amd.AnnMatcher(keys, ratio).compute_matches()
+        assert_same(got, oracle.compute_self_matches(d, reg, ratio))
+        assert len(got) > 100
+
+
 def test_sift_keypoints_of_shifted_frames(oracle):
     """The consumer's use: keypoints of a frame against those of the same scene
     shifted by a few pixels (match(), KeypointMatching.cpp:19-25)."""
