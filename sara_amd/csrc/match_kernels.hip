@@ -248,6 +248,135 @@ namespace sara_hip {
     }
   }
 
+  // ---- the whole tail of compute_matches on the device (squared ratio <= 1) ---
+  //! AnnMatcher.cpp:126-147 for both directions plus the sort by (x, y, score)
+  //! and the std::unique of :239-254: thread q < n1 is key q of the first set
+  //! (direction 0), thread n1 + q key q of the second (direction 1).  A pair
+  //! (x, y) found from both sides is kept once, with the lower score
+  //! (direction 0 on equal scores - the order the restated sort leaves).
+  //! have0 / have1: the direction has >= 2 candidates (a single candidate
+  //! scores 1 and never passes a squared ratio <= 1, :87-101).
+  __global__ void mutual_filter_kernel(const float* __restrict__ top_d0,
+                                       const int* __restrict__ top_i0, int n1,
+                                       const float* __restrict__ top_d1,
+                                       const int* __restrict__ top_i1, int n2,
+                                       int have0, int have1,
+                                       float squared_ratio_thres,
+                                       sara_match* __restrict__ out,
+                                       int* __restrict__ count)
+  {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n1 + n2)
+      return;
+    auto best = [&](int dir, int q, int& idx, float& score) -> bool {
+      const float* td = dir == 0 ? top_d0 : top_d1;
+      const int* ti = dir == 0 ? top_i0 : top_i1;
+      const int nq = dir == 0 ? n1 : n2;
+      if (!(dir == 0 ? have0 : have1))
+        return false;
+      idx = ti[q];
+      const float d0 = td[q], d1 = td[nq + q];
+      score = d1 > 0.f ? d0 / d1 : 0.f;
+      return idx >= 0 && !(score > squared_ratio_thres);
+    };
+    const int dir = t < n1 ? 0 : 1;
+    const int q = dir == 0 ? t : t - n1;
+    int other = -1, back = -1;
+    float score = 0.f, score_back = 0.f;
+    if (!best(dir, q, other, score))
+      return;
+    // the same pair from the other side?
+    const bool twin = best(1 - dir, other, back, score_back) && back == q;
+    if (twin && (dir == 0 ? score_back < score : score_back <= score))
+      return;
+    sara_match m;
+    m.x_index = dir == 0 ? q : other;
+    m.y_index = dir == 0 ? other : q;
+    m.score = score;
+    m.rank = 1;
+    m.direction = dir;
+    out[atomicAdd(count, 1)] = m;
+  }
+
+  //! The final std::sort by score (AnnMatcher.cpp:256-258; equal scores by
+  //! (x, y), one of the orders it may leave) as a rank sort: every match counts
+  //! the matches that precede it - the keys are distinct - and moves to that
+  //! position.  2-D grid: block (bx, by) counts, for the 256 matches of tile
+  //! bx, their predecessors inside tile by (a 1-D version - each thread against
+  //! all n - kept 17 workgroups busy for 0.28 ms).
+  __device__ inline void match_key(const sara_match& m, unsigned long long& k1,
+                                   int& k2)
+  {
+    // scores are >= 0: their bit patterns order like unsigned integers
+    k1 = (static_cast<unsigned long long>(__float_as_uint(m.score)) << 32) |
+         static_cast<unsigned>(m.x_index);
+    k2 = m.y_index;
+  }
+
+  __global__ __launch_bounds__(256) void rank_count_kernel(
+      const sara_match* __restrict__ in, const int* __restrict__ count,
+      int* __restrict__ rank)
+  {
+    __shared__ unsigned long long s_k1[256];
+    __shared__ int s_k2[256];
+    const int n = *count;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int base = blockIdx.y * 256;
+    if (int(blockIdx.x) * 256 >= n || base >= n)
+      return;
+    const int f = base + threadIdx.x;
+    unsigned long long o1 = ~0ull;
+    int o2 = 0x7fffffff;
+    if (f < n)
+      match_key(in[f], o1, o2);
+    s_k1[threadIdx.x] = o1;
+    s_k2[threadIdx.x] = o2;
+    __syncthreads();
+    if (e >= n)
+      return;
+    unsigned long long k1;
+    int k2;
+    match_key(in[e], k1, k2);
+    int before = 0;
+    const int m = min(256, n - base);
+#pragma unroll 8
+    for (int k = 0; k < m; ++k)
+    {
+      const unsigned long long p1 = s_k1[k];
+      before += (p1 < k1 || (p1 == k1 && s_k2[k] < k2)) ? 1 : 0;
+    }
+    if (before)
+      atomicAdd(rank + e, before);
+  }
+
+  __global__ void rank_scatter_kernel(const sara_match* __restrict__ in,
+                                      const int* __restrict__ count,
+                                      const int* __restrict__ rank,
+                                      sara_match* __restrict__ out)
+  {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < *count)
+      out[rank[e]] = in[e];
+  }
+
+  void launch_finish_matches(const float* top_d0, const int* top_i0, int n1,
+                             const float* top_d1, const int* top_i1, int n2,
+                             int have0, int have1, float squared_ratio_thres,
+                             sara_match* scratch, int* rank_scratch, int* count,
+                             sara_match* out, hipStream_t stream)
+  {
+    const int n = n1 + n2;
+    const int tiles = (n + 255) / 256;
+    (void) hipMemsetAsync(rank_scratch, 0, sizeof(int) * size_t(n), stream);
+    hipLaunchKernelGGL(mutual_filter_kernel, dim3(tiles), dim3(256), 0, stream,
+                       top_d0, top_i0, n1, top_d1, top_i1, n2, have0, have1,
+                       squared_ratio_thres, scratch, count);
+    hipLaunchKernelGGL(rank_count_kernel, dim3(tiles, tiles), dim3(256), 0, stream,
+                       scratch, count, rank_scratch);
+    hipLaunchKernelGGL(rank_scatter_kernel, dim3(tiles), dim3(256), 0, stream,
+                       scratch, count, rank_scratch, out);
+  }
+
   void match_chunking(int nq, int nt, int* chunk, int* nchunks)
   {
     // enough (query block, chunk) waves to fill the chip, chunks of whole tiles

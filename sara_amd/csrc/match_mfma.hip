@@ -43,12 +43,16 @@
 #include <atomic>
 #include <cfloat>
 #include <climits>
+#include <cstdio>
+#include <vector>
 
 namespace sara_hip {
 
   namespace {
     constexpr int kTile = 128;         // rows and columns of a macro tile
-    constexpr int kLdsStride = 130;    // floats per staged row: conflict-free
+    constexpr int kChunk = 64;         // k staged per chunk
+    constexpr int kPanelStride = 68;   // floats per staged row (16-byte aligned)
+    constexpr int kQueue = 3072;       // LDS queue of the emit pass, in hits
     constexpr int kDStride = 129;      // floats per row of the distance tile
     constexpr float kGuard = 1.25f;    // slack on the error bound
     constexpr float kUnit = 5.9604645e-8f;  // 2^-24
@@ -94,27 +98,51 @@ namespace sara_hip {
       m1 = fminf(m1, v);
     }
 
-    //! |x_i|^2 of every row and the maximum over the rows (norms are >= 0, so
-    //! their bit patterns order like unsigned integers).
-    __global__ void row_norms_kernel(const float* __restrict__ x, int n, int dim,
-                                     float* __restrict__ norms,
-                                     unsigned* __restrict__ max_bits)
+    //! |x_i|^2 of every row of both key sets and the maximum over each set
+    //! (norms are >= 0, so their bit patterns order like unsigned integers).
+    //! 16 lanes per row, 4 rows per wave; any summation order fits the bound.
+    __global__ __launch_bounds__(1024) void row_norms_kernel(
+        const float* __restrict__ x1, int n1, const float* __restrict__ x2, int n2,
+        int dim, float* __restrict__ norms1, float* __restrict__ norms2,
+        unsigned* __restrict__ max_bits)
     {
-      const int i = blockIdx.x * blockDim.x + threadIdx.x;
+      const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;  // row of both
+      const int sub = threadIdx.x & 15;
+      const bool second = g >= n1;
+      const int i = second ? g - n1 : g;
+      const int n = second ? n2 : n1;
+      const float* x = second ? x2 : x1;
       float s = 0.f;
       if (i < n)
       {
         const float* r = x + size_t(i) * dim;
-        for (int k = 0; k < dim; ++k)
+        for (int k = sub; k < dim; k += 16)
           s += r[k] * r[k];
-        norms[i] = s;
       }
-      // wave maximum, one atomic per wave
-      float m = s;
+      for (int o = 8; o > 0; o >>= 1)
+        s += __shfl_xor(s, o);
+      if (i < n && sub == 0)
+        (second ? norms2 : norms1)[i] = s;
+      // maxima of the two sets: wave -> workgroup -> one atomic pair per
+      // workgroup (an atomic per row serialised 8.6 k of them: 100 us)
+      __shared__ unsigned s_max[2];
+      if (threadIdx.x < 2)
+        s_max[threadIdx.x] = 0u;
+      __syncthreads();
+      float m0 = (i < n && !second) ? s : 0.f, m1 = (i < n && second) ? s : 0.f;
       for (int o = 32; o > 0; o >>= 1)
-        m = fmaxf(m, __shfl_xor(m, o));
+      {
+        m0 = fmaxf(m0, __shfl_xor(m0, o));
+        m1 = fmaxf(m1, __shfl_xor(m1, o));
+      }
       if ((threadIdx.x & 63) == 0)
-        atomicMax(max_bits, __float_as_uint(m));
+      {
+        atomicMax(&s_max[0], __float_as_uint(m0));
+        atomicMax(&s_max[1], __float_as_uint(m1));
+      }
+      __syncthreads();
+      if (threadIdx.x < 2 && s_max[threadIdx.x] != 0u)
+        atomicMax(max_bits + threadIdx.x, s_max[threadIdx.x]);
     }
 
     enum
@@ -125,10 +153,17 @@ namespace sara_hip {
 
     //! One 128 x 128 tile of approximate squared distances between rows
     //! [row0, row0 + 128) of A and [col0, col0 + 128) of B.  256 threads = 4
-    //! waves, each a 64 x 64 quadrant = 2 x 2 MFMA blocks of 32 x 32; both
-    //! operand panels sit in LDS for the whole contraction (dim <= 128).
+    //! waves, each a 64 x 64 quadrant = 2 x 2 MFMA blocks of 32 x 32.
+    //! The contraction runs in chunks of 64 k: both operand panels of a chunk
+    //! take 68 KB of LDS, so TWO workgroups share a CU and one's matrix-core
+    //! phase covers the other's staging and epilogue (with the whole k range
+    //! staged at once - 133 KB, one workgroup per CU - the matrix cores idled
+    //! through every staging phase: 84 us per pass against 50).
+    //! Inside a chunk row the k are stored even ones first, odd ones second:
+    //! the 32 x 32 x 2 instruction wants k = 2 s + (lane >> 5) in lane, so each
+    //! half of the wave reads ITS 32 values of a row as 8 x ds_read_b128.
     template <int MODE>
-    __global__ __launch_bounds__(256) void mfma_tiles_kernel(
+    __global__ __launch_bounds__(256, 2) void mfma_tiles_kernel(
         const float* __restrict__ A, int n1, const float* __restrict__ B, int n2,
         int dim, const float* __restrict__ na, const float* __restrict__ nb,
         // MINIMA: [tiles along the other axis][n][3]
@@ -137,79 +172,131 @@ namespace sara_hip {
         const float* __restrict__ tau_row, const float* __restrict__ tau_col,
         int* __restrict__ cand_row, int* __restrict__ cnt_row,
         int* __restrict__ cand_col, int* __restrict__ cnt_col, int cap,
-        int with_cols)
+        int with_cols_and_debug)
     {
       extern __shared__ __attribute__((aligned(16))) float lds[];
+      // timing experiments (SARA_HIP_MATCH_SKIP, bits: 1 no staging, 2 no
+      // contraction, 4 no epilogue); 0 in production
+      const int debug = with_cols_and_debug >> 8;
+      const int with_cols = with_cols_and_debug & 1;
       float* sA = lds;
-      float* sB = lds + kTile * kLdsStride;
+      float* sB = lds + kTile * kPanelStride;
       const int tid = threadIdx.x;
       const int row0 = blockIdx.y * kTile, col0 = blockIdx.x * kTile;
-      const int k2 = (dim + 1) / 2;  // MFMA steps of two k each
-
-      // ---- stage the two panels (zero-padded) --------------------------------
-      const bool vec4 = (dim % 4 == 0) &&
-                        ((reinterpret_cast<uintptr_t>(A) |
-                          reinterpret_cast<uintptr_t>(B)) % 16 == 0);
-      if (vec4)
-      {
-        const int q = dim / 4;
-        for (int idx = tid; idx < kTile * q; idx += 256)
-        {
-          const int r = idx / q, c = idx - r * q;
-          float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-          if (row0 + r < n1)
-            va = *reinterpret_cast<const float4*>(A + size_t(row0 + r) * dim + 4 * c);
-          if (col0 + r < n2)
-            vb = *reinterpret_cast<const float4*>(B + size_t(col0 + r) * dim + 4 * c);
-          float* pa = sA + r * kLdsStride + 4 * c;
-          float* pb = sB + r * kLdsStride + 4 * c;
-          *reinterpret_cast<float2*>(pa) = make_float2(va.x, va.y);
-          *reinterpret_cast<float2*>(pa + 2) = make_float2(va.z, va.w);
-          *reinterpret_cast<float2*>(pb) = make_float2(vb.x, vb.y);
-          *reinterpret_cast<float2*>(pb + 2) = make_float2(vb.z, vb.w);
-        }
-      }
-      else
-      {
-        const int kk = 2 * k2;
-        for (int idx = tid; idx < kTile * kk; idx += 256)
-        {
-          const int r = idx / kk, k = idx - r * kk;
-          sA[r * kLdsStride + k] =
-              (row0 + r < n1 && k < dim) ? A[size_t(row0 + r) * dim + k] : 0.f;
-          sB[r * kLdsStride + k] =
-              (col0 + r < n2 && k < dim) ? B[size_t(col0 + r) * dim + k] : 0.f;
-        }
-      }
-      __syncthreads();
-
-      // ---- the contraction -----------------------------------------------------
       const int lane = tid & 63, wave = tid >> 6;
       const int wm = wave >> 1, wn = wave & 1;
       const int li = lane & 31, half = lane >> 5;
-      const float* pa0 = sA + (wm * 64 + li) * kLdsStride + half;
-      const float* pa1 = pa0 + 32 * kLdsStride;
-      const float* pb0 = sB + (wn * 64 + li) * kLdsStride + half;
-      const float* pb1 = pb0 + 32 * kLdsStride;
+      const bool vec4 = (dim % 4 == 0) &&
+                        ((reinterpret_cast<uintptr_t>(A) |
+                          reinterpret_cast<uintptr_t>(B)) % 16 == 0);
       f32x16 acc00 = {}, acc01 = {}, acc10 = {}, acc11 = {};
-#pragma unroll 4
-      for (int s = 0; s < k2; ++s)
+
+      for (int k0 = 0; k0 < dim; k0 += kChunk)
       {
-        const float a0 = pa0[2 * s], a1 = pa1[2 * s];
-        const float b0 = pb0[2 * s], b1 = pb1[2 * s];
-        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
-        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
-        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
-        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+        if (k0 > 0)
+          __syncthreads();  // the previous chunk's panels have been consumed
+        // ---- stage the two panels of this chunk (zero-padded) ----------------
+        if (debug & 1)
+          ;
+        else if (vec4)
+        {
+          // 16 float4 per row and panel, 8 per thread: every load is in flight
+          // before the first LDS write
+          float4 va[8], vb[8];
+#pragma unroll
+          for (int it = 0; it < 8; ++it)
+          {
+            const int idx = tid + it * 256, r = idx >> 4, c = idx & 15;
+            const int k = k0 + 4 * c;
+            va[it] = (row0 + r < n1 && k < dim)
+                         ? *reinterpret_cast<const float4*>(A + size_t(row0 + r) * dim + k)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int it = 0; it < 8; ++it)
+          {
+            const int idx = tid + it * 256, r = idx >> 4, c = idx & 15;
+            const int k = k0 + 4 * c;
+            vb[it] = (col0 + r < n2 && k < dim)
+                         ? *reinterpret_cast<const float4*>(B + size_t(col0 + r) * dim + k)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int it = 0; it < 8; ++it)
+          {
+            const int idx = tid + it * 256, r = idx >> 4, c = idx & 15;
+            // k = 4 c .. 4 c + 3 -> even ones at 2 c, 2 c + 1, odd ones 32 further
+            float* pa = sA + r * kPanelStride + 2 * c;
+            *reinterpret_cast<float2*>(pa) = make_float2(va[it].x, va[it].z);
+            *reinterpret_cast<float2*>(pa + 32) = make_float2(va[it].y, va[it].w);
+            float* pb = sB + r * kPanelStride + 2 * c;
+            *reinterpret_cast<float2*>(pb) = make_float2(vb[it].x, vb[it].z);
+            *reinterpret_cast<float2*>(pb + 32) = make_float2(vb[it].y, vb[it].w);
+          }
+        }
+        else
+        {
+          for (int idx = tid; idx < kTile * kChunk; idx += 256)
+          {
+            const int r = idx / kChunk, kl = idx - r * kChunk;
+            const int k = k0 + kl, pos = (kl >> 1) + 32 * (kl & 1);
+            sA[r * kPanelStride + pos] =
+                (row0 + r < n1 && k < dim) ? A[size_t(row0 + r) * dim + k] : 0.f;
+            sB[r * kPanelStride + pos] =
+                (col0 + r < n2 && k < dim) ? B[size_t(col0 + r) * dim + k] : 0.f;
+          }
+        }
+        __syncthreads();
+
+        // ---- the contraction over this chunk: 32 steps of two k -----------------
+        const float4* qa0 = reinterpret_cast<const float4*>(
+            sA + (wm * 64 + li) * kPanelStride + 32 * half);
+        const float4* qa1 = reinterpret_cast<const float4*>(
+            sA + (wm * 64 + 32 + li) * kPanelStride + 32 * half);
+        const float4* qb0 = reinterpret_cast<const float4*>(
+            sB + (wn * 64 + li) * kPanelStride + 32 * half);
+        const float4* qb1 = reinterpret_cast<const float4*>(
+            sB + (wn * 64 + 32 + li) * kPanelStride + 32 * half);
+        float4 a0 = qa0[0], a1 = qa1[0], b0 = qb0[0], b1 = qb1[0];
+        if (!(debug & 2))
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+        {
+          // operands of the next four steps are requested before this group's
+          // sixteen instructions go to the matrix cores
+          const int tn = t < 7 ? t + 1 : 7;
+          const float4 na0 = qa0[tn], na1 = qa1[tn], nb0 = qb0[tn], nb1 = qb1[tn];
+#define SARA_MFMA_STEP(c)                                                      \
+  acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b0.c, acc00, 0, 0, 0);     \
+  acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b1.c, acc01, 0, 0, 0);     \
+  acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b0.c, acc10, 0, 0, 0);     \
+  acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b1.c, acc11, 0, 0, 0);
+          SARA_MFMA_STEP(x)
+          SARA_MFMA_STEP(y)
+          SARA_MFMA_STEP(z)
+          SARA_MFMA_STEP(w)
+#undef SARA_MFMA_STEP
+          a0 = na0;
+          a1 = na1;
+          b0 = nb0;
+          b1 = nb1;
+        }
       }
       __syncthreads();  // the panels are dead: their LDS is reused below
+      if (debug & 4)
+      {
+        if (acc00[0] + acc01[1] + acc10[2] + acc11[3] == 12345.f && rowmin)
+          rowmin[0] = 0.f;  // keeps the contraction alive
+        return;
+      }
 
-      // squared norms of this tile's rows / columns (+inf-like for the padding:
+      // squared norms of this tile's rows / columns (>= FLT_MAX for the padding:
       // a row or column past the end can never be anyone's neighbour)
       float* sNa = lds + kTile * kDStride;  // behind the distance tile
       float* sNb = sNa + kTile;
       float* sTr = sNb + kTile;
       float* sTc = sTr + kTile;
+      int* sQueue = reinterpret_cast<int*>(lds);  // EMIT: [0] = count, then hits
       if (tid < kTile)
       {
         sNa[tid] = row0 + tid < n1 ? na[row0 + tid] : FLT_MAX;
@@ -223,17 +310,23 @@ namespace sara_hip {
         if (MODE == kEmit)
           sTc[c] = (with_cols && col0 + c < n2) ? tau_col[col0 + c] : -FLT_MAX;
       }
+      if (MODE == kEmit && tid == 0)
+        sQueue[0] = 0;
       __syncthreads();
 
       // C/D layout of the 32 x 32 blocks: lane -> column lane & 31, register r
-      // -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-      auto approx = [&](const f32x16& acc, int bi, int bj, int r, int& row,
-                        int& col) -> float {
-        row = wm * 64 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        col = wn * 64 + bj * 32 + li;
-        const float s = sNa[row] + sNb[col];  // >= FLT_MAX for the padding
-        // +inf: below no threshold (they are <= FLT_MAX), above every minimum
-        return s >= FLT_MAX ? __builtin_huge_valf() : s - 2.f * acc[r];
+      // -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  A lane owns 2 columns
+      // (one per block column) and 32 rows.  Padding rows / columns get +inf:
+      // below no threshold (they are <= FLT_MAX), above every minimum.
+      const int colA = wn * 64 + li, colB = colA + 32;
+      const float nbA = sNb[colA], nbB = sNb[colB];
+      const float inf = __builtin_huge_valf();
+      auto approx = [&](float nrow, float ncol, float dot) -> float {
+        const float s = nrow + ncol;  // >= FLT_MAX for the padding
+        return s >= FLT_MAX ? inf : s - 2.f * dot;
+      };
+      auto row_of = [&](int bi, int r) -> int {
+        return wm * 64 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       };
 
       if (MODE == kMinima)
@@ -242,22 +335,19 @@ namespace sara_hip {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
         {
-          int row, col;
-          float v = approx(acc00, 0, 0, r, row, col);
-          sD[row * kDStride + col] = v;
-          v = approx(acc01, 0, 1, r, row, col);
-          sD[row * kDStride + col] = v;
-          v = approx(acc10, 1, 0, r, row, col);
-          sD[row * kDStride + col] = v;
-          v = approx(acc11, 1, 1, r, row, col);
-          sD[row * kDStride + col] = v;
+          const int r0 = row_of(0, r), r1 = row_of(1, r);
+          const float n0 = sNa[r0], n1r = sNa[r1];
+          sD[r0 * kDStride + colA] = approx(n0, nbA, acc00[r]);
+          sD[r0 * kDStride + colB] = approx(n0, nbB, acc01[r]);
+          sD[r1 * kDStride + colA] = approx(n1r, nbA, acc10[r]);
+          sD[r1 * kDStride + colB] = approx(n1r, nbB, acc11[r]);
         }
         __syncthreads();
         float m1 = FLT_MAX, m2 = FLT_MAX, m3 = FLT_MAX;
         if (tid < kTile)
         {
           const float* p = sD + tid * kDStride;
-#pragma unroll 8
+#pragma unroll 16
           for (int c = 0; c < kTile; ++c)
             min3_update(p[c], m1, m2, m3);
           if (row0 + tid < n1)
@@ -272,7 +362,7 @@ namespace sara_hip {
         {
           const int c = tid - kTile;
           const float* p = sD + c;
-#pragma unroll 8
+#pragma unroll 16
           for (int r = 0; r < kTile; ++r)
             min3_update(p[r * kDStride], m1, m2, m3);
           if (col0 + c < n2)
@@ -286,32 +376,70 @@ namespace sara_hip {
       }
       else
       {
-        auto emit = [&](const f32x16& acc, int bi, int bj) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
+        // Hits are rare (about three per query in the whole matrix) but a
+        // returning global atomic under a divergent branch costs the whole wave
+        // hundreds of cycles each time: they are queued in LDS (row, column,
+        // which list) and the workgroup claims their slots together at the end.
+        const float tcA = sTc[colA], tcB = sTc[colB];
+        auto claim = [&](int row, int col, int which) {
+          if (which == 0)
           {
-            int row, col;
-            const float v = approx(acc, bi, bj, r, row, col);
-            if (v <= sTr[row])
-            {
-              const int q = row0 + row;
-              const int slot = atomicAdd(cnt_row + q, 1);
-              if (slot < cap)
-                cand_row[size_t(q) * cap + slot] = col0 + col;
-            }
-            if (v <= sTc[col])
-            {
-              const int q = col0 + col;
-              const int slot = atomicAdd(cnt_col + q, 1);
-              if (slot < cap)
-                cand_col[size_t(q) * cap + slot] = row0 + row;
-            }
+            const int q = row0 + row;
+            const int slot = atomicAdd(cnt_row + q, 1);
+            if (slot < cap)
+              cand_row[size_t(q) * cap + slot] = col0 + col;
+          }
+          else
+          {
+            const int q = col0 + col;
+            const int slot = atomicAdd(cnt_col + q, 1);
+            if (slot < cap)
+              cand_col[size_t(q) * cap + slot] = row0 + row;
           }
         };
-        emit(acc00, 0, 0);
-        emit(acc01, 0, 1);
-        emit(acc10, 1, 0);
-        emit(acc11, 1, 1);
+        auto hit = [&](float v, float trow, float tcol, int row, int col) {
+          if (v <= trow)
+          {
+            const int e = atomicAdd(&sQueue[0], 1);
+            if (e < kQueue)
+              sQueue[1 + e] = (row << 8) | col;
+            else
+              claim(row, col, 0);
+          }
+          if (v <= tcol)
+          {
+            const int e = atomicAdd(&sQueue[0], 1);
+            if (e < kQueue)
+              sQueue[1 + e] = (1 << 16) | (row << 8) | col;
+            else
+              claim(row, col, 1);
+          }
+        };
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+        {
+          const int r0 = row_of(0, r), r1 = row_of(1, r);
+          const float n0 = sNa[r0], n1r = sNa[r1];
+          const float t0 = sTr[r0], t1 = sTr[r1];
+          const float v00 = approx(n0, nbA, acc00[r]), v01 = approx(n0, nbB, acc01[r]);
+          const float v10 = approx(n1r, nbA, acc10[r]), v11 = approx(n1r, nbB, acc11[r]);
+          // one test per register quad before the four exact ones
+          const float lo0 = fminf(v00, v01), lo1 = fminf(v10, v11);
+          if (lo0 <= t0 || lo1 <= t1 || fminf(v00, v10) <= tcA || fminf(v01, v11) <= tcB)
+          {
+            hit(v00, t0, tcA, r0, colA);
+            hit(v01, t0, tcB, r0, colB);
+            hit(v10, t1, tcA, r1, colA);
+            hit(v11, t1, tcB, r1, colB);
+          }
+        }
+        __syncthreads();
+        const int queued = min(sQueue[0], kQueue);
+        for (int e = tid; e < queued; e += 256)
+        {
+          const int w = sQueue[1 + e];
+          claim((w >> 8) & 255, w & 255, w >> 16);
+        }
       }
     }
 
@@ -415,9 +543,31 @@ namespace sara_hip {
       }
     }
 
-    //! Queries whose candidate slots overflowed: exhaustive search, one wave
-    //! per query, lanes stride over the candidates.
-    __global__ __launch_bounds__(64) void fallback_kernel(
+    __device__ inline bool closer(float d, int i, float od, int oi)
+    {
+      return d < od || (d == od && i < oi);
+    }
+    __device__ inline void top3_insert_ordered(float d, int j, float (&b)[3],
+                                               int (&bi)[3])
+    {
+      if (closer(d, j, b[0], bi[0]))
+      {
+        b[2] = b[1]; bi[2] = bi[1]; b[1] = b[0]; bi[1] = bi[0]; b[0] = d; bi[0] = j;
+      }
+      else if (closer(d, j, b[1], bi[1]))
+      {
+        b[2] = b[1]; bi[2] = bi[1]; b[1] = d; bi[1] = j;
+      }
+      else if (closer(d, j, b[2], bi[2]))
+      {
+        b[2] = d; bi[2] = j;
+      }
+    }
+
+    //! Queries whose candidate slots overflowed: exhaustive search, one
+    //! 1024-thread workgroup per query (a single wave per query spent 0.3 ms on
+    //! its 67 dependent row reads per lane).
+    __global__ __launch_bounds__(1024) void fallback_kernel(
         const float* __restrict__ q, int nq, const float* __restrict__ t, int nt,
         int dim, const int* __restrict__ flagged,
         const int* __restrict__ flagged_count, float squared_ratio_thres, int top1,
@@ -425,7 +575,10 @@ namespace sara_hip {
         MatchNeighbour* __restrict__ radius_out, int radius_cap,
         int* __restrict__ radius_count)
     {
-      const int lane = threadIdx.x;
+      __shared__ float s_d[1024 * 3];
+      __shared__ int s_i[1024 * 3];
+      __shared__ float s_radius;
+      const int tid = threadIdx.x;
       const int n = *flagged_count;
       for (int k = blockIdx.x; k < n; k += gridDim.x)
       {
@@ -433,56 +586,58 @@ namespace sara_hip {
         const float* qr = q + size_t(qi) * dim;
         float b[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
         int bi[3] = {INT_MAX, INT_MAX, INT_MAX};
-        for (int j = lane; j < nt; j += 64)
-        {
-          const float d = flann_l2_rows(qr, t + size_t(j) * dim, dim);
-          if (d < b[0])
-          {
-            b[2] = b[1]; bi[2] = bi[1]; b[1] = b[0]; bi[1] = bi[0]; b[0] = d; bi[0] = j;
-          }
-          else if (d < b[1])
-          {
-            b[2] = b[1]; bi[2] = bi[1]; b[1] = d; bi[1] = j;
-          }
-          else if (d < b[2])
-          {
-            b[2] = d; bi[2] = j;
-          }
-        }
-        // three rounds: the wave's smallest (distance, index), popped from
-        // the lane that holds it
-        float d_top1 = FLT_MAX;
+        for (int j = tid; j < nt; j += 1024)
+          top3_insert_ordered(flann_l2_rows(qr, t + size_t(j) * dim, dim), j, b, bi);
         for (int r = 0; r < 3; ++r)
         {
-          float md = b[0];
-          int mi = bi[0];
-          for (int o = 32; o > 0; o >>= 1)
-          {
-            const float od = __shfl_xor(md, o);
-            const int oi = __shfl_xor(mi, o);
-            if (od < md || (od == md && oi < mi))
-            {
-              md = od;
-              mi = oi;
-            }
-          }
-          if (bi[0] == mi && mi != INT_MAX)
-          {
-            b[0] = b[1]; bi[0] = bi[1]; b[1] = b[2]; bi[1] = bi[2];
-            b[2] = FLT_MAX; bi[2] = INT_MAX;
-          }
-          if (lane == 0)
-          {
-            top_d[size_t(r) * nq + qi] = mi == INT_MAX ? FLT_MAX : md;
-            top_i[size_t(r) * nq + qi] = mi == INT_MAX ? -1 : mi;
-          }
-          if (r == top1 && mi != INT_MAX)
-            d_top1 = md;
+          s_d[tid * 3 + r] = b[r];
+          s_i[tid * 3 + r] = bi[r];
         }
-        if (squared_ratio_thres > 1.f && d_top1 < FLT_MAX)
+        __syncthreads();
+        if (tid < 64)
         {
-          const float radius = d_top1 * squared_ratio_thres;
-          for (int j = lane; j < nt; j += 64)
+          float c[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+          int ci[3] = {INT_MAX, INT_MAX, INT_MAX};
+          for (int e = tid; e < 1024 * 3; e += 64)
+            if (s_i[e] != INT_MAX)
+              top3_insert_ordered(s_d[e], s_i[e], c, ci);
+          // three rounds: the wave's smallest (distance, index), popped from
+          // the lane that holds it
+          float d_top1 = FLT_MAX;
+          for (int r = 0; r < 3; ++r)
+          {
+            float md = c[0];
+            int mi = ci[0];
+            for (int o = 32; o > 0; o >>= 1)
+            {
+              const float od = __shfl_xor(md, o);
+              const int oi = __shfl_xor(mi, o);
+              if (closer(od, oi, md, mi))
+              {
+                md = od;
+                mi = oi;
+              }
+            }
+            if (ci[0] == mi && mi != INT_MAX)
+            {
+              c[0] = c[1]; ci[0] = ci[1]; c[1] = c[2]; ci[1] = ci[2];
+              c[2] = FLT_MAX; ci[2] = INT_MAX;
+            }
+            if (tid == 0)
+            {
+              top_d[size_t(r) * nq + qi] = mi == INT_MAX ? FLT_MAX : md;
+              top_i[size_t(r) * nq + qi] = mi == INT_MAX ? -1 : mi;
+            }
+            if (r == top1 && mi != INT_MAX)
+              d_top1 = md;
+          }
+          if (tid == 0)
+            s_radius = d_top1 < FLT_MAX ? d_top1 * squared_ratio_thres : -1.f;
+        }
+        __syncthreads();
+        const float radius = s_radius;
+        if (squared_ratio_thres > 1.f && radius >= 0.f)
+          for (int j = tid; j < nt; j += 1024)
           {
             const float d = flann_l2_rows(qr, t + size_t(j) * dim, dim);
             if (d < radius)
@@ -492,7 +647,7 @@ namespace sara_hip {
                 radius_out[o] = MatchNeighbour{qi, j, d};
             }
           }
-        }
+        __syncthreads();
       }
     }
 
@@ -555,19 +710,45 @@ namespace sara_hip {
     int* flag_c = flag_r + n1;
     int* cand_r = flag_c + n2;
     int* cand_c = cand_r + size_t(n1) * cap;
+    static const bool prof = getenv("SARA_HIP_MATCH_PROF") != nullptr;
+    static hipEvent_t pev[12];
+    static bool pev_made = false;
+    int pk = 0;
+    auto tick = [&]() {
+      if (!prof)
+        return;
+      if (!pev_made)
+      {
+        for (auto& e : pev)
+          (void) hipEventCreate(&e);
+        pev_made = true;
+      }
+      (void) hipEventRecord(pev[pk++], stream);
+    };
+    tick();
     (void) hipMemsetAsync(maxbits, 0, 16 * sizeof(float), stream);
     (void) hipMemsetAsync(cnt_r, 0, sizeof(int) * (size_t(n1) + n2 + 16), stream);
-    hipLaunchKernelGGL(row_norms_kernel, dim3((n1 + 255) / 256), dim3(256), 0, stream,
-                       d1, n1, dim, na, maxbits);
-    hipLaunchKernelGGL(row_norms_kernel, dim3((n2 + 255) / 256), dim3(256), 0, stream,
-                       d2, n2, dim, nb, maxbits + 1);
-    const size_t lds = sizeof(float) * 2 * kTile * kLdsStride;
+    hipLaunchKernelGGL(row_norms_kernel, dim3((n1 + n2 + 63) / 64), dim3(1024), 0,
+                       stream, d1, n1, d2, n2, dim, na, nb, maxbits);
+    // panels of one chunk, or the distance tile + norms / thresholds (minima),
+    // or the hit queue in front of the norms / thresholds (emit: the queue must
+    // end before the norm arrays start at kTile * kDStride floats)
+    static_assert(1 + kQueue <= kTile * kDStride, "the queue overlaps the norms");
+    tick();  // 1: memsets + norms
+    const size_t lds = sizeof(float) * std::max(2 * kTile * kPanelStride,
+                                                kTile * kDStride + 4 * kTile);
     allow_big_lds(mfma_tiles_kernel<kMinima>);
     allow_big_lds(mfma_tiles_kernel<kEmit>);
     const dim3 grid(tn, tm);
+    static const int skip = [] {
+      const char* e = getenv("SARA_HIP_MATCH_SKIP");
+      return e ? atoi(e) : 0;
+    }();
+    const int cols_arg = (with_dir1 ? 1 : 0) | (skip << 8);
     hipLaunchKernelGGL(mfma_tiles_kernel<kMinima>, grid, dim3(256), lds, stream, d1,
                        n1, d2, n2, dim, na, nb, rowmin, colmin, nullptr, nullptr,
-                       nullptr, nullptr, nullptr, nullptr, cap, with_dir1);
+                       nullptr, nullptr, nullptr, nullptr, cap, cols_arg);
+    tick();  // 2: minima
     hipLaunchKernelGGL(thresholds_kernel, dim3((n1 + 255) / 256), dim3(256), 0, stream,
                        rowmin, tn, n1, na, maxbits + 1, dim, squared_ratio_thres,
                        top1, tau_r);
@@ -575,9 +756,11 @@ namespace sara_hip {
       hipLaunchKernelGGL(thresholds_kernel, dim3((n2 + 255) / 256), dim3(256), 0,
                          stream, colmin, tm, n2, nb, maxbits, dim,
                          squared_ratio_thres, top1, tau_c);
+    tick();  // 3: thresholds
     hipLaunchKernelGGL(mfma_tiles_kernel<kEmit>, grid, dim3(256), lds, stream, d1, n1,
                        d2, n2, dim, na, nb, nullptr, nullptr, tau_r, tau_c, cand_r,
-                       cnt_r, cand_c, cnt_c, cap, with_dir1);
+                       cnt_r, cand_c, cnt_c, cap, cols_arg);
+    tick();  // 4: emit
     auto rerank = [&](const float* q, int nq, const float* t, int nt, const int* cand,
                       const int* cnt, float* td, int* ti, MatchNeighbour* ro, int rcap,
                       int* rcount, int* flagged, int* fcount) {
@@ -591,7 +774,7 @@ namespace sara_hip {
         hipLaunchKernelGGL(rerank_kernel<32>, g, dim3(256), 0, stream, q, nq, t, dim,
                            cand, cnt, squared_ratio_thres, top1, td, ti, ro, rcap,
                            rcount, flagged, fcount);
-      hipLaunchKernelGGL(fallback_kernel, dim3(std::min(nq, 512)), dim3(64), 0, stream,
+      hipLaunchKernelGGL(fallback_kernel, dim3(std::min(nq, 256)), dim3(1024), 0, stream,
                          q, nq, t, nt, dim, flagged, fcount, squared_ratio_thres,
                          top1, td, ti, ro, rcap, rcount);
     };
@@ -600,6 +783,39 @@ namespace sara_hip {
     if (with_dir1)
       rerank(d2, n2, d1, n1, cand_c, cnt_c, top21_d, top21_i, radius21, radius21_cap,
              radius21_count, flag_c, scal + 1);
+    tick();  // 5: rerank + fallback
+    if (prof)
+    {
+      (void) hipStreamSynchronize(stream);
+      const char* names[] = {"norms", "minima", "thresholds", "emit", "rerank"};
+      for (int k = 0; k + 1 < pk; ++k)
+      {
+        float ms = 0.f;
+        (void) hipEventElapsedTime(&ms, pev[k], pev[k + 1]);
+        std::fprintf(stderr, "[match prof]   %-10s %8.1f us\n", names[k], 1e3 * ms);
+      }
+    }
+    static const bool debug = getenv("SARA_HIP_MATCH_DEBUG") != nullptr;
+    if (debug)
+    {
+      int h[2] = {0, 0};
+      std::vector<int> hc(size_t(n1) + n2);
+      (void) hipStreamSynchronize(stream);
+      (void) hipMemcpy(h, scal, sizeof(h), hipMemcpyDeviceToHost);
+      (void) hipMemcpy(hc.data(), cnt_r, sizeof(int) * hc.size(), hipMemcpyDeviceToHost);
+      long long sum = 0;
+      int mx = 0;
+      for (int v : hc)
+      {
+        sum += v;
+        mx = std::max(mx, v);
+      }
+      std::fprintf(stderr,
+                   "[sara_hip match] cap %d thres2 %.3f: flagged %d / %d of %d / %d "
+                   "queries; candidates %.2f per query, max %d\n",
+                   cap, squared_ratio_thres, h[0], h[1], n1, n2,
+                   double(sum) / double(hc.size()), mx);
+    }
   }
 
 }  // namespace sara_hip

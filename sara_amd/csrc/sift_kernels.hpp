@@ -322,6 +322,15 @@ namespace sara_hip {
                            float squared_ratio_thres, int direction,
                            sara_match* out, int capacity, int* count,
                            hipStream_t stream);
+  //! compute_matches' tail for squared ratios <= 1, entirely on the device:
+  //! ratio test of both directions, duplicates (x, y) dropped, sorted by
+  //! (score, x, y).  scratch: n1 + n2 records, rank_scratch: n1 + n2 ints;
+  //! *count: number of matches.
+  void launch_finish_matches(const float* top_d0, const int* top_i0, int n1,
+                             const float* top_d1, const int* top_i1, int n2,
+                             int have0, int have1, float squared_ratio_thres,
+                             sara_match* scratch, int* rank_scratch, int* count,
+                             sara_match* out, hipStream_t stream);
   //! radiusSearch of every query: neighbours with distance <
   //! top_d[top1][query] * squared_ratio_thres, appended in no particular order.
   void launch_radius_exhaustive(const float* q, int nq, const float* t, int nt,

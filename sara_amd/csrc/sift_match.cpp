@@ -12,6 +12,8 @@
 #include "sift_kernels.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -84,6 +86,15 @@ namespace {
         (void) hipHostFree(pinned);
       pinned = nullptr;
       pinned_bytes = 0;
+      if (done)
+        (void) hipEventDestroy(done);
+      done = nullptr;
+      if (stream)
+      {
+        std::lock_guard<std::recursive_mutex> lock(sara_hip::runtime_mutex());
+        (void) hipStreamDestroy(stream);
+      }
+      stream = nullptr;
       device = -1;
     }
     ~Workspace() { release(); }
@@ -106,6 +117,43 @@ namespace {
       }
       p = static_cast<T*>(dev[k]);
       return hipSuccess;
+    }
+    //! Waits for everything enqueued on `stream` by polling an event:
+    //! hipStreamSynchronize parks the thread and its wake-up alone cost
+    //! about 0.3 ms per call - more than the whole search.
+    //! Everything the matcher enqueues goes to this non-blocking stream: on
+    //! the legacy NULL stream - which orders itself against every blocking
+    //! stream of the process - the dozen launches of a search took 0.53 ms on
+    //! the GPU although the kernels add up to 0.26 ms.
+    hipStream_t stream = nullptr;
+    hipError_t ensure_stream()
+    {
+      if (stream)
+        return hipSuccess;
+      std::lock_guard<std::recursive_mutex> lock(sara_hip::runtime_mutex());
+      return hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    }
+    hipEvent_t done = nullptr;
+    hipError_t wait(hipStream_t stream)
+    {
+      static const bool spin = [] {
+        const char* e = getenv("SARA_HIP_MATCH_WAIT");
+        return !(e && std::string(e) == "block");
+      }();
+      if (!spin)
+        return hipStreamSynchronize(stream);
+      if (!done)
+      {
+        const hipError_t e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+        if (e != hipSuccess)
+          return e;
+      }
+      hipError_t e = hipEventRecord(done, stream);
+      if (e != hipSuccess)
+        return e;
+      while ((e = hipEventQuery(done)) == hipErrorNotReady)
+        ;
+      return e;
     }
     hipError_t host(size_t bytes, void*& p)
     {
@@ -352,7 +400,7 @@ namespace {
       if (radius_on)
       {
         HIPM_TRY(ws.get(Workspace::kRadius, cap[0] + cap[1], list));
-        HIPM_TRY(hipMemsetAsync(d_count, 0, 4 * sizeof(int), nullptr));
+        HIPM_TRY(hipMemsetAsync(d_count, 0, 4 * sizeof(int), ws.stream));
       }
       r.radius[0] = list;
       r.radius[1] = list ? list + cap[0] : nullptr;
@@ -366,7 +414,7 @@ namespace {
         launch_match_mfma(d1, n1, d2, n2, dim, thres2, top1, r.have[1] ? 1 : 0, fs,
                           is, slots, r.top_d[0], r.top_i[0], r.top_d[1], r.top_i[1],
                           r.radius[0], int(cap[0]), d_count, r.radius[1],
-                          int(cap[1]), d_count + 1, nullptr);
+                          int(cap[1]), d_count + 1, ws.stream);
       }
       else
         for (int dir = 0; dir < 2; ++dir)
@@ -383,16 +431,17 @@ namespace {
           HIPM_TRY(ws.get(Workspace::kPartD, 3 * size_t(nchunks) * nq, part_d));
           HIPM_TRY(ws.get(Workspace::kPartI, 3 * size_t(nchunks) * nq, part_i));
           launch_nn3_exhaustive(q, nq, t, nt, dim, part_d, part_i, r.top_d[dir],
-                                r.top_i[dir], nullptr);
+                                r.top_i[dir], ws.stream);
           if (radius_on && nt > top1 + 1)
             launch_radius_exhaustive(q, nq, t, nt, dim, r.top_d[dir], top1, thres2,
                                      r.radius[dir], int(cap[dir]), d_count + dir,
-                                     nullptr);
+                                     ws.stream);
         }
       HIPM_TRY(hipGetLastError());
       if (!radius_on)
         break;
       int found[2] = {0, 0};
+      HIPM_TRY(ws.wait(ws.stream));  // the copies below use the NULL stream
       HIPM_TRY(hipMemcpy(found, d_count, 2 * sizeof(int), hipMemcpyDeviceToHost));
       r.radius_found[0] = found[0];
       r.radius_found[1] = found[1];
@@ -407,8 +456,10 @@ namespace {
 
   //! One direction of a DeviceSearch on the host, radius members sorted the
   //! way FLANN's RadiusResultSet hands them out: by (distance, index).
-  sara_hip_status to_host(const DeviceSearch& r, int dir, Neighbours* nb)
+  sara_hip_status to_host(Workspace& ws, const DeviceSearch& r, int dir,
+                          Neighbours* nb)
   {
+    HIPM_TRY(ws.wait(ws.stream));  // the copies below use the NULL stream
     const int nq = r.nq[dir];
     nb->nq = nq;
     nb->nt = r.nt[dir];
@@ -479,10 +530,30 @@ sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,
                      "descriptor dimension must be in 1..128");
   if (sift_ratio_thres != sift_ratio_thres)
     return set_error(SARA_HIP_INVALID_PARAMS, "the ratio threshold is NaN");
+  static const bool prof = getenv("SARA_HIP_MATCH_PROF") != nullptr;
+  const auto tp0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (prof)
+      std::fprintf(stderr, "[match prof] %-10s %8.1f us\n", what,
+                   std::chrono::duration<double, std::micro>(
+                       std::chrono::steady_clock::now() - tp0).count());
+  };
   const sara_hip_status st = use_device(device);
   if (st != SARA_HIP_OK)
     return st;
   Workspace& ws = workspace(device);
+  HIPM_TRY(ws.ensure_stream());
+  lap("device");
+  static hipEvent_t pe0 = nullptr, pe1 = nullptr;
+  if (prof)
+  {
+    if (!pe0)
+    {
+      (void) hipEventCreate(&pe0);
+      (void) hipEventCreate(&pe1);
+    }
+    (void) hipEventRecord(pe0, ws.stream);
+  }
   const float thres2 = sift_ratio_thres * sift_ratio_thres;
   const float *d1 = desc1, *d2 = desc2;
   if (!on_device)
@@ -491,9 +562,9 @@ sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,
     HIPM_TRY(ws.get(Workspace::kDescA, size_t(n1) * dim, a));
     HIPM_TRY(ws.get(Workspace::kDescB, size_t(n2) * dim, b));
     HIPM_TRY(hipMemcpyAsync(a, desc1, size_t(n1) * dim * sizeof(float),
-                            hipMemcpyHostToDevice, nullptr));
+                            hipMemcpyHostToDevice, ws.stream));
     HIPM_TRY(hipMemcpyAsync(b, desc2, size_t(n2) * dim * sizeof(float),
-                            hipMemcpyHostToDevice, nullptr));
+                            hipMemcpyHostToDevice, ws.stream));
     d1 = a;
     d2 = b;
   }
@@ -503,43 +574,65 @@ sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,
       device_search(ws, d1, n1, d2, n2, dim, thres2, 0, false, &ds);
   if (ss != SARA_HIP_OK)
     return ss;
+  lap("search");
   if (!(thres2 > 1.f))
   {
-    // Only the best neighbour can pass: the ratio test runs on the device and
-    // nothing but the matches comes back.  A single candidate gets score 1
-    // (AnnMatcher.cpp:87-101), which never passes a squared ratio <= 1.
+    // Only the best neighbour can pass (K = 1, AnnMatcher.cpp:131): the ratio
+    // test of both directions, the removal of (x, y) duplicates and the sort by
+    // score all run on the device; one copy brings the finished list back.
     struct Header
     {
       int count, pad[3];
     };
     const int cap_dev = n1 + n2;
-    unsigned char* d_out = nullptr;
-    const size_t out_bytes = sizeof(Header) + sizeof(sara_match) * size_t(cap_dev);
+    unsigned char *d_out = nullptr, *d_tmp = nullptr;
+    const size_t list_bytes = sizeof(sara_match) * size_t(cap_dev);
+    const size_t out_bytes = sizeof(Header) + list_bytes;
     HIPM_TRY(ws.get(Workspace::kOut, out_bytes, d_out));
-    HIPM_TRY(hipMemsetAsync(d_out, 0, sizeof(Header), nullptr));
-    int* d_count = reinterpret_cast<int*>(d_out);
-    sara_match* d_m = reinterpret_cast<sara_match*>(d_out + sizeof(Header));
-    for (int dir = 0; dir < 2; ++dir)
-      if (ds.have[dir])
-        launch_ratio_filter(ds.top_d[dir], ds.top_i[dir], ds.nq[dir], thres2, dir,
-                            d_m, cap_dev, d_count, nullptr);
+    HIPM_TRY(ws.get(Workspace::kAux3, list_bytes + sizeof(int) * size_t(cap_dev), d_tmp));
+    HIPM_TRY(hipMemsetAsync(d_out, 0, sizeof(Header), ws.stream));
+    launch_finish_matches(ds.top_d[0], ds.top_i[0], n1, ds.top_d[1], ds.top_i[1], n2,
+                          ds.have[0] ? 1 : 0, ds.have[1] ? 1 : 0, thres2,
+                          reinterpret_cast<sara_match*>(d_tmp),
+                          reinterpret_cast<int*>(d_tmp + list_bytes),
+                          reinterpret_cast<int*>(d_out),
+                          reinterpret_cast<sara_match*>(d_out + sizeof(Header)),
+                          ws.stream);
     HIPM_TRY(hipGetLastError());
     void* h = nullptr;
     HIPM_TRY(ws.host(out_bytes, h));
-    // the header first tells how much of the rest is valid
-    HIPM_TRY(hipMemcpyAsync(h, d_out, sizeof(Header), hipMemcpyDeviceToHost, nullptr));
-    HIPM_TRY(hipStreamSynchronize(nullptr));
-    const int found = std::min(static_cast<Header*>(h)->count, cap_dev);
-    if (found > 0)
+    static hipEvent_t pe2 = nullptr;
+    if (prof)
     {
-      HIPM_TRY(hipMemcpyAsync(static_cast<unsigned char*>(h) + sizeof(Header), d_m,
-                              sizeof(sara_match) * size_t(found),
-                              hipMemcpyDeviceToHost, nullptr));
-      HIPM_TRY(hipStreamSynchronize(nullptr));
-      const sara_match* hm = reinterpret_cast<const sara_match*>(
-          static_cast<unsigned char*>(h) + sizeof(Header));
-      m.assign(hm, hm + found);
+      if (!pe2)
+        (void) hipEventCreate(&pe2);
+      (void) hipEventRecord(pe2, ws.stream);
     }
+    lap("finish");
+    HIPM_TRY(hipMemcpyAsync(h, d_out, out_bytes, hipMemcpyDeviceToHost, ws.stream));
+    lap("copy");
+    if (prof)
+      (void) hipEventRecord(pe1, ws.stream);
+    HIPM_TRY(ws.wait(ws.stream));
+    lap("wait");
+    if (prof)
+    {
+      float ms = 0.f;
+      (void) hipEventElapsedTime(&ms, pe0, pe1);
+      std::fprintf(stderr, "[match prof] gpu span   %8.1f us\n", 1e3 * ms);
+      (void) hipEventElapsedTime(&ms, pe2, pe1);
+      std::fprintf(stderr, "[match prof] d2h copy   %8.1f us (%zu bytes)\n", 1e3 * ms,
+                   out_bytes);
+    }
+    const int found = std::min(static_cast<Header*>(h)->count, cap_dev);
+    *count = found;
+    if (found > capacity)
+      return set_error(SARA_HIP_CAPACITY_EXCEEDED,
+                       "more matches than `capacity` (*count holds the number "
+                       "needed)");
+    std::memcpy(matches, static_cast<unsigned char*>(h) + sizeof(Header),
+                sizeof(sara_match) * size_t(found));
+    return SARA_HIP_OK;
   }
   else
   {
@@ -547,7 +640,7 @@ sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,
     Neighbours nb;
     for (int dir = 0; dir < 2; ++dir)
     {
-      const sara_hip_status hs = to_host(ds, dir, &nb);
+      const sara_hip_status hs = to_host(ws, ds, dir, &nb);
       if (hs != SARA_HIP_OK)
         return hs;
       append_matches(nb, thres2, dir, false, unused, nullptr, nullptr, m);
@@ -579,6 +672,7 @@ sara_hip_status sara_hip_self_match_descriptors(
   if (st != SARA_HIP_OK)
     return st;
   Workspace& ws = workspace(device);
+  HIPM_TRY(ws.ensure_stream());
   const float thres2 = sift_ratio_thres * sift_ratio_thres;
   const float* d = desc;
   if (!desc_on_device)
@@ -586,7 +680,7 @@ sara_hip_status sara_hip_self_match_descriptors(
     float* a = nullptr;
     HIPM_TRY(ws.get(Workspace::kDescA, size_t(n) * dim, a));
     HIPM_TRY(hipMemcpyAsync(a, desc, size_t(n) * dim * sizeof(float),
-                            hipMemcpyHostToDevice, nullptr));
+                            hipMemcpyHostToDevice, ws.stream));
     d = a;
   }
   std::vector<Feat> f(static_cast<size_t>(n));
@@ -601,7 +695,7 @@ sara_hip_status sara_hip_self_match_descriptors(
   if (ss != SARA_HIP_OK)
     return ss;
   Neighbours nb;
-  const sara_hip_status hs = to_host(ds, 0, &nb);
+  const sara_hip_status hs = to_host(ws, ds, 0, &nb);
   if (hs != SARA_HIP_OK)
     return hs;
   std::vector<sara_match> m;
