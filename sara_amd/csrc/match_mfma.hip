@@ -155,10 +155,15 @@ namespace sara_hip {
     //! [row0, row0 + 128) of A and [col0, col0 + 128) of B.  256 threads = 4
     //! waves, each a 64 x 64 quadrant = 2 x 2 MFMA blocks of 32 x 32.
     //! The contraction runs in chunks of 64 k: both operand panels of a chunk
-    //! take 68 KB of LDS, so TWO workgroups share a CU and one's matrix-core
-    //! phase covers the other's staging and epilogue (with the whole k range
-    //! staged at once - 133 KB, one workgroup per CU - the matrix cores idled
-    //! through every staging phase: 84 us per pass against 50).
+    //! take 68 KB of LDS, so two workgroups share a CU (with the whole k range
+    //! staged at once - 133 KB - it is one).  Measured per pass over 4.3 k x
+    //! 4.3 k keys (SARA_HIP_MATCH_SKIP): contraction alone 40 us (78 % of the
+    //! f32 MFMA peak), staging alone 23, minima epilogue alone 16 - and 80
+    //! together: co-resident workgroups fall into step (the contraction is the
+    //! longest phase and the one they share a unit for), so the phases add up;
+    //! a persistent variant that started every second workgroup of a CU a
+    //! staging phase late changed nothing.  What would: prefetching the next
+    //! chunk's panels into registers under the contraction.
     //! Inside a chunk row the k are stored even ones first, odd ones second:
     //! the 32 x 32 x 2 instruction wants k = 2 s + (lane >> 5) in lane, so each
     //! half of the wave reads ITS 32 values of a row as 8 x ds_read_b128.
@@ -651,7 +656,9 @@ namespace sara_hip {
       }
     }
 
-    template <typename K>
+    //! Dynamic LDS above 64 KB has to be allowed per kernel and per device
+    //! (WHICH keeps one table per kernel: both instantiations share a type).
+    template <int WHICH, typename K>
     void allow_big_lds(K kernel)
     {
       static std::atomic<bool> done[64];
@@ -661,7 +668,7 @@ namespace sara_hip {
       {
         (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024);
+                                   160 * 1024 - 64);
         done[dev & 63].store(true, std::memory_order_release);
       }
     }
@@ -737,8 +744,8 @@ namespace sara_hip {
     tick();  // 1: memsets + norms
     const size_t lds = sizeof(float) * std::max(2 * kTile * kPanelStride,
                                                 kTile * kDStride + 4 * kTile);
-    allow_big_lds(mfma_tiles_kernel<kMinima>);
-    allow_big_lds(mfma_tiles_kernel<kEmit>);
+    allow_big_lds<kMinima>(mfma_tiles_kernel<kMinima>);
+    allow_big_lds<kEmit>(mfma_tiles_kernel<kEmit>);
     const dim3 grid(tn, tm);
     static const int skip = [] {
       const char* e = getenv("SARA_HIP_MATCH_SKIP");
