@@ -1216,6 +1216,15 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     const size_t pl0 = size_t(sc.oct[0].w) * sc.oct[0].h;
     float* G00 = c->G[0];
     const size_t g_stride0 = pl0 * S;
+    // Launch-chain-bound regime (octave pipelining = small batches): the blurs
+    // of the spine go out as chains of two or three per launch where the radii
+    // have a fused kernel (launch_gaussian_blur_chain).  Octave 0's chain
+    // starts from the source frame: initial blur, s = 1, s = 2.
+    const Taps* chain0_taps[3] = {&c->init_taps, &c->taps[1], &c->taps[2]};
+    const bool chain0 =
+        pipe && c->pyr.first_octave_index == 0 && sc.init_blur && !gray8_fused &&
+        !c->fma_blur && sc.downscale_index == 2 && S > 3 && !time_launches &&
+        gaussian_blur_chain_available(chain0_taps, 3, sc.oct[0].w, sc.oct[0].h, batch);
     if (c->pyr.first_octave_index < 0)
     {
       launch_enlarge(src, src_stride, width, height, G00, g_stride0, sc.oct[0].w,
@@ -1235,6 +1244,10 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       }
       launch_scale(blurred, bstride, width, height, G00, g_stride0, sc.oct[0].w,
                    sc.oct[0].h, batch, stream);
+    }
+    else if (sc.init_blur && chain0)
+    {
+      // G(0, 0) .. G(2, 0) come out of one launch on the spine (below)
     }
     else if (sc.init_blur)
     {
@@ -1301,6 +1314,51 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       }
       base_ready = false;
     };
+    // blurs s_lo .. s_hi of octave o, fused where a chain kernel exists
+    auto enqueue_blurs = [&](int o, int s_lo, int s_hi, hipStream_t st) {
+      const int w = sc.oct[o].w, h = sc.oct[o].h;
+      const size_t pl = size_t(w) * h;
+      const size_t gs = pl * S;
+      int s = s_lo;
+      while (s <= s_hi)
+      {
+        bool fused = false;
+        for (int n = std::min(3, s_hi - s + 1); n >= 2 && !fused && !c->fma_blur &&
+                                                !time_launches;
+             --n)
+        {
+          const Taps* tp[3] = {&c->taps[s], &c->taps[s + 1],
+                               n == 3 ? &c->taps[s + 2] : nullptr};
+          if (!gaussian_blur_chain_available(tp, n, w, h, batch))
+            continue;
+          float* dst[3] = {c->G[o] + pl * s, c->G[o] + pl * (s + 1),
+                           n == 3 ? c->G[o] + pl * (s + 2) : nullptr};
+          float* dec = nullptr;
+          size_t dec_stride = 0;
+          int dec_stage = -1;
+          if (o < last && dsi >= s && dsi < s + n)
+          {
+            dec = c->G[o + 1];
+            dec_stride = size_t(sc.oct[o + 1].w) * sc.oct[o + 1].h * S;
+            dec_stage = dsi - s;
+          }
+          fused = launch_gaussian_blur_chain(c->G[o] + pl * (s - 1), gs, dst, gs, w, h,
+                                             batch, tp, n, st, dec, dec_stride,
+                                             dec_stage);
+          if (fused)
+          {
+            if (dec)
+              base_ready = true;
+            s += n;
+          }
+        }
+        if (!fused)
+        {
+          enqueue_blur(o, s, st);
+          ++s;
+        }
+      }
+    };
     if (pipe)
     {
       // Small batches are bound by the chain of dependent launches, and a
@@ -1321,15 +1379,27 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       // a queue of its own.  With plain streams the same order simply works.
       hipStream_t side0 = c->oct_stream[1];
       enqueue_base(0, stream);
-      for (int s = 1; s <= dsi; ++s)
-        enqueue_blur(0, s, stream);
+      if (chain0)
+      {
+        float* dst[3] = {G00, G00 + pl0, G00 + 2 * pl0};
+        float* dec = last > 0 ? c->G[1] : nullptr;
+        const size_t dec_stride =
+            last > 0 ? size_t(sc.oct[1].w) * sc.oct[1].h * S : 0;
+        (void) launch_gaussian_blur_chain(src, src_stride, dst, g_stride0,
+                                          sc.oct[0].w, sc.oct[0].h, batch,
+                                          chain0_taps, 3, stream, dec, dec_stride,
+                                          last > 0 ? 2 : -1);
+        if (dec)
+          base_ready = true;
+      }
+      else
+        enqueue_blurs(0, 1, dsi, stream);
       HIP_TRY(hipEventRecord(c->oct_ready[0], stream));
       // the last octave's gradients go behind the side chain of octave last-2
       // (done early, and not the queue finish_sites is waiting for)
       const int grad_last_side = std::max(0, last - 2);
       auto enqueue_side = [&](int o, hipStream_t so) -> sara_hip_status {
-        for (int s = dsi + 1; s < S; ++s)
-          enqueue_blur(o, s, so);
+        enqueue_blurs(o, dsi + 1, S - 1, so);
         const sara_hip_status sst = enqueue_scan(o, so);
         if (sst != SARA_HIP_OK)
           return sst;
@@ -1353,8 +1423,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       {
         enqueue_base(o, tail);
         const int s_hi = o == last ? S - 1 : dsi;
-        for (int s = 1; s <= s_hi; ++s)
-          enqueue_blur(o, s, tail);
+        enqueue_blurs(o, 1, s_hi, tail);
         if (o < last)
           HIP_TRY(hipEventRecord(c->oct_ready[o], tail));
       }

@@ -169,6 +169,18 @@ namespace sara_hip {
   //! on the fly as float(v) / 255.f.  Returns false (nothing launched) when the
   //! marching kernel cannot take the shape / radius: the caller then converts
   //! into a float plane first.
+  //! Two or three consecutive blurs of one plane chain in ONE launch (small
+  //! launches only: a chain of dependent launches, not bandwidth, bounds them).
+  //! taps[s] / dst[s]: stage s; dec: nearest-neighbour half of stage dec_stage's
+  //! output (the next octave's first plane), or NULL.  false = not available
+  //! for these radii / this size: launch the blurs one by one.
+  bool gaussian_blur_chain_available(const Taps* const* taps, int n, int w, int h,
+                                     int batch);
+  bool launch_gaussian_blur_chain(const float* src, size_t src_stride,
+                                  float* const* dst, size_t dst_stride, int w, int h,
+                                  int batch, const Taps* const* taps, int n,
+                                  hipStream_t stream, float* dec, size_t dec_stride,
+                                  int dec_stage);
   bool launch_gaussian_blur_gray8(const unsigned char* src, size_t src_stride,
                                   float* dst, size_t dst_stride, int w, int h,
                                   int batch, const Taps& taps, hipStream_t stream);

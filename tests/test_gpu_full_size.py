@@ -200,6 +200,55 @@ def test_default_small_launch_threshold(oracle, tmp_path):
     assert np.max(np.abs(got["kdesc"][off:off + len(rk)] - rdesc)) <= 2e-3
 
 
+def test_single_frame_schedule_with_blur_chains(oracle, tmp_path):
+    """The one-frame-per-call schedule (HIP-graph replay, octave pipelining,
+    small octaves through the tiled blur) in a fresh process with the shipped
+    launch rules, once as shipped and once with SARA_HIP_BLUR_CHAIN=1 (two or
+    three consecutive blurs per launch, gaussian_blur_chain_kernel): every
+    Gaussian plane bit-identical to the oracle's, keypoints at the usual bars."""
+    import os
+    import subprocess
+    import sys
+    w, h, noct = 1920, 1080, 4
+    img = synth(w, h, 4242)
+    np.save(tmp_path / "img.npy", img)
+    ref = oracle.RefSift(img, oracle.PyramidParams(0, 6, None, 1, 0.5, 1.6, noct),
+                         parallel=True)
+    rk, rso, rdesc = ref.keypoints()
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import sara_amd\n"
+        "img = np.load(%r)\n"
+        "p = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=%d)\n"
+        "with sara_amd.SiftContext(%d, %d, 1, p) as ctx:\n"
+        "    for _ in range(2):\n"          # the second call replays the graph
+        "        ctx.detect(img)\n"
+        "        kc, kreg, kdesc, kso = ctx.fetch()\n"
+        "    g = [ctx.gaussian(s, o) for o in range(%d) for s in range(6)]\n"
+        "np.savez(sys.argv[1], kreg=kreg.view(np.uint8), kdesc=kdesc, kso=kso,\n"
+        "         **{'g%%d' %% i: a for i, a in enumerate(g)})\n"
+        % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+           str(tmp_path / "img.npy"), noct, w, h, noct))
+    for chain in ("0", "1"):
+        out = tmp_path / ("out%s.npz" % chain)
+        env = dict(os.environ, SARA_HIP_BLUR_CHAIN=chain)
+        env.pop("SARA_HIP_MARCH_MIN_PIXELS", None)   # the shipped launch rules
+        subprocess.run([sys.executable, str(script), str(out)], check=True, env=env)
+        got = np.load(out)
+        i = 0
+        for o in range(noct):
+            for s in range(6):
+                assert np.array_equal(got["g%d" % i], ref.gaussian(s, o)), (chain, s, o)
+                i += 1
+        kreg = common.regions_from_bytes(got["kreg"])
+        assert len(kreg) == len(rk)
+        common.assert_regions_equal(kreg, rk, rtol_shape=1e-6, atol_theta=1e-6)
+        assert np.array_equal(got["kso"], rso)
+        assert np.max(np.abs(got["kdesc"] - rdesc)) <= 2e-3
+
+
 def test_benchmark_batch_geometry_against_oracle(oracle):
     """The benchmarked launch geometry itself - 64 distinct 1080p frames in one
     batch (segments per strip, XCD work-item map and persistent-block walk all
