@@ -195,8 +195,14 @@ namespace sara_hip {
     const int x0 = strip * W;
     const int colA = x0 + 2 * lane, colB = x0 + 128 + 2 * lane;
     const bool okA = colA < w, okB = colB < w;
-    const int mcolA = okA ? colA : w - 2;
-    const int mcolB = okB ? colB : w - 2;
+    // odd width: the pair that starts at the last column has one pixel.  It
+    // loads (w-2, w-1) and keeps the second value twice: the right neighbour
+    // of column w-1 is then the column itself, which is the one-sided
+    // difference the border takes (rows are only 4-byte aligned here; the
+    // stores 8-byte: tools/ubench/unaligned_check.hip).
+    const bool fullA = colA + 1 < w, fullB = colB + 1 < w;
+    const int mcolA = fullA ? colA : w - 2;
+    const int mcolB = fullB ? colB : w - 2;
     const int y0 = seg * seg_rows;
     const int y1 = min(h, y0 + seg_rows);
     // strip-edge neighbours: lane 0 needs column x0-1, lane 63 column x0+256
@@ -210,6 +216,11 @@ namespace sara_hip {
       const float2 pa = *reinterpret_cast<const float2*>(rowp + mcolA);
       const float2 pb = *reinterpret_cast<const float2*>(rowp + mcolB);
       m = make_float4(pa.x, pa.y, pb.x, pb.y);
+      if (w & 1)  // wave-uniform
+      {
+        m.x = (okA && !fullA) ? pa.y : m.x;
+        m.z = (okB && !fullB) ? pb.y : m.z;
+      }
       e = 0.f;
       if (edge_lane)
         e = rowp[ecol];
@@ -345,15 +356,19 @@ namespace sara_hip {
           {
             // lane l: 16 bytes at (x0 + 2l) and at (x0 + 128 + 2l) - contiguous
             float4* ob = reinterpret_cast<float4*>(o + (size_t(y) * w + x0) * 2);
-            if (okA)
+            if (fullA)
               ob[lane] = make_float4(res[0], res[1], res[2], res[3]);
-            if (okB)
+            else if (okA)
+              *reinterpret_cast<float2*>(ob + lane) = make_float2(res[0], res[1]);
+            if (fullB)
               ob[64 + lane] = make_float4(res[4], res[5], res[6], res[7]);
+            else if (okB)
+              *reinterpret_cast<float2*>(ob + 64 + lane) = make_float2(res[4], res[5]);
           }
           if (cm)
           {
-            float mA = okA ? fmaxf(res[0], res[2]) : 0.f;
-            float mB = okB ? fmaxf(res[4], res[6]) : 0.f;
+            float mA = okA ? fmaxf(res[0], fullA ? res[2] : 0.f) : 0.f;
+            float mB = okB ? fmaxf(res[4], fullB ? res[6] : 0.f) : 0.f;
             // max over the 8 lanes of a 16-column group: the two quad
             // permutations, then the mirror of the 8-lane half row
             auto max8 = [](float m) {
@@ -462,10 +477,8 @@ namespace sara_hip {
                                         const float* dst, size_t dst_stride,
                                         int w, int h, int batch)
   {
-    const bool aligned4 = (w % 4 == 0) && w >= 4 && h >= 2 &&
-                          (src_stride % 4 == 0) && (dst_stride % 4 == 0) &&
-                          (reinterpret_cast<uintptr_t>(src) % 16 == 0) &&
-                          (reinterpret_cast<uintptr_t>(dst) % 16 == 0);
+    // any width (gradient_polar_march_kernel: pairs, odd tail)
+    const bool aligned4 = w >= 4 && h >= 2;
     // the tiled kernel (and SARA_HIP_GRAD_BANDS=0) use atomicMax
     return !(aligned4 && g_use_march && grad_bands(batch));
   }
@@ -475,10 +488,8 @@ namespace sara_hip {
                              int batch, hipStream_t stream, unsigned* cmax,
                              size_t cmax_stride)
   {
-    const bool aligned4 = (w % 4 == 0) && w >= 4 && h >= 2 &&
-                          (src_stride % 4 == 0) && (dst_stride % 4 == 0) &&
-                          (reinterpret_cast<uintptr_t>(src) % 16 == 0) &&
-                          (reinterpret_cast<uintptr_t>(dst) % 16 == 0);
+    // any width (gradient_polar_march_kernel: pairs, odd tail)
+    const bool aligned4 = w >= 4 && h >= 2;
     if (aligned4 && g_use_march)
     {
       const int nstrips = (w + 255) / 256;
@@ -1123,12 +1134,22 @@ namespace sara_hip {
     const int y1 = min(h, y0 + seg_rows);
     const float thr8 = 0.8f * p.extremum_thres;
 
+    // odd width: the lane whose pair starts at the last column loads the pair
+    // (w-2, w-1) and keeps the second value as its first (rows are then only
+    // 4-byte aligned: tools/ubench/unaligned_check.hip)
+    const bool odd_tail = col == w - 1;
     auto load_row = [&](int yy, float2 (&r)[NG]) {
       const int gy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
       const float* rowp = g + size_t(gy) * w + mcol;
 #pragma unroll
       for (int l = 0; l < NG; ++l)
         r[l] = *reinterpret_cast<const float2*>(rowp + size_t(l) * plane);
+      if (w & 1)  // wave-uniform
+      {
+#pragma unroll
+        for (int l = 0; l < NG; ++l)
+          r[l].x = odd_tail ? r[l].y : r[l].x;
+      }
     };
 
     float2 pg[PF][NG];
@@ -1378,12 +1399,11 @@ namespace sara_hip {
     const int nscan = gauss.scales - 3;  // DoG layers 1 .. (scales-1)-2
     if (nscan <= 0)
       return false;
-    const bool aligned2 = (gauss.w % 2 == 0) && gauss.w >= 4 &&
-                          (gauss.plane % 2 == 0) &&
-                          (reinterpret_cast<uintptr_t>(gauss.base) % 8 == 0);
+    // any width (odd ones: extrema_march_kernel's odd_tail)
+    const bool wide_enough = gauss.w >= 4;
     // the Halide-branch classifier (signed_type) also classifies the border
     // pixels: it runs on the general path
-    if (aligned2 && g_use_march && gauss.scales == 6 && !p.signed_type)
+    if (wide_enough && g_use_march && gauss.scales == 6 && !p.signed_type)
     {
       const int nstrips = (gauss.w - 2 + 125) / 126;
       int nseg = (g_extrema_waves + nstrips * batch - 1) / (nstrips * batch);
@@ -1391,7 +1411,8 @@ namespace sara_hip {
       const int seg_rows = (gauss.h + nseg - 1) / nseg;
       nseg = (gauss.h + seg_rows - 1) / seg_rows;
       const bool fuse = grad != nullptr && cmax != nullptr && g_fuse_gradient &&
-                        gauss.h >= 2 &&
+                        gauss.h >= 2 && (gauss.w % 2 == 0) &&
+                        (gauss.plane % 2 == 0) &&
                         (reinterpret_cast<uintptr_t>(grad) % 16 == 0) &&
                         (grad_frame_stride % 4 == 0);
       const int total = xcd_map_enabled() ? nstrips * nseg * batch : 0;

@@ -313,7 +313,12 @@ namespace sara_hip {
     const int y0 = seg * seg_rows;
     const int y1 = min(h, y0 + seg_rows);
     const int col = x0 + CPL * lane;
-    const bool col_ok = col < w;  // w % 4 == 0: a float4 is all in or all out
+    // w % 4 == 0: a float4 is all in or all out; any other width comes here
+    // with w >= W only, where every strip is full (the last one moved left).
+    // Rows and strips are then only 4-byte aligned, which gfx950's 16-byte
+    // global loads / stores take at 96-100 % of the aligned rate
+    // (tools/ubench/unaligned_check.hip).
+    const bool col_ok = col < w;
     // halo column of this lane (lanes < 2R)
     int hcol = lane < R ? x0 - R + lane : x0 + W + (lane - R);
     hcol = hcol < 0 ? 0 : (hcol > w - 1 ? w - 1 : hcol);
@@ -418,8 +423,22 @@ namespace sara_hip {
           *reinterpret_cast<float4*>(dst + size_t(o) * w + col) =
               make_float4(A[i][0], A[i][1], A[i][2], A[i][3]);
           if (DEC && (o & 1) == 0 && (o >> 1) < dh)
-            *reinterpret_cast<float2*>(dec + size_t(o >> 1) * dw + (col >> 1)) =
-                make_float2(A[i][0], A[i][2]);
+          {
+            float* dp = dec + size_t(o >> 1) * dw;
+            if ((col & 1) == 0)  // wave-uniform: col - x0 is a multiple of 4
+              *reinterpret_cast<float2*>(dp + (col >> 1)) =
+                  make_float2(A[i][0], A[i][2]);
+            else
+            {
+              // odd width, last strip (x0 = w - 256 is odd): the even source
+              // columns are the lane's second and fourth, and the last one,
+              // w - 1, has no place in a plane of w / 2 columns
+              const int dx = (col + 1) >> 1;
+              dp[dx] = A[i][1];
+              if (dx + 1 < dw)
+                dp[dx + 1] = A[i][3];
+            }
+          }
         }
       }
       // re-align the prefetch ring: the row of step n0+K+q sits in slot
@@ -617,7 +636,9 @@ namespace sara_hip {
     const int y0 = seg * seg_rows;
     const int y1 = min(h, y0 + seg_rows);
     const int col = x0 + CPL * lane;
-    const bool col_ok = col < w;  // w % 2 == 0: a float2 is all in or all out
+    // w % 2 == 0: a float2 is all in or all out; odd widths only with w >= W
+    // (every strip full, see gaussian_blur_march_kernel)
+    const bool col_ok = col < w;
     int hcol = lane < R ? x0 - R + lane : x0 + W + (lane - R);
     hcol = hcol < 0 ? 0 : (hcol > w - 1 ? w - 1 : hcol);
     const int hslot = lane < R ? RP - R + lane : RP + W + (lane - R);
@@ -1080,10 +1101,10 @@ namespace sara_hip {
   {
     const int R = taps.size / 2;
     const bool big_enough = size_t(w) * h * batch >= g_march_min_pixels;
-    const bool ok = big_enough && g_use_march && (w % 4 == 0) && w >= 4 &&
-                    (src_stride % 4 == 0) && (dst_stride % 4 == 0) &&
-                    (reinterpret_cast<uintptr_t>(src) % 4 == 0) &&
-                    (reinterpret_cast<uintptr_t>(dst) % 16 == 0);
+    // any width from one full strip up (element-aligned vector accesses), or
+    // a multiple of 4
+    const bool ok = big_enough && g_use_march &&
+                    ((w % 4 == 0 && w >= 4) || w >= 256);
     if (!ok)
       return false;
     const float* s = reinterpret_cast<const float*>(src);
@@ -1109,25 +1130,25 @@ namespace sara_hip {
                             bool fma)
   {
     const int R = taps.size / 2;
-    // fast path: strips of float4 columns need 16-byte aligned rows
+    // fast path: strips of float4 / float2 columns.  A width that is not a
+    // multiple of the vector leaves a partial vector at the end of the row -
+    // unless the row holds at least one full strip: the last strip is moved
+    // left and every vector is whole.  Alignment is not a condition: rows of
+    // such widths start at any multiple of 4 bytes and gfx950 takes 8- and
+    // 16-byte global accesses there at 96-100 % of the aligned rate
+    // (tools/ubench/unaligned_check.hip).  Round 2 sent these widths to the
+    // tiled kernel: 64 x 1366 x 768 ran the pyramid 1.9x slower than 1368.
     const bool big_enough = size_t(w) * h * batch >= g_march_min_pixels;
-    const bool aligned4 = big_enough && (w % 4 == 0) && w >= 4 &&
-                          (src_stride % 4 == 0) &&
-                          (dst_stride % 4 == 0) &&
-                          (reinterpret_cast<uintptr_t>(src) % 16 == 0) &&
-                          (reinterpret_cast<uintptr_t>(dst) % 16 == 0) &&
-                          dog == nullptr;
-    // the fused half-size output needs 8-byte aligned rows of w/2 floats
-    const bool dec_ok = dec == nullptr ||
-                        ((reinterpret_cast<uintptr_t>(dec) % 8 == 0) &&
-                         (dec_stride % 2 == 0) && g_fuse_decimate);
-    if (!dec_ok)
+    const bool base_ok = big_enough && dog == nullptr;
+    const bool march4_ok = base_ok && ((w % 4 == 0 && w >= 4) || w >= 256);
+    const bool march2_ok = base_ok && ((w % 4 == 0 && w >= 4) || w >= 128);
+    if (!g_fuse_decimate)
       dec = nullptr;
     // the hand-scheduled kernel shares the products of mirrored taps
     bool symmetric = true;
     for (int j = 0; j < R; ++j)
       symmetric &= std::memcmp(&taps.k[j], &taps.k[2 * R - j], sizeof(float)) == 0;
-    if (aligned4 && g_use_march && g_use_march2 && dec == nullptr && symmetric)
+    if (march2_ok && g_use_march && g_use_march2 && dec == nullptr && symmetric)
     {
       switch (R)
       {
@@ -1147,7 +1168,7 @@ namespace sara_hip {
         break;
       }
     }
-    if (aligned4 && g_use_march)
+    if (march4_ok && g_use_march)
     {
 #define SARA_MARCH_CASE(r)                                                     \
   case r:                                                                      \

@@ -40,7 +40,12 @@ def test_blur_of_constant_is_constant():
                                    # strip edges of the marching kernels (128- and
                                    # 256-column strips) and several row segments
                                    (40, 256), (90, 260), (50, 124), (300, 132),
-                                   (26, 384)])
+                                   (26, 384),
+                                   # widths that are not multiples of 4 on the
+                                   # marching kernels (one full strip or more:
+                                   # element-aligned rows, last strip moved left)
+                                   (45, 683), (38, 1366), (70, 257), (52, 341),
+                                   (41, 129), (33, 255)])
 @pytest.mark.parametrize("sigma", [0.5, 1.2262735, 1.5198685, 1.946588, 2.4525296,
                                    3.0900156, 4.1])
 def test_gaussian_filter_matches_oracle_bit_exact(oracle, shape, sigma):
@@ -115,7 +120,11 @@ def test_polar_gradient_of_ramp():
             assert g[y, x, 1] == 0.0
 
 
-@pytest.mark.parametrize("shape", [(2, 2), (3, 7), (64, 64), (135, 240), (101, 67)])
+@pytest.mark.parametrize("shape", [(2, 2), (3, 7), (64, 64), (135, 240), (101, 67),
+                                   # odd widths and widths = 2 (mod 4) on the
+                                   # marching kernel, tails in either pair group
+                                   (40, 683), (35, 1366), (21, 257), (19, 385),
+                                   (18, 129), (17, 127), (23, 255), (9, 5)])
 def test_polar_gradient_matches_oracle_bit_exact(oracle, shape):
     src = RNG.random(shape, dtype=np.float32)
     got = sara_amd.gradient_polar_coordinates(src)

@@ -82,7 +82,13 @@ def run_lists(ctx):
 
 
 @pytest.mark.parametrize("w,h,noct", [(640, 480, 4), (501, 377, 4), (320, 200, 3),
-                                      (96, 64, 9)])
+                                      (96, 64, 9),
+                                      # widths that are not multiples of 4, on the
+                                      # marching kernels from one strip up: odd
+                                      # and = 2 (mod 4) octave widths, odd strip
+                                      # origins in the fused half-size output
+                                      (1366, 200, 4), (1027, 150, 3), (683, 301, 3),
+                                      (517, 160, 2)])
 def test_full_parity_synthetic(oracle, w, h, noct):
     img = synth(w, h, 1234)
     ref = oracle.RefSift(img, ref_params(oracle, 0, noct))
@@ -406,13 +412,15 @@ def test_detect_u8_equals_detect_on_converted_frames(oracle):
 
 
 @pytest.mark.parametrize("w,h,cam", [(160, 120, 0.5), (320, 96, 0.5), (162, 120, 0.5),
-                                     (160, 120, 1.6)])
+                                     (160, 120, 1.6), (341, 90, 0.5), (258, 70, 0.5)])
 def test_gray8_read_by_the_first_blur(oracle, w, h, cam):
     """Batches too large for graph replay: the base blur of octave 0 reads the
     gray8 frames itself (float(v) / 255.f as it loads, no conversion pass).
     Byte-identical keypoints to detect() on the converted float frames, for
-    widths the marching kernel takes, one it does not (162), and a camera
-    scale without an initial blur; also through stage() / detect_staged()."""
+    widths the marching kernel takes (multiples of 4, any width from one
+    256-column strip up: byte-aligned 4-byte loads), one it does not (162), and
+    a camera scale without an initial blur; also through stage() /
+    detect_staged()."""
     batch = 10  # > SARA_HIP_GRAPH_MAX_BATCH
     u8 = (synth_batch(w, h, batch) * 255).astype(np.uint8)
     f32 = u8.astype(np.float32) / np.float32(255)
