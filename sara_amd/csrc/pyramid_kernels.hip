@@ -79,46 +79,73 @@ namespace sara_hip {
     return !(e && std::string(e) == "0");
   }();
 
-  template <int R>
-  __global__ __launch_bounds__(NT) void gaussian_blur_kernel(
+  // Round 3: the tile geometry is a template parameter and the window is staged
+  // with 16-byte loads.  One frame per call is a chain of dependent launches of
+  // 3-17 MB each; tools/ubench/tile_blur_b1.hip times such chains: an empty
+  // kernel costs 2.8 us per launch, round 2's kernel (64 x 32 tiles, 256
+  // threads, one clamped 4-byte load per window element) 13.1 / 8.2 / 7.0 / 7.4
+  // us at R = 6 on 1920x1080 / 960x540 / 480x270 / 240x135, and 9.8 us when it
+  // only copies its tile through LDS - staging, not arithmetic, was the cost.
+  // With the rows staged as float4 from the 16-byte column below x0 - R
+  // (clamped element loads only in tiles that touch the left / right border)
+  // and 512 threads per 64 x 32 tile: 10.9 / 5.3 us; the small octaves want
+  // more, smaller tiles (a 240 x 135 plane is 20 tiles of 64 x 32 on 256 CUs):
+  // 64 x 16 / 256 threads 4.1 us at 480x270, 32 x 16 / 128 threads 3.7 us at
+  // 240x135.  launch_blur_r picks the geometry from the number of tiles.
+  template <int R, int TX_, int TY_, int NT_>
+  __global__ __launch_bounds__(NT_) void gaussian_blur_kernel(
       const float* __restrict__ src, size_t src_stride,
       float* __restrict__ dst, size_t dst_stride, float* __restrict__ dog,
       size_t dog_stride, int w, int h, Taps taps, float* __restrict__ dec,
       size_t dec_stride)
   {
     constexpr int K = 2 * R + 1;
-    constexpr int IW = TX + 2 * R;
-    constexpr int IH = TY + 2 * R;
-    constexpr int NQ = (4 + 2 * R + 3) / 4;       // b128 reads per 4 outputs
-    constexpr int IP = ((IW + 3) / 4) * 4 + 4;    // row pitch, over-read safe
+    constexpr int RP = ((R + 3) / 4) * 4;     // left halo rounded up to 16 bytes
+    constexpr int D = RP - R;
+    constexpr int IW4 = (RP + TX_ + RP) / 4;  // float4 per staged row
+    constexpr int IP = IW4 * 4 + 4;           // row pitch, over-read safe
+    constexpr int IH = TY_ + 2 * R;
+    constexpr int NQ = (D + 4 + 2 * R + 3) / 4;  // b128 reads per 4 outputs
+    constexpr int CR = TX_ * TY_ / NT_;       // rows per thread, column pass
+    static_assert(TX_ % 4 == 0 && (TX_ * TY_) % NT_ == 0 && NT_ % TX_ == 0, "geometry");
     __shared__ __attribute__((aligned(16))) float s_in[IH * IP];
-    __shared__ __attribute__((aligned(16))) float s_tmp[IH * TX];
+    __shared__ __attribute__((aligned(16))) float s_tmp[IH * TX_];
 
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * TX;
-    const int y0 = blockIdx.y * TY;
+    const int x0 = blockIdx.x * TX_;
+    const int y0 = blockIdx.y * TY_;
     const size_t b = blockIdx.z;
     src += b * src_stride;
     dst += b * dst_stride;
 
-    // Stage the clamped source window.
-    for (int idx = tid; idx < IH * IW; idx += NT)
+    // Stage the clamped source window, columns x0 - RP .. x0 + TX + RP - 1.
+    const bool inside = x0 - RP >= 0 && x0 + TX_ + RP <= w;  // block-uniform
+    for (int idx = tid; idx < IH * IW4; idx += NT_)
     {
-      const int r = idx / IW;
-      const int c = idx - r * IW;
+      const int r = idx / IW4;
+      const int c4 = idx - r * IW4;
       int gy = y0 - R + r;
-      int gx = x0 - R + c;
       gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
-      gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
-      s_in[r * IP + c] = src[size_t(gy) * w + gx];
+      const float* rowp = src + size_t(gy) * w;
+      const int gx = x0 - RP + 4 * c4;
+      float4 t;
+      if (inside)  // 16-byte load; rows of any width (element-aligned is enough)
+        t = *reinterpret_cast<const float4*>(rowp + gx);
+      else
+      {
+        const int xa = min(max(gx, 0), w - 1), xb = min(max(gx + 1, 0), w - 1);
+        const int xc = min(max(gx + 2, 0), w - 1), xd = min(max(gx + 3, 0), w - 1);
+        t = make_float4(rowp[xa], rowp[xb], rowp[xc], rowp[xd]);
+      }
+      *reinterpret_cast<float4*>(&s_in[r * IP + 4 * c4]) = t;
     }
     __syncthreads();
 
     // Row pass.
-    for (int it = tid; it < IH * (TX / 4); it += NT)
+    for (int it = tid; it < IH * (TX_ / 4); it += NT_)
     {
-      const int r = it / (TX / 4);
-      const int q = it - r * (TX / 4);
+      const int r = it / (TX_ / 4);
+      const int q = it - r * (TX_ / 4);
       float v[NQ * 4];
       const float4* p = reinterpret_cast<const float4*>(&s_in[r * IP + 4 * q]);
 #pragma unroll
@@ -137,22 +164,22 @@ namespace sara_hip {
         float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < K; ++j)
-          sum += v[i + j] * taps.k[j];
+          sum += v[D + i + j] * taps.k[j];
         acc[i] = sum;
       }
-      *reinterpret_cast<float4*>(&s_tmp[r * TX + 4 * q]) =
+      *reinterpret_cast<float4*>(&s_tmp[r * TX_ + 4 * q]) =
           make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
     __syncthreads();
 
-    // Column pass: lane -> column tx, 8 consecutive rows.
-    const int tx = tid & 63;
-    const int yq = tid >> 6;
-    constexpr int NV = 8 + 2 * R;
+    // Column pass: thread -> column tx, CR consecutive rows.
+    const int tx = tid % TX_;
+    const int yq = tid / TX_;
+    constexpr int NV = CR + 2 * R;
     float v[NV];
 #pragma unroll
     for (int m = 0; m < NV; ++m)
-      v[m] = s_tmp[(yq * 8 + m) * TX + tx];
+      v[m] = s_tmp[(yq * CR + m) * TX_ + tx];
 
     const int gx = x0 + tx;
     if (gx >= w)
@@ -160,18 +187,18 @@ namespace sara_hip {
     if (dog)
       dog += b * dog_stride;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < CR; ++i)
     {
       float sum = 0.f;
 #pragma unroll
       for (int j = 0; j < K; ++j)
         sum += v[i + j] * taps.k[j];
-      const int gy = y0 + yq * 8 + i;
+      const int gy = y0 + yq * CR + i;
       if (gy < h)
       {
         dst[size_t(gy) * w + gx] = sum;
         if (dog)
-          dog[size_t(gy) * w + gx] = sum - s_in[(yq * 8 + i + R) * IP + tx + R];
+          dog[size_t(gy) * w + gx] = sum - s_in[(yq * CR + i + R) * IP + RP + tx];
         // nearest-neighbour half of the output = first plane of the next
         // octave (Resize.cpp:45-84: int(x * (w / (w/2))) == 2x), see the
         // marching kernel's DEC
@@ -819,16 +846,49 @@ namespace sara_hip {
                          h, seg_rows, nstrips, nseg, total, taps);
   }
 
+  template <int R, int TX_, int TY_, int NT_>
+  static void launch_blur_geom(const float* src, size_t src_stride, float* dst,
+                               size_t dst_stride, float* dog, size_t dog_stride,
+                               int w, int h, int batch, const Taps& taps,
+                               hipStream_t stream, float* dec, size_t dec_stride)
+  {
+    const dim3 grid((w + TX_ - 1) / TX_, (h + TY_ - 1) / TY_, batch);
+    hipLaunchKernelGGL((gaussian_blur_kernel<R, TX_, TY_, NT_>), grid, dim3(NT_), 0,
+                       stream, src, src_stride, dst, dst_stride, dog, dog_stride, w,
+                       h, taps, dec, dec_stride);
+  }
+
+  //! SARA_HIP_TILE_GEOM=0 / 1 / 2 forces the 64 x 32 / 64 x 16 / 32 x 16 tiles.
+  static const int g_tile_geom = [] {
+    const char* e = getenv("SARA_HIP_TILE_GEOM");
+    return e ? atoi(e) : -1;
+  }();
+
   template <int R>
   static void launch_blur_r(const float* src, size_t src_stride, float* dst,
                             size_t dst_stride, float* dog, size_t dog_stride,
                             int w, int h, int batch, const Taps& taps,
                             hipStream_t stream, float* dec, size_t dec_stride)
   {
-    const dim3 grid((w + TX - 1) / TX, (h + TY - 1) / TY, batch);
-    hipLaunchKernelGGL(gaussian_blur_kernel<R>, grid, dim3(NT), 0, stream, src,
-                       src_stride, dst, dst_stride, dog, dog_stride, w, h, taps,
-                       dec, dec_stride);
+    // enough tiles for the 256 CUs (gaussian_blur_kernel's header has the
+    // measurements behind the thresholds)
+    const long long tiles6432 =
+        (long long) ((w + 63) / 64) * ((h + 31) / 32) * batch;
+    int geom = tiles6432 >= 200 ? 0 : (tiles6432 >= 48 ? 1 : 2);
+    if (g_tile_geom >= 0 && g_tile_geom <= 2)
+      geom = g_tile_geom;
+    if (geom == 0)
+      launch_blur_geom<R, 64, 32, 512>(src, src_stride, dst, dst_stride, dog,
+                                       dog_stride, w, h, batch, taps, stream, dec,
+                                       dec_stride);
+    else if (geom == 1)
+      launch_blur_geom<R, 64, 16, 256>(src, src_stride, dst, dst_stride, dog,
+                                       dog_stride, w, h, batch, taps, stream, dec,
+                                       dec_stride);
+    else
+      launch_blur_geom<R, 32, 16, 128>(src, src_stride, dst, dst_stride, dog,
+                                       dog_stride, w, h, batch, taps, stream, dec,
+                                       dec_stride);
   }
 
   // ======================================================================== //

@@ -311,3 +311,63 @@ def test_extremum_map_halide_seam(oracle):
     want = oracle.halide_dog_extremum_map(layers[0], layers[1], layers[2], 10.0, 0.01)
     assert np.array_equal(got, want)
     assert got[0, 5] == 1 and got[h - 1, 0] == -1 and np.count_nonzero(got) > 20
+
+
+@pytest.mark.parametrize("geom", [0, 1, 2])
+def test_tiled_blur_geometries_bit_exact(oracle, tmp_path, geom):
+    """The tiled blur (what launches too small for the marching kernels use, and
+    every launch of a one-frame call) has three tile geometries, picked from the
+    number of tiles (64 x 32 / 512 threads, 64 x 16 / 256, 32 x 16 / 128).  Each
+    is forced in a fresh process (SARA_HIP_BLUR=tile, SARA_HIP_TILE_GEOM) on
+    shapes with borders in every position of a tile, interior tiles (16-byte
+    staging) and odd widths, for every radius of the pyramid and a few others;
+    the fused half-size output is checked through a 3-octave pyramid."""
+    import os
+    import subprocess
+    import sys
+    shapes = [(3, 3), (5, 64), (33, 65), (97, 131), (135, 240), (70, 517),
+              (41, 129), (50, 124), (66, 300), (17, 1366)]
+    sigmas = [0.5, 1.2262735, 1.5198685, 1.946588, 2.4525296, 3.0900156, 4.1, 0.9,
+              2.2, 3.6]
+    rng = np.random.default_rng(11 + geom)
+    srcs = [rng.random(s, dtype=np.float32) for s in shapes]
+    inp = tmp_path / "in.npz"
+    out = tmp_path / "out.npz"
+    np.savez(inp, **{"s%d" % i: a for i, a in enumerate(srcs)})
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import sara_amd\n"
+        "from sara_amd.synth import synth\n"
+        "d = np.load(%r)\n"
+        "sig = %r\n"
+        "res = {}\n"
+        "for i in range(len(d.files)):\n"
+        "    for j, s in enumerate(sig):\n"
+        "        res['b%%d_%%d' %% (i, j)] = sara_amd.apply_gaussian_filter(d['s%%d' %% i], s)\n"
+        "img = synth(301, 222, 99)\n"
+        "p = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=3)\n"
+        "with sara_amd.SiftContext(301, 222, 1, p) as ctx:\n"
+        "    ctx.detect(img)\n"
+        "    for o in range(3):\n"
+        "        for s in range(6):\n"
+        "            res['g%%d_%%d' %% (o, s)] = ctx.gaussian(s, o, 0)\n"
+        "np.savez(%r, **res)\n"
+        % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(inp),
+           sigmas, str(out)))
+    env = dict(os.environ)
+    env["SARA_HIP_BLUR"] = "tile"
+    env["SARA_HIP_TILE_GEOM"] = str(geom)
+    subprocess.run([sys.executable, str(script)], check=True, env=env)
+    got = np.load(out)
+    for i, src in enumerate(srcs):
+        for j, s in enumerate(sigmas):
+            assert np.array_equal(got["b%d_%d" % (i, j)],
+                                  oracle.apply_gaussian_filter(src, s)), (shapes[i], s)
+    from sara_amd.synth import synth
+    ref = oracle.RefSift(synth(301, 222, 99),
+                         oracle.PyramidParams(0, 6, None, 1, 0.5, 1.6, 3))
+    for o in range(3):
+        for s in range(6):
+            assert np.array_equal(got["g%d_%d" % (o, s)], ref.gaussian(s, o)), (o, s)
