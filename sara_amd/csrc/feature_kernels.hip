@@ -201,6 +201,7 @@ namespace sara_hip {
     // difference the border takes (rows are only 4-byte aligned here; the
     // stores 8-byte: tools/ubench/unaligned_check.hip).
     const bool fullA = colA + 1 < w, fullB = colB + 1 < w;
+    const bool tailA = okA && !fullA, tailB = okB && !fullB;
     const int mcolA = fullA ? colA : w - 2;
     const int mcolB = fullB ? colB : w - 2;
     const int y0 = seg * seg_rows;
@@ -216,11 +217,6 @@ namespace sara_hip {
       const float2 pa = *reinterpret_cast<const float2*>(rowp + mcolA);
       const float2 pb = *reinterpret_cast<const float2*>(rowp + mcolB);
       m = make_float4(pa.x, pa.y, pb.x, pb.y);
-      if (w & 1)  // wave-uniform
-      {
-        m.x = (okA && !fullA) ? pa.y : m.x;
-        m.z = (okB && !fullB) ? pb.y : m.z;
-      }
       e = 0.f;
       if (edge_lane)
         e = rowp[ecol];
@@ -248,6 +244,10 @@ namespace sara_hip {
         const int n = n0 + i;
         const int yy = y0 - 1 + n;  // source row arriving now
         ring[i % 3] = pm[i % PF];
+        // odd tail (see fullA / fullB): here, where the prefetched row is
+        // consumed, not behind the load
+        ring[i % 3].x = tailA ? ring[i % 3].y : ring[i % 3].x;
+        ring[i % 3].z = tailB ? ring[i % 3].w : ring[i % 3].z;
         ering[i % 3] = pe[i % PF];
         load_row(yy + PF, pm[i % PF], pe[i % PF]);
 
@@ -414,6 +414,117 @@ namespace sara_hip {
     }
   }
 
+  //! Pixel-parallel form for launches too small for the marching kernel (one
+  //! frame per call: a 240 x 135 octave is 27 marching waves of 18 dependent
+  //! row steps each, 20 us; here it is 108 workgroups, 4 us).  A workgroup of
+  //! 256 threads owns a tile of 64 columns x 16 rows - exactly four 16 x 16
+  //! blocks of the coarse magnitude map, which it writes with plain stores (no
+  //! atomics, no zero-fill); a thread computes 4 consecutive rows of one
+  //! column from a 6-row register window, horizontal neighbours from the
+  //! adjacent lane (DPP) and, at the tile's edge columns, one extra load.  The
+  //! arithmetic is gradient_polar_march_kernel's (same expressions, same
+  //! device_math.hpp forms): bit-identical planes.
+  __global__ __launch_bounds__(256) void gradient_polar_tile_kernel(
+      const float* __restrict__ src, size_t src_stride,
+      float* __restrict__ dst, size_t dst_stride, int w, int h, int nscales,
+      unsigned* __restrict__ cmax, size_t cmax_stride)
+  {
+    __shared__ __attribute__((aligned(16))) float s_atan[kAtanLutFloats];
+    __shared__ float s_max[4][4];
+    const int tid = threadIdx.x;
+    fill_atan_lut(s_atan, tid, 256);
+    __syncthreads();
+    const int lane = tid & 63, ty = tid >> 6;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+    const int z = blockIdx.z;
+    const size_t b = z / nscales;
+    const size_t s = z - b * nscales;
+    const size_t plane = size_t(w) * h;
+    const float* f = src + b * src_stride + s * plane;
+    float* o = dst + b * dst_stride + s * plane * 2;
+    const int x = x0 + lane;
+    const int xc = min(x, w - 1);
+    const bool okx = x < w;
+    const int ya = y0 + 4 * ty;  // first output row of this thread
+    // rows ya-1 .. ya+4 of the own column (clamped: the border rows repeat,
+    // which is the one-sided difference, Differential.hpp:46-61)
+    float v[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+    {
+      const int gy = min(max(ya - 1 + r, 0), h - 1);
+      v[r] = f[size_t(gy) * w + xc];
+    }
+    // edge columns of the tile: the left neighbour of lane 0, the right one of
+    // lane 63 (clamped at the image border as well)
+    const bool edge = lane == 0 || lane == 63;
+    const int ex = lane == 0 ? max(x0 - 1, 0) : min(x0 + 64, w - 1);
+    float e[4] = {0.f, 0.f, 0.f, 0.f};
+    if (edge)
+    {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        e[r] = f[size_t(min(ya + r, h - 1)) * w + ex];
+    }
+    float run_max = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+    {
+      const int y = ya + r;
+      const float mid = v[r + 1];
+      float left = shift_from_prev(mid);
+      float right = shift_from_next(mid);
+      if (lane == 0)
+        left = e[r];
+      if (lane == 63)
+        right = e[r];
+      if (x + 1 >= w)
+        right = mid;
+      const float gx = (right - left) / 2;
+      const float gy = (v[r + 2] - v[r]) / 2;
+      const float ss = gx * gx + gy * gy;
+      float a = atan2f_lut_nonzero_x(gy, gx, s_atan);
+      if ((__float_as_uint(gx) << 1) == 0u)
+        a = atan2f_zero_x(gy, gx);
+      const bool odd = sqrt_short_exponent(ss) < kSqrtShortMinExponent ||
+                       !(ss < __builtin_inff());
+      float m;
+      if (__builtin_expect(__ballot(odd) != 0ull, 0))
+        m = 2 * sqrtf(ss);
+      else
+        m = 2 * sqrt_rn_short(ss);
+      if (okx && y < h)
+      {
+        *reinterpret_cast<float2*>(o + (size_t(y) * w + x) * 2) = make_float2(m, a);
+        run_max = fmaxf(run_max, m);
+      }
+    }
+    if (cmax)
+    {
+      // maximum over the 16 lanes of a DPP row = one 16-column block
+      float m = run_max;
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0xB1, 0xf, 0xf, true)));
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0x4E, 0xf, 0xf, true)));
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0x141, 0xf, 0xf, true)));
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0x140, 0xf, 0xf, true)));
+      if ((lane & 15) == 0)
+        s_max[ty][lane >> 4] = m;
+      __syncthreads();
+      if (tid < 4)
+      {
+        const int cw = (w + 15) / 16, ch = (h + 15) / 16;
+        const int cx = (x0 >> 4) + tid;
+        if (cx < cw)
+        {
+          const float t = fmaxf(fmaxf(s_max[0][tid], s_max[1][tid]),
+                                fmaxf(s_max[2][tid], s_max[3][tid]));
+          cmax[b * cmax_stride + (s * ch + (y0 >> 4)) * size_t(cw) + cx] =
+              __float_as_uint(t);
+        }
+      }
+    }
+  }
+
   static const bool g_use_march = [] {
     const char* e = getenv("SARA_HIP_FEATURES");
     return !(e && std::string(e) == "tile");
@@ -473,13 +584,26 @@ namespace sara_hip {
     return e ? std::max(64, atoi(e)) : 4096;
   }();
 
+  //! Planes below this many pixels per launch (w x h x batch) go to the
+  //! pixel-parallel gradient kernel (SARA_HIP_GRAD_TILE_PIXELS; 0 = never).
+  static const long long g_grad_tile_pixels = [] {
+    const char* e = getenv("SARA_HIP_GRAD_TILE_PIXELS");
+    return e ? atoll(e) : (long long) 4 << 20;
+  }();
+  static inline bool grad_small_launch(int w, int h, int batch)
+  {
+    return w >= 2 && h >= 2 && (long long) w * h * batch < g_grad_tile_pixels;
+  }
+
   bool gradient_polar_needs_zeroed_cmax(const float* src, size_t src_stride,
                                         const float* dst, size_t dst_stride,
                                         int w, int h, int batch)
   {
     // any width (gradient_polar_march_kernel: pairs, odd tail)
     const bool aligned4 = w >= 4 && h >= 2;
-    // the tiled kernel (and SARA_HIP_GRAD_BANDS=0) use atomicMax
+    if (grad_small_launch(w, h, batch))
+      return false;  // gradient_polar_tile_kernel: one writer per entry
+    // the generic kernel (and SARA_HIP_GRAD_BANDS=0) use atomicMax
     return !(aligned4 && g_use_march && grad_bands(batch));
   }
 
@@ -490,6 +614,14 @@ namespace sara_hip {
   {
     // any width (gradient_polar_march_kernel: pairs, odd tail)
     const bool aligned4 = w >= 4 && h >= 2;
+    if (grad_small_launch(w, h, batch))
+    {
+      const dim3 grid((w + 63) / 64, (h + 15) / 16, batch * nscales);
+      hipLaunchKernelGGL(gradient_polar_tile_kernel, grid, dim3(256), 0, stream, src,
+                         src_stride, dst, dst_stride, w, h, nscales, cmax,
+                         cmax_stride);
+      return;
+    }
     if (aligned4 && g_use_march)
     {
       const int nstrips = (w + 255) / 256;
@@ -1136,7 +1268,9 @@ namespace sara_hip {
 
     // odd width: the lane whose pair starts at the last column loads the pair
     // (w-2, w-1) and keeps the second value as its first (rows are then only
-    // 4-byte aligned: tools/ubench/unaligned_check.hip)
+    // 4-byte aligned: tools/ubench/unaligned_check.hip).  The select is applied
+    // where the prefetched row is consumed - touching the registers right
+    // after the load would make every load wait for its data.
     const bool odd_tail = col == w - 1;
     auto load_row = [&](int yy, float2 (&r)[NG]) {
       const int gy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
@@ -1144,12 +1278,6 @@ namespace sara_hip {
 #pragma unroll
       for (int l = 0; l < NG; ++l)
         r[l] = *reinterpret_cast<const float2*>(rowp + size_t(l) * plane);
-      if (w & 1)  // wave-uniform
-      {
-#pragma unroll
-        for (int l = 0; l < NG; ++l)
-          r[l].x = odd_tail ? r[l].y : r[l].x;
-      }
     };
 
     float2 pg[PF][NG];
@@ -1181,15 +1309,18 @@ namespace sara_hip {
       {
         const int n = n0 + i;
         const int yy = y0 - 1 + n;
+        float2 cur[NG];
+#pragma unroll
+        for (int l = 0; l < NG; ++l)
+          cur[l] = make_float2(odd_tail ? pg[i][l].y : pg[i][l].x, pg[i][l].y);
 #pragma unroll
         for (int l = 0; l < ND; ++l)
-          ring[i][l] = make_float2(pg[i][l + 1].x - pg[i][l].x,
-                                   pg[i][l + 1].y - pg[i][l].y);
+          ring[i][l] = make_float2(cur[l + 1].x - cur[l].x, cur[l + 1].y - cur[l].y);
         if (GRAD)
         {
 #pragma unroll
           for (int t = 0; t < NS; ++t)
-            gring[i][t] = pg[i][t + 1];
+            gring[i][t] = cur[t + 1];
         }
         load_row(yy + PF, pg[i]);
 
@@ -1403,11 +1534,23 @@ namespace sara_hip {
     const bool wide_enough = gauss.w >= 4;
     // the Halide-branch classifier (signed_type) also classifies the border
     // pixels: it runs on the general path
-    if (wide_enough && g_use_march && gauss.scales == 6 && !p.signed_type)
+    // SARA_HIP_EXTREMA_TILE_PIXELS (experiment, default 0): launches below this
+    // many pixels take the pixel-parallel general kernel
+    static const long long tile_pixels = [] {
+      const char* e = getenv("SARA_HIP_EXTREMA_TILE_PIXELS");
+      return e ? atoll(e) : 0ll;
+    }();
+    const bool small_launch = (long long) gauss.w * gauss.h * batch < tile_pixels;
+    if (wide_enough && g_use_march && gauss.scales == 6 && !p.signed_type &&
+        !small_launch)
     {
       const int nstrips = (gauss.w - 2 + 125) / 126;
       int nseg = (g_extrema_waves + nstrips * batch - 1) / (nstrips * batch);
-      nseg = std::max(1, std::min(nseg, (gauss.h + 15) / 16));
+      static const int min_rows = [] {
+        const char* e = getenv("SARA_HIP_EXTREMA_MINROWS");
+        return e ? std::max(1, atoi(e)) : 16;
+      }();
+      nseg = std::max(1, std::min(nseg, (gauss.h + min_rows - 1) / min_rows));
       const int seg_rows = (gauss.h + nseg - 1) / nseg;
       nseg = (gauss.h + seg_rows - 1) / seg_rows;
       const bool fuse = grad != nullptr && cmax != nullptr && g_fuse_gradient &&
@@ -2260,12 +2403,42 @@ namespace sara_hip {
   {
     __shared__ int s_part[1024];
     __shared__ int s_last;
-    const int b = blockIdx.x;
+    __shared__ int s_before;
+    const int b = blockIdx.y;
     const int tid = threadIdx.x;
     const int n = min(cand.count[b], cand.cap);
     const size_t row = size_t(b) * cand.cap;
-    const int per = (n + 1023) / 1024;
-    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    // Small batches (round 3): a frame is cut into gridDim.x consecutive parts,
+    // one workgroup each - one frame's 4 300 extrema took 20 us on a single
+    // workgroup (four dependent rounds of loads and stores per thread).  A
+    // part first sums the counts in front of it (every thread a strided share,
+    // one block reduction).
+    const int parts = gridDim.x, part = blockIdx.x;
+    const int chunk = (n + parts - 1) / parts;
+    const int plo = min(part * chunk, n), phi = min(plo + chunk, n);
+    int before = 0;
+    if (parts > 1)
+    {
+      int acc = 0;
+      for (int i = tid; i < plo; i += 1024)
+        acc += ori.peak_count[row + i];
+      acc = wave_inclusive_scan(acc);
+      if ((tid & 63) == 63)
+        s_part[tid >> 6] = acc;
+      __syncthreads();
+      if (tid == 0)
+      {
+        int t = 0;
+        for (int k = 0; k < 16; ++k)
+          t += s_part[k];
+        s_before = t;
+      }
+      __syncthreads();
+      before = s_before;
+      __syncthreads();
+    }
+    const int per = (phi - plo + 1023) / 1024;
+    const int lo = min(plo + tid * per, phi), hi = min(lo + per, phi);
     int sum = 0;
     for (int i = lo; i < hi; ++i)
       sum += ori.peak_count[row + i];
@@ -2287,7 +2460,7 @@ namespace sara_hip {
     __syncthreads();
     if (tid == 1023)
       s_part[1023] = total;  // read below as the frame's keypoint count
-    int at = wave_base + incl_w - sum;
+    int at = before + wave_base + incl_w - sum;
     auto expand = [&](int i, const KeypointRecord& rec) {
       const int v = rec.npeaks;
       ori.offset[row + i] = at;
@@ -2306,9 +2479,13 @@ namespace sara_hip {
       expand(i, ori.record[row + i]);
     if (tid == 1023)
     {
-      ori.kp_count[b] = s_part[1023];
-      __threadfence();  // the count is visible before the arrival is
-      s_last = atomicAdd(done, 1) == batch - 1;
+      s_last = 0;
+      if (part == parts - 1)  // the frame's last part knows the frame's total
+      {
+        ori.kp_count[b] = before + s_part[1023];
+        __threadfence();  // the count is visible before the arrival is
+        s_last = atomicAdd(done, 1) == batch - 1;
+      }
     }
     __syncthreads();
     if (s_last && tid == 0)
@@ -2344,8 +2521,15 @@ namespace sara_hip {
   void launch_scan_peaks(const CandidateLists& cand, const OrientationLists& ori,
                          int* done_counter, int batch, hipStream_t stream)
   {
-    hipLaunchKernelGGL(scan_peaks_kernel, dim3(batch), dim3(1024), 0, stream, cand,
-                       ori, done_counter, batch);
+    // parts per frame: ~1 extremum per thread at the list sizes of a video
+    // frame when the batch alone cannot fill the chip
+    static const int parts_env = [] {
+      const char* e = getenv("SARA_HIP_SCAN_PARTS");
+      return e ? std::max(1, atoi(e)) : 0;
+    }();
+    const int parts = parts_env ? parts_env : (batch <= 2 ? 4 : (batch <= 8 ? 2 : 1));
+    hipLaunchKernelGGL(scan_peaks_kernel, dim3(parts, batch), dim3(1024), 0, stream,
+                       cand, ori, done_counter, batch);
   }
 
   void launch_extrema_offsets(const CandidateLists& cand, int* ex_offset,

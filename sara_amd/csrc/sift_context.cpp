@@ -398,6 +398,14 @@ struct sara_hip_sift
   int graph_w_s[2] = {0, 0}, graph_h_s[2] = {0, 0}, graph_batch_s[2] = {0, 0},
       graph_stage_s[2] = {-1, -1};
   bool graph_broken = false;  // a capture failed once: stay on plain launches
+  // Round 3: the replay is a sequence of LINEAR graphs (detect() says why)
+  struct GraphSegment
+  {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+  };
+  GraphSegment seg_s[2][4];
+  bool graph_segments = false;  // SARA_HIP_GRAPH_SEGMENTS=1 (experiment, see detect())
   hipEvent_t ev[SARA_HIP_TIME_COUNT + 1] = {};
   bool ev_recorded[SARA_HIP_TIME_COUNT + 1] = {};
   // SARA_HIP_OPT_LAUNCH_TIMERS: one event pair around every launch of the
@@ -545,6 +553,8 @@ namespace {
       c->use_graph = std::string(e) != "0";
     if (const char* e = getenv("SARA_HIP_GRAPH_MAX_BATCH"))
       c->graph_max_batch = atoi(e);
+    if (const char* e = getenv("SARA_HIP_GRAPH_SEGMENTS"))
+      c->graph_segments = std::string(e) != "0";
 
     // ---- taps and tables (host arithmetic as in GaussianPyramid.hpp:106-121)
     const float k = pyr.scale_geometric_factor;
@@ -878,6 +888,13 @@ sara_hip_status sara_hip_sift_destroy(sara_hip_sift* c)
       (void) hipGraphExecDestroy(c->graph_exec_s[k]);
     if (c->graph_s[k])
       (void) hipGraphDestroy(c->graph_s[k]);
+    for (auto& g : c->seg_s[k])
+    {
+      if (g.exec)
+        (void) hipGraphExecDestroy(g.exec);
+      if (g.graph)
+        (void) hipGraphDestroy(g.graph);
+    }
     sara_hip_sift::RingSlot& r = c->ring[k];
     if (r.done)
       (void) hipEventDestroy(r.done);
@@ -1139,23 +1156,34 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       (void) hipEventRecord(c->launch_rec[size_t(rec)].end, st);
   };
 
-  auto enqueue = [&]() -> sara_hip_status {
-
   static const bool fuse_gradient_env = [] {
     const char* e = getenv("SARA_HIP_FUSE_GRADIENT");
     return e && std::string(e) == "1";
   }();
+  // Segment replay (see the end of this function): enqueue() is then called
+  // once per segment and emits only that segment's launches on seg_stream.
+  //   0: octave 0 up to G(downscale_index, 0) (+ the base of octave 1)
+  //   1: octaves 1.. : blurs, scans, gradients   (second stream)
+  //   2: the rest of octave 0, its scan and gradients
+  //   3: refinement, ordering, orientations, descriptors
+  int seg_phase = -1;
+  hipStream_t seg_stream = nullptr;
+  bool seg_base_ready = false;  // base_ready handed from segment 0 to 1
+
+  auto enqueue = [&]() -> sara_hip_status {
+
   const bool want_gradients = last_stage >= SARA_HIP_STAGE_GRADIENT;
   const bool side = c->side_gradient && want_gradients && !fuse_gradient_env &&
                     !debug_sync;
   // see SiftContext::octave_pipeline
-  const bool pipe = c->multi_stream && sc.num_octaves > 1 &&
-                    last_stage >= SARA_HIP_STAGE_EXTREMA && !fuse_gradient_env &&
-                    !debug_sync && (!want_gradients || side) &&
-                    (c->octave_pipeline < 0 ? graph_mode : c->octave_pipeline != 0);
+  const bool pipe = seg_phase >= 0 ||
+                    (c->multi_stream && sc.num_octaves > 1 &&
+                     last_stage >= SARA_HIP_STAGE_EXTREMA && !fuse_gradient_env &&
+                     !debug_sync && (!want_gradients || side) &&
+                     (c->octave_pipeline < 0 ? graph_mode : c->octave_pipeline != 0));
   bool grad_fused[16] = {};
   // the stream the extrema .. descriptor stages are enqueued on
-  hipStream_t tail = stream;
+  hipStream_t tail = seg_phase >= 0 ? seg_stream : stream;
 
   // polar gradients of one octave (the planes the later stages read)
   auto enqueue_gradient = [&](int o, hipStream_t gs) -> sara_hip_status {
@@ -1206,13 +1234,14 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
           want_grad ? c->CM[o] : nullptr, cpl * S);
     return SARA_HIP_OK;
   };
-  if (pipe)  // the scans start before the pyramid is complete
+  if (pipe && seg_phase <= 0)  // the scans start before the pyramid is complete
     HIP_TRY(hipMemsetAsync(c->d_counters, 0,
-                           sizeof(int) * counters_padded(c->max_batch), stream));
+                           sizeof(int) * counters_padded(c->max_batch), tail));
 
   // ---- Gaussian pyramid + fused DoG ---------------------------------------
-  if (sc.num_octaves > 0)
+  if (sc.num_octaves > 0 && seg_phase != 3)
   {
+    hipStream_t stream = tail;  // segment replay: this segment's stream
     const size_t pl0 = size_t(sc.oct[0].w) * sc.oct[0].h;
     float* G00 = c->G[0];
     const size_t g_stride0 = pl0 * S;
@@ -1222,10 +1251,15 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     // starts from the source frame: initial blur, s = 1, s = 2.
     const Taps* chain0_taps[3] = {&c->init_taps, &c->taps[1], &c->taps[2]};
     const bool chain0 =
-        pipe && c->pyr.first_octave_index == 0 && sc.init_blur && !gray8_fused &&
+        pipe && seg_phase < 0 && c->pyr.first_octave_index == 0 && sc.init_blur &&
+        !gray8_fused &&
         !c->fma_blur && sc.downscale_index == 2 && S > 3 && !time_launches &&
         gaussian_blur_chain_available(chain0_taps, 3, sc.oct[0].w, sc.oct[0].h, batch);
-    if (c->pyr.first_octave_index < 0)
+    if (seg_phase > 0)
+    {
+      // G(0, 0) belongs to segment 0
+    }
+    else if (c->pyr.first_octave_index < 0)
     {
       launch_enlarge(src, src_stride, width, height, G00, g_stride0, sc.oct[0].w,
                      sc.oct[0].h, batch, stream);
@@ -1324,7 +1358,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       {
         bool fused = false;
         for (int n = std::min(3, s_hi - s + 1); n >= 2 && !fused && !c->fma_blur &&
-                                                !time_launches;
+                                                !time_launches && seg_phase < 0;
              --n)
         {
           const Taps* tp[3] = {&c->taps[s], &c->taps[s + 1],
@@ -1359,7 +1393,57 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
         }
       }
     };
-    if (pipe)
+    if (seg_phase >= 0)
+    {
+      const bool scans = last_stage >= SARA_HIP_STAGE_EXTREMA;
+      if (seg_phase == 0)
+      {
+        enqueue_base(0, stream);
+        for (int s = 1; s <= dsi && s < S; ++s)
+          enqueue_blur(0, s, stream);
+        seg_base_ready = base_ready;
+      }
+      else if (seg_phase == 1)
+      {
+        base_ready = seg_base_ready;
+        for (int o = 1; o <= last; ++o)
+        {
+          enqueue_base(o, stream);
+          for (int s = 1; s < S; ++s)
+            enqueue_blur(o, s, stream);
+          if (scans)
+          {
+            const sara_hip_status sst = enqueue_scan(o, stream);
+            if (sst != SARA_HIP_OK)
+              return sst;
+          }
+        }
+        for (int o = 1; o <= last && want_gradients; ++o)
+        {
+          const sara_hip_status gst = enqueue_gradient(o, stream);
+          if (gst != SARA_HIP_OK)
+            return gst;
+        }
+      }
+      else
+      {
+        for (int s = dsi + 1; s < S; ++s)
+          enqueue_blur(0, s, stream);
+        if (scans)
+        {
+          const sara_hip_status sst = enqueue_scan(0, stream);
+          if (sst != SARA_HIP_OK)
+            return sst;
+        }
+        if (want_gradients)
+        {
+          const sara_hip_status gst = enqueue_gradient(0, stream);
+          if (gst != SARA_HIP_OK)
+            return gst;
+        }
+      }
+    }
+    else if (pipe)
     {
       // Small batches are bound by the chain of dependent launches, and a
       // dependency that crosses hardware queues costs ~12 us against ~0 on
@@ -1498,6 +1582,11 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     }
   }
   HIP_TRY(mark(2));
+  if (seg_phase >= 0 && seg_phase != 3)
+  {
+    HIP_TRY(hipGetLastError());
+    return SARA_HIP_OK;
+  }
 
   // ---- polar gradients on the side stream, next to the extrema stage --------
   auto enqueue_gradients = [&](hipStream_t gs) -> sara_hip_status {
@@ -1557,7 +1646,11 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   HIP_TRY(mark(3));
 
   // ---- polar gradients ----------------------------------------------------
-  if (pipe)
+  if (pipe && seg_phase >= 0)
+  {
+    // the segments are ordered by events between their launches
+  }
+  else if (pipe)
   {
     // join the side chains (their gradients follow their scans)
     for (int o = 0; o + 1 < sc.num_octaves; ++o)
@@ -1588,7 +1681,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     launch_descriptors(*c->h_grad, c->cand, c->ori, batch, c->d_feat, c->d_so,
                        c->d_desc, last_stage >= SARA_HIP_STAGE_DESCRIPTOR ? 1 : 0,
                        c->root_sift ? 1 : 0, tail);
-  if (tail != stream)
+  if (tail != stream && seg_phase < 0)
   {
     // back to the caller's stream
     HIP_TRY(hipEventRecord(c->aux_join, tail));
@@ -1609,6 +1702,130 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   }
   std::lock_guard<std::recursive_mutex> graph_lock(runtime_mutex());
   const int gs = c->write_slot;
+  static const bool trace_graph = getenv("SARA_HIP_TRACE_GRAPH") != nullptr;
+
+  // ---- Round 3 experiment (SARA_HIP_GRAPH_SEGMENTS=1, off by default): replay
+  // as a sequence of LINEAR graphs.
+  // hipGraphLaunch of a graph with forks hands its nodes to the queues one by
+  // one, 3.3 us each on the host (the ~42 nodes of a 4-octave call: 75-130 us
+  // inside the launch call, and a branch that comes late in the runtime's order
+  // starts that late), while a graph captured from ONE stream is submitted in
+  // 7-9 us whatever its length (tools/ubench/graph_launch_cost.hip: 32 kernels
+  // 8.6 us linear, 107 us forked, 106 us as plain launches).  Here the call is
+  // cut into four linear graphs on two streams, launched in the order of the
+  // critical path, with two event hand-offs between them:
+  //   stream:     [0: octave 0 up to G(downscale_index)]  [2: rest of octave 0,
+  //               its scan and gradients]   (wait)  [3: refinement .. descriptors]
+  //   aux_stream: (wait 0)  [1: octaves 1.., their scans and gradients]
+  // Measured on one 1080p frame: the host leaves detect() after 20-45 us instead
+  // of 75-90, but the call takes 0.29 / 0.46 ms (extrema only / full) against
+  // 0.20 / 0.32 ms for the forked graph in the same run - two-way concurrency
+  // and 13-19 us per hand-off between graphs (tools/ubench/graph_sched.hip)
+  // lose more than the host gains; the forked graph keeps four queues busy.
+  // Kept for the next look at this regime, not selected.
+  const bool seg_ok = c->graph_segments && !fuse_gradient_env &&
+                      (last_stage < SARA_HIP_STAGE_GRADIENT || c->side_gradient) &&
+                      sc.num_octaves > 0;
+  if (seg_ok)
+  {
+    sara_hip_sift::GraphSegment* seg = c->seg_s[gs];
+    const int last = sc.num_octaves - 1;
+    const bool have[4] = {true, last >= 1, true,
+                          last_stage >= SARA_HIP_STAGE_EXTREMA};
+    hipStream_t seg_streams[4] = {stream, c->aux_stream, stream, stream};
+    bool cached = c->graph_w_s[gs] == width && c->graph_h_s[gs] == height &&
+                  c->graph_batch_s[gs] == batch &&
+                  c->graph_stage_s[gs] == int(last_stage);
+    for (int k = 0; k < 4 && cached; ++k)
+      cached = !have[k] || seg[k].exec != nullptr;
+    bool ok = true;
+    if (!cached)
+    {
+      for (int k = 0; k < 4; ++k)
+      {
+        if (seg[k].exec)
+          (void) hipGraphExecDestroy(seg[k].exec);
+        if (seg[k].graph)
+          (void) hipGraphDestroy(seg[k].graph);
+        seg[k].exec = nullptr;
+        seg[k].graph = nullptr;
+      }
+      // the forked graph of this slot (if any) is stale as well
+      if (c->graph_exec_s[gs])
+        (void) hipGraphExecDestroy(c->graph_exec_s[gs]);
+      if (c->graph_s[gs])
+        (void) hipGraphDestroy(c->graph_s[gs]);
+      c->graph_exec_s[gs] = nullptr;
+      c->graph_s[gs] = nullptr;
+      c->graph_stage_s[gs] = -1;
+      for (int k = 0; k < 4 && ok; ++k)
+      {
+        if (!have[k])
+          continue;
+        seg_phase = k;
+        seg_stream = seg_streams[k];
+        ok = hipStreamBeginCapture(seg_stream, hipStreamCaptureModeRelaxed) ==
+             hipSuccess;
+        if (!ok)
+          break;
+        const sara_hip_status est = enqueue();
+        const hipError_t ee = hipStreamEndCapture(seg_stream, &seg[k].graph);
+        ok = est == SARA_HIP_OK && ee == hipSuccess && seg[k].graph != nullptr;
+        if (ok)
+          ok = hipGraphInstantiate(&seg[k].exec, seg[k].graph, nullptr, nullptr, 0) ==
+               hipSuccess;
+        if (trace_graph)
+          std::fprintf(stderr, "[sara_hip] segment %d captured: %d\n", k, int(ok));
+      }
+      seg_phase = -1;
+      if (!ok)
+      {
+        // fall back to the forked graph for good; clear the sticky error
+        (void) hipGetLastError();
+        for (int k = 0; k < 4; ++k)
+        {
+          if (seg[k].exec)
+            (void) hipGraphExecDestroy(seg[k].exec);
+          if (seg[k].graph)
+            (void) hipGraphDestroy(seg[k].graph);
+          seg[k].exec = nullptr;
+          seg[k].graph = nullptr;
+        }
+        c->graph_segments = false;
+      }
+      else
+      {
+        c->graph_w_s[gs] = width;
+        c->graph_h_s[gs] = height;
+        c->graph_batch_s[gs] = batch;
+        c->graph_stage_s[gs] = int(last_stage);
+      }
+    }
+    if (ok)
+    {
+      HIP_TRY(hipGraphLaunch(seg[0].exec, stream));
+      if (have[1])
+      {
+        HIP_TRY(hipEventRecord(c->oct_ready[0], stream));
+        HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->oct_ready[0], 0));
+        HIP_TRY(hipGraphLaunch(seg[1].exec, c->aux_stream));
+        HIP_TRY(hipEventRecord(c->aux_join, c->aux_stream));
+      }
+      HIP_TRY(hipGraphLaunch(seg[2].exec, stream));
+      if (have[1])
+        HIP_TRY(hipStreamWaitEvent(stream, c->aux_join, 0));
+      if (have[3])
+        HIP_TRY(hipGraphLaunch(seg[3].exec, stream));
+      if (c->timers)
+      {
+        c->ev_recorded[SARA_HIP_TIME_TOTAL] = true;
+        HIP_TRY(hipEventRecord(c->ev[SARA_HIP_TIME_TOTAL], stream));
+      }
+      c->has_result = true;
+      return SARA_HIP_OK;
+    }
+  }
+
   hipGraph_t& graph = c->graph_s[gs];
   hipGraphExec_t& graph_exec = c->graph_exec_s[gs];
   const bool cached = graph_exec && c->graph_w_s[gs] == width &&
@@ -1623,7 +1840,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       (void) hipGraphDestroy(graph);
     graph_exec = nullptr;
     graph = nullptr;
-    static const bool trace = getenv("SARA_HIP_TRACE_GRAPH") != nullptr;
+    const bool trace = trace_graph;
     bool ok = hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed) ==
               hipSuccess;
     if (trace) std::fprintf(stderr, "[sara_hip] capture begun: %d\n", int(ok));

@@ -32,7 +32,19 @@ with sara_amd.SiftContext(W, H, 1, p4, device=0) as c1:
     def run(stage):
         c1.detect_device(d_one.data_ptr(), 1, W, H, last_stage=stage)
         c1.synchronize()
+    def enq(stage):
+        t = time.perf_counter()
+        c1.detect_device(d_one.data_ptr(), 1, W, H, last_stage=stage)
+        dt = time.perf_counter() - t
+        c1.synchronize()
+        return dt
     for _ in range(reps):
+        for st in (2, 5):
+            for _ in range(20):
+                enq(st)
+            e = [enq(st) for _ in range(200)]
+            print("stage %d: host time inside detect() %.4f ms (median %.4f)"
+                  % (st, 1e3 * np.mean(e), 1e3 * np.median(e)))
         t2 = timed(lambda: run(2), 200, 20)
         t5 = timed(lambda: run(5), 200, 20)
         h2h = timed(lambda: c1.collect(c1.submit(one)), 100, 10)
