@@ -503,6 +503,13 @@ SARA_HIP_API sara_hip_status sara_hip_match_release_workspace(int device);
 /* gather of that ticket has returned (decode the next frames into another      */
 /* buffer; two alternating buffers suffice).  Device frames (images_on_device)  */
 /* are read by the kernels of the batch: same rule.                             */
+/* submit_staged() is submit() for the batch that sara_hip_sift_stage() put on   */
+/* its way: stage(i + 1); collect(i - 1); submit_staged(i + 1) starts upload     */
+/* i + 1 BEFORE the host waits for the read-back of batch i - 1, so that the     */
+/* copy engine goes from one upload straight into the next (stage() only waits  */
+/* - on the device - until the first blur of the batch that used its buffer has */
+/* read the frames).  With float32 frames, whose upload is longer than the       */
+/* kernels, the step is then the upload alone instead of kernels + read-back.    */
 /* collect() blocks until the batch of `ticket` is in pinned host memory owned  */
 /* by the context and returns pointers into it.  features / descriptors /       */
 /* scale_octave AND frame_offsets all live in the ticket's ring slot: they stay */
@@ -515,6 +522,8 @@ SARA_HIP_API sara_hip_status sara_hip_match_release_workspace(int device);
 /* SARA_HIP_CAPACITY_EXCEEDED is reported by collect() (the truncated lists are */
 /* still delivered).                                                            */
 /* -------------------------------------------------------------------------- */
+SARA_HIP_API sara_hip_status sara_hip_sift_submit_staged(
+    sara_hip_sift* ctx, sara_hip_stage last_stage, int* ticket);
 SARA_HIP_API sara_hip_status sara_hip_sift_submit(
     sara_hip_sift* ctx, const void* images, size_t frame_stride, int channels,
     int batch, int width, int height, int images_on_device,

@@ -289,6 +289,26 @@ class SiftContext:
         self._inflight[ticket.value] = (a, b)
         return ticket.value
 
+    def stage_raw(self, ptr, channels, batch, width, height, frame_stride=0):
+        """stage() from a raw host pointer (the caller keeps the memory alive
+        and unmodified until the batch has been collected)."""
+        self._staged_keepalive = None
+        self._staged_batch = batch
+        capi.check(capi.load().sara_hip_sift_stage(
+            self._h, ptr, frame_stride, channels, batch, width, height))
+        return self
+
+    def submit_staged(self, last_stage=STAGE_DESCRIPTOR):
+        """submit() for the batch stage() put on its way: ``stage(i + 1);
+        collect(i - 1); submit_staged(i + 1)`` starts the next upload before
+        the host waits for a read-back (sara_hip_sift_submit_staged)."""
+        ticket = C.c_int(-1)
+        capi.check(capi.load().sara_hip_sift_submit_staged(
+            self._h, int(last_stage), C.byref(ticket)))
+        self._inflight = getattr(self, "_inflight", {})
+        self._inflight[ticket.value] = (self._staged_keepalive, self._staged_batch)
+        return ticket.value
+
     def submit_raw(self, ptr, channels, batch, width, height, on_device=False,
                    frame_stride=0, last_stage=STAGE_DESCRIPTOR):
         """submit() from a raw pointer: pinned / pageable host memory, or HBM

@@ -95,7 +95,7 @@ EXPORTS = [
     "sara_hip_sift_stage", "sara_hip_sift_detect_staged", "sara_hip_root_sift",
     "sara_hip_selfcheck_device_math", "sara_hip_selfcheck_sincos",
     "sara_hip_selfcheck_definiteness", "sara_hip_selfcheck_orientation_bins",
-    "sara_hip_sift_submit", "sara_hip_sift_collect",
+    "sara_hip_sift_submit", "sara_hip_sift_submit_staged", "sara_hip_sift_collect",
     "sara_hip_shard_range", "sara_hip_copy_to_host", "sara_hip_comm_unique_id", "sara_hip_comm_create",
     "sara_hip_comm_gather", "sara_hip_comm_destroy",
     "sara_hip_sift_group_create", "sara_hip_sift_group_size",
@@ -201,6 +201,7 @@ def _declare(lib):
     lib.sara_hip_sift_submit.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(C.c_int)]
+    lib.sara_hip_sift_submit_staged.argtypes = [_vp, C.c_int, C.POINTER(C.c_int)]
     lib.sara_hip_sift_collect.argtypes = [_vp, C.c_int, C.POINTER(_vp),
                                           C.POINTER(_vp), C.POINTER(_vp),
                                           C.POINTER(_vp), C.POINTER(C.c_int)]

@@ -371,7 +371,19 @@ struct sara_hip_sift
     float* h_desc = nullptr;
     int32_t* h_so = nullptr;
     size_t h_cap = 0;            // keypoints the pinned arrays hold
+    // read-back enqueued by submit() itself, sized from the previous batch
+    // (collect() copies what is missing): rows already on their way to the
+    // pinned arrays, 0 = none
+    size_t spec_rows = 0;
+    bool spec_desc = false;
   } ring[2];
+  size_t last_total = 0;        // keypoints of the batch collected last
+  // detect_staged(): recorded by detect() as soon as the last kernel that
+  // reads the input frames has been enqueued (the staging buffer is free for
+  // the next upload long before the batch is complete)
+  hipEvent_t consumed_event = nullptr;
+  bool consumed_recorded = false;
+  bool speculative_d2h = false;  // SARA_HIP_SPEC_D2H=1 (experiment, see submit())
   hipStream_t d2h_stream = nullptr;
   int next_ticket = 0;
   sara_oeregion* d_ex_regions = nullptr;
@@ -555,6 +567,8 @@ namespace {
       c->graph_max_batch = atoi(e);
     if (const char* e = getenv("SARA_HIP_GRAPH_SEGMENTS"))
       c->graph_segments = std::string(e) != "0";
+    if (const char* e = getenv("SARA_HIP_SPEC_D2H"))
+      c->speculative_d2h = std::string(e) != "0";
 
     // ---- taps and tables (host arithmetic as in GaussianPyramid.hpp:106-121)
     const float k = pyr.scale_geometric_factor;
@@ -1110,20 +1124,28 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   size_t src_stride = frame_stride;
   if (!images_on_device)
   {
-    HIP_TRY(hipMemcpy2DAsync(c->d_input, in_plane * sizeof(float), images,
-                             frame_stride * sizeof(float),
-                             in_plane * sizeof(float), batch,
+    if (frame_stride == in_plane)  // contiguous frames: one linear copy
+      HIP_TRY(hipMemcpyAsync(c->d_input, images, in_plane * sizeof(float) * batch,
                              hipMemcpyHostToDevice, stream));
+    else
+      HIP_TRY(hipMemcpy2DAsync(c->d_input, in_plane * sizeof(float), images,
+                               frame_stride * sizeof(float),
+                               in_plane * sizeof(float), batch,
+                               hipMemcpyHostToDevice, stream));
     src = c->d_input;
     src_stride = in_plane;
   }
   else if (graph_mode && images != c->d_input)
   {
     // the graph's first kernel reads a fixed address
-    HIP_TRY(hipMemcpy2DAsync(c->d_input, in_plane * sizeof(float), images,
-                             frame_stride * sizeof(float),
-                             in_plane * sizeof(float), batch,
+    if (frame_stride == in_plane)
+      HIP_TRY(hipMemcpyAsync(c->d_input, images, in_plane * sizeof(float) * batch,
                              hipMemcpyDeviceToDevice, stream));
+    else
+      HIP_TRY(hipMemcpy2DAsync(c->d_input, in_plane * sizeof(float), images,
+                               frame_stride * sizeof(float),
+                               in_plane * sizeof(float), batch,
+                               hipMemcpyDeviceToDevice, stream));
     src = c->d_input;
     src_stride = in_plane;
   }
@@ -1304,6 +1326,13 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     else
     {
       launch_copy_planes(src, src_stride, G00, g_stride0, pl0, batch, stream);
+    }
+
+    // nothing reads the caller's / staged frames beyond this point
+    if (c->consumed_event && !graph_mode && !chain0 && seg_phase < 0)
+    {
+      HIP_TRY(hipEventRecord(c->consumed_event, stream));
+      c->consumed_recorded = true;
     }
 
     // Octave o+1 starts from G(downscale_index, o): its chain runs on its
@@ -1502,6 +1531,23 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
         if (st0 != SARA_HIP_OK)
           return st0;
       }
+      // Octaves whose side chain is captured BEFORE the spine goes on (bit o):
+      // under graph replay the runtime hands the nodes to the queues depth
+      // first, so a side chain captured after the whole spine reaches its
+      // queue last - octave 1's, the heaviest of them, started 80 us after
+      // its input was ready.  Captured first it keeps the spine's queue and
+      // the spine hops to the next one (one more cross-queue dependency,
+      // ~12 us, on a path that has the slack).
+      static const int side_first_env = [] {
+        const char* e = getenv("SARA_HIP_SIDE_FIRST");
+        return e ? atoi(e) : 0;
+      }();
+      // Measured on one 1080p frame (tools/b1_bench.py, no profiler): mask 0
+      // 0.204 / 0.292 ms (extrema only / full), mask 2 (octave 1) 0.204 / 0.312,
+      // mask 6 0.207 / 0.315 - although the profiler's timeline, whose dispatch
+      // interception slows the host side down, shows the opposite (span 320 ->
+      // 293 us).  Off.
+      const int side_first = graph_mode ? side_first_env : 0;
       // the spine
       for (int o = 1; o <= last; ++o)
       {
@@ -1510,6 +1556,14 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
         enqueue_blurs(o, 1, s_hi, tail);
         if (o < last)
           HIP_TRY(hipEventRecord(c->oct_ready[o], tail));
+        if (o < last && ((side_first >> o) & 1))
+        {
+          hipStream_t so = c->oct_stream[o + 1];
+          HIP_TRY(hipStreamWaitEvent(so, c->oct_ready[o], 0));
+          const sara_hip_status sto = enqueue_side(o, so);
+          if (sto != SARA_HIP_OK)
+            return sto;
+        }
       }
       HIP_TRY(hipEventRecord(c->aux_fork, tail));  // the last octave's planes
       {
@@ -1529,7 +1583,8 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       {
         hipStream_t so = c->oct_stream[o + 1];
         int fillers = 0;
-        if (graph_mode)
+        const bool captured = ((side_first >> o) & 1) != 0;
+        if (graph_mode && !captured)
           for (; fillers < last - 1 - o && fillers < 3; ++fillers)
           {
             hipStream_t fs = c->filler_stream[fillers];
@@ -1539,10 +1594,13 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
                 sizeof(int), fs));
             HIP_TRY(hipEventRecord(c->filler_done[fillers], fs));
           }
-        HIP_TRY(hipStreamWaitEvent(so, c->oct_ready[o], 0));
-        const sara_hip_status sto = enqueue_side(o, so);
-        if (sto != SARA_HIP_OK)
-          return sto;
+        if (!captured)
+        {
+          HIP_TRY(hipStreamWaitEvent(so, c->oct_ready[o], 0));
+          const sara_hip_status sto = enqueue_side(o, so);
+          if (sto != SARA_HIP_OK)
+            return sto;
+        }
         if (want_gradients && o == grad_last_side)
         {
           HIP_TRY(hipStreamWaitEvent(so, c->aux_fork, 0));
@@ -2001,9 +2059,13 @@ sara_hip_status sara_hip_sift_stage(sara_hip_sift* c, const void* images,
   // the pipeline that last read this buffer must be done with it
   if (c->stage_used[k])
     HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->stage_free[k], 0));
-  HIP_TRY(hipMemcpy2DAsync(c->d_stage[k], px * elem, images, stride_bytes,
-                           px * elem, batch, hipMemcpyHostToDevice,
-                           c->copy_stream));
+  if (stride_bytes == px * elem)  // contiguous frames: one linear copy
+    HIP_TRY(hipMemcpyAsync(c->d_stage[k], images, px * elem * batch,
+                           hipMemcpyHostToDevice, c->copy_stream));
+  else
+    HIP_TRY(hipMemcpy2DAsync(c->d_stage[k], px * elem, images, stride_bytes,
+                             px * elem, batch, hipMemcpyHostToDevice,
+                             c->copy_stream));
   HIP_TRY(hipEventRecord(c->stage_ready[k], c->copy_stream));
   c->staged = k;
   c->stage_next = 1 - k;
@@ -2030,6 +2092,12 @@ sara_hip_status sara_hip_sift_detect_staged(sara_hip_sift* c,
   HIP_TRY(hipStreamWaitEvent(stream, c->stage_ready[k], 0));
   const size_t px = size_t(c->staged_w) * c->staged_h;
   sara_hip_status st;
+  // the staging buffer is handed back when its frames have been consumed
+  // (detect() records the event behind the first blur), not when the batch is
+  // complete: stage(i + 2) can then follow upload(i + 1) on the copy engine
+  // without waiting for the kernels of batch i
+  c->consumed_event = c->stage_free[k];
+  c->consumed_recorded = false;
   if (c->staged_channels == 0)
     st = sara_hip_sift_detect(c, static_cast<const float*>(c->d_stage[k]), px,
                               c->staged_batch, c->staged_w, c->staged_h, 1,
@@ -2039,9 +2107,11 @@ sara_hip_status sara_hip_sift_detect_staged(sara_hip_sift* c,
                                  px * c->staged_channels, c->staged_channels,
                                  c->staged_batch, c->staged_w, c->staged_h, 1,
                                  last_stage, hip_stream);
+  c->consumed_event = nullptr;
   if (st != SARA_HIP_OK)
     return st;
-  HIP_TRY(hipEventRecord(c->stage_free[k], stream));
+  if (!c->consumed_recorded)  // graph replay, fused chains: at the end of the batch
+    HIP_TRY(hipEventRecord(c->stage_free[k], stream));
   c->stage_used[k] = true;
   return SARA_HIP_OK;
 }
@@ -2070,6 +2140,13 @@ namespace {
   }
 }  // namespace
 
+namespace {
+  sara_hip_status submit_impl(sara_hip_sift* c, const void* images,
+                              size_t frame_stride, int channels, int batch,
+                              int width, int height, int images_on_device,
+                              sara_hip_stage last_stage, int* ticket);
+}
+
 sara_hip_status sara_hip_sift_submit(sara_hip_sift* c, const void* images,
                                      size_t frame_stride, int channels,
                                      int batch, int width, int height,
@@ -2078,6 +2155,27 @@ sara_hip_status sara_hip_sift_submit(sara_hip_sift* c, const void* images,
 {
   if (!c || !images || !ticket)
     return fail(SARA_HIP_INVALID_PARAMS, "null context, images or ticket");
+  return submit_impl(c, images, frame_stride, channels, batch, width, height,
+                     images_on_device, last_stage, ticket);
+}
+
+sara_hip_status sara_hip_sift_submit_staged(sara_hip_sift* c,
+                                            sara_hip_stage last_stage, int* ticket)
+{
+  if (!c || !ticket)
+    return fail(SARA_HIP_INVALID_PARAMS, "null context or ticket");
+  if (c->staged < 0)
+    return fail(SARA_HIP_NOT_READY, "no batch has been staged");
+  return submit_impl(c, nullptr, 0, 0, c->staged_batch, c->staged_w, c->staged_h, 0,
+                     last_stage, ticket);
+}
+
+namespace {
+sara_hip_status submit_impl(sara_hip_sift* c, const void* images,
+                            size_t frame_stride, int channels, int batch,
+                            int width, int height, int images_on_device,
+                            sara_hip_stage last_stage, int* ticket)
+{
   if (last_stage < SARA_HIP_STAGE_ORIENTATION)
     return fail(SARA_HIP_INVALID_PARAMS,
                 "submit() delivers keypoints: last_stage must be >= ORIENTATION");
@@ -2108,7 +2206,9 @@ sara_hip_status sara_hip_sift_submit(sara_hip_sift* c, const void* images,
   sara_hip_status st = select_result_slot(c, slot);
   if (st != SARA_HIP_OK)
     return st;
-  if (!images_on_device)
+  if (!images)  // submit_staged(): the batch is on its way already
+    st = sara_hip_sift_detect_staged(c, last_stage, nullptr);
+  else if (!images_on_device)
   {
     // upload on the copy stream (double-buffered staging), then the pipeline
     st = sara_hip_sift_stage(c, images, frame_stride, channels, batch, width,
@@ -2131,6 +2231,32 @@ sara_hip_status sara_hip_sift_submit(sara_hip_sift* c, const void* images,
                          sizeof(int) * (4 * size_t(c->max_batch) + 1),
                          hipMemcpyDeviceToHost, c->last_stream));
   HIP_TRY(hipEventRecord(r.done, c->last_stream));
+  // Speculative read-back (round 3 experiment, SARA_HIP_SPEC_D2H=1, off).
+  // collect() waits for the batch, reads its size and only then starts the
+  // copies; here they are enqueued at once, behind the batch on the read-back
+  // stream, for 1.15 x the keypoints of the batch collected last, and collect()
+  // adds the rows that are missing.  Measured: 64 x 1080p float32 host -> host
+  // 10.9 -> 21.7 ms per step - hipMemcpyAsync of a device-to-host copy behind
+  // an event that has not fired yet keeps the HOST inside the call until the
+  // batch is done (ROCm 7.0 and 7.2 alike), so submit() no longer returns
+  // early and upload, kernels and read-back run one after the other.
+  r.spec_rows = 0;
+  if (c->speculative_d2h && c->last_total > 0 && r.h_cap > 0)
+  {
+    const size_t rows = std::min(
+        r.h_cap, std::min(size_t(c->max_batch) * c->cap,
+                          c->last_total + c->last_total / 7 + 256));
+    HIP_TRY(hipStreamWaitEvent(c->d2h_stream, r.done, 0));
+    HIP_TRY(hipMemcpyAsync(r.h_feat, c->d_feat_s[slot], sizeof(sara_oeregion) * rows,
+                           hipMemcpyDeviceToHost, c->d2h_stream));
+    HIP_TRY(hipMemcpyAsync(r.h_so, c->d_so_s[slot], sizeof(int32_t) * 2 * rows,
+                           hipMemcpyDeviceToHost, c->d2h_stream));
+    r.spec_desc = last_stage >= SARA_HIP_STAGE_DESCRIPTOR;
+    if (r.spec_desc)
+      HIP_TRY(hipMemcpyAsync(r.h_desc, c->d_desc_s[slot], sizeof(float) * 128 * rows,
+                             hipMemcpyDeviceToHost, c->d2h_stream));
+    r.spec_rows = rows;
+  }
   r.ticket = c->next_ticket;
   r.pending = true;
   r.batch = batch;
@@ -2138,6 +2264,7 @@ sara_hip_status sara_hip_sift_submit(sara_hip_sift* c, const void* images,
   *ticket = c->next_ticket++;
   return SARA_HIP_OK;
 }
+}  // namespace
 
 sara_hip_status sara_hip_sift_collect(sara_hip_sift* c, int ticket,
                                       const sara_oeregion** features,
@@ -2170,6 +2297,9 @@ sara_hip_status sara_hip_sift_collect(sara_hip_sift* c, int ticket,
                     "max_keypoints: the lists are truncated");
   if (size_t(n) > r.h_cap)
   {
+    if (r.spec_rows)  // a speculative read-back is writing the arrays
+      HIP_TRY(hipStreamSynchronize(c->d2h_stream));
+    r.spec_rows = 0;
     if (r.h_feat)
       (void) hipHostFree(r.h_feat);
     if (r.h_desc)
@@ -2200,7 +2330,31 @@ sara_hip_status sara_hip_sift_collect(sara_hip_sift* c, int ticket,
       const char* e = getenv("SARA_HIP_D2H");
       return e && std::string(e) == "kernel";
     }();
-    if (by_kernel)
+    // rows [0, have) were copied by submit()'s speculative read-back
+    const size_t have = std::min(r.spec_rows, size_t(n));
+    const bool desc_have = have > 0 && r.spec_desc;
+    if (have > 0)
+    {
+      const size_t m = size_t(n) - have;
+      if (m > 0)
+      {
+        HIP_TRY(hipMemcpyAsync(r.h_feat + have, c->d_feat_s[slot] + have,
+                               sizeof(sara_oeregion) * m, hipMemcpyDeviceToHost,
+                               c->d2h_stream));
+        HIP_TRY(hipMemcpyAsync(r.h_so + 2 * have, c->d_so_s[slot] + 2 * have,
+                               sizeof(int32_t) * 2 * m, hipMemcpyDeviceToHost,
+                               c->d2h_stream));
+      }
+      if (descriptors)
+      {
+        const size_t from = desc_have ? have : 0;
+        if (size_t(n) > from)
+          HIP_TRY(hipMemcpyAsync(r.h_desc + 128 * from, c->d_desc_s[slot] + 128 * from,
+                                 sizeof(float) * 128 * (size_t(n) - from),
+                                 hipMemcpyDeviceToHost, c->d2h_stream));
+      }
+    }
+    else if (by_kernel)
     {
       launch_blit(c->d_feat_s[slot], r.h_feat, sizeof(sara_oeregion) * size_t(n),
                   c->d2h_stream);
@@ -2224,6 +2378,10 @@ sara_hip_status sara_hip_sift_collect(sara_hip_sift* c, int ticket,
     }
     HIP_TRY(hipStreamSynchronize(c->d2h_stream));
   }
+  else if (r.spec_rows)
+    HIP_TRY(hipStreamSynchronize(c->d2h_stream));
+  r.spec_rows = 0;
+  c->last_total = size_t(n);
   r.pending = false;
   if (features)
     *features = r.h_feat;
@@ -2331,7 +2489,12 @@ namespace sara_hip {
       return;
     sara_hip_sift::RingSlot& r = c->ring[ticket & 1];
     if (r.pending && r.ticket == ticket)
+    {
+      if (r.spec_rows && c->d2h_stream)  // the device arrays are still being read
+        (void) hipStreamSynchronize(c->d2h_stream);
+      r.spec_rows = 0;
       r.pending = false;
+    }
   }
 }  // namespace sara_hip
 

@@ -651,6 +651,44 @@ def test_submit_collect_pipeline(oracle):
             ctx.collect(12345)
 
 
+@pytest.mark.parametrize("batch", [3, 10])
+def test_stage_collect_submit_staged(oracle, batch):
+    """stage(i + 1); collect(i - 1); submit_staged(i + 1): the next upload is on
+    its way before the host waits for a read-back, and the staging buffer is
+    handed back as soon as the first blur of its batch has read it (batch 10:
+    plain launches; batch 3: graph replay, where it is handed back at the end).
+    Byte-identical to detect() + fetch(), float and 8-bit frames alternating."""
+    frames = [synth_batch(160, 120, batch, first_index=7 * i) for i in range(6)]
+    frames = [f if i % 2 == 0 else (f * 255).astype(np.uint8)
+              for i, f in enumerate(frames)]
+    with sara_amd.SiftContext(160, 120, batch, hip_params(0, 3)) as ctx:
+        want = []
+        for f in frames:
+            if f.dtype == np.uint8:
+                ctx.detect_u8(f)
+            else:
+                ctx.detect(f)
+            want.append(ctx.fetch())
+        with pytest.raises(sara_amd.SaraHipError):
+            ctx.submit_staged()  # nothing staged
+        tickets, got = [], []
+        ctx.stage(frames[0])
+        tickets.append(ctx.submit_staged())
+        for i in range(1, len(frames)):
+            ctx.stage(frames[i])
+            if len(tickets) == 2:
+                got.append(ctx.collect(tickets.pop(0), copy=True))
+            tickets.append(ctx.submit_staged())
+        for t in tickets:
+            got.append(ctx.collect(t, copy=True))
+        assert len(got) == len(want)
+        for (counts, regions, desc, so), (offsets, g_regions, g_desc, g_so) in zip(want, got):
+            assert np.array_equal(np.diff(offsets), counts)
+            assert regions.tobytes() == g_regions.tobytes()
+            assert np.array_equal(desc, g_desc) and np.array_equal(so, g_so)
+        assert int(sum(w[0].sum() for w in want)) > 0
+
+
 def test_compute_sift_keypoints_keeps_its_context(oracle):
     """The free function reuses the context of the previous call with the same
     parameters and size (one per thread): same results, no re-allocation."""
