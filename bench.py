@@ -206,30 +206,51 @@ def host_to_host(ctx, frames_host, args, torch):
             ("gray8", np.round(frames_host * 255.0).astype(np.uint8), 1)):
         pinned = torch.from_numpy(np.ascontiguousarray(arr)).pin_memory()
         ptr = pinned.data_ptr()
-        state = {"ticket": None, "kp": 0}
+        state = {"tickets": [], "kp": 0}
 
         def step():
-            t = ctx.submit_raw(ptr, ch, B, W, H, on_device=False)
-            if state["ticket"] is not None:
-                off, _, _, _ = ctx.collect(state["ticket"])
+            # stage(i + 1); collect(i - 1); submit_staged(i + 1): the next
+            # upload is enqueued before the host waits for a read-back
+            ctx.stage_raw(ptr, ch, B, W, H)
+            if len(state["tickets"]) == 2:
+                off, _, _, _ = ctx.collect(state["tickets"].pop(0))
                 state["kp"] += int(off[-1])
-            state["ticket"] = t
+            state["tickets"].append(ctx.submit_staged())
 
         for _ in range(4):  # grows the pinned result buffers of both slots
             step()
-        ctx.collect(state["ticket"])
-        state.update(ticket=None, kp=0)
         steps = max(args.steps, 8)
+        state["kp"] = 0
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(steps):  # steady state: `steps` uploads, `steps` read-backs
             step()
-        off, _, _, _ = ctx.collect(state["ticket"])
-        state["kp"] += int(off[-1])
         dt = time.perf_counter() - t0
+        for t in state["tickets"]:
+            ctx.collect(t)
         out[name] = {"keypoints_per_s": state["kp"] / dt,
                      "ms_per_step": 1e3 * dt / steps}
         del pinned
     return out
+
+
+def host_to_host_system_runtime(args):
+    """The same step in a subprocess WITHOUT torch (tools/h2h_notorch.py says
+    why: torch's wheel loads its own, older HIP runtime, under which upload and
+    read-back do not overlap on the copy engines).  None when it cannot run."""
+    import subprocess
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools",
+                          "h2h_notorch.py")
+    try:
+        res = subprocess.run(
+            [sys.executable, script, "--json", "--steps", str(max(args.steps, 8)),
+             "--frames", str(args.frames_per_gpu), "--width", str(args.width),
+             "--height", str(args.height), "--octaves", str(args.octaves)],
+            capture_output=True, text=True, timeout=300)
+        line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:  # noqa: BLE001 - a secondary measurement
+        sys.stderr.write("host_to_host_system_runtime: %r\n" % (e,))
+        return None
 
 
 def pyramid_per_kernel(args, torch, dev, frames):
@@ -909,8 +930,18 @@ def main():
                               "OERegion[] + descriptors in pinned host memory, "
                               "two batches in flight (submit/collect); `value` "
                               "above is the HBM-resident rate",
-                "gray8": h2h["gray8"], "float32": h2h["float32"]}
+                "gray8": h2h["gray8"], "float32": h2h["float32"],
+                "call_order": "stage(i+1); collect(i-1); submit_staged(i+1)",
+                "hip_runtime": [l.split()[-1] for l in open("/proc/self/maps")
+                                if "libamdhip64" in l][:1]}
             ctx.close()
+            sysrt = host_to_host_system_runtime(args)
+            if sysrt is not None:
+                # the library as a C++ caller loads it: the image's ROCm runtime
+                # instead of the one inside the torch wheel
+                out["config"]["host_to_host"]["without_torch_in_the_process"] = sysrt
+                out["value_host_to_host_float32_system_runtime"] = \
+                    sysrt["float32"]["keypoints_per_s"]
             out["config"].update(secondary_configs(args, torch, dev))
             out["config"]["width_not_multiple_of_4"] = odd_width_case(torch, dev)
             out["config"]["match"] = match_config(torch, dev)

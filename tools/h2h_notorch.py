@@ -1,13 +1,34 @@
-"""Developer probe: the host-to-host step (pinned float32 / gray8 frames ->
-keypoints in pinned memory, two batches in flight) WITHOUT torch in the
-process, and with it (`python tools/h2h_notorch.py torch`): torch's wheel
-carries its own HIP runtime, and whichever libamdhip64.so.7 is loaded first
-serves both."""
+"""The host -> host step (pinned float32 / gray8 frames ->
+keypoints in pinned memory) measured WITHOUT torch in the process.
+
+Why it exists: the torch wheel carries its own HIP runtime (ROCm 7.0.2 next to
+the image's 7.2.0) and whichever libamdhip64.so.7 is loaded first serves the
+whole process.  Under the 7.0.2 runtime an upload and a read-back on two
+streams run one after the other on the copy engines; under 7.2.0 they overlap
+(tools/ubench/pcie_duplex.hip).  A C++ caller of the library (Sara) links the
+system runtime: this script is that case.  bench.py runs it as a subprocess
+(--json) next to its own in-process measurement.
+
+   python tools/h2h_notorch.py [--json] [--steps N] [--torch] [--kinds f32,u8]
+"""
+import argparse
+import json
 import os
 import sys
 import time
 
-if len(sys.argv) > 1 and sys.argv[1] == "torch":
+ap = argparse.ArgumentParser()
+ap.add_argument("--json", action="store_true")
+ap.add_argument("--steps", type=int, default=12)
+ap.add_argument("--torch", action="store_true", help="import torch first (A/B)")
+ap.add_argument("--kinds", default="f32,u8")
+ap.add_argument("--frames", type=int, default=64)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--octaves", type=int, default=4)
+ap.add_argument("--unique", type=int, default=16)
+args = ap.parse_args()
+if args.torch:
     import torch
     torch.cuda.init()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,68 +38,53 @@ import sara_amd  # noqa: E402
 from sara_amd import capi  # noqa: E402
 from sara_amd.synth import synth_batch  # noqa: E402
 
-B, W, H = 64, 1920, 1080
-f = np.ascontiguousarray(synth_batch(W, H, B, unique=16))
+B, W, H = args.frames, args.width, args.height
+f = np.ascontiguousarray(synth_batch(W, H, B, unique=min(args.unique, B)))
 u8 = np.ascontiguousarray(np.round(f * 255).astype(np.uint8))
 lib = capi.load()
 capi.check(lib.sara_hip_host_register(f.ctypes.data, f.nbytes))
 capi.check(lib.sara_hip_host_register(u8.ctypes.data, u8.nbytes))
-ctx = sara_amd.SiftContext(W, H, B, sara_amd.ImagePyramidParams(0, 6, num_octaves_max=4))
+ctx = sara_amd.SiftContext(W, H, B, sara_amd.ImagePyramidParams(
+    0, 6, num_octaves_max=args.octaves))
 
 
-def run_staged(kind, n=12):
-    """stage(i + 1); collect(i - 1); submit_staged(i + 1)"""
+def run(kind, stage_first, n):
+    """-> (ms per step in the steady state, keypoints per step).  stage_first:
+    stage(i + 1); collect(i - 1); submit_staged(i + 1) instead of submit(i + 1);
+    collect(i)."""
     ptr, ch = (u8.ctypes.data, 1) if kind == "u8" else (f.ctypes.data, 0)
-    tickets = []
-    ctx.stage_raw(ptr, ch, B, W, H)
-    tickets.append(ctx.submit_staged())
-    ts = [0.0, 0.0, 0.0]
-    for i in range(n + 3):
-        if i == 3:
-            t0 = time.perf_counter()
-            ts = [0.0, 0.0, 0.0]
-        a = time.perf_counter()
-        ctx.stage_raw(ptr, ch, B, W, H)
-        b = time.perf_counter()
-        if len(tickets) == 2:
-            ctx.collect(tickets.pop(0))
-        c = time.perf_counter()
-        tickets.append(ctx.submit_staged())
-        d = time.perf_counter()
-        ts[0] += b - a
-        ts[1] += c - b
-        ts[2] += d - c
+    tickets, kp = [], 0
+    t0 = None
+    for i in range(n + 4):
+        if i == 4:
+            t0, kp = time.perf_counter(), 0
+        if stage_first:
+            ctx.stage_raw(ptr, ch, B, W, H)
+            if len(tickets) == 2:
+                kp += int(ctx.collect(tickets.pop(0))[0][-1])
+            tickets.append(ctx.submit_staged())
+        else:
+            tickets.append(ctx.submit_raw(ptr, ch, B, W, H))
+            if len(tickets) == 2:
+                kp += int(ctx.collect(tickets.pop(0))[0][-1])
+    dt = time.perf_counter() - t0  # n submits and n collects: the steady state
     for t in tickets:
         ctx.collect(t)
-    print("%-4s host -> host, stage first: %.2f ms per 64-frame step  (host: stage %.2f collect %.2f submit_staged %.2f)" %
-          (kind, 1e3 * (time.perf_counter() - t0) / n, 1e3 * ts[0] / n, 1e3 * ts[1] / n, 1e3 * ts[2] / n), flush=True)
+    return 1e3 * dt / n, kp / n
 
 
-def run(kind, n=12):
-    t_prev = None
-    ts = [0.0, 0.0]
-    for i in range(n + 3):
-        if i == 3:
-            t0 = time.perf_counter()
-            ts = [0.0, 0.0]
-        a = time.perf_counter()
-        if kind == "u8":
-            t = ctx.submit_raw(u8.ctypes.data, 1, B, W, H)
-        else:
-            t = ctx.submit_raw(f.ctypes.data, 0, B, W, H)
-        b = time.perf_counter()
-        if t_prev is not None:
-            ctx.collect(t_prev)
-        ts[0] += b - a
-        ts[1] += time.perf_counter() - b
-        t_prev = t
-    ctx.collect(t_prev)
-    print("%-4s host -> host: %.2f ms per 64-frame step  (host: submit %.2f collect %.2f)" %
-          (kind, 1e3 * (time.perf_counter() - t0) / n, 1e3 * ts[0] / n, 1e3 * ts[1] / n), flush=True)
-
-
-for k in (("f32", "f32") if "f32only" in sys.argv else ("f32", "u8", "f32", "u8")):
-    run(k)
-    run_staged(k)
-import ctypes
-print("HIP runtime:", [l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][:1])
+out = {"runtime": [l.split()[-1] for l in open("/proc/self/maps")
+                   if "libamdhip64" in l][:1]}
+for kind in args.kinds.split(","):
+    name = {"f32": "float32", "u8": "gray8"}[kind]
+    a, kpa = run(kind, False, args.steps)
+    b, kpb = run(kind, True, args.steps)
+    out[name] = {"ms_per_step": min(a, b), "keypoints_per_s": 1e3 * kpa / min(a, b),
+                 "ms_submit_then_collect": a, "ms_stage_collect_submit_staged": b}
+    if not args.json:
+        print("%-7s submit; collect %.2f ms   stage; collect; submit_staged %.2f ms "
+              "per %d-frame step (%.0f keypoints)" % (name, a, b, B, kpa), flush=True)
+if args.json:
+    print(json.dumps(out))
+else:
+    print("HIP runtime:", out["runtime"])
