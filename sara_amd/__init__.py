@@ -490,6 +490,31 @@ class SiftContext:
         return dict(zip(capi.TIME_NAMES, list(ms)))
 
 
+def pinned_empty(shape, dtype=np.float32):
+    """numpy array in pinned host memory (sara_hip_host_alloc = hipHostMalloc):
+    what submit() / stage() upload fastest from.  The memory lives as long as
+    the array (and its views)."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    ptr = C.c_void_p()
+    capi.check(capi.load().sara_hip_host_alloc(C.byref(ptr), max(n, 1)))
+
+    class _Owner:
+        def __init__(self, p):
+            self.p = p
+
+        def __del__(self):
+            try:
+                capi.load().sara_hip_host_free(self.p)
+            except Exception:  # interpreter shutdown
+                pass
+
+    buf = (C.c_char * max(n, 1)).from_address(ptr.value)
+    buf._owner = _Owner(ptr)
+    arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+    return arr
+
+
 def compute_sift_keypoints(image, pyramid_params=None, gauss_truncate=4.0,
                            extremum_thres=0.01, edge_ratio_thres=10.0,
                            extremum_refinement_iter=5, parallel=True, device=0):

@@ -103,6 +103,7 @@ EXPORTS = [
     "sara_hip_sift_group_gather", "sara_hip_sift_group_destroy",
     "sara_hip_sift_ticket_counts", "sara_hip_sift_collect_into",
     "sara_hip_host_register", "sara_hip_host_unregister",
+    "sara_hip_host_alloc", "sara_hip_host_free",
     "sara_hip_comm_transport", "sara_hip_sift_group_collect_host",
     "sara_hip_sift_group_transport", "sara_hip_self_match_descriptors",
     "sara_hip_match_release_workspace", "sara_hip_sift_pyramid_launches",
@@ -240,6 +241,8 @@ def _declare(lib):
     lib.sara_hip_sift_collect_into.argtypes = [_vp, C.c_int, _vp, _vp, _vp]
     lib.sara_hip_host_register.argtypes = [_vp, C.c_size_t]
     lib.sara_hip_host_unregister.argtypes = [_vp]
+    lib.sara_hip_host_alloc.argtypes = [C.POINTER(_vp), C.c_size_t]
+    lib.sara_hip_host_free.argtypes = [_vp]
     lib.sara_hip_selfcheck_sincos.argtypes = [_f32p, _f32p, _f32p, C.c_size_t]
     lib.sara_hip_selfcheck_sincos.restype = None
     lib.sara_hip_selfcheck_orientation_bins.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]

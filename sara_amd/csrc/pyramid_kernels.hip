@@ -1407,7 +1407,8 @@ namespace sara_hip {
       dst_tail[threadIdx.x] = src_tail[threadIdx.x];
   }
 
-  void launch_blit(const void* src, void* dst, size_t bytes, hipStream_t stream)
+  void launch_blit(const void* src, void* dst, size_t bytes, hipStream_t stream,
+                   int nblocks)
   {
     if (bytes == 0)
       return;
@@ -1421,7 +1422,8 @@ namespace sara_hip {
       const char* e = getenv("SARA_HIP_BLIT_BLOCKS");
       return e ? std::max(1, atoi(e)) : 64;
     }();
-    const int blocks = int(std::min<size_t>(size_t(max_blocks), (n16 + 255) / 256 + 1));
+    const int blocks = int(std::min<size_t>(size_t(nblocks > 0 ? nblocks : max_blocks),
+                                            (n16 + 255) / 256 + 1));
     hipLaunchKernelGGL(blit_kernel, dim3(blocks), dim3(256), 0, stream,
                        reinterpret_cast<const uint4*>(s), reinterpret_cast<uint4*>(d),
                        n16, s + n16 * 16, d + n16 * 16, tail);

@@ -724,6 +724,23 @@ sara_hip_status sara_hip_host_unregister(void* ptr)
   return SARA_HIP_OK;
 }
 
+sara_hip_status sara_hip_host_alloc(void** ptr, size_t bytes)
+{
+  if (!ptr || !bytes)
+    return set_error(SARA_HIP_INVALID_PARAMS, "null pointer or zero size");
+  *ptr = nullptr;
+  HIPC_TRY(hipHostMalloc(ptr, bytes, hipHostMallocPortable));
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_host_free(void* ptr)
+{
+  if (!ptr)
+    return set_error(SARA_HIP_INVALID_PARAMS, "null pointer");
+  HIPC_TRY(hipHostFree(ptr));
+  return SARA_HIP_OK;
+}
+
 const char* sara_hip_comm_transport(const sara_hip_comm* c)
 {
   return c && c->tr ? c->tr->name() : "";

@@ -2059,7 +2059,35 @@ sara_hip_status sara_hip_sift_stage(sara_hip_sift* c, const void* images,
   // the pipeline that last read this buffer must be done with it
   if (c->stage_used[k])
     HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->stage_free[k], 0));
-  if (stride_bytes == px * elem)  // contiguous frames: one linear copy
+  // SARA_HIP_H2D=kernel (experiment, off): upload by a copy KERNEL when the
+  // frames are in pinned (device-visible) host memory.  Why it was tried: the
+  // float32 host -> host step flips between 9.1 and 12.5 ms from process to
+  // process (both HIP runtimes) - when the upload and the read-back of the
+  // batch before end up behind one another on the copy engines instead of side
+  // by side.  A kernel reading host memory and a copy engine writing it cannot
+  // collide, and alone they overlap perfectly (tools/ubench/pcie_duplex.hip:
+  // 9.44 ms for 0.53 GB up with 32 workgroups + 0.14 GB down, 9.25 ms for the
+  // upload alone).  Next to the pipeline's kernels, however, the copy kernel
+  // is starved: 11.8-12.1 ms per float32 step in every run, gray8 7.1 -> 7.3.
+  static const bool h2d_kernel = [] {
+    const char* e = getenv("SARA_HIP_H2D");
+    return e && std::string(e) == "kernel";
+  }();
+  bool pinned = false;
+  if (h2d_kernel && stride_bytes == px * elem)
+  {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, images) == hipSuccess)
+      pinned = attr.type == hipMemoryTypeHost;
+    else
+      (void) hipGetLastError();  // pageable memory: not an error
+  }
+  if (pinned)
+  {
+    launch_blit(images, c->d_stage[k], px * elem * batch, c->copy_stream, 32);
+    HIP_TRY(hipGetLastError());
+  }
+  else if (stride_bytes == px * elem)  // contiguous frames: one linear copy
     HIP_TRY(hipMemcpyAsync(c->d_stage[k], images, px * elem * batch,
                            hipMemcpyHostToDevice, c->copy_stream));
   else

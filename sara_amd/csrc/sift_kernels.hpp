@@ -195,7 +195,10 @@ namespace sara_hip {
                       float* dst, size_t dst_stride, int dw, int dh, int batch,
                       hipStream_t stream);
 
-  void launch_blit(const void* src, void* dst, size_t bytes, hipStream_t stream);
+  //! Byte copy by the shader cores (pinned host memory on either side);
+  //! blocks = 0: SARA_HIP_BLIT_BLOCKS (64).
+  void launch_blit(const void* src, void* dst, size_t bytes, hipStream_t stream,
+                   int blocks = 0);
   void launch_copy_planes(const float* src, size_t src_stride, float* dst,
                           size_t dst_stride, size_t count, int batch,
                           hipStream_t stream);

@@ -27,6 +27,9 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--octaves", type=int, default=4)
 ap.add_argument("--unique", type=int, default=16)
+ap.add_argument("--torch-pinned", action="store_true")
+ap.add_argument("--registered", action="store_true",
+                help="frames in hipHostRegister'ed memory instead of hipHostMalloc")
 args = ap.parse_args()
 if args.torch:
     import torch
@@ -39,11 +42,22 @@ from sara_amd import capi  # noqa: E402
 from sara_amd.synth import synth_batch  # noqa: E402
 
 B, W, H = args.frames, args.width, args.height
-f = np.ascontiguousarray(synth_batch(W, H, B, unique=min(args.unique, B)))
-u8 = np.ascontiguousarray(np.round(f * 255).astype(np.uint8))
+src = synth_batch(W, H, B, unique=min(args.unique, B))
 lib = capi.load()
-capi.check(lib.sara_hip_host_register(f.ctypes.data, f.nbytes))
-capi.check(lib.sara_hip_host_register(u8.ctypes.data, u8.nbytes))
+if args.registered:  # A/B: numpy's own pages, hipHostRegister'ed
+    f = np.ascontiguousarray(src)
+    u8 = np.ascontiguousarray(np.round(f * 255).astype(np.uint8))
+    capi.check(lib.sara_hip_host_register(f.ctypes.data, f.nbytes))
+    capi.check(lib.sara_hip_host_register(u8.ctypes.data, u8.nbytes))
+elif args.torch_pinned:  # A/B: torch's caching host allocator
+    tf = torch.from_numpy(np.ascontiguousarray(src)).pin_memory()
+    tu = torch.from_numpy(np.round(src * 255).astype(np.uint8)).pin_memory()
+    f, u8 = tf.numpy(), tu.numpy()
+else:  # hipHostMalloc (sara_hip_host_alloc)
+    f = sara_amd.pinned_empty(src.shape, np.float32)
+    f[...] = src
+    u8 = sara_amd.pinned_empty(src.shape, np.uint8)
+    u8[...] = np.round(src * 255).astype(np.uint8)
 ctx = sara_amd.SiftContext(W, H, B, sara_amd.ImagePyramidParams(
     0, 6, num_octaves_max=args.octaves))
 
