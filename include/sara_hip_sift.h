@@ -590,6 +590,17 @@ SARA_HIP_API sara_hip_status sara_hip_copy_to_host(void* dst,
                                                   const void* src_device,
                                                   size_t bytes, int device);
 
+/* The other direction, and HBM buffers, for the same kind of caller: frames    */
+/* that several calls reuse (images_on_device = 1) are uploaded once.  A context */
+/* replaying its HIP graph (batches <= 8) reads such frames IN PLACE; they must  */
+/* stay unmodified until the results of the call have been fetched / collected. */
+SARA_HIP_API sara_hip_status sara_hip_copy_to_device(void* dst_device,
+                                                    const void* src, size_t bytes,
+                                                    int device);
+SARA_HIP_API sara_hip_status sara_hip_device_alloc(void** ptr, size_t bytes,
+                                                  int device);
+SARA_HIP_API sara_hip_status sara_hip_device_free(void* ptr, int device);
+
 /* --- one process per GPU --------------------------------------------------- */
 #define SARA_HIP_COMM_ID_BYTES 128
 typedef struct sara_hip_comm sara_hip_comm; /* one rank of a gather group */

@@ -27,7 +27,8 @@ __all__ = [
     "gradient_polar_coordinates", "scale_space_dog_extremum_map",
     "from_rgb8_to_gray32f", "from_gray8_to_gray32f", "AnnMatcher", "match",
     "MATCH_DTYPE", "write_keypoints", "read_keypoints", "root_sift", "H5File",
-    "make_gaussian_kernel", "SaraHipError", "OEREGION_DTYPE",
+    "make_gaussian_kernel", "SaraHipError", "OEREGION_DTYPE", "DeviceArray",
+    "pinned_empty",
 ]
 
 _K_DEFAULT = float(np.power(np.float32(2.0), np.float32(1.0) / np.float32(3.0)))
@@ -488,6 +489,40 @@ class SiftContext:
         ms = (C.c_float * 7)()
         capi.check(capi.load().sara_hip_sift_stage_times(self._h, ms))
         return dict(zip(capi.TIME_NAMES, list(ms)))
+
+
+class DeviceArray:
+    """A host array uploaded once into HBM (sara_hip_device_alloc +
+    sara_hip_copy_to_device): ``ptr`` goes to detect_device() / submit_raw(...,
+    on_device=True).  Freed by close() / the context manager / the collector."""
+
+    def __init__(self, array, device=0):
+        a = np.ascontiguousarray(array)
+        self.shape, self.dtype, self.device = a.shape, a.dtype, device
+        p = C.c_void_p()
+        capi.check(capi.load().sara_hip_device_alloc(C.byref(p), max(a.nbytes, 1),
+                                                     device))
+        self.ptr = p.value
+        if a.nbytes:
+            capi.check(capi.load().sara_hip_copy_to_device(self.ptr, a.ctypes.data,
+                                                           a.nbytes, device))
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            capi.load().sara_hip_device_free(self.ptr, self.device)
+            self.ptr = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
 
 
 def pinned_empty(shape, dtype=np.float32):

@@ -104,6 +104,7 @@ EXPORTS = [
     "sara_hip_sift_ticket_counts", "sara_hip_sift_collect_into",
     "sara_hip_host_register", "sara_hip_host_unregister",
     "sara_hip_host_alloc", "sara_hip_host_free",
+    "sara_hip_copy_to_device", "sara_hip_device_alloc", "sara_hip_device_free",
     "sara_hip_comm_transport", "sara_hip_sift_group_collect_host",
     "sara_hip_sift_group_transport", "sara_hip_self_match_descriptors",
     "sara_hip_match_release_workspace", "sara_hip_sift_pyramid_launches",
@@ -241,6 +242,9 @@ def _declare(lib):
     lib.sara_hip_sift_collect_into.argtypes = [_vp, C.c_int, _vp, _vp, _vp]
     lib.sara_hip_host_register.argtypes = [_vp, C.c_size_t]
     lib.sara_hip_host_unregister.argtypes = [_vp]
+    lib.sara_hip_copy_to_device.argtypes = [_vp, _vp, C.c_size_t, C.c_int]
+    lib.sara_hip_device_alloc.argtypes = [C.POINTER(_vp), C.c_size_t, C.c_int]
+    lib.sara_hip_device_free.argtypes = [_vp, C.c_int]
     lib.sara_hip_host_alloc.argtypes = [C.POINTER(_vp), C.c_size_t]
     lib.sara_hip_host_free.argtypes = [_vp]
     lib.sara_hip_selfcheck_sincos.argtypes = [_f32p, _f32p, _f32p, C.c_size_t]

@@ -708,6 +708,35 @@ sara_hip_status sara_hip_copy_to_host(void* dst, const void* src_device,
   return SARA_HIP_OK;
 }
 
+sara_hip_status sara_hip_copy_to_device(void* dst_device, const void* src,
+                                        size_t bytes, int device)
+{
+  if (!dst_device || !src)
+    return set_error(SARA_HIP_INVALID_PARAMS, "null pointer");
+  HIPC_TRY(hipSetDevice(device));
+  HIPC_TRY(hipMemcpy(dst_device, src, bytes, hipMemcpyHostToDevice));
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_device_alloc(void** ptr, size_t bytes, int device)
+{
+  if (!ptr || !bytes)
+    return set_error(SARA_HIP_INVALID_PARAMS, "null pointer or zero size");
+  *ptr = nullptr;
+  HIPC_TRY(hipSetDevice(device));
+  HIPC_TRY(hipMalloc(ptr, bytes));
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_device_free(void* ptr, int device)
+{
+  if (!ptr)
+    return set_error(SARA_HIP_INVALID_PARAMS, "null pointer");
+  HIPC_TRY(hipSetDevice(device));
+  HIPC_TRY(hipFree(ptr));
+  return SARA_HIP_OK;
+}
+
 sara_hip_status sara_hip_host_register(void* ptr, size_t bytes)
 {
   if (!ptr || !bytes)

@@ -410,6 +410,16 @@ struct sara_hip_sift
   int graph_w_s[2] = {0, 0}, graph_h_s[2] = {0, 0}, graph_batch_s[2] = {0, 0},
       graph_stage_s[2] = {-1, -1};
   bool graph_broken = false;  // a capture failed once: stay on plain launches
+  // Round 3: device-resident frames are read IN PLACE by the replayed graph.
+  // The captured kernels that take the frames as their first argument are
+  // remembered per slot; when the caller's pointer changes, their argument is
+  // rewritten in the executable graph (hipGraphExecKernelNodeSetParams)
+  // instead of copying the frames to a fixed address first (8.3 MB and one
+  // more enqueue per 1080p call).  SARA_HIP_GRAPH_INPLACE=0 restores the copy.
+  bool graph_inplace = true;
+  const void* graph_src_s[2] = {nullptr, nullptr};     // pointer baked into the slot's graph
+  size_t graph_src_stride_s[2] = {0, 0};
+  std::vector<hipGraphNode_t> graph_src_nodes_s[2];    // kernels reading it
   // Round 3: the replay is a sequence of LINEAR graphs (detect() says why)
   struct GraphSegment
   {
@@ -567,6 +577,8 @@ namespace {
       c->graph_max_batch = atoi(e);
     if (const char* e = getenv("SARA_HIP_GRAPH_SEGMENTS"))
       c->graph_segments = std::string(e) != "0";
+    if (const char* e = getenv("SARA_HIP_GRAPH_INPLACE"))
+      c->graph_inplace = std::string(e) != "0";
     if (const char* e = getenv("SARA_HIP_SPEC_D2H"))
       c->speculative_d2h = std::string(e) != "0";
 
@@ -1122,6 +1134,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   // ---- upload -------------------------------------------------------------
   const float* src = images;
   size_t src_stride = frame_stride;
+  bool src_in_place = false;
   if (!images_on_device)
   {
     if (frame_stride == in_plane)  // contiguous frames: one linear copy
@@ -1134,6 +1147,12 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
                                hipMemcpyHostToDevice, stream));
     src = c->d_input;
     src_stride = in_plane;
+  }
+  else if (graph_mode && images != c->d_input && c->graph_inplace &&
+           !c->graph_segments && !gray8)
+  {
+    // the graph reads the caller's frames where they are (see graph_inplace)
+    src_in_place = true;
   }
   else if (graph_mode && images != c->d_input)
   {
@@ -1886,12 +1905,50 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
 
   hipGraph_t& graph = c->graph_s[gs];
   hipGraphExec_t& graph_exec = c->graph_exec_s[gs];
+  // a graph captured on the caller's frames serves other frames after an
+  // argument update; one captured on d_input serves only d_input (and v.v.)
+  const bool src_kind_ok =
+      src_in_place ? (c->graph_src_s[gs] != nullptr &&
+                      c->graph_src_stride_s[gs] == src_stride &&
+                      (c->graph_src_s[gs] == static_cast<const void*>(src) ||
+                       !c->graph_src_nodes_s[gs].empty()))
+                   : c->graph_src_s[gs] == nullptr;
   const bool cached = graph_exec && c->graph_w_s[gs] == width &&
                       c->graph_h_s[gs] == height &&
                       c->graph_batch_s[gs] == batch &&
-                      c->graph_stage_s[gs] == int(last_stage);
+                      c->graph_stage_s[gs] == int(last_stage) && src_kind_ok;
+  if (cached && src_in_place && c->graph_src_s[gs] != static_cast<const void*>(src))
+  {
+    // new frame address: rewrite the first argument of the kernels that read it
+    bool ok = true;
+    for (hipGraphNode_t node : c->graph_src_nodes_s[gs])
+    {
+      hipKernelNodeParams kp;
+      ok = ok && hipGraphKernelNodeGetParams(node, &kp) == hipSuccess &&
+           kp.kernelParams != nullptr;
+      if (!ok)
+        break;
+      *static_cast<const void**>(kp.kernelParams[0]) = src;
+      ok = hipGraphKernelNodeSetParams(node, &kp) == hipSuccess &&
+           hipGraphExecKernelNodeSetParams(graph_exec, node, &kp) == hipSuccess;
+    }
+    if (!ok)
+    {
+      // this runtime cannot do it: copy to a fixed address from now on
+      (void) hipGetLastError();
+      c->graph_inplace = false;
+      c->graph_stage_s[gs] = -1;
+      return sara_hip_sift_detect(c, images, frame_stride, batch, width, height,
+                                  images_on_device, last_stage, hip_stream);
+    }
+    if (trace_graph)
+      std::fprintf(stderr, "[sara_hip] frame address rewritten in the graph\n");
+    c->graph_src_s[gs] = src;
+  }
   if (!cached)
   {
+    c->graph_src_s[gs] = nullptr;
+    c->graph_src_nodes_s[gs].clear();
     if (graph_exec)
       (void) hipGraphExecDestroy(graph_exec);
     if (graph)
@@ -1933,6 +1990,39 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     c->graph_h_s[gs] = height;
     c->graph_batch_s[gs] = batch;
     c->graph_stage_s[gs] = int(last_stage);
+    if (src_in_place)
+    {
+      // the kernel nodes whose first argument is the frame pointer
+      c->graph_src_s[gs] = src;
+      c->graph_src_stride_s[gs] = src_stride;
+      size_t n_nodes = 0;
+      if (hipGraphGetNodes(graph, nullptr, &n_nodes) == hipSuccess && n_nodes > 0)
+      {
+        std::vector<hipGraphNode_t> nodes(n_nodes);
+        if (hipGraphGetNodes(graph, nodes.data(), &n_nodes) == hipSuccess)
+          for (size_t i = 0; i < n_nodes; ++i)
+          {
+            hipGraphNodeType type;
+            hipKernelNodeParams kp;
+            if (hipGraphNodeGetType(nodes[i], &type) != hipSuccess ||
+                type != hipGraphNodeTypeKernel ||
+                hipGraphKernelNodeGetParams(nodes[i], &kp) != hipSuccess ||
+                !kp.kernelParams || !kp.kernelParams[0])
+              continue;
+            if (*static_cast<const void* const*>(kp.kernelParams[0]) ==
+                static_cast<const void*>(src))
+              c->graph_src_nodes_s[gs].push_back(nodes[i]);
+          }
+      }
+      (void) hipGetLastError();
+      // no such node found: the graph stays valid for this address only, and
+      // the next address makes src_kind_ok false -> fall back to the copy
+      if (trace_graph)
+        std::fprintf(stderr, "[sara_hip] frames read in place by %zu kernel node(s)\n",
+                     c->graph_src_nodes_s[gs].size());
+      if (c->graph_src_nodes_s[gs].empty())
+        c->graph_inplace = false;
+    }
   }
   HIP_TRY(hipGraphLaunch(graph_exec, stream));
   if (c->timers)

@@ -689,6 +689,55 @@ def test_stage_collect_submit_staged(oracle, batch):
         assert int(sum(w[0].sum() for w in want)) > 0
 
 
+@pytest.mark.parametrize("first", [0, -1, 1])
+def test_device_frames_read_in_place_by_the_graph(oracle, first):
+    """Frames that are already in HBM: a context replaying its HIP graph
+    (batch <= 8) reads them where they are and rewrites the kernel argument
+    when the address changes (no copy to a fixed address).  Three buffers in
+    rotation, through detect_device() and through submit / collect (two result
+    slots = two graphs), for the three kinds of first kernel (blur, enlarge,
+    blur + sub-sampling): byte-identical to detect() on the host arrays."""
+    w, h, batch = (96, 80, 2) if first == -1 else (200, 150, 2)
+    frames = [synth_batch(w, h, batch, first_index=5 * i) for i in range(5)]
+    with sara_amd.SiftContext(w, h, batch, hip_params(first, 3)) as ctx:
+        want = []
+        for f in frames:
+            ctx.detect(f)
+            want.append(ctx.fetch())
+        bufs = [sara_amd.DeviceArray(f) for f in frames]
+        try:
+            for rnd in range(2):
+                for i in (0, 1, 2, 0, 3, 4, 4, 1):
+                    ctx.detect_device(bufs[i].ptr, batch, w, h)
+                    for x, y in zip(want[i], ctx.fetch()):
+                        assert x.tobytes() == y.tobytes(), (rnd, i)
+            order = (0, 1, 2, 3, 4, 2, 2, 0)
+            tickets = []
+            for k, i in enumerate(order):
+                tickets.append((i, ctx.submit_raw(bufs[i].ptr, 0, batch, w, h,
+                                                  on_device=True)))
+                if len(tickets) == 2:
+                    j, t = tickets.pop(0)
+                    offsets, regions, desc, so = ctx.collect(t, copy=True)
+                    assert np.array_equal(np.diff(offsets), want[j][0])
+                    assert regions.tobytes() == want[j][1].tobytes()
+                    assert np.array_equal(desc, want[j][2])
+            for j, t in tickets:
+                offsets, regions, desc, so = ctx.collect(t, copy=True)
+                assert regions.tobytes() == want[j][1].tobytes()
+            # a host array in between (fixed-address graph), then in place again
+            ctx.detect(frames[3])
+            for x, y in zip(want[3], ctx.fetch()):
+                assert x.tobytes() == y.tobytes()
+            ctx.detect_device(bufs[1].ptr, batch, w, h)
+            for x, y in zip(want[1], ctx.fetch()):
+                assert x.tobytes() == y.tobytes()
+        finally:
+            for b in bufs:
+                b.close()
+        assert int(sum(wn[0].sum() for wn in want)) > 0
+
+
 def test_compute_sift_keypoints_keeps_its_context(oracle):
     """The free function reuses the context of the previous call with the same
     parameters and size (one per thread): same results, no re-allocation."""
