@@ -206,29 +206,48 @@ def host_to_host(ctx, frames_host, args, torch):
             ("gray8", np.round(frames_host * 255.0).astype(np.uint8), 1)):
         pinned = torch.from_numpy(np.ascontiguousarray(arr)).pin_memory()
         ptr = pinned.data_ptr()
-        state = {"tickets": [], "kp": 0}
+        # Two call orders: "stage first" enqueues the next
+        # upload before the host waits for a read-back - the copy engine goes
+        # from one upload straight into the next - but how the runtime then
+        # places upload and read-back on the copy engines differs from process
+        # to process (8.7-9.1 or 12.4 ms per float32 step); "submit first" is
+        # the round-2 order.  Both are measured, the better one is reported.
+        best = None
+        for order in ("stage(i+1); collect(i-1); submit_staged(i+1)",
+                      "submit(i+1); collect(i)"):
+            state = {"tickets": [], "kp": 0}
 
-        def step():
-            # stage(i + 1); collect(i - 1); submit_staged(i + 1): the next
-            # upload is enqueued before the host waits for a read-back
-            ctx.stage_raw(ptr, ch, B, W, H)
-            if len(state["tickets"]) == 2:
-                off, _, _, _ = ctx.collect(state["tickets"].pop(0))
-                state["kp"] += int(off[-1])
-            state["tickets"].append(ctx.submit_staged())
+            def step():
+                if order.startswith("stage"):
+                    ctx.stage_raw(ptr, ch, B, W, H)
+                    if len(state["tickets"]) == 2:
+                        off, _, _, _ = ctx.collect(state["tickets"].pop(0))
+                        state["kp"] += int(off[-1])
+                    state["tickets"].append(ctx.submit_staged())
+                else:
+                    state["tickets"].append(ctx.submit_raw(ptr, ch, B, W, H))
+                    if len(state["tickets"]) == 2:
+                        off, _, _, _ = ctx.collect(state["tickets"].pop(0))
+                        state["kp"] += int(off[-1])
 
-        for _ in range(4):  # grows the pinned result buffers of both slots
-            step()
-        steps = max(args.steps, 8)
-        state["kp"] = 0
-        t0 = time.perf_counter()
-        for _ in range(steps):  # steady state: `steps` uploads, `steps` read-backs
-            step()
-        dt = time.perf_counter() - t0
-        for t in state["tickets"]:
-            ctx.collect(t)
-        out[name] = {"keypoints_per_s": state["kp"] / dt,
-                     "ms_per_step": 1e3 * dt / steps}
+            for _ in range(4):  # grows the pinned result buffers of both slots
+                step()
+            steps = max(args.steps, 8)
+            state["kp"] = 0
+            t0 = time.perf_counter()
+            for _ in range(steps):  # steady state: `steps` uploads and read-backs
+                step()
+            dt = time.perf_counter() - t0
+            for t in state["tickets"]:
+                ctx.collect(t)
+            res = {"keypoints_per_s": state["kp"] / dt,
+                   "ms_per_step": 1e3 * dt / steps, "call_order": order}
+            if best is None:
+                best = dict(res, ms_per_step_by_order={})
+            if res["ms_per_step"] < best["ms_per_step"]:
+                best.update(res)
+            best["ms_per_step_by_order"][order] = res["ms_per_step"]
+        out[name] = best
         del pinned
     return out
 
@@ -404,6 +423,23 @@ def secondary_configs(args, torch, dev):
         u8 = np.round(one * 255.0).astype(np.uint8)
         h2h8 = timed(lambda: c1.collect(c1.submit(u8)), 100, 10)
         n1 = int(c1.collect(c1.submit(one))[0][-1])
+        # a video stream: frame i + 1 is submitted before frame i is collected
+        # (pinned frames; per-frame period, not the latency of one call)
+        pin = {}
+        for name, arr, ch in (("float32", one, 0), ("gray8", u8, 1)):
+            pa = sara_amd.pinned_empty(arr.shape, arr.dtype)
+            pa[...] = arr
+            state = {"t": None}
+
+            def step(pa=pa, ch=ch, state=state):
+                t = c1.submit_raw(pa.ctypes.data, ch, 1, W, H)
+                if state["t"] is not None:
+                    c1.collect(state["t"])
+                state["t"] = t
+
+            pin[name] = timed(step, 200, 20)
+            c1.collect(state["t"])
+            del pa
     out["config2"] = {
         "workload": "1 x 1920x1080, pyramid + DoG + extrema only (stage 2), "
                     "frame resident in HBM, HIP-graph replay",
@@ -419,6 +455,11 @@ def secondary_configs(args, torch, dev):
         "ms_hbm_resident": 1e3 * t5,
         "ms_host_float32_to_host": 1e3 * h2h,
         "ms_host_gray8_to_host": 1e3 * h2h8,
+        "ms_per_frame_two_in_flight_float32": 1e3 * pin["float32"],
+        "ms_per_frame_two_in_flight_gray8": 1e3 * pin["gray8"],
+        "two_in_flight": "submit(frame i+1) before collect(frame i), pinned host "
+                         "frames: the period of a video stream, not the latency "
+                         "of one call",
         "keypoints_per_s_host_to_host": n1 / h2h,
     }
     # ---- config 5: 4K, 5 octaves
@@ -931,7 +972,6 @@ def main():
                               "two batches in flight (submit/collect); `value` "
                               "above is the HBM-resident rate",
                 "gray8": h2h["gray8"], "float32": h2h["float32"],
-                "call_order": "stage(i+1); collect(i-1); submit_staged(i+1)",
                 "hip_runtime": [l.split()[-1] for l in open("/proc/self/maps")
                                 if "libamdhip64" in l][:1]}
             ctx.close()

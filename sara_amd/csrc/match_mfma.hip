@@ -68,6 +68,7 @@ namespace sara_hip {
       const bool vec4 = ((reinterpret_cast<uintptr_t>(a) |
                           reinterpret_cast<uintptr_t>(b)) & 15) == 0;
       if (vec4)
+#pragma unroll 8
         for (; i + 3 < dim; i += 4)
         {
           const float4 x = *reinterpret_cast<const float4*>(a + i);
@@ -775,6 +776,10 @@ namespace sara_hip {
       const dim3 g(unsigned((threads + 255) / 256));
       if (cap == 8)
         hipLaunchKernelGGL(rerank_kernel<8>, g, dim3(256), 0, stream, q, nq, t, dim,
+                           cand, cnt, squared_ratio_thres, top1, td, ti, ro, rcap,
+                           rcount, flagged, fcount);
+      else if (cap == 64)
+        hipLaunchKernelGGL(rerank_kernel<64>, g, dim3(256), 0, stream, q, nq, t, dim,
                            cand, cnt, squared_ratio_thres, top1, td, ti, ro, rcap,
                            rcount, flagged, fcount);
       else

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -306,10 +307,17 @@ namespace {
     }
   }
 
-  //! compute_matches' tail, AnnMatcher.cpp:239-258.
+  //! compute_matches' tail, AnnMatcher.cpp:239-258: sort by (x, y, score, ..),
+  //! drop duplicates of (x, y), sort by (score, x, y).
+  //! Round 3: two comparison sorts of the 17 k matches of a 4.3 k x 4.3 k pair at
+  //! the default ratio took 0.8 ms.  The first order is a counting sort on x
+  //! with the two to four entries of an x ordered by insertion; the second a
+  //! stable radix sort on the score's bits (scores are >= 0, so their bit
+  //! patterns order like the floats; -0.f does not occur: a score is 0.f or a
+  //! quotient of non-negative distances) of a list that is in (x, y) order.
   void finish_matches(std::vector<sara_match>& m, const Feat* f1, const Feat* f2)
   {
-    std::sort(m.begin(), m.end(), [](const sara_match& a, const sara_match& b) {
+    const auto before = [](const sara_match& a, const sara_match& b) {
       if (a.x_index != b.x_index)
         return a.x_index < b.x_index;
       if (a.y_index != b.y_index)
@@ -319,7 +327,41 @@ namespace {
       if (a.direction != b.direction)
         return a.direction < b.direction;
       return a.rank < b.rank;
-    });
+    };
+    const size_t n = m.size();
+    if (n == 0)
+      return;
+    int max_x = 0;
+    bool plain = true;  // indices >= 0, scores >= +0.f and not NaN
+    for (const sara_match& e : m)
+    {
+      max_x = std::max(max_x, e.x_index);
+      plain = plain && e.x_index >= 0 && e.score >= 0.f && !std::signbit(e.score);
+    }
+    std::vector<sara_match> tmp(n);
+    if (!plain)
+      std::sort(m.begin(), m.end(), before);
+    else
+    {
+      std::vector<int> begin(size_t(max_x) + 2, 0);
+      for (const sara_match& e : m)
+        ++begin[size_t(e.x_index) + 1];
+      for (int x = 0; x <= max_x; ++x)
+        begin[size_t(x) + 1] += begin[size_t(x)];
+      std::vector<int> cursor(begin.begin(), begin.end() - 1);
+      for (const sara_match& e : m)
+      {
+        const int lo = begin[size_t(e.x_index)];
+        int at = cursor[size_t(e.x_index)]++;
+        while (at > lo && before(e, tmp[size_t(at - 1)]))
+        {
+          tmp[size_t(at)] = tmp[size_t(at - 1)];
+          --at;
+        }
+        tmp[size_t(at)] = e;
+      }
+      m.swap(tmp);
+    }
     m.erase(std::unique(m.begin(), m.end(),
                         [&](const sara_match& a, const sara_match& b) {
                           if (f1 && f2)  // Match::operator== compares by value
@@ -328,13 +370,42 @@ namespace {
                           return a.x_index == b.x_index && a.y_index == b.y_index;
                         }),
             m.end());
-    std::sort(m.begin(), m.end(), [](const sara_match& a, const sara_match& b) {
-      if (a.score != b.score)
-        return a.score < b.score;
-      if (a.x_index != b.x_index)
-        return a.x_index < b.x_index;
-      return a.y_index < b.y_index;
-    });
+    if (!plain)
+    {
+      std::sort(m.begin(), m.end(), [](const sara_match& a, const sara_match& b) {
+        if (a.score != b.score)
+          return a.score < b.score;
+        if (a.x_index != b.x_index)
+          return a.x_index < b.x_index;
+        return a.y_index < b.y_index;
+      });
+      return;
+    }
+    // m is in (x, y) order: a stable sort on the score alone gives (score, x, y)
+    const size_t k = m.size();
+    tmp.resize(k);
+    sara_match* a = m.data();
+    sara_match* b = tmp.data();
+    for (int pass = 0; pass < 3; ++pass)
+    {
+      const int shift = 11 * pass;
+      const unsigned mask = pass == 2 ? 0x3ffu : 0x7ffu;
+      unsigned hist[2049] = {0};
+      auto digit = [&](const sara_match& e) {
+        uint32_t u;
+        std::memcpy(&u, &e.score, 4);
+        return (u >> shift) & mask;
+      };
+      for (size_t i = 0; i < k; ++i)
+        ++hist[digit(a[i]) + 1];
+      for (int d = 0; d < 2048; ++d)
+        hist[d + 1] += hist[d];
+      for (size_t i = 0; i < k; ++i)
+        b[hist[digit(a[i])]++] = a[i];
+      std::swap(a, b);
+    }
+    if (a != m.data())  // three passes: the result is in tmp
+      m.swap(tmp);
   }
 
   //! Which producer answers the neighbour queries: "mfma" = MFMA prefilter +
@@ -406,7 +477,11 @@ namespace {
       r.radius[1] = list ? list + cap[0] : nullptr;
       if (mfma)
       {
-        const int slots = radius_on ? 32 : 8;
+        static const int radius_slots = [] {
+          const char* e = getenv("SARA_HIP_MATCH_SLOTS");
+          return e && atoi(e) == 64 ? 64 : 32;  // 64: fewer fall-backs, same time
+        }();
+        const int slots = radius_on ? radius_slots : 8;
         float* fs = nullptr;
         int* is = nullptr;
         HIPM_TRY(ws.get(Workspace::kAux1, match_mfma_scratch_floats(n1, n2), fs));
@@ -454,44 +529,90 @@ namespace {
     return SARA_HIP_OK;
   }
 
-  //! One direction of a DeviceSearch on the host, radius members sorted the
+  //! Both directions of a DeviceSearch on the host, radius members sorted the
   //! way FLANN's RadiusResultSet hands them out: by (distance, index).
-  sara_hip_status to_host(Workspace& ws, const DeviceSearch& r, int dir,
-                          Neighbours* nb)
+  //! Round 3: six blocking copies into pageable vectors and a comparison sort
+  //! of all radius members took 0.3 ms per direction; now every array goes
+  //! through the workspace's pinned buffer behind ONE wait, and the members
+  //! are grouped by query with a counting sort (a query has a handful of
+  //! them, ordered by insertion).
+  sara_hip_status to_host(Workspace& ws, const DeviceSearch& r, Neighbours nb[2])
   {
-    HIPM_TRY(ws.wait(ws.stream));  // the copies below use the NULL stream
-    const int nq = r.nq[dir];
-    nb->nq = nq;
-    nb->nt = r.nt[dir];
-    nb->top_d.assign(3 * size_t(nq), 0.f);
-    nb->top_i.assign(3 * size_t(nq), -1);
-    nb->radius.clear();
-    nb->begin.assign(size_t(nq) + 1, 0);
-    if (!r.have[dir])
-      return SARA_HIP_OK;
-    HIPM_TRY(hipMemcpy(nb->top_d.data(), r.top_d[dir], sizeof(float) * 3 * nq,
-                       hipMemcpyDeviceToHost));
-    HIPM_TRY(hipMemcpy(nb->top_i.data(), r.top_i[dir], sizeof(int) * 3 * nq,
-                       hipMemcpyDeviceToHost));
-    const int found = r.radius_found[dir];
-    if (found > 0)
+    size_t off[2][3], total = 0;
+    for (int dir = 0; dir < 2; ++dir)
     {
-      nb->radius.resize(size_t(found));
-      HIPM_TRY(hipMemcpy(nb->radius.data(), r.radius[dir],
-                         sizeof(MatchNeighbour) * size_t(found),
-                         hipMemcpyDeviceToHost));
-      std::sort(nb->radius.begin(), nb->radius.end(),
-                [](const MatchNeighbour& a, const MatchNeighbour& b) {
-                  if (a.query != b.query)
-                    return a.query < b.query;
-                  if (a.distance != b.distance)
-                    return a.distance < b.distance;
-                  return a.index < b.index;
-                });
-      for (const MatchNeighbour& n : nb->radius)
-        ++nb->begin[size_t(n.query) + 1];
+      const size_t nq = size_t(r.nq[dir]);
+      const size_t found = r.have[dir] ? size_t(std::max(r.radius_found[dir], 0)) : 0;
+      off[dir][0] = total;
+      total += sizeof(float) * 3 * nq;
+      off[dir][1] = total;
+      total += sizeof(int) * 3 * nq;
+      off[dir][2] = total;
+      total += sizeof(MatchNeighbour) * found;
+      total = (total + 15) & ~size_t(15);
+    }
+    void* hv = nullptr;
+    HIPM_TRY(ws.host(total + 16, hv));
+    unsigned char* h = static_cast<unsigned char*>(hv);
+    for (int dir = 0; dir < 2; ++dir)
+    {
+      if (!r.have[dir])
+        continue;
+      const size_t nq = size_t(r.nq[dir]);
+      const size_t found = size_t(std::max(r.radius_found[dir], 0));
+      if (nq)
+      {
+        HIPM_TRY(hipMemcpyAsync(h + off[dir][0], r.top_d[dir], sizeof(float) * 3 * nq,
+                                hipMemcpyDeviceToHost, ws.stream));
+        HIPM_TRY(hipMemcpyAsync(h + off[dir][1], r.top_i[dir], sizeof(int) * 3 * nq,
+                                hipMemcpyDeviceToHost, ws.stream));
+      }
+      if (found)
+        HIPM_TRY(hipMemcpyAsync(h + off[dir][2], r.radius[dir],
+                                sizeof(MatchNeighbour) * found, hipMemcpyDeviceToHost,
+                                ws.stream));
+    }
+    HIPM_TRY(ws.wait(ws.stream));
+    for (int dir = 0; dir < 2; ++dir)
+    {
+      Neighbours& n = nb[dir];
+      const int nq = r.nq[dir];
+      n.nq = nq;
+      n.nt = r.nt[dir];
+      n.top_d.assign(3 * size_t(nq), 0.f);
+      n.top_i.assign(3 * size_t(nq), -1);
+      n.radius.clear();
+      n.begin.assign(size_t(nq) + 1, 0);
+      if (!r.have[dir])
+        continue;
+      std::memcpy(n.top_d.data(), h + off[dir][0], sizeof(float) * 3 * size_t(nq));
+      std::memcpy(n.top_i.data(), h + off[dir][1], sizeof(int) * 3 * size_t(nq));
+      const int found = std::max(r.radius_found[dir], 0);
+      if (found == 0)
+        continue;
+      const MatchNeighbour* src =
+          reinterpret_cast<const MatchNeighbour*>(h + off[dir][2]);
+      for (int i = 0; i < found; ++i)
+        ++n.begin[size_t(src[i].query) + 1];
       for (int i = 0; i < nq; ++i)
-        nb->begin[size_t(i) + 1] += nb->begin[size_t(i)];
+        n.begin[size_t(i) + 1] += n.begin[size_t(i)];
+      n.radius.resize(size_t(found));
+      std::vector<int> cursor(n.begin.begin(), n.begin.end() - 1);
+      for (int i = 0; i < found; ++i)
+      {
+        // insertion into the query's (distance, index)-ordered run
+        const MatchNeighbour& e = src[i];
+        const int lo = n.begin[size_t(e.query)];
+        int at = cursor[size_t(e.query)]++;
+        while (at > lo && (n.radius[size_t(at - 1)].distance > e.distance ||
+                           (n.radius[size_t(at - 1)].distance == e.distance &&
+                            n.radius[size_t(at - 1)].index > e.index)))
+        {
+          n.radius[size_t(at)] = n.radius[size_t(at - 1)];
+          --at;
+        }
+        n.radius[size_t(at)] = e;
+      }
     }
     return SARA_HIP_OK;
   }
@@ -637,16 +758,17 @@ sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,
   else
   {
     const KeyProximity unused{0.f, 0.f};
-    Neighbours nb;
+    Neighbours nb[2];
+    const sara_hip_status hs = to_host(ws, ds, nb);
+    if (hs != SARA_HIP_OK)
+      return hs;
+    lap("to_host");
     for (int dir = 0; dir < 2; ++dir)
-    {
-      const sara_hip_status hs = to_host(ws, ds, dir, &nb);
-      if (hs != SARA_HIP_OK)
-        return hs;
-      append_matches(nb, thres2, dir, false, unused, nullptr, nullptr, m);
-    }
+      append_matches(nb[dir], thres2, dir, false, unused, nullptr, nullptr, m);
+    lap("append");
   }
   finish_matches(m, nullptr, nullptr);
+  lap("finish");
   return deliver(m, matches, capacity, count);
 }
 
@@ -694,10 +816,11 @@ sara_hip_status sara_hip_self_match_descriptors(
   const sara_hip_status ss = device_search(ws, d, n, d, n, dim, thres2, 1, true, &ds);
   if (ss != SARA_HIP_OK)
     return ss;
-  Neighbours nb;
-  const sara_hip_status hs = to_host(ws, ds, 0, &nb);
+  Neighbours nbs[2];
+  const sara_hip_status hs = to_host(ws, ds, nbs);
   if (hs != SARA_HIP_OK)
     return hs;
+  const Neighbours& nb = nbs[0];
   std::vector<sara_match> m;
   append_matches(nb, thres2, 0, true, too_close, f.data(), f.data(), m);
   append_matches(nb, thres2, 1, true, too_close, f.data(), f.data(), m);
