@@ -539,7 +539,33 @@ namespace {
                           std::string(#expr) + ": " + hipGetErrorString(e_))); \
   } while (0)
 
-    TRY_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    // SARA_HIP_CU_COUNT=n (experiment): the pipeline's streams may only use n
+    // of the 256 CUs (hipExtStreamCreateWithCUMask, every (256/n)-th CU
+    // pattern spread over the XCDs) - measures how each stage scales with CUs,
+    // which decides whether a CU-partitioned overlap of one batch's
+    // per-keypoint kernels with the next batch's pyramid can pay (DESIGN.md
+    // section 4, round 3).
+    static const int cu_count = [] {
+      const char* e = getenv("SARA_HIP_CU_COUNT");
+      return e ? std::max(8, std::min(256, atoi(e))) : 0;
+    }();
+    auto make_stream = [&](hipStream_t* st) -> hipError_t {
+      if (cu_count <= 0 || cu_count >= 256)
+        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      // Bresenham: cu_count bits set, evenly spaced over 256
+      for (int i = 0, acc = 0; i < 256; ++i)
+      {
+        acc += cu_count;
+        if (acc >= 256)
+        {
+          acc -= 256;
+          mask[i >> 5] |= 1u << (i & 31);
+        }
+      }
+      return hipExtStreamCreateWithCUMask(st, 8, mask);
+    };
+    TRY_HIP(make_stream(&c->own_stream));
     for (auto& r : c->launch_rec)
   {
     if (r.begin)
@@ -555,7 +581,7 @@ namespace {
       TRY_HIP(hipEventCreateWithFlags(&c->oct_done[o], hipEventDisableTiming));
       TRY_HIP(hipEventCreateWithFlags(&c->scan_done[o], hipEventDisableTiming));
       if (o > 0 && o < c->max_sched.num_octaves)
-        TRY_HIP(hipStreamCreateWithFlags(&c->oct_stream[o], hipStreamNonBlocking));
+        TRY_HIP(make_stream(&c->oct_stream[o]));
     }
     if (const char* e = getenv("SARA_HIP_STREAMS"))
       c->multi_stream = std::string(e) != "1";
@@ -563,7 +589,7 @@ namespace {
       c->side_gradient = std::string(e) != "0";
     if (const char* e = getenv("SARA_HIP_OCTAVE_PIPELINE"))
       c->octave_pipeline = std::string(e) != "0" ? 1 : 0;
-    TRY_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    TRY_HIP(make_stream(&c->aux_stream));
     for (int k = 0; k < 3; ++k)
     {
       TRY_HIP(hipStreamCreateWithFlags(&c->filler_stream[k], hipStreamNonBlocking));
