@@ -55,6 +55,8 @@ namespace sara_hip {
     constexpr int kQueue = 3072;       // LDS queue of the emit pass, in hits
     constexpr int kDStride = 129;      // floats per row of the distance tile
     constexpr float kGuard = 1.25f;    // slack on the error bound
+    constexpr int kFallbackSlots = 128;  // flagged queries whose distances are staged
+    constexpr int kFallbackParts = 8;    // workgroups per staged query
     constexpr float kUnit = 5.9604645e-8f;  // 2^-24
 
     using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -570,6 +572,28 @@ namespace sara_hip {
       }
     }
 
+    //! Round 3: the exact distances of the first kFallbackSlots flagged queries
+    //! to EVERY target, kFallbackParts workgroups per query, into `staged`
+    //! ([slot][nt]).  The fall-back kernel below then selects from them instead
+    //! of computing 4-5 distances per thread one after the other, twice (top-3
+    //! pass and radius pass): with 33 flagged queries of 8 600 it ran on 33
+    //! workgroups for 130 us per direction - a latency chain, not work.
+    __global__ __launch_bounds__(256) void fallback_distances_kernel(
+        const float* __restrict__ q, const float* __restrict__ t, int nt, int dim,
+        const int* __restrict__ flagged, const int* __restrict__ flagged_count,
+        float* __restrict__ staged)
+    {
+      const int n = min(*flagged_count, kFallbackSlots);
+      const int per = (nt + kFallbackParts - 1) / kFallbackParts;
+      for (int k = blockIdx.y; k < n; k += gridDim.y)
+      {
+        const float* qr = q + size_t(flagged[k]) * dim;
+        const int lo = blockIdx.x * per, hi = min(nt, lo + per);
+        for (int j = lo + threadIdx.x; j < hi; j += 256)
+          staged[size_t(k) * nt + j] = flann_l2_rows(qr, t + size_t(j) * dim, dim);
+      }
+    }
+
     //! Queries whose candidate slots overflowed: exhaustive search, one
     //! 1024-thread workgroup per query (a single wave per query spent 0.3 ms on
     //! its 67 dependent row reads per lane).
@@ -579,7 +603,7 @@ namespace sara_hip {
         const int* __restrict__ flagged_count, float squared_ratio_thres, int top1,
         float* __restrict__ top_d, int* __restrict__ top_i,
         MatchNeighbour* __restrict__ radius_out, int radius_cap,
-        int* __restrict__ radius_count)
+        int* __restrict__ radius_count, const float* __restrict__ staged)
     {
       __shared__ float s_d[1024 * 3];
       __shared__ int s_i[1024 * 3];
@@ -590,10 +614,14 @@ namespace sara_hip {
       {
         const int qi = flagged[k];
         const float* qr = q + size_t(qi) * dim;
+        // distances staged by fallback_distances_kernel (same function, same
+        // floats), or computed here for the queries beyond its slots
+        const float* sd = (staged && k < kFallbackSlots) ? staged + size_t(k) * nt : nullptr;
         float b[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
         int bi[3] = {INT_MAX, INT_MAX, INT_MAX};
         for (int j = tid; j < nt; j += 1024)
-          top3_insert_ordered(flann_l2_rows(qr, t + size_t(j) * dim, dim), j, b, bi);
+          top3_insert_ordered(sd ? sd[j] : flann_l2_rows(qr, t + size_t(j) * dim, dim), j,
+                              b, bi);
         for (int r = 0; r < 3; ++r)
         {
           s_d[tid * 3 + r] = b[r];
@@ -645,7 +673,7 @@ namespace sara_hip {
         if (squared_ratio_thres > 1.f && radius >= 0.f)
           for (int j = tid; j < nt; j += 1024)
           {
-            const float d = flann_l2_rows(qr, t + size_t(j) * dim, dim);
+            const float d = sd ? sd[j] : flann_l2_rows(qr, t + size_t(j) * dim, dim);
             if (d < radius)
             {
               const int o = atomicAdd(radius_count, 1);
@@ -680,7 +708,8 @@ namespace sara_hip {
   {
     const size_t tm = (size_t(n1) + kTile - 1) / kTile, tn = (size_t(n2) + kTile - 1) / kTile;
     // norms (n1 + n2 + 2), tau (n1 + n2), row minima [tn][n1][3], column minima [tm][n2][3]
-    return 2 * (size_t(n1) + n2) + 16 + 3 * (tn * n1 + tm * n2);
+    return 2 * (size_t(n1) + n2) + 16 + 3 * (tn * n1 + tm * n2) +
+           size_t(kFallbackSlots) * size_t(std::max(n1, n2));  // staged distances
   }
 
   size_t match_mfma_scratch_ints(int n1, int n2, int cap)
@@ -711,6 +740,7 @@ namespace sara_hip {
     float* tau_c = tau_r + n1;
     float* rowmin = tau_c + n2;
     float* colmin = rowmin + 3 * size_t(tn) * n1;
+    float* staged = colmin + 3 * size_t(tm) * n2;  // [kFallbackSlots][max(n1, n2)]
     int* cnt_r = iscratch;
     int* cnt_c = cnt_r + n1;
     int* scal = cnt_c + n2;  // [0] flagged rows, [1] flagged columns
@@ -786,9 +816,18 @@ namespace sara_hip {
         hipLaunchKernelGGL(rerank_kernel<32>, g, dim3(256), 0, stream, q, nq, t, dim,
                            cand, cnt, squared_ratio_thres, top1, td, ti, ro, rcap,
                            rcount, flagged, fcount);
+      // (the two directions share `staged`: they run one after the other)
+      // staged only for the radius search, where overflowing queries are the
+      // rule (ratio <= 1: a handful of candidates per query, no query flagged
+      // on the benchmark pair - not worth a launch)
+      const bool stage = squared_ratio_thres > 1.f;
+      if (stage)
+        hipLaunchKernelGGL(fallback_distances_kernel,
+                           dim3(kFallbackParts, std::min(nq, kFallbackSlots)), dim3(256),
+                           0, stream, q, t, nt, dim, flagged, fcount, staged);
       hipLaunchKernelGGL(fallback_kernel, dim3(std::min(nq, 256)), dim3(1024), 0, stream,
                          q, nq, t, nt, dim, flagged, fcount, squared_ratio_thres,
-                         top1, td, ti, ro, rcap, rcount);
+                         top1, td, ti, ro, rcap, rcount, stage ? staged : nullptr);
     };
     rerank(d1, n1, d2, n2, cand_r, cnt_r, top12_d, top12_i, radius12, radius12_cap,
            radius12_count, flag_r, scal);
