@@ -4,8 +4,8 @@ R=$GRAFT_REPO_ROOT
 D=$R/gpurun_out/prof
 mkdir -p $D
 cd $R
-env "$@" rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $D -o h2h -- python tools/h2h_notorch.py f32only > $D/h2h.log 2>&1
-grep "host ->" $D/h2h.log
+env "$@" rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $D -o h2h -- python tools/h2h_notorch.py --kinds f32 > $D/h2h.log 2>&1
+grep "per .*step" $D/h2h.log
 python - <<'PY'
 import csv, os
 D = os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/prof"
