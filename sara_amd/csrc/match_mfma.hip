@@ -27,6 +27,10 @@
 //   tau_r = (m_top1 + E) thres^2 (1 + 1e-4) + E
 // it contains every j with d_f(j) < d_f(top1) * thres^2 (the radius search).
 //
+// Round 3: for ratios <= 1 the two passes over the tiles below are ONE
+// (kPacked / select_packed_kernel: minima kept with their positions); the
+// radius search keeps both.
+//
 // Pipeline (one stream, no host round trip inside):
 //   row_norms                |a_i|^2, |b_j|^2, their maxima
 //   mfma_tiles<MINIMA>       128 x 128 tiles: 3 smallest approximations of every
@@ -151,8 +155,36 @@ namespace sara_hip {
     enum
     {
       kMinima = 0,
-      kEmit = 1
+      kEmit = 1,
+      kPacked = 2  // round 3: minima WITH their column / row, one pass (ratios <= 1)
     };
+
+    // ---- packed minima (kPacked) ------------------------------------------------
+    // An approximate distance and the position of its column inside the tile in
+    // one 32-bit key that orders like the distance: the float's bits mapped to a
+    // monotone integer, the low 7 bits replaced by the position.  The value read
+    // back from a key is <= the approximation and within 2^-16 of it (relative).
+    __device__ inline int ordered_bits(float v)
+    {
+      const int b = __float_as_int(v);
+      return b ^ ((b >> 31) & 0x7fffffff);
+    }
+    __device__ inline float from_ordered_bits(int o)
+    {
+      return __int_as_float(o ^ ((o >> 31) & 0x7fffffff));
+    }
+    constexpr int kNoKey = 0x7f7fff80;  // keys of +inf / FLT_MAX sums: padding
+    __device__ inline int med3i(int a, int b, int c)
+    {
+      return max(min(a, b), min(max(a, b), c));
+    }
+    __device__ inline void min4_update(int v, int& k1, int& k2, int& k3, int& k4)
+    {
+      k4 = med3i(k3, k4, v);
+      k3 = med3i(k2, k3, v);
+      k2 = med3i(k1, k2, v);
+      k1 = min(k1, v);
+    }
 
     //! One 128 x 128 tile of approximate squared distances between rows
     //! [row0, row0 + 128) of A and [col0, col0 + 128) of B.  256 threads = 4
@@ -337,7 +369,44 @@ namespace sara_hip {
         return wm * 64 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       };
 
-      if (MODE == kMinima)
+      if (MODE == kPacked)
+      {
+        float* sD = lds;  // [128][129]
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+        {
+          const int r0 = row_of(0, r), r1 = row_of(1, r);
+          const float n0 = sNa[r0], n1r = sNa[r1];
+          sD[r0 * kDStride + colA] = approx(n0, nbA, acc00[r]);
+          sD[r0 * kDStride + colB] = approx(n0, nbB, acc01[r]);
+          sD[r1 * kDStride + colA] = approx(n1r, nbA, acc10[r]);
+          sD[r1 * kDStride + colB] = approx(n1r, nbB, acc11[r]);
+        }
+        __syncthreads();
+        int k1 = INT_MAX, k2 = INT_MAX, k3 = INT_MAX, k4 = INT_MAX;
+        if (tid < kTile)
+        {
+          const float* p = sD + tid * kDStride;
+#pragma unroll 16
+          for (int c = 0; c < kTile; ++c)
+            min4_update((ordered_bits(p[c]) & ~127) | c, k1, k2, k3, k4);
+          if (row0 + tid < n1)
+            reinterpret_cast<int4*>(rowmin)[size_t(blockIdx.x) * n1 + row0 + tid] =
+                make_int4(k1, k2, k3, k4);
+        }
+        else if (with_cols)
+        {
+          const int c = tid - kTile;
+          const float* p = sD + c;
+#pragma unroll 16
+          for (int r = 0; r < kTile; ++r)
+            min4_update((ordered_bits(p[r * kDStride]) & ~127) | r, k1, k2, k3, k4);
+          if (col0 + c < n2)
+            reinterpret_cast<int4*>(colmin)[size_t(blockIdx.y) * n2 + col0 + c] =
+                make_int4(k1, k2, k3, k4);
+        }
+      }
+      else if (MODE == kMinima)
       {
         float* sD = lds;  // [128][129]
 #pragma unroll
@@ -482,6 +551,84 @@ namespace sara_hip {
         t = fmaxf(t, r + fabsf(r) * 1e-4f + e);
       }
       tau[i] = t;
+    }
+
+    //! kPacked: the candidates of every query straight from the tiles' four
+    //! smallest keys.  m3 = third smallest value over all tiles (read back from
+    //! the keys: <= the true third smallest approximation, within 2^-16), tau =
+    //! m3 + 2e-4 |m3| + 2.01 E >= the tau of thresholds_kernel, and a key passes
+    //! when its value is <= tau - every approximation <= tau does, because a
+    //! key's value never exceeds its approximation.  A tile lists all of its
+    //! entries below tau unless its FOURTH key passes too: then a fifth might,
+    //! and the query is handed to the exhaustive fall-back (count > cap).
+    //! 16 lanes per query (a thread per query walked the 34 tiles of a 4.3 k set
+    //! twice, 68 dependent-latency loads on 17 workgroups: 23 us per direction):
+    //! a lane takes the tiles t = lane, lane + 16, ..; the three smallest keys
+    //! are merged across the 16 lanes by xor shuffles, every lane then emits
+    //! the passing keys of its own tiles (slots claimed with atomicAdd on the
+    //! query's counter, which the launch zeroes).
+    __global__ __launch_bounds__(256) void select_packed_kernel(
+        const int4* __restrict__ partial, int ntiles, int n,
+        const float* __restrict__ norms, const unsigned* __restrict__ other_max_bits,
+        int dim, int cap, int* __restrict__ cand, int* __restrict__ cnt)
+    {
+      const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+      const int i = gid >> 4, sub = gid & 15;
+      const bool live = i < n;
+      int m1 = INT_MAX, m2 = INT_MAX, m3 = INT_MAX;
+      auto take = [&](int v) {
+        m3 = med3i(m2, m3, v);
+        m2 = med3i(m1, m2, v);
+        m1 = min(m1, v);
+      };
+      if (live)
+        for (int t = sub; t < ntiles; t += 16)
+        {
+          const int4 k = partial[size_t(t) * n + i];
+          if (k.x < kNoKey) take(k.x);
+          if (k.y < kNoKey) take(k.y);
+          if (k.z < kNoKey) take(k.z);
+          if (k.w < kNoKey) take(k.w);
+        }
+      // the three smallest of the 16 lanes' triples (all 16 lanes of a group
+      // are in one wave and take part, live or not)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1)
+      {
+        const int a = __shfl_xor(m1, o), b = __shfl_xor(m2, o), c = __shfl_xor(m3, o);
+        take(a);
+        take(b);
+        take(c);
+      }
+      if (!live)
+        return;
+      const float e = kGuard * float(2 * dim + 8) * kUnit *
+                      (norms[i] + __uint_as_float(*other_max_bits));
+      int tau_key = kNoKey - 1;  // fewer than three candidates: everything passes
+      if (m3 != INT_MAX)
+      {
+        const float m = from_ordered_bits(m3 & ~127);
+        const float tau = m + fabsf(m) * 2e-4f + 2.01f * e;
+        if (tau < FLT_MAX)
+          tau_key = min(ordered_bits(tau) | 127, kNoKey - 1);
+      }
+      for (int t = sub; t < ntiles; t += 16)
+      {
+        const int4 k = partial[size_t(t) * n + i];
+        const int v[4] = {k.x, k.y, k.z, k.w};
+        int pass = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          pass += v[r] <= tau_key ? 1 : 0;  // the keys of a tile are ascending
+        if (pass == 0)
+          continue;
+        // a passing fourth key: a fifth entry of the tile might pass as well
+        const int claim = pass == 4 ? cap + 1 : pass;
+        const int at = atomicAdd(cnt + i, claim);
+        for (int r = 0; r < pass && r < 3; ++r)
+          if (at + r < cap)
+            cand[size_t(i) * cap + at + r] = t * kTile + (v[r] & 127);
+      }
     }
 
     //! Exact distances of every query's candidate slots; CAP lanes per query.
@@ -708,7 +855,7 @@ namespace sara_hip {
   {
     const size_t tm = (size_t(n1) + kTile - 1) / kTile, tn = (size_t(n2) + kTile - 1) / kTile;
     // norms (n1 + n2 + 2), tau (n1 + n2), row minima [tn][n1][3], column minima [tm][n2][3]
-    return 2 * (size_t(n1) + n2) + 16 + 3 * (tn * n1 + tm * n2) +
+    return 2 * (size_t(n1) + n2) + 16 + 4 * (tn * n1 + tm * n2) + 8 +
            size_t(kFallbackSlots) * size_t(std::max(n1, n2));  // staged distances
   }
 
@@ -738,9 +885,11 @@ namespace sara_hip {
     unsigned* maxbits = reinterpret_cast<unsigned*>(nb + n2);  // [0] of A, [1] of B
     float* tau_r = nb + n2 + 16;
     float* tau_c = tau_r + n1;
+    // minima: [tiles][n][3] floats, or [tiles][n] int4 keys (16-byte aligned)
     float* rowmin = tau_c + n2;
-    float* colmin = rowmin + 3 * size_t(tn) * n1;
-    float* staged = colmin + 3 * size_t(tm) * n2;  // [kFallbackSlots][max(n1, n2)]
+    rowmin += (4 - ((rowmin - fscratch) & 3)) & 3;
+    float* colmin = rowmin + 4 * size_t(tn) * n1;
+    float* staged = colmin + 4 * size_t(tm) * n2;  // [kFallbackSlots][max(n1, n2)]
     int* cnt_r = iscratch;
     int* cnt_c = cnt_r + n1;
     int* scal = cnt_c + n2;  // [0] flagged rows, [1] flagged columns
@@ -783,6 +932,37 @@ namespace sara_hip {
       return e ? atoi(e) : 0;
     }();
     const int cols_arg = (with_dir1 ? 1 : 0) | (skip << 8);
+    // Round 3, ratios <= 1 (only the three nearest neighbours matter): ONE pass
+    // over the tiles that keeps, per row and column of a tile, the four smallest
+    // approximations together with where they are (kPacked), and the candidates
+    // are picked from those lists - the second contraction (emit, 82 us of the
+    // 0.28 ms per 4.3 k x 4.3 k pair) is gone.  SARA_HIP_MATCH_PASSES=2 keeps the
+    // two passes; the radius search (ratios > 1) always takes them: a tile can
+    // hold any number of radius members.
+    static const bool two_passes_env = [] {
+      const char* e = getenv("SARA_HIP_MATCH_PASSES");
+      return e && atoi(e) == 2;
+    }();
+    const bool one_pass = !(squared_ratio_thres > 1.f) && top1 == 0 && !two_passes_env;
+    if (one_pass)
+    {
+      allow_big_lds<kPacked>(mfma_tiles_kernel<kPacked>);
+      hipLaunchKernelGGL(mfma_tiles_kernel<kPacked>, grid, dim3(256), lds, stream, d1,
+                         n1, d2, n2, dim, na, nb, rowmin, colmin, nullptr, nullptr,
+                         nullptr, nullptr, nullptr, nullptr, cap, cols_arg);
+      tick();  // 2: minima
+      hipLaunchKernelGGL(select_packed_kernel, dim3((n1 + 15) / 16), dim3(256), 0,
+                         stream, reinterpret_cast<const int4*>(rowmin), tn, n1, na,
+                         maxbits + 1, dim, cap, cand_r, cnt_r);
+      if (with_dir1)
+        hipLaunchKernelGGL(select_packed_kernel, dim3((n2 + 15) / 16), dim3(256), 0,
+                           stream, reinterpret_cast<const int4*>(colmin), tm, n2, nb,
+                           maxbits, dim, cap, cand_c, cnt_c);
+      tick();  // 3: thresholds
+      tick();  // 4: emit (none)
+    }
+    else
+    {
     hipLaunchKernelGGL(mfma_tiles_kernel<kMinima>, grid, dim3(256), lds, stream, d1,
                        n1, d2, n2, dim, na, nb, rowmin, colmin, nullptr, nullptr,
                        nullptr, nullptr, nullptr, nullptr, cap, cols_arg);
@@ -799,6 +979,7 @@ namespace sara_hip {
                        d2, n2, dim, na, nb, nullptr, nullptr, tau_r, tau_c, cand_r,
                        cnt_r, cand_c, cnt_c, cap, cols_arg);
     tick();  // 4: emit
+    }
     auto rerank = [&](const float* q, int nq, const float* t, int nt, const int* cand,
                       const int* cnt, float* td, int* ti, MatchNeighbour* ro, int rcap,
                       int* rcount, int* flagged, int* fcount) {

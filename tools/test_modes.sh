@@ -11,7 +11,7 @@ for mode in "A=1" "SARA_HIP_GRAPH=0" "SARA_HIP_STREAMS=1" "SARA_HIP_RANK=count" 
   env $mode python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_operators.py tests/test_gpu_full_size.py -m gpu -x -q 2>&1 | tail -1
 done
 # the two producers of the matcher's neighbour lists, forced for every size
-for mode in "SARA_HIP_MATCH=mfma" "SARA_HIP_MATCH=exhaustive"; do
+for mode in "SARA_HIP_MATCH=mfma" "SARA_HIP_MATCH=exhaustive" "SARA_HIP_MATCH=mfma SARA_HIP_MATCH_PASSES=2"; do
   echo "== $mode"
   env $mode python -m pytest tests/test_gpu_matching.py tests/test_gpu_cpp_shim.py -m gpu -x -q 2>&1 | tail -1
 done
