@@ -510,6 +510,10 @@ SARA_HIP_API sara_hip_status sara_hip_match_release_workspace(int device);
 /* - on the device - until the first blur of the batch that used its buffer has */
 /* read the frames).  With float32 frames, whose upload is longer than the       */
 /* kernels, the step is then the upload alone instead of kernels + read-back.    */
+/* From HIP runtime 7.2 on stage() first waits (on the host) for the upload      */
+/* staged before it: one upload at a time on the copy engines keeps an engine    */
+/* free for the read-back (9.4 ms per 64 x 1080p float frames in every process;  */
+/* SARA_HIP_STAGE_WAIT=0 / 1 overrides).                    */
 /* collect() blocks until the batch of `ticket` is in pinned host memory owned  */
 /* by the context and returns pointers into it.  features / descriptors /       */
 /* scale_octave AND frame_offsets all live in the ticket's ring slot: they stay */

@@ -2130,6 +2130,48 @@ sara_hip_status sara_hip_sift_detect_u8(sara_hip_sift* c, const uint8_t* images,
   return st;
 }
 
+namespace {
+  //! The read-back stream.  SARA_HIP_D2H_FIRST=1 (experiment, off) also makes
+  //! it copy 8 MB device -> host right away, i.e. before the upload stream's
+  //! first copy - a guess at how the runtime binds streams to copy engines
+  //! that did not hold: the float32 host -> host step got worse under the 7.0.2
+  //! runtime (9.3 -> 12.6 ms) and no more predictable under 7.2.
+  sara_hip_status ensure_d2h_stream(sara_hip_sift* c)
+  {
+    if (c->d2h_stream)
+      return SARA_HIP_OK;
+    // highest priority: the read-back kernel's few workgroups should not
+    // queue behind the next batch's launches
+    int lo = 0, hi = 0;
+    std::lock_guard<std::recursive_mutex> runtime_lock(runtime_mutex());
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(hipStreamCreateWithPriority(&c->d2h_stream, hipStreamNonBlocking, hi));
+    static const bool first = [] {
+      const char* e = getenv("SARA_HIP_D2H_FIRST");
+      return e && e[0] == '1';
+    }();
+    if (first && c->d_input)
+    {
+      // a copy large enough to go through a copy engine (small ones do not)
+      static const size_t prime_bytes = [] {
+        const char* e = getenv("SARA_HIP_D2H_PRIME_BYTES");
+        return e ? size_t(atoll(e)) : size_t(8) << 20;
+      }();
+      const size_t bytes = std::min(prime_bytes, size_t(c->max_w) * c->max_h *
+                                                     sizeof(float) * c->max_batch);
+      void* tmp = nullptr;
+      HIP_TRY(hipHostMalloc(&tmp, bytes));
+      const hipError_t e1 = hipMemcpyAsync(tmp, c->d_input, bytes,
+                                           hipMemcpyDeviceToHost, c->d2h_stream);
+      const hipError_t e2 = hipStreamSynchronize(c->d2h_stream);
+      (void) hipHostFree(tmp);
+      HIP_TRY(e1);
+      HIP_TRY(e2);
+    }
+    return SARA_HIP_OK;
+  }
+}  // namespace
+
 sara_hip_status sara_hip_sift_stage(sara_hip_sift* c, const void* images,
                                     size_t frame_stride, int channels, int batch,
                                     int width, int height)
@@ -2157,6 +2199,9 @@ sara_hip_status sara_hip_sift_stage(sara_hip_sift* c, const void* images,
   HIP_TRY(hipSetDevice(c->device));
   if (!c->copy_stream)
   {
+    const sara_hip_status ds = ensure_d2h_stream(c);  // before the first upload
+    if (ds != SARA_HIP_OK)
+      return ds;
     std::lock_guard<std::recursive_mutex> runtime_lock(runtime_mutex());
     HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (int k = 0; k < 2; ++k)
@@ -2172,6 +2217,23 @@ sara_hip_status sara_hip_sift_stage(sara_hip_sift* c, const void* images,
     }
   }
   const int k = c->stage_next;
+  // The host waits here for the upload BEFORE this one, so that never more
+  // than one upload is bound to a copy engine when the read-back of an older
+  // batch asks for one.  Measured with stage(i + 1); collect(i - 1);
+  // submit_staged(i + 1) on 64 x 1080p float32 frames:
+  // under the ROCm 7.2 runtime 9.4 ms per step in every process with the wait,
+  // 8.9 or 12.4 ms without (which of the two depends on what the process
+  // copied first); under the 7.0.2 runtime (the one inside the torch wheel)
+  // 12.5 ms with the wait and 9.2-9.4 ms without.  Hence the default follows
+  // the runtime's version; SARA_HIP_STAGE_WAIT=0 / 1 forces it.
+  static const bool stage_wait = [] {
+    if (const char* e = getenv("SARA_HIP_STAGE_WAIT"))
+      return e[0] == '1';
+    int v = 0;
+    return hipRuntimeGetVersion(&v) == hipSuccess && v >= 70200000;
+  }();
+  if (stage_wait)
+    HIP_TRY(hipStreamSynchronize(c->copy_stream));
   // the pipeline that last read this buffer must be done with it
   if (c->stage_used[k])
     HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->stage_free[k], 0));
@@ -2338,14 +2400,10 @@ sara_hip_status submit_impl(sara_hip_sift* c, const void* images,
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r.h_counters),
                           sizeof(int) * (4 * size_t(c->max_batch) + 1)));
   }
-  if (!c->d2h_stream)
   {
-    // highest priority: the read-back kernel's few workgroups should not
-    // queue behind the next batch's launches
-    int lo = 0, hi = 0;
-    std::lock_guard<std::recursive_mutex> runtime_lock(runtime_mutex());
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIP_TRY(hipStreamCreateWithPriority(&c->d2h_stream, hipStreamNonBlocking, hi));
+    const sara_hip_status ds = ensure_d2h_stream(c);
+    if (ds != SARA_HIP_OK)
+      return ds;
   }
   sara_hip_status st = select_result_slot(c, slot);
   if (st != SARA_HIP_OK)

@@ -28,6 +28,8 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--octaves", type=int, default=4)
 ap.add_argument("--unique", type=int, default=16)
 ap.add_argument("--torch-pinned", action="store_true")
+ap.add_argument("--stage-first-first", action="store_true",
+                help="measure the stage-first order before the submit-first one")
 ap.add_argument("--registered", action="store_true",
                 help="frames in hipHostRegister'ed memory instead of hipHostMalloc")
 args = ap.parse_args()
@@ -91,8 +93,12 @@ out = {"runtime": [l.split()[-1] for l in open("/proc/self/maps")
                    if "libamdhip64" in l][:1]}
 for kind in args.kinds.split(","):
     name = {"f32": "float32", "u8": "gray8"}[kind]
-    a, kpa = run(kind, False, args.steps)
-    b, kpb = run(kind, True, args.steps)
+    if args.stage_first_first:
+        b, kpb = run(kind, True, args.steps)
+        a, kpa = run(kind, False, args.steps)
+    else:
+        a, kpa = run(kind, False, args.steps)
+        b, kpb = run(kind, True, args.steps)
     out[name] = {"ms_per_step": min(a, b), "keypoints_per_s": 1e3 * kpa / min(a, b),
                  "ms_submit_then_collect": a, "ms_stage_collect_submit_staged": b}
     if not args.json:
