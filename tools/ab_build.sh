@@ -13,7 +13,7 @@ files="$*"
 flags="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -fvisibility=hidden $extra"
 mkdir -p ../lib/ab /tmp/ab_$name
 objs=""
-for f in pyramid_kernels.hip feature_kernels.hip match_kernels.hip sift_context.cpp sift_comm.cpp; do
+for f in pyramid_kernels.hip feature_kernels.hip match_kernels.hip match_mfma.hip sift_context.cpp sift_comm.cpp sift_match.cpp; do
   o=${f%.*}.o
   if echo " $files " | grep -q " $f "; then
     x=""; [ "$f" = match_kernels.hip ] && x="-fno-slp-vectorize"
