@@ -386,14 +386,18 @@ def match_config(torch, dev):
     # exact arithmetic of the exhaustive search: n1*n2*128 (sub, mul, add) per
     # direction; the prefilter path does one n1*n2*128 f32 MFMA contraction
     out["pair_distance_terms"] = 2 * n1 * n2 * 128
-    # the prefilter's two MFMA passes: 2 x (2 n1 n2 128) flop against the f32
-    # MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md (157.3 TF)
-    flop = 2 * 2.0 * n1 * n2 * 128
-    out["mfma_flop_per_pair"] = flop
-    out["mfma_time_at_peak_us"] = flop / 157.3e12 * 1e6
+    # one pass over the n1 x n2 tiles = 2 n1 n2 128 flop on the matrix cores
+    # (ratios <= 1: one pass; the radius search of ratios > 1: two), against the
+    # f32 MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md (157.3 TF)
+    flop = 2.0 * n1 * n2 * 128
+    out["mfma_flop_per_pass"] = flop
+    out["mfma_passes"] = {"ratio_0.6": 1, "ratio_1.2_default": 2}
+    out["mfma_time_at_peak_us_per_pass"] = flop / 157.3e12 * 1e6
     out["producer"] = ("MFMA prefilter (v_mfma_f32_32x32x2_f32, both directions from "
-                       "one contraction, rigorous error guard) + exact FLANN-order "
-                       "re-ranking; identical lists to the exhaustive search")
+                       "one contraction, rigorous error guard; tile minima carry "
+                       "their position, so ratios <= 1 need one pass) + exact "
+                       "FLANN-order re-ranking; identical lists to the exhaustive "
+                       "search")
     return out
 
 
