@@ -223,11 +223,11 @@ int main(int argc, char** argv)
           SARA_HIP_OK)
         return 17;
       const auto t2 = clk::now();
-      auto feats = std::vector<sara::OERegion>(size_t(total));
+      // as compute_sift_keypoints() fills them: one pass, no value-initialisation
+      const sara::OERegion* fr = reinterpret_cast<const sara::OERegion*>(pf);
+      auto feats = std::vector<sara::OERegion>(fr, fr + total);
       auto desc = sara::Tensor_<float, 2>{};
-      desc.resize(total, 128);
-      std::memcpy(static_cast<void*>(feats.data()), pf, sizeof(sara_oeregion) * size_t(total));
-      std::memcpy(desc.data(), pd, sizeof(float) * 128 * size_t(total));
+      desc.assign(pd, total, 128);
       const auto t3 = clk::now();
       ms_submit += std::chrono::duration<double, std::milli>(t1 - t0).count() / reps;
       ms_collect += std::chrono::duration<double, std::milli>(t2 - t1).count() / reps;
