@@ -443,6 +443,10 @@ def secondary_configs(args, torch, dev):
 
             pin[name] = timed(step, 200, 20)
             c1.collect(state["t"])
+            # the latency of one call when the frame is decoded into pinned memory
+            pin[name + "_latency"] = timed(
+                lambda pa=pa, ch=ch: c1.collect(c1.submit_raw(pa.ctypes.data, ch, 1, W, H)),
+                100, 10)
             del pa
     out["config2"] = {
         "workload": "1 x 1920x1080, pyramid + DoG + extrema only (stage 2), "
@@ -459,6 +463,8 @@ def secondary_configs(args, torch, dev):
         "ms_hbm_resident": 1e3 * t5,
         "ms_host_float32_to_host": 1e3 * h2h,
         "ms_host_gray8_to_host": 1e3 * h2h8,
+        "ms_host_float32_pinned_to_host": 1e3 * pin["float32_latency"],
+        "ms_host_gray8_pinned_to_host": 1e3 * pin["gray8_latency"],
         "ms_per_frame_two_in_flight_float32": 1e3 * pin["float32"],
         "ms_per_frame_two_in_flight_gray8": 1e3 * pin["gray8"],
         "two_in_flight": "submit(frame i+1) before collect(frame i), pinned host "
