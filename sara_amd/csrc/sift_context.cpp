@@ -1119,6 +1119,20 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   const bool graph_mode = c->use_graph && !c->graph_broken && !hip_stream &&
                           graph_thread_ok() &&
                           batch <= c->graph_max_batch && !debug_sync;
+  // Small images under graph replay: everything on ONE stream.  A graph captured
+  // from one stream is submitted in ~15 us whatever its length, a forked one
+  // costs the host 3.3 us per node (tools/ubench/graph_launch_cost.hip); when
+  // the kernels are so small that the call is the host's enqueue time anyway,
+  // running them one after the other is faster than running them side by side
+  // late.  SARA_HIP_LINEAR_GRAPH_PIXELS (pixels x batch; 0 = never).
+  static const long long linear_pixels = [] {
+    const char* e = getenv("SARA_HIP_LINEAR_GRAPH_PIXELS");
+    return e ? atoll(e) : 0ll;
+  }();
+  const bool linear_graph =
+      graph_mode && (long long) width * height * batch <= linear_pixels;
+  const bool multi_stream = c->multi_stream && !linear_graph;
+  const bool side_gradient = c->side_gradient && !linear_graph;
   const bool timing = c->timers && !graph_mode;
   // 8-bit gray frames not converted yet (detect_u8): the first blur of the
   // pyramid reads them directly when it is the marching blur of octave 0 and
@@ -1240,11 +1254,11 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   auto enqueue = [&]() -> sara_hip_status {
 
   const bool want_gradients = last_stage >= SARA_HIP_STAGE_GRADIENT;
-  const bool side = c->side_gradient && want_gradients && !fuse_gradient_env &&
+  const bool side = side_gradient && want_gradients && !fuse_gradient_env &&
                     !debug_sync;
   // see SiftContext::octave_pipeline
   const bool pipe = seg_phase >= 0 ||
-                    (c->multi_stream && sc.num_octaves > 1 &&
+                    (multi_stream && sc.num_octaves > 1 &&
                      last_stage >= SARA_HIP_STAGE_EXTREMA && !fuse_gradient_env &&
                      !debug_sync && (!want_gradients || side) &&
                      (c->octave_pipeline < 0 ? graph_mode : c->octave_pipeline != 0));
@@ -1382,7 +1396,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
 
     // Octave o+1 starts from G(downscale_index, o): its chain runs on its
     // own stream as soon as that plane exists and is joined at the end.
-    const bool ms = c->multi_stream && sc.num_octaves > 1;
+    const bool ms = multi_stream && sc.num_octaves > 1;
     const int dsi = sc.downscale_index;
     const int last = sc.num_octaves - 1;
     bool base_ready = true;  // G(0, o) already written by the previous octave

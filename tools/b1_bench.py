@@ -1,6 +1,6 @@
 """Developer probe: the numbers bench.py reports as config2 / single_image (one
 1080p frame per call, HIP-graph replay), without the rest of the benchmark.
-   python tools/b1_bench.py [repeats]"""
+   python tools/b1_bench.py [repeats [width height]]"""
 import os
 import sys
 import time
@@ -22,7 +22,8 @@ def timed(fn, n, warm):
     return (time.perf_counter() - t) / n
 
 
-W, H = 1920, 1080
+W = int(sys.argv[2]) if len(sys.argv) > 3 else 1920
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
 dev = torch.device("cuda:0")
 one = synth_batch(W, H, 1)
 d_one = torch.from_numpy(one).to(dev)
