@@ -50,6 +50,13 @@ def parse():
                          "(0 = skip)")
     ap.add_argument("--stage", type=int, default=5,
                     help="last pipeline stage (5 = full SIFT)")
+    ap.add_argument("--launch", choices=("auto", "procs", "group"), default="auto",
+                    help="N > 1 without a launcher (WORLD_SIZE unset): 'procs' "
+                         "re-executes this script under torch.distributed.run, one "
+                         "process per GPU; 'group' drives all GPUs from this one "
+                         "process (sara_hip_sift_group_*, the C++ caller's form); "
+                         "'auto' = procs when the box has >= N devices, else group "
+                         "over the loopback test transport (said so in the line)")
     return ap.parse_args()
 
 
@@ -645,16 +652,178 @@ def host_to_host_multi(ctx, frames_host, args, torch, dist, rank, world, kp_hint
                           "PCIe link; counts over gloo"}
 
 
+def rccl_version_string():
+    import ctypes as C
+    from sara_amd import capi
+    v = C.c_int(0)
+    if capi.load().sara_hip_rccl_version(C.byref(v)) != 0 or v.value <= 0:
+        return None
+    return "%d.%d.%d" % (v.value // 10000, v.value // 100 % 100, v.value % 100)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_procs(args):
+    """`python bench.py --gpus N` without a launcher: the same script again under
+    torch.distributed.run, one process per GPU on this node (what the driver's
+    own N > 1 command does).  Its rank 0 prints the line; the exit code is
+    passed on."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+        "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.stderr.write("bench: --gpus %d without WORLD_SIZE: %s\n" %
+                     (args.gpus, " ".join(cmd)))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def run_group(args, ndev):
+    """N GPUs driven by THIS process: sara_hip_sift_group_* (one host thread and
+    one context per device, ncclCommInitAll, frames sharded in contiguous
+    blocks, gatherv to device 0) - the form a C++ caller of Sara uses, no
+    launcher and no torch.distributed.  On a box with fewer devices than N the
+    ranks share the devices and the exchange runs over the library's loopback
+    test transport; the line then says so (transport / parallelism) - that is a
+    plumbing check, not a scaling measurement."""
+    import ctypes as C
+    import hashlib
+    import torch
+    import sara_amd
+    from sara_amd import capi
+    from sara_amd.distributed import SiftGroup
+    from sara_amd.synth import synth_batch
+
+    N, B, W, H = args.gpus, args.frames_per_gpu, args.width, args.height
+    loopback = N > ndev
+    if loopback:
+        os.environ["SARA_HIP_COMM_TRANSPORT"] = "loopback"
+        sys.stderr.write(
+            "bench: --gpus %d on a box with %d device(s): the %d ranks share the "
+            "device(s) and the gather runs over the LOOPBACK test transport, not "
+            "RCCL\n" % (N, ndev, N))
+    elif os.environ.get("SARA_HIP_COMM_TRANSPORT") == "loopback":
+        raise SystemExit("SARA_HIP_COMM_TRANSPORT=loopback is set although the box "
+                         "has %d >= %d devices: refusing to report a loopback run "
+                         "as an RCCL one" % (ndev, N))
+    devices = [i % ndev for i in range(N)]
+    params = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=args.octaves)
+    # create() fails loudly (non-zero exit) when RCCL cannot form the group
+    group = SiftGroup(W, H, B, params, n_dev=N, devices=devices)
+    transport = group.transport
+    if transport != ("loopback" if loopback else "rccl"):
+        raise SystemExit("group transport is %r" % transport)
+    lib = capi.load()
+    frames_host = [synth_batch(W, H, B, first_index=r * B,
+                               unique=args.unique_frames or None) for r in range(N)]
+    frames = [torch.from_numpy(f).to(torch.device("cuda", devices[r]))
+              for r, f in enumerate(frames_host)]
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    ptrs = (C.c_void_p * N)(*[f.data_ptr() for f in frames])
+    batch = (C.c_int * N)(*([B] * N))
+
+    def step():
+        capi.check(lib.sara_hip_sift_group_detect(
+            group._h, ptrs, batch, 0, 0, W, H, 1, int(args.stage)))
+        res = group.gather(root=0, with_descriptors=args.stage >= 5)
+        return res
+
+    for _ in range(args.warmup):
+        step()
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    kp_total = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kp_total += step().total       # gather() returns with the root's arrays complete
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    elapsed = time.perf_counter() - t0
+
+    # outside the timed region: the bytes on the root against every rank's own
+    # detect() + fetch() (the pipeline is deterministic)
+    res = step()
+    f, dsc, so = res.host()
+    at, verified = 0, args.stage >= 5
+    for r in range(N if args.stage >= 5 else 0):
+        with sara_amd.SiftContext(W, H, B, params, device=devices[r]) as c:
+            c.detect_device(frames[r].data_ptr(), B, W, H, last_stage=5)
+            _, reg, desc, rso = c.fetch()
+        n = len(reg)
+        same = (res.counts[r] == n and
+                f[at:at + n].tobytes() == reg.tobytes() and
+                dsc[at:at + n].tobytes() == desc.tobytes() and
+                so[at:at + n].tobytes() == rso.tobytes())
+        if not same:
+            raise SystemExit("gather: the bytes of rank %d on the root differ from "
+                             "what it computed" % r)
+        at += n
+    steps = max(args.steps, 1)
+    out = {
+        "metric": "SIFT keypoints/sec @1080p (4 octaves, 3 scales/oct); 1/2/4/8 GPU",
+        "value": kp_total / elapsed, "unit": "keypoints/s", "n_gpus": N,
+        "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "transport": transport, "rccl_nranks": N if transport == "rccl" else 0,
+        "rccl_version": rccl_version_string() if transport == "rccl" else None,
+        "gather_verified": bool(verified),
+        "launch": "one process, one host thread per GPU (sara_hip_sift_group_*)",
+        "value_definition": (
+            "HBM-resident: frames in HBM when the timed region starts, keypoint "
+            "arrays of all ranks in the HBM of device 0 when it ends; detect and "
+            "gather of a step are not overlapped with the next step in this form"),
+        "config": {
+            "workload": "full SIFT on %d synthetic %dx%d frames per GPU, %d octaves "
+                        "x 3 scales/octave, frames resident in HBM" %
+                        (B, W, H, args.octaves),
+            "frames_per_gpu": B, "global_frames": B * N,
+            "keypoints_per_frame": kp_total / (steps * B * N),
+            "frames_per_s": steps * B * N / elapsed,
+            "devices": devices, "devices_on_the_box": ndev,
+            "parallelism": (
+                "frames sharded %d/GPU over %d ranks, gatherv of keypoints to "
+                "rank 0: %s" % (B, N,
+                "LOOPBACK test transport (the ranks share %d device(s): plumbing "
+                "check, not a scaling measurement)" % ndev if loopback else
+                "library RCCL (ncclCommInitAll; grouped ncclSend/ncclRecv at the "
+                "global offsets)")),
+            "last_stage": args.stage,
+        },
+    }
+    if verified:
+        out["config"]["gather_verified"] = {
+            "ranks": N, "keypoints": at,
+            "what": "OERegion[], descriptors and (s,o) of every rank's shard on "
+                    "the root == that rank's own detect() + fetch(), byte for byte"}
+    print(json.dumps(out))
+    group.close()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: start the N-GPU job from here
+        from sara_amd import capi as _capi
+        ndev = _capi.require_gpu()
+        mode = args.launch
+        if mode == "auto":
+            mode = "procs" if ndev >= args.gpus else "group"
+        if mode == "procs":
+            launch_procs(args)
+        return run_group(args, ndev)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run "
-                             "--nproc-per-node %d bench.py ...`" %
-                             (args.gpus, args.gpus))
         args.gpus = world
 
     import torch
@@ -705,10 +874,19 @@ def main():
                 if comm is not None:
                     comm.close()
                 comm = None
+                if world <= ndev:
+                    # a node with a device per rank on which RCCL cannot form the
+                    # communicator is a failure, not something to paper over
+                    raise SystemExit(
+                        "rank %d: the RCCL communicator could not be created "
+                        "although the box has %d devices for %d ranks" %
+                        (rank, ndev, world))
                 gather_mode, backend = "torch", "gloo"
                 if rank == 0:
-                    print("falling back to the torch.distributed gather over "
-                          "gloo", file=sys.stderr)
+                    print("bench: %d ranks on %d device(s): ranks share devices, "
+                          "RCCL refuses that - the gather runs over "
+                          "torch.distributed/GLOO (said so in the line)" %
+                          (world, ndev), file=sys.stderr)
         elif backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=dev)
@@ -937,6 +1115,14 @@ def main():
                 "us_per_frame": 1e3 * pyr_ms / B,
             },
         }
+        if world > 1:
+            out["transport"] = (comm.transport if comm is not None else
+                                "torch.distributed/" + backend)
+            out["rccl_nranks"] = world if out["transport"] == "rccl" else 0
+            out["rccl_version"] = (rccl_version_string()
+                                   if out["transport"] == "rccl" else None)
+            out["gather_verified"] = gather_check is not None
+            out["launch"] = "one process per GPU (torch.distributed.run)"
         if gather_check is not None:
             out["config"]["gather_verified"] = gather_check
         if h2h_multi is not None:

@@ -461,6 +461,13 @@ SARA_HIP_API sara_hip_status sara_hip_root_sift(float* desc, int n, int dim,
 /* matches: on SARA_HIP_CAPACITY_EXCEEDED *count holds the number needed).      */
 /* Empty key sets: SARA_HIP_RUNTIME_ERROR, like the reference's                 */
 /* std::runtime_error (AnnMatcher.cpp:44-45).                                   */
+/* Ordering: the search runs on a private non-blocking stream of the calling    */
+/* thread and is NOT ordered after any other stream.  Device descriptors        */
+/* (on_device != 0) must therefore be complete before the call - e.g. those of  */
+/* sara_hip_sift_device_results() only after sara_hip_sift_counts() /           */
+/* sara_hip_sift_synchronize() (the key counts n1 / n2 come from counts()       */
+/* anyway) - and must stay unmodified until it returns.  The call itself        */
+/* returns with the match list complete.                                        */
 SARA_HIP_API sara_hip_status sara_hip_match_descriptors(
     const float* desc1, int n1, const float* desc2, int n2, int dim,
     float sift_ratio_thres, int on_device, sara_match* matches, int capacity,
@@ -485,7 +492,9 @@ SARA_HIP_API sara_hip_status sara_hip_self_match_descriptors(
     int* count, int device);
 
 /* The matcher keeps grow-only scratch buffers per (calling thread, device)     */
-/* between calls (allocating them costs more than a search); this frees them.   */
+/* between calls (allocating them costs more than a search); this frees those   */
+/* of the calling thread on `device`, if any (other devices' buffers and the     */
+/* thread's current HIP device are left alone).                                  */
 SARA_HIP_API sara_hip_status sara_hip_match_release_workspace(int device);
 
 /* -------------------------------------------------------------------------- */
@@ -634,6 +643,11 @@ SARA_HIP_API sara_hip_status sara_hip_comm_gather(
 SARA_HIP_API sara_hip_status sara_hip_comm_destroy(sara_hip_comm* comm);
 /* "rccl" or "loopback". */
 SARA_HIP_API const char* sara_hip_comm_transport(const sara_hip_comm* comm);
+/* Ranks of the communicator. */
+SARA_HIP_API int sara_hip_comm_size(const sara_hip_comm* comm);
+/* ncclGetVersion() of the librccl the library bound (e.g. 22703 = 2.27.3), so  */
+/* that a benchmark line can say which RCCL carried the gather.                 */
+SARA_HIP_API sara_hip_status sara_hip_rccl_version(int* version);
 
 /* --- one process, one host thread per GPU ---------------------------------- */
 typedef struct sara_hip_sift_group sara_hip_sift_group;

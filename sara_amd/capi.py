@@ -108,6 +108,7 @@ EXPORTS = [
     "sara_hip_comm_transport", "sara_hip_sift_group_collect_host",
     "sara_hip_sift_group_transport", "sara_hip_self_match_descriptors",
     "sara_hip_match_release_workspace", "sara_hip_sift_pyramid_launches",
+    "sara_hip_comm_size", "sara_hip_rccl_version",
 ]
 
 _f32p = C.POINTER(C.c_float)
@@ -236,6 +237,9 @@ def _declare(lib):
     lib.sara_hip_sift_group_transport.restype = C.c_char_p
     lib.sara_hip_comm_transport.argtypes = [_vp]
     lib.sara_hip_comm_transport.restype = C.c_char_p
+    lib.sara_hip_comm_size.argtypes = [_vp]
+    lib.sara_hip_comm_size.restype = C.c_int
+    lib.sara_hip_rccl_version.argtypes = [C.POINTER(C.c_int)]
     lib.sara_hip_sift_ticket_counts.argtypes = [_vp, C.c_int, _vp,
                                                 C.POINTER(C.c_int),
                                                 C.POINTER(C.c_int)]

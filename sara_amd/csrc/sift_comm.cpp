@@ -78,6 +78,7 @@ namespace {
     int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, ncclComm_t,
                      hipStream_t) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
     std::string error;
   };
 
@@ -118,6 +119,7 @@ namespace {
       SARA_RCCL_SYM(Send, "ncclSend");
       SARA_RCCL_SYM(Recv, "ncclRecv");
       SARA_RCCL_SYM(AllGather, "ncclAllGather");
+      SARA_RCCL_SYM(GetVersion, "ncclGetVersion");
 #undef SARA_RCCL_SYM
     });
     return &r;
@@ -393,7 +395,9 @@ struct sara_hip_comm
   int nranks = 1, rank = 0, device = 0;
   hipStream_t stream = nullptr;  // the exchange runs beside the next batch
   // header of a gather: kHdr ints per rank (count or -1, root capacity);
-  // [nranks * kHdr ..] is this rank's own entry, the AllGather's send buffer
+  // [nranks * kHdr ..] is this rank's own entry, the AllGather's send buffer;
+  // [(nranks + 1) * kHdr ..] is a constant entry of -1s, sent instead when the
+  // upload of the own entry fails (the collective still has to be entered)
   int* d_hdr = nullptr;
   int* h_hdr = nullptr;  // pinned, same layout
   // gather buffers on the root (grown on demand)
@@ -412,9 +416,11 @@ namespace {
     HIPC_TRY(hipSetDevice(c->device));
     std::lock_guard<std::recursive_mutex> runtime_lock(runtime_mutex());
     HIPC_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    const size_t ints = size_t(kHdr) * (size_t(c->nranks) + 1);
+    const size_t ints = size_t(kHdr) * (size_t(c->nranks) + 2);
     HIPC_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_hdr), sizeof(int) * ints));
     HIPC_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_hdr), sizeof(int) * ints));
+    HIPC_TRY(hipMemset(c->d_hdr + size_t(kHdr) * (size_t(c->nranks) + 1), 0xff,
+                       sizeof(int) * kHdr));
     return SARA_HIP_OK;
   }
 
@@ -578,16 +584,33 @@ namespace {
   }
 
   //! Header exchange of the process-per-GPU form: own entry -> everyone's.
+  //! Collective: the AllGather is posted whatever happens locally (a rank that
+  //! returned before it would leave its peers blocked in theirs); when the
+  //! upload of the own entry fails the constant -1 entry travels instead, and
+  //! the local error is returned once the collective has been entered.
   sara_hip_status exchange_header(sara_hip_comm* c, int v0, int v1)
   {
     int* mine = c->h_hdr + size_t(kHdr) * c->nranks;
     mine[0] = v0;
     mine[1] = v1;
     mine[2] = mine[3] = 0;
-    HIPC_TRY(hipMemcpyAsync(c->d_hdr + size_t(kHdr) * c->nranks, mine,
-                            sizeof(int) * kHdr, hipMemcpyHostToDevice, c->stream));
-    const sara_hip_status st = c->tr->all_gather_i32(
-        c->d_hdr + size_t(kHdr) * c->nranks, c->d_hdr, kHdr, c->stream);
+    const int* d_send = c->d_hdr + size_t(kHdr) * c->nranks;
+    sara_hip_status local = SARA_HIP_OK;
+    const hipError_t up =
+        hipMemcpyAsync(c->d_hdr + size_t(kHdr) * c->nranks, mine,
+                       sizeof(int) * kHdr, hipMemcpyHostToDevice, c->stream);
+    if (up != hipSuccess)
+    {
+      local = set_error(SARA_HIP_RUNTIME_ERROR,
+                        (std::string("gather header upload: ") +
+                         hipGetErrorString(up)).c_str());
+      d_send = c->d_hdr + size_t(kHdr) * (size_t(c->nranks) + 1);
+    }
+    const std::string local_msg = local != SARA_HIP_OK ? sara_hip_last_error() : "";
+    const sara_hip_status st =
+        c->tr->all_gather_i32(d_send, c->d_hdr, kHdr, c->stream);
+    if (local != SARA_HIP_OK)
+      return set_error(local, local_msg.c_str());
     if (st != SARA_HIP_OK)
       return st;
     HIPC_TRY(hipMemcpyAsync(c->h_hdr, c->d_hdr, sizeof(int) * kHdr * c->nranks,
@@ -773,6 +796,20 @@ sara_hip_status sara_hip_host_free(void* ptr)
 const char* sara_hip_comm_transport(const sara_hip_comm* c)
 {
   return c && c->tr ? c->tr->name() : "";
+}
+
+int sara_hip_comm_size(const sara_hip_comm* c) { return c ? c->nranks : 0; }
+
+sara_hip_status sara_hip_rccl_version(int* version)
+{
+  if (!version)
+    return set_error(SARA_HIP_INVALID_PARAMS, "null output");
+  *version = 0;
+  const sara_hip_status st = rccl_ready();
+  if (st != SARA_HIP_OK)
+    return st;
+  const int e = rccl()->GetVersion(version);
+  return e ? RcclTransport::fail("ncclGetVersion", e) : SARA_HIP_OK;
 }
 
 sara_hip_status sara_hip_comm_unique_id(unsigned char* id)

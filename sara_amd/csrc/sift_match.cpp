@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -71,10 +72,14 @@ namespace {
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
 
+    //! Frees everything on the workspace's device and leaves the thread's
+    //! current device as it found it.
     void release()
     {
       if (device < 0)
         return;
+      int current = -1;
+      (void) hipGetDevice(&current);
       (void) hipSetDevice(device);
       for (int k = 0; k < kSlots; ++k)
       {
@@ -97,6 +102,8 @@ namespace {
       }
       stream = nullptr;
       device = -1;
+      if (current >= 0)
+        (void) hipSetDevice(current);
     }
     ~Workspace() { release(); }
 
@@ -175,21 +182,19 @@ namespace {
     }
   };
 
+  //! One workspace per (thread, device): a thread that walks over all GPUs of
+  //! a node keeps one each, nothing is ever evicted behind the caller's back.
+  std::map<int, Workspace>& workspaces()
+  {
+    thread_local std::map<int, Workspace> ws;
+    return ws;
+  }
+
   Workspace& workspace(int device)
   {
-    thread_local Workspace ws[2];  // the two devices a thread used last
-    for (Workspace& w : ws)
-      if (w.device == device)
-        return w;
-    for (Workspace& w : ws)
-      if (w.device < 0)
-      {
-        w.device = device;
-        return w;
-      }
-    ws[1].release();
-    ws[1].device = device;
-    return ws[1];
+    Workspace& w = workspaces()[device];
+    w.device = device;
+    return w;
   }
 
   //! OERegion fields KeyProximity and Match::operator== read.
@@ -830,9 +835,12 @@ sara_hip_status sara_hip_self_match_descriptors(
 
 sara_hip_status sara_hip_match_release_workspace(int device)
 {
-  if (use_device(device) != SARA_HIP_OK)
-    return SARA_HIP_OK;  // nothing can be held without a device
-  workspace(device).release();
+  // only an existing workspace of the calling thread is released: looking one
+  // up must not create (or evict) anything, and the current device is kept
+  auto& all = workspaces();
+  const auto it = all.find(device);
+  if (it != all.end())
+    all.erase(it);  // ~Workspace() frees on its device, restores the current one
   return SARA_HIP_OK;
 }
 

@@ -257,3 +257,88 @@ def test_collect_into_caller_memory_and_stage_check():
         assert e.value.status == sara_amd.capi.NOT_READY
         _, r2, d2, _ = ctx.collect(t, with_descriptors=False)   # still pending
         assert d2 is None and len(r2) == total
+
+
+# --------------------------------------------------------------------------- #
+# bench.py --gpus N as the driver starts it: `python bench.py --gpus N ...`
+# with no launcher and no WORLD_SIZE.  On the one-GPU test box N = 2 exceeds the
+# device count, so the run goes through the single-process group form over the
+# loopback transport and must SAY so; with a launcher (--launch procs) the two
+# ranks share the GPU, RCCL refuses, and the line must say gloo - never "rccl".
+# --------------------------------------------------------------------------- #
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*argv, timeout=900):
+    env = dict(os.environ)
+    env.pop("SARA_HIP_COMM_TRANSPORT", None)
+    env.pop("SARA_HIP_MARCH_MIN_PIXELS", None)     # the shipped kernel selection
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv),
+                       capture_output=True, text=True, timeout=timeout, env=env,
+                       cwd=ROOT)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-2000:],
+                                                   p.stderr[-4000:])
+    return json.loads(lines[0]), p.stderr
+
+
+def test_bench_two_gpus_without_a_launcher():
+    line, err = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras")
+    assert line["n_gpus"] == 2 and line["steps"] == 2
+    assert line["metric"].startswith("SIFT keypoints/sec @1080p")
+    assert line["config"]["global_frames"] == 128
+    assert line["gather_verified"] is True
+    assert line["value"] > 0 and line["ms_per_step"] > 0
+    import sara_amd.capi as capi
+    if capi.load().sara_hip_device_count() >= 2:
+        assert line["transport"] == "rccl" and line["rccl_nranks"] == 2
+        assert line["rccl_version"]
+    else:
+        # one device: honest about not being an RCCL run
+        assert line["transport"] == "loopback" and line["rccl_nranks"] == 0
+        assert "LOOPBACK" in line["config"]["parallelism"]
+        assert "LOOPBACK" in err
+    # 2 x 64 frames of ~4.4 k keypoints each
+    assert 3500 < line["config"]["keypoints_per_frame"] < 5500
+
+
+def test_bench_two_ranks_under_the_launcher():
+    line, err = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras",
+                       "--launch", "procs", "--frames-per-gpu", "4", "--width", "640",
+                       "--height", "360")
+    assert line["n_gpus"] == 2 and line["config"]["global_frames"] == 8
+    import sara_amd.capi as capi
+    if capi.load().sara_hip_device_count() >= 2:
+        assert line["transport"] == "rccl" and line["rccl_nranks"] == 2
+        assert line["gather_verified"] is True
+    else:
+        assert line["transport"] == "torch.distributed/gloo"
+        assert line["rccl_nranks"] == 0 and "GLOO" in err
+
+
+def test_bench_refuses_loopback_on_a_box_with_enough_devices():
+    """SARA_HIP_COMM_TRANSPORT=loopback must not turn an N <= device_count run
+    into a line that reads like RCCL: --gpus 1 is unaffected, and the group form
+    refuses outright when the box has a device per rank."""
+    env = dict(os.environ, SARA_HIP_COMM_TRANSPORT="loopback")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    import sara_amd.capi as capi
+    ndev = capi.load().sara_hip_device_count()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus",
+                        str(max(ndev, 2)), "--steps", "1", "--warmup", "0",
+                        "--no-extras", "--launch", "group", "--frames-per-gpu", "2",
+                        "--width", "320", "--height", "240"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    if ndev >= 2:
+        assert p.returncode != 0 and "refusing" in p.stderr
+    else:
+        line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+        assert line["transport"] == "loopback"
