@@ -814,9 +814,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        # no launcher: start the N-GPU job from here
-        from sara_amd import capi as _capi
-        ndev = _capi.require_gpu()
+        # no launcher: start the N-GPU job from here.  torch first: its wheel
+        # brings its own HIP runtime, which must be the one the process loads
+        # before the library pulls in the image's (the other order leaves torch
+        # without devices)
+        import torch
+        ndev = torch.cuda.device_count()
+        if ndev < 1:
+            raise SystemExit("bench: no HIP device")
         mode = args.launch
         if mode == "auto":
             mode = "procs" if ndev >= args.gpus else "group"

@@ -1804,11 +1804,22 @@ namespace sara_ref {
   // duplicates of a keypoint.  The two-set entry below has no features and
   // compares indices; the self-matching entry compares values as the
   // reference does.
-  // PARITY UNPINNED against the reference's FLANN results; pinned by the
-  // reference's only matcher test (test_featurematching_matching.cpp:29-62:
-  // one match, score 0 - reproduced with the default-ratio rule above only
-  // because that test passes ratio 1.0) and test_featurematching_key_proximity
-  // .cpp.  Distance ties: the lower index first (FLANN: traversal order).
+  // PINNED (round 4) for the exact part: the reference's vendored FLANN is
+  // header-only and compiles here (oracle/Makefile `_ref`,
+  // oracle/flann_ref_harness.cpp calls it as AnnMatcher.cpp does).  With
+  // flann::LinearIndexParams - FLANN's exact index - knnSearch(3),
+  // radiusSearch(d_best * 1.44) and the whole compute_matches() list (ratios
+  // 0.6 / 0.8 / 1.0 / 1.2, and the self-matching constructor) equal this
+  // restatement BIT FOR BIT on the SIFT descriptors of two overlapping 1080p
+  // frames and of the sunflower crop: neighbours, float distances, tie order,
+  // strict radius (tests/test_oracle_flann_pins.py, fixtures
+  // tests/golden/flann_pins.npz).  What stays different BY DESIGN is the index:
+  // the reference asks KDTreeIndexParams(8) with 32 checks (AnnMatcher.cpp:227),
+  // an approximate search; the same test records how its lists relate to the
+  // exact ones (ratio 0.6: 4138 of 4140 matches common; default ratio 1.2: the
+  // kd-trees find 2790 matches, the exact radius search 7281).  Also pinned by
+  // the reference's only matcher test (test_featurematching_matching.cpp:29-62)
+  // and test_featurematching_key_proximity.cpp.
   // ======================================================================== //
   struct Match
   {
@@ -1882,6 +1893,21 @@ namespace sara_ref {
     }
   };
 
+  //! What tree.knnSearch / tree.radiusSearch return for an exact index
+  //! (flann::LinearIndexParams: every point is examined, the result set orders
+  //! by (distance, index) - flann/util/result_set.h - and RadiusResultSet keeps
+  //! dist < radius, strict): all nt candidates of one query in that order.
+  //! Pinned against the reference's vendored FLANN by
+  //! tests/test_oracle_flann_pins.py (oracle/flann_ref_harness.cpp).
+  inline void exhaustive_neighbours(const float* query, const float* t, int nt,
+                                    int dim, std::vector<std::pair<float, int>>& nn)
+  {
+    nn.resize(static_cast<size_t>(nt));
+    for (int j = 0; j < nt; ++j)
+      nn[size_t(j)] = {flann_l2(query, t + size_t(j) * dim, dim), j};
+    std::sort(nn.begin(), nn.end());
+  }
+
   //! append_nearest_neighbors for every row of `q` against `t`
   //! (AnnMatcher.cpp:59-170).  fq / ft: features (self-matching only).
   inline void append_matches(const float* q, int nq, const float* t, int nt,
@@ -1906,10 +1932,8 @@ namespace sara_ref {
           push(i, 0, 1.f, 1);
         continue;
       }
-      for (int j = 0; j < nt; ++j)
-        nn[size_t(j)] = {flann_l2(q + size_t(i) * dim, t + size_t(j) * dim, dim), j};
       // FLANN's result sets order by (distance, index)
-      std::sort(nn.begin(), nn.end());
+      exhaustive_neighbours(q + size_t(i) * dim, t, nt, dim, nn);
       if (nt == 2 && self_matching)
       {
         // AnnMatcher.cpp:103-120: the second neighbour, score 1, no proximity test

@@ -319,6 +319,44 @@ float ref_flann_l2(const float* a, const float* b, int size)
   return flann_l2(a, b, size);
 }
 
+//! The neighbour lists the matcher ranks (exhaustive_neighbours): the k nearest
+//! of every query row in (distance, index) order; idx / dist: nq x k.
+void ref_exhaustive_knn(const float* t, int nt, int dim, const float* q, int nq,
+                        int k, int* idx, float* dist)
+{
+  std::vector<std::pair<float, int>> nn;
+  for (int i = 0; i < nq; ++i)
+  {
+    exhaustive_neighbours(q + size_t(i) * dim, t, nt, dim, nn);
+    for (int r = 0; r < k && r < nt; ++r)
+    {
+      dist[size_t(i) * k + r] = nn[size_t(r)].first;
+      idx[size_t(i) * k + r] = nn[size_t(r)].second;
+    }
+  }
+}
+
+//! ... and the members of the strict radius search dist < radius[i] in the same
+//! order, rows of max_nn entries; count[i] = members.
+void ref_exhaustive_radius(const float* t, int nt, int dim, const float* q, int nq,
+                           const float* radius, int max_nn, int* idx, float* dist,
+                           int* count)
+{
+  std::vector<std::pair<float, int>> nn;
+  for (int i = 0; i < nq; ++i)
+  {
+    exhaustive_neighbours(q + size_t(i) * dim, t, nt, dim, nn);
+    int K = 0;
+    while (K < nt && K < max_nn && nn[size_t(K)].first < radius[i])
+    {
+      dist[size_t(i) * max_nn + K] = nn[size_t(K)].first;
+      idx[size_t(i) * max_nn + K] = nn[size_t(K)].second;
+      ++K;
+    }
+    count[i] = K;
+  }
+}
+
 void ref_root_sift(float* desc, int n, int dim)
 {
   for (int i = 0; i < n; ++i)

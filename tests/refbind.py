@@ -401,6 +401,41 @@ def compute_self_matches(desc, regions, sift_ratio_thres=1.2,
         cap = k
 
 
+def exhaustive_knn(data, queries, k):
+    """The oracle's exhaustive neighbour lists (what it ranks instead of FLANN's
+    tree queries): k nearest per query in (distance, index) order."""
+    d = np.ascontiguousarray(data, np.float32)
+    q = np.ascontiguousarray(queries, np.float32)
+    idx = np.zeros((len(q), k), np.int32)
+    dist = np.zeros((len(q), k), np.float32)
+    fn = lib().ref_exhaustive_knn
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                   C.c_void_p, C.c_void_p]
+    fn(d.ctypes.data, len(d), d.shape[1], q.ctypes.data, len(q), k,
+       idx.ctypes.data, dist.ctypes.data)
+    return idx, dist
+
+
+def exhaustive_radius(data, queries, radii, max_nn=None):
+    """Members of the strict radius search per query -> list of (idx, dist)."""
+    d = np.ascontiguousarray(data, np.float32)
+    q = np.ascontiguousarray(queries, np.float32)
+    r = np.ascontiguousarray(radii, np.float32)
+    max_nn = max_nn or len(d)
+    idx = np.zeros((len(q), max_nn), np.int32)
+    dist = np.zeros((len(q), max_nn), np.float32)
+    count = np.zeros(len(q), np.int32)
+    fn = lib().ref_exhaustive_radius
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn(d.ctypes.data, len(d), d.shape[1], q.ctypes.data, len(q), r.ctypes.data,
+       max_nn, idx.ctypes.data, dist.ctypes.data, count.ctypes.data)
+    return [(idx[i, :count[i]].copy(), dist[i, :count[i]].copy())
+            for i in range(len(q))]
+
+
 def key_proximity(f1, f2, metric_dist_thres=0.5, pixel_dist_thres=10.0):
     """KeyProximity{metric, pixel}(f1, f2), KeyProximity.cpp:17-30; f = 8 floats
     as match_features() lays them out."""

@@ -297,3 +297,61 @@ def test_root_sift_option_of_the_pipeline(oracle):
     assert np.allclose(root.descriptor_matrix, want, rtol=4e-6, atol=0)
     assert np.allclose((root.descriptor_matrix.astype(np.float64) ** 2).sum(1), 1,
                        atol=1e-5)
+
+
+# --------------------------------------------------------------------------- #
+# Round 4: the GPU matcher against the reference's OWN FLANN.  The fixture
+# tests/golden/flann_pins.npz holds what flann::Index<L2<float>> with
+# LinearIndexParams (FLANN's exact index, the vendored header-only library under
+# /root/reference/cpp/third-party/flann) returns when it is called as
+# FeatureMatching/AnnMatcher.cpp:59-268 calls it; tests/test_oracle_flann_pins.py
+# proves the oracle equal to it on the CPU.  Here the C-ABI entry points must
+# return the same bytes: indices, ranks, directions, float scores.
+# --------------------------------------------------------------------------- #
+import hashlib
+import os
+
+from common import GOLDEN
+
+
+def _sha(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+@pytest.fixture(scope="module")
+def flann_pins():
+    return np.load(os.path.join(GOLDEN, "flann_pins.npz"))
+
+
+@pytest.fixture(scope="module")
+def flann_pair(oracle, flann_pins):
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_flann_pins import pair_descriptors
+    d1, d2 = pair_descriptors()
+    assert _sha(d1, d2) == str(flann_pins["pair_sha256"])
+    return d1, d2
+
+
+@pytest.mark.parametrize("ratio", [0.6, 0.8, 1.0, 1.2])
+def test_gpu_matcher_equals_annmatcher_on_flann_linear(flann_pair, flann_pins, ratio):
+    d1, d2 = flann_pair
+    got = sara_amd.AnnMatcher(d1, d2, ratio).compute_matches()
+    want = flann_pins["linear_matches_%.1f" % ratio]
+    assert len(got) == len(want) > 4000
+    assert got.tobytes() == want.tobytes()
+
+
+def test_gpu_self_matcher_equals_annmatcher_on_flann_linear(flann_pins):
+    z = np.load(os.path.join(GOLDEN, "sunflower_crop.npz"))
+    assert _sha(z["descriptors"], z["regions"]) == str(flann_pins["crop_sha256"])
+    reg = np.ascontiguousarray(z["regions"]).view(sara_amd.OEREGION_DTYPE).reshape(-1)
+    keys = sara_amd.KeypointList(reg, np.ascontiguousarray(z["descriptors"]),
+                                 np.ascontiguousarray(z["scale_octave"]))
+    got = sara_amd.AnnMatcher(keys, 1.2, 0.5, 10.0).compute_matches()
+    want = flann_pins["linear_self_matches_crop"]
+    assert len(got) == len(want) > 10000
+    assert got.tobytes() == want.tobytes()
