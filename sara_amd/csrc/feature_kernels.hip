@@ -529,60 +529,30 @@ namespace sara_hip {
     const char* e = getenv("SARA_HIP_FEATURES");
     return !(e && std::string(e) == "tile");
   }();
-  //! Target number of waves per marching launch (tuning knobs; the defaults
-  //! come from sweeps on MI355X with 64 x 1080p frames: the extremum scan
-  //! likes long segments, the gradient kernel many short ones).
-  //! Consecutive workgroups (4 keypoints each) that stay on one XCD.
-  static const int g_xcd_run = [] {
-    const char* e = getenv("SARA_HIP_XCD_RUN");
-    return e ? std::max(1, atoi(e)) : 128;
-  }();
-  //! Run-groups (8 * SARA_HIP_XCD_RUN blocks of 4 keypoints) in the grid of the
-  //! per-keypoint kernels per frame; the blocks loop over the rest.
-  static const int g_persist_units_env = [] {
-    const char* e = getenv("SARA_HIP_PERSIST_UNITS");
-    return e ? std::max(1, atoi(e)) : 0;
-  }();
-  //! One run-group per frame fills the chip when there are many frames; a
-  //! small batch gets as many groups as it takes to put ~8 waves on every
-  //! SIMD (one 1080p frame: 4 300 keypoints on 1 024 one-wave blocks would
-  //! walk 4 keypoints each, one after the other).
+  //! Consecutive workgroups (one work item each) of the per-keypoint kernels
+  //! that stay on one XCD (xcd_local_block).
+  constexpr int g_xcd_run = 128;
+  //! Run-groups (8 * g_xcd_run blocks) in the grid of the per-keypoint kernels
+  //! per frame; the blocks loop over the rest.  One run-group per frame fills
+  //! the chip when there are many frames; a small batch gets as many groups as
+  //! it takes to put ~8 waves on every SIMD (one 1080p frame: 4 300 keypoints
+  //! on 1 024 one-wave blocks would walk 4 keypoints each, one after the other).
   static inline int persist_units(int batch, int waves_per_block)
   {
-    if (g_persist_units_env > 0)
-      return g_persist_units_env;
     const int per_unit = 8 * g_xcd_run * waves_per_block * std::max(batch, 1);
     return std::max(1, (8192 + per_unit - 1) / per_unit);
   }
-  //! Off by default: measured on MI355X the fused pass takes as long as the
-  //! two separate kernels (3.3 ms per 64 frames either way - the gradient's
-  //! exact atan2/sqrt/div sequence is VALU-bound, not bandwidth-bound).
-  static const bool g_fuse_gradient = [] {
-    const char* e = getenv("SARA_HIP_FUSE_GRADIENT");
-    return e && std::string(e) == "1";
-  }();
   //! Segments of the marching gradient kernel made of whole 16-row bands (one
-  //! writer per entry of the coarse magnitude map, no memset); 0 = round 1's
-  //! split with atomicMax.
-  //! Default: only for small batches, where the saved memset launches count
-  //! (one 1080p frame: -20 us); with 64 frames the aligned split runs the
-  //! overlapped extrema + gradient stage 0.15 ms slower than round 1's.
-  static const int g_grad_bands_env = [] {
-    const char* e = getenv("SARA_HIP_GRAD_BANDS");
-    return e ? (std::string(e) == "0" ? 0 : 1) : -1;
-  }();
-  static inline bool grad_bands(int batch)
-  {
-    return g_grad_bands_env >= 0 ? g_grad_bands_env != 0 : batch <= 8;
-  }
-  static const int g_grad_waves = [] {
-    const char* e = getenv("SARA_HIP_GRAD_WAVES");
-    return e ? std::max(64, atoi(e)) : 18432;
-  }();
-  static const int g_extrema_waves = [] {
-    const char* e = getenv("SARA_HIP_EXTREMA_WAVES");
-    return e ? std::max(64, atoi(e)) : 4096;
-  }();
+  //! writer per entry of the coarse magnitude map, no memset) for small
+  //! batches, where the saved memset launches count (one 1080p frame: -20 us);
+  //! with 64 frames the aligned split runs the overlapped extrema + gradient
+  //! stage 0.15 ms slower than the free split with atomicMax.
+  static inline bool grad_bands(int batch) { return batch <= 8; }
+  //! Target number of waves per marching launch (sweeps on MI355X with 64 x
+  //! 1080p frames: the extremum scan likes long segments, the gradient kernel
+  //! many short ones).
+  constexpr int g_grad_waves = 18432;
+  constexpr int g_extrema_waves = 4096;
 
   //! Planes below this many pixels per launch (w x h x batch) go to the
   //! pixel-parallel gradient kernel (SARA_HIP_GRAD_TILE_PIXELS; 0 = never).
@@ -603,7 +573,7 @@ namespace sara_hip {
     const bool aligned4 = w >= 4 && h >= 2;
     if (grad_small_launch(w, h, batch))
       return false;  // gradient_polar_tile_kernel: one writer per entry
-    // the generic kernel (and SARA_HIP_GRAD_BANDS=0) use atomicMax
+    // the generic kernel and the free split of big batches use atomicMax
     return !(aligned4 && g_use_march && grad_bands(batch));
   }
 
@@ -1215,38 +1185,18 @@ namespace sara_hip {
     __builtin_amdgcn_wave_barrier();
   }
 
-  //! GRAD: the same pass also writes the polar gradients (2|grad|, atan2) of
-  //! the Gaussian planes 1..ND-2 - the only ones the orientation and descriptor
-  //! stages read - and their coarse 16x16 magnitude maxima.  The scan is
-  //! bandwidth-bound with idle VALUs and the gradient is VALU-heavy, so the
-  //! fused pass costs about max(...) instead of the sum and saves re-reading
-  //! the three planes (see gradient_polar_march_kernel for the stand-alone
-  //! form and the reference citations).
 #ifndef SARA_EXTREMA_WAVES_PER_EU
 #define SARA_EXTREMA_WAVES_PER_EU 4
 #endif
-  template <int ND, int PF, bool GRAD>
-#ifndef SARA_FUSED_WAVES_PER_EU
-#define SARA_FUSED_WAVES_PER_EU 2
-#endif
-  __global__ __launch_bounds__(64, GRAD ? SARA_FUSED_WAVES_PER_EU : SARA_EXTREMA_WAVES_PER_EU) void extrema_march_kernel(
+  template <int ND, int PF>
+  __global__ __launch_bounds__(64, SARA_EXTREMA_WAVES_PER_EU) void extrema_march_kernel(
       OctaveView gauss, int octave, ExtremaParams p, SiteLists sites,
-      int seg_rows, int nstrips, int nseg, int xcd_total,
-      float* __restrict__ grad, size_t grad_frame_stride,
-      unsigned* __restrict__ cmax, size_t cmax_stride)
+      int seg_rows, int nstrips, int nseg, int xcd_total)
   {
     static_assert(PF == 3, "the row loop is unrolled 3x");
     __shared__ unsigned long long s_queue[128];
-    __shared__ __attribute__((aligned(16))) float s_atan[GRAD ? kAtanLutFloats : 8];
-    if (GRAD)
-    {
-      fill_atan_lut(s_atan, threadIdx.x, 64);
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
-    }
     int qn = 0;  // wave-uniform fill of the queue
     constexpr int NG = ND + 1;
-    constexpr int NS = ND - 2;  // scanned scales = gradient planes 1..NS
     constexpr int STRIDE = 126;
     const int lane = threadIdx.x;
     int strip, seg;
@@ -1282,21 +1232,6 @@ namespace sara_hip {
 
     float2 pg[PF][NG];
     float2 ring[3][ND];
-    float2 gring[3][GRAD ? NS : 1];  // Gaussian rows y-1, y, y+1 of planes 1..NS
-    float run_max[GRAD ? NS : 1];
-#pragma unroll
-    for (int t = 0; t < (GRAD ? NS : 1); ++t)
-      run_max[t] = 0.f;
-    const int cw = (w + 15) / 16, ch = (h + 15) / 16;
-    if (GRAD)
-    {
-      grad += size_t(b) * grad_frame_stride;
-      cmax += size_t(b) * cmax_stride;
-    }
-    // column validity of the gradient outputs (interior of the strip, or an
-    // image border column where the one-sided difference needs no neighbour)
-    const bool gvalid0 = (col < w) && (lane > 0 || col == 0);
-    const bool gvalid1 = (col + 1 < w) && (lane < 63 || col + 1 == w - 1);
 #pragma unroll
     for (int q = 0; q < PF; ++q)
       load_row(y0 - 1 + q, pg[q]);
@@ -1316,116 +1251,10 @@ namespace sara_hip {
 #pragma unroll
         for (int l = 0; l < ND; ++l)
           ring[i][l] = make_float2(cur[l + 1].x - cur[l].x, cur[l + 1].y - cur[l].y);
-        if (GRAD)
-        {
-#pragma unroll
-          for (int t = 0; t < NS; ++t)
-            gring[i][t] = cur[t + 1];
-        }
         load_row(yy + PF, pg[i]);
 
         const int y = yy - 1;
         const int ia = (i + 1) % 3, ib = (i + 2) % 3, ic = i;  // y-1, y, y+1
-        if (GRAD && n >= 2 && y < y1)
-        {
-#pragma unroll
-          for (int t = 0; t < NS; ++t)
-          {
-            const float2 up = gring[ia][t], mid = gring[ib][t], dn = gring[ic][t];
-            const float left = shift_from_prev(mid.y);
-            const float right = shift_from_next(mid.x);
-            // Differential.hpp:46-61: central difference / 2, one-sided on
-            // the image borders
-            float gx0, gx1, gy0, gy1;
-            if (col == 0)
-              gx0 = (mid.y - mid.x) / 2;
-            else
-              gx0 = (mid.y - left) / 2;
-            if (col + 1 == w - 1)
-              gx1 = (mid.y - mid.x) / 2;
-            else
-              gx1 = (right - mid.x) / 2;
-            if (y == 0)
-            {
-              gy0 = (dn.x - mid.x) / 2;
-              gy1 = (dn.y - mid.y) / 2;
-            }
-            else if (y == h - 1)
-            {
-              gy0 = (mid.x - up.x) / 2;
-              gy1 = (mid.y - up.y) / 2;
-            }
-            else
-            {
-              gy0 = (dn.x - up.x) / 2;
-              gy1 = (dn.y - up.y) / 2;
-            }
-            // the short forms of gradient_polar_march_kernel (see there)
-            const float ss0 = gx0 * gx0 + gy0 * gy0;
-            const float ss1 = gx1 * gx1 + gy1 * gy1;
-            float r0, r1;
-            const bool odd =
-                min(sqrt_short_exponent(ss0), sqrt_short_exponent(ss1)) <
-                    kSqrtShortMinExponent ||
-                !(fmaxf(ss0, ss1) < __builtin_inff());
-            if (__builtin_expect(__ballot(odd) != 0ull, 0))
-            {
-              r0 = 2 * sqrtf(ss0);
-              r1 = 2 * sqrtf(ss1);
-            }
-            else
-            {
-              r0 = 2 * sqrt_rn_short(ss0);
-              r1 = 2 * sqrt_rn_short(ss1);
-            }
-            float a0 = atan2f_lut_nonzero_x(gy0, gx0, s_atan);
-            float a1 = atan2f_lut_nonzero_x(gy1, gx1, s_atan);
-            const bool z0 = (__float_as_uint(gx0) << 1) == 0u;
-            const bool z1 = (__float_as_uint(gx1) << 1) == 0u;
-            if (__ballot(z0 || z1) != 0ull)
-            {
-              a0 = z0 ? atan2f_zero_x(gy0, gx0) : a0;
-              a1 = z1 ? atan2f_zero_x(gy1, gx1) : a1;
-            }
-            float* op = grad + (size_t(t + 1) * plane + size_t(y) * w + col) * 2;
-            if (gvalid0 && gvalid1)
-              *reinterpret_cast<float4*>(op) = make_float4(r0, a0, r1, a1);
-            else if (gvalid0)
-              *reinterpret_cast<float2*>(op) = make_float2(r0, a0);
-            else if (gvalid1)
-              *reinterpret_cast<float2*>(op + 2) = make_float2(r1, a1);
-            run_max[t] = fmaxf(run_max[t], fmaxf(gvalid0 ? r0 : 0.f,
-                                                 gvalid1 ? r1 : 0.f));
-          }
-#ifndef SARA_FUSED_NO_CMAX
-#define SARA_FUSED_NO_CMAX 0
-#endif
-          if (!SARA_FUSED_NO_CMAX && ((y & 15) == 15 || y == y1 - 1))
-          {
-            // one atomicMax per 16-column cell touched by this wave
-            const int cell = col >> 4;
-#pragma unroll
-            for (int t = 0; t < NS; ++t)
-            {
-              unsigned long long todo = __ballot(col < w);
-              while (todo != 0ull)
-              {
-                const int leader = __ffsll((long long) todo) - 1;
-                const int cid = __builtin_amdgcn_readlane(cell, leader);
-                const bool same = (cell == cid) && (col < w);
-                float m = same ? run_max[t] : 0.f;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1)
-                  m = fmaxf(m, __shfl_xor(m, off));
-                if (lane == leader)
-                  atomicMax(cmax + (size_t(t + 1) * ch + (y >> 4)) * cw + cid,
-                            __float_as_uint(m));
-                todo &= ~__ballot(same);
-              }
-              run_max[t] = 0.f;
-            }
-          }
-        }
         if (n < 2 || y >= y1 || y < pad || y >= h - pad)
           continue;  // wave-uniform
 
@@ -1520,62 +1349,36 @@ namespace sara_hip {
                        tab, sites, cand);
   }
 
-  bool launch_extrema_scan(const OctaveView& gauss, int octave, int batch,
+  void launch_extrema_scan(const OctaveView& gauss, int octave, int batch,
                            const ExtremaParams& p, const ScaleTable* tab,
                            const CandidateLists& cand, const SiteLists& sites,
-                           hipStream_t stream, float* grad,
-                           size_t grad_frame_stride, unsigned* cmax,
-                           size_t cmax_stride)
+                           hipStream_t stream)
   {
     const int nscan = gauss.scales - 3;  // DoG layers 1 .. (scales-1)-2
     if (nscan <= 0)
-      return false;
+      return;
     // any width (odd ones: extrema_march_kernel's odd_tail)
     const bool wide_enough = gauss.w >= 4;
     // the Halide-branch classifier (signed_type) also classifies the border
     // pixels: it runs on the general path
-    // SARA_HIP_EXTREMA_TILE_PIXELS (experiment, default 0): launches below this
-    // many pixels take the pixel-parallel general kernel
-    static const long long tile_pixels = [] {
-      const char* e = getenv("SARA_HIP_EXTREMA_TILE_PIXELS");
-      return e ? atoll(e) : 0ll;
-    }();
-    const bool small_launch = (long long) gauss.w * gauss.h * batch < tile_pixels;
-    if (wide_enough && g_use_march && gauss.scales == 6 && !p.signed_type &&
-        !small_launch)
+    if (wide_enough && g_use_march && gauss.scales == 6 && !p.signed_type)
     {
       const int nstrips = (gauss.w - 2 + 125) / 126;
       int nseg = (g_extrema_waves + nstrips * batch - 1) / (nstrips * batch);
-      static const int min_rows = [] {
-        const char* e = getenv("SARA_HIP_EXTREMA_MINROWS");
-        return e ? std::max(1, atoi(e)) : 16;
-      }();
+      constexpr int min_rows = 16;
       nseg = std::max(1, std::min(nseg, (gauss.h + min_rows - 1) / min_rows));
       const int seg_rows = (gauss.h + nseg - 1) / nseg;
       nseg = (gauss.h + seg_rows - 1) / seg_rows;
-      const bool fuse = grad != nullptr && cmax != nullptr && g_fuse_gradient &&
-                        gauss.h >= 2 && (gauss.w % 2 == 0) &&
-                        (gauss.plane % 2 == 0) &&
-                        (reinterpret_cast<uintptr_t>(grad) % 16 == 0) &&
-                        (grad_frame_stride % 4 == 0);
       const int total = xcd_map_enabled() ? nstrips * nseg * batch : 0;
       const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(nstrips * nseg, batch);
-      if (fuse)
-        hipLaunchKernelGGL((extrema_march_kernel<5, 3, true>), grid, dim3(64), 0,
-                           stream, gauss, octave, p, sites, seg_rows, nstrips,
-                           nseg, total, grad, grad_frame_stride, cmax,
-                           cmax_stride);
-      else
-        hipLaunchKernelGGL((extrema_march_kernel<5, 3, false>), grid, dim3(64), 0,
-                           stream, gauss, octave, p, sites, seg_rows, nstrips,
-                           nseg, total, nullptr, 0, nullptr, 0);
-      return fuse;
+      hipLaunchKernelGGL((extrema_march_kernel<5, 3>), grid, dim3(64), 0, stream,
+                         gauss, octave, p, sites, seg_rows, nstrips, nseg, total);
+      return;
     }
     const dim3 block(64, 4);
     const dim3 grid((gauss.w + 63) / 64, (gauss.h + 3) / 4, batch * nscan);
     hipLaunchKernelGGL(extrema_scan_kernel, grid, block, 0, stream, gauss, octave,
                        nscan, p, tab, cand);
-    return false;
   }
 
   __global__ void extremum_map_kernel(const float* __restrict__ a,
@@ -1621,48 +1424,8 @@ namespace sara_hip {
   // (DoG.cpp:62-82, RefineExtremum.cpp:497-515).  Keys are unique per frame,
   // so rank = number of smaller keys.
   // ------------------------------------------------------------------------ //
-  __global__ __launch_bounds__(256) void rank_candidates_kernel(
-      CandidateLists cand)
-  {
-    __shared__ unsigned long long s_keys[256];
-    const int b = blockIdx.y;
-    const int n = min(cand.count[b], cand.cap);
-    if (int(blockIdx.x) * 256 >= n)
-      return;
-    const unsigned long long* keys = cand.key + size_t(b) * cand.cap;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const unsigned long long mine = i < n ? keys[i] : ~0ull;
-    int rank = 0;
-    for (int base = 0; base < n; base += 256)
-    {
-      const int j = base + threadIdx.x;
-      s_keys[threadIdx.x] = j < n ? keys[j] : ~0ull;
-      __syncthreads();
-      const int m = min(256, n - base);
-      for (int t = 0; t < m; ++t)
-        rank += (s_keys[t] < mine);
-      __syncthreads();
-    }
-    if (i < n)
-    {
-      const size_t row = size_t(b) * cand.cap;
-      cand.order[row + rank] = i;
-      cand.skey[row + rank] = mine;
-      cand.sdata[row + rank] = cand.data[row + i];
-    }
-  }
-
-  void launch_rank_candidates(const CandidateLists& cand, int batch,
-                              hipStream_t stream)
-  {
-    const dim3 grid((cand.cap + 255) / 256, batch);
-    hipLaunchKernelGGL(rank_candidates_kernel, grid, dim3(256), 0, stream, cand);
-  }
-
-  // The rank-by-counting kernel above compares every key with every other key
-  // of its frame: 4.2 k extrema per 1080p frame are fine (0.14 ms per 64
-  // frames), 17 k per 4K frame are not (0.55 ms per 16 frames).  The bucketed
-  // version is a counting sort on the key's (octave, scale, y) prefix - one
+  // Comparing every key with every other key of its frame is O(n^2) (round 1:
+  // 0.55 ms per 16 4K frames).  This is a counting sort on the key's (octave, scale, y) prefix - one
   // bucket per image row of every scanned plane - followed by a rank inside
   // the bucket, which holds a handful of keys: O(n + rows) instead of O(n^2).
   __device__ inline int key_row_bucket(unsigned long long key, const RowBuckets& rb)
@@ -1843,13 +1606,9 @@ namespace sara_hip {
                                        hipStream_t stream)
   {
     // fused form when the buckets fit in LDS (images up to about 6000 rows
-    // per octave-0 plane set); SARA_HIP_SORT=split keeps the four launches
-    static const bool split = [] {
-      const char* e = getenv("SARA_HIP_SORT");
-      return e && std::string(e) == "split";
-    }();
+    // per octave-0 plane set), four launches beyond that (8K frames)
     const size_t lds = sizeof(int) * (size_t(rb.total) + 1 + 1024);
-    if (!split && lds <= 150 * 1024)
+    if (lds <= 150 * 1024)
     {
       // the attribute is per DEVICE (one process may drive all GPUs of a
       // node, sara_hip_sift_group_*) and several host threads may get here
@@ -2363,17 +2122,11 @@ namespace sara_hip {
   {
     // xcd_local_block() spreads ceil(n/4) work items over 8 chunks, so the
     // grid has to be a multiple of 8 blocks
-    static const int ori_run = [] {
-      const char* e = getenv("SARA_HIP_ORI_XCD_RUN");
-      return e ? std::max(1, atoi(e)) : g_xcd_run;
-    }();
+    constexpr int ori_run = g_xcd_run;
     const int unit = 8 * ori_run;
     const int needed =
         unit * (((cand.cap + kOriWaves - 1) / kOriWaves + unit - 1) / unit);
-    const int units = g_persist_units_env > 0
-                          ? g_persist_units_env
-                          : std::max(1, (8192 + unit * kOriWaves * std::max(batch, 1) - 1) /
-                                            (unit * kOriWaves * std::max(batch, 1)));
+    const int units = persist_units(batch, kOriWaves);
     const dim3 grid(std::min(needed, unit * units), batch);
     // weight tables in LDS when they leave room for 8 blocks per CU
     const size_t wbytes = sizeof(double) * size_t(n_weights);
@@ -2523,11 +2276,7 @@ namespace sara_hip {
   {
     // parts per frame: ~1 extremum per thread at the list sizes of a video
     // frame when the batch alone cannot fill the chip
-    static const int parts_env = [] {
-      const char* e = getenv("SARA_HIP_SCAN_PARTS");
-      return e ? std::max(1, atoi(e)) : 0;
-    }();
-    const int parts = parts_env ? parts_env : (batch <= 2 ? 4 : (batch <= 8 ? 2 : 1));
+    const int parts = batch <= 2 ? 4 : (batch <= 8 ? 2 : 1);
     hipLaunchKernelGGL(scan_peaks_kernel, dim3(parts, batch), dim3(1024), 0, stream,
                        cand, ori, done_counter, batch);
   }

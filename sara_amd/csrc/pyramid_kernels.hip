@@ -42,14 +42,9 @@ namespace sara_hip {
     const char* e = getenv("SARA_HIP_BLUR");
     return !(e && std::string(e) == "tile");
   }();
-  static const bool g_fuse_decimate = [] {
-    const char* e = getenv("SARA_HIP_FUSE_DECIMATE");
-    return !(e && std::string(e) == "0");
-  }();
-  static const int g_march_minrows = [] {
-    const char* e = getenv("SARA_HIP_MARCH_MINROWS");
-    return e ? std::max(0, atoi(e)) : 4;
-  }();
+  //! Marching segments are at least max(32, 4 R) rows tall: every segment
+  //! re-filters 2R halo rows.
+  constexpr int g_march_minrows = 4;
   //! Target number of waves per marching launch (tuning knobs; the launch
   //! rounds up to whole segments).  4-column kernel (R <= 6, latency-bound:
   //! VALU pipe 26-34 % busy): 4 per SIMD - 1080p x 64: 116 -> 111 us (R = 5),
@@ -73,12 +68,6 @@ namespace sara_hip {
     const char* e = getenv("SARA_HIP_MARCH_MIN_PIXELS");
     return e ? size_t(atoll(e)) : size_t(4) << 20;
   }();
-  //! SARA_HIP_BLUR_ASM=0 keeps the compiler-scheduled kernel for every radius.
-  static const bool g_use_march2 = [] {
-    const char* e = getenv("SARA_HIP_BLUR_ASM");
-    return !(e && std::string(e) == "0");
-  }();
-
   // Round 3: the tile geometry is a template parameter and the window is staged
   // with 16-byte loads.  One frame per call is a chain of dependent launches of
   // 3-17 MB each; tools/ubench/tile_blur_b1.hip times such chains: an empty
@@ -823,13 +812,7 @@ namespace sara_hip {
     constexpr int W = 128;
     constexpr int PF = 4;
     const int nstrips = (w + W - 1) / W;
-    // per-radius override for sweeps: SARA_HIP_MARCH2_WAVES_8 / _10 / _12
-    static const int waves_r = [] {
-      const std::string name = "SARA_HIP_MARCH2_WAVES_" + std::to_string(R);
-      const char* e = getenv(name.c_str());
-      return e ? std::max(64, atoi(e)) : g_march2_waves;
-    }();
-    int nseg = (waves_r + nstrips * batch - 1) / (nstrips * batch);
+    int nseg = (g_march2_waves + nstrips * batch - 1) / (nstrips * batch);
     const int min_rows = std::max(32, g_march_minrows * R);
     nseg = std::max(1, std::min(nseg, (h + min_rows - 1) / min_rows));
     const int seg_rows = (h + nseg - 1) / nseg;
@@ -858,12 +841,6 @@ namespace sara_hip {
                        h, taps, dec, dec_stride);
   }
 
-  //! SARA_HIP_TILE_GEOM=0 / 1 / 2 forces the 64 x 32 / 64 x 16 / 32 x 16 tiles.
-  static const int g_tile_geom = [] {
-    const char* e = getenv("SARA_HIP_TILE_GEOM");
-    return e ? atoi(e) : -1;
-  }();
-
   template <int R>
   static void launch_blur_r(const float* src, size_t src_stride, float* dst,
                             size_t dst_stride, float* dog, size_t dog_stride,
@@ -874,9 +851,7 @@ namespace sara_hip {
     // measurements behind the thresholds)
     const long long tiles6432 =
         (long long) ((w + 63) / 64) * ((h + 31) / 32) * batch;
-    int geom = tiles6432 >= 200 ? 0 : (tiles6432 >= 48 ? 1 : 2);
-    if (g_tile_geom >= 0 && g_tile_geom <= 2)
-      geom = g_tile_geom;
+    const int geom = tiles6432 >= 200 ? 0 : (tiles6432 >= 48 ? 1 : 2);
     if (geom == 0)
       launch_blur_geom<R, 64, 32, 512>(src, src_stride, dst, dst_stride, dog,
                                        dog_stride, w, h, batch, taps, stream, dec,
@@ -889,270 +864,6 @@ namespace sara_hip {
       launch_blur_geom<R, 32, 16, 128>(src, src_stride, dst, dst_stride, dog,
                                        dog_stride, w, h, batch, taps, stream, dec,
                                        dec_stride);
-  }
-
-  // ======================================================================== //
-  // Chains of two or three consecutive blurs in ONE launch, for the regime
-  // where a call is a chain of dependent launches rather than bandwidth (one
-  // 1080p frame: 14 dependent blurs of 8-18 us for 3 us of traffic each).
-  //
-  // G(s) = blur(G(s-1)) three times over means three kernel boundaries and
-  // three times a tile's load -> sync -> rows -> sync -> columns -> store
-  // latency.  Here a workgroup stages its 64 x 32 tile with the halo of ALL
-  // the blurs of the chain (R0 + R1 + R2), runs blur 0 on the tile extended by
-  // R1 + R2, blur 1 on the tile extended by R2, blur 2 on the tile, each from
-  // LDS to LDS, and stores the tile of every intermediate plane (they are
-  // pyramid planes too).  Each value is computed from the same inputs with
-  // the same instruction sequence as in the one-blur kernel - the halo cells
-  // are merely computed by more than one workgroup - so the planes are
-  // bit-identical.  Borders: the reference replicates the edge of EACH blur's
-  // input (LinearFiltering.hpp:93-99), so after every stage the cells of the
-  // extended tile that lie outside the image are overwritten with the stage's
-  // output at the clamped coordinates before the next stage reads them.
-  // ======================================================================== //
-  struct ChainTaps
-  {
-    float k[3][25];  // radii <= 12
-  };
-
-  constexpr int chain_pitch(int width) { return ((width + 3) / 4) * 4 + 4; }
-
-  //! One stage: sIn (pitch PI, origin = tile - (H + R)) -> sOut (pitch PO, origin
-  //! = tile - H), through sTmp; stores the tile itself to dst.
-  template <int R, int H, bool LAST>
-  __device__ inline void chain_stage(const float* __restrict__ sIn, float* sTmp,
-                                     float* sOut, const float* __restrict__ k,
-                                     float* __restrict__ dst, int w, int h, int x0,
-                                     int y0, float* __restrict__ dec)
-  {
-    constexpr int K = 2 * R + 1;
-    constexpr int WO = TX + 2 * H, HO = TY + 2 * H;
-    constexpr int HI = HO + 2 * R;
-    constexpr int PI = chain_pitch(WO + 2 * R);
-    constexpr int PT = ((WO + 3) / 4) * 4;
-    constexpr int PO = chain_pitch(WO);
-    constexpr int NQ = (4 + 2 * R + 3) / 4;
-    constexpr int NQW = (WO + 3) / 4;
-    const int tid = threadIdx.x;
-    // rows
-    for (int it = tid; it < HI * NQW; it += NT)
-    {
-      const int r = it / NQW, q = it - r * NQW;
-      float v[NQ * 4];
-      const float4* p = reinterpret_cast<const float4*>(&sIn[r * PI + 4 * q]);
-#pragma unroll
-      for (int m = 0; m < NQ; ++m)
-      {
-        const float4 t = p[m];
-        v[4 * m + 0] = t.x;
-        v[4 * m + 1] = t.y;
-        v[4 * m + 2] = t.z;
-        v[4 * m + 3] = t.w;
-      }
-      float acc[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-      {
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < K; ++j)
-          sum += v[i + j] * k[j];
-        acc[i] = sum;
-      }
-      *reinterpret_cast<float4*>(&sTmp[r * PT + 4 * q]) =
-          make_float4(acc[0], acc[1], acc[2], acc[3]);
-    }
-    __syncthreads();
-    // columns: 8 consecutive rows per item
-    constexpr int NG = (HO + 7) / 8;
-    constexpr int NV = 8 + 2 * R;
-    for (int it = tid; it < NG * WO; it += NT)
-    {
-      const int g = it / WO, c = it - g * WO;
-      float v[NV];
-#pragma unroll
-      for (int m = 0; m < NV; ++m)
-        v[m] = sTmp[(g * 8 + m) * PT + c];  // sTmp has 8 spare rows
-      const int gx = x0 - H + c;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-      {
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < K; ++j)
-          sum += v[i + j] * k[j];
-        const int r = g * 8 + i;
-        if (r >= HO)
-          break;
-        if (!LAST)
-          sOut[r * PO + c] = sum;
-        const int gy = y0 - H + r;
-        const bool interior = c >= H && c < H + TX && r >= H && r < H + TY;
-        if (interior && gx < w && gy < h)
-        {
-          dst[size_t(gy) * w + gx] = sum;
-          // nearest-neighbour half = first plane of the next octave
-          // (Resize.cpp:45-84), as in gaussian_blur_kernel
-          if (dec && ((gx | gy) & 1) == 0 && (gx >> 1) < (w >> 1) && (gy >> 1) < (h >> 1))
-            dec[size_t(gy >> 1) * (w >> 1) + (gx >> 1)] = sum;
-        }
-      }
-    }
-    if (LAST)
-      return;
-    __syncthreads();
-    // replicate this plane's edge into the cells outside the image
-    const int ox = x0 - H, oy = y0 - H;
-    if (ox < 0 || oy < 0 || ox + WO > w || oy + HO > h)
-    {
-      for (int it = tid; it < HO * WO; it += NT)
-      {
-        const int r = it / WO, c = it - r * WO;
-        const int gx = ox + c, gy = oy + r;
-        const int cx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
-        const int cy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
-        if (cx != gx || cy != gy)
-          sOut[r * PO + c] = sOut[(cy - oy) * PO + (cx - ox)];
-      }
-      __syncthreads();
-    }
-  }
-
-  template <int R0, int R1, int R2>
-  __global__ __launch_bounds__(NT) void gaussian_blur_chain_kernel(
-      const float* __restrict__ src, size_t src_stride, float* __restrict__ dst0,
-      float* __restrict__ dst1, float* __restrict__ dst2, size_t dst_stride, int w,
-      int h, ChainTaps taps, float* __restrict__ dec, size_t dec_stride,
-      int dec_stage)
-  {
-    constexpr int HIN = R0 + R1 + R2;
-    constexpr int H0 = R1 + R2, H1 = R2;
-    constexpr int WI = TX + 2 * HIN, HI = TY + 2 * HIN;
-    constexpr int PA = chain_pitch(WI);
-    constexpr int SZ_A = HI * PA;
-    constexpr int SZ_T = (HI + 8) * (((TX + 2 * H0 + 3) / 4) * 4);
-    extern __shared__ __attribute__((aligned(16))) float s_chain[];
-    float* sA = s_chain;
-    float* sT = sA + SZ_A;
-    float* sB = sT + SZ_T;
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
-    const size_t b = blockIdx.z;
-    src += b * src_stride;
-    dst0 += b * dst_stride;
-    dst1 += b * dst_stride;
-    if (R2)
-      dst2 += b * dst_stride;
-    if (dec)
-      dec += b * dec_stride;
-    // the clamped source window of the whole chain
-    for (int idx = tid; idx < HI * WI; idx += NT)
-    {
-      const int r = idx / WI, c = idx - r * WI;
-      int gy = y0 - HIN + r, gx = x0 - HIN + c;
-      gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
-      gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
-      sA[r * PA + c] = src[size_t(gy) * w + gx];
-    }
-    __syncthreads();
-    chain_stage<R0, H0, false>(sA, sT, sB, taps.k[0], dst0, w, h, x0, y0,
-                               dec_stage == 0 ? dec : nullptr);
-    if (R2)
-    {
-      chain_stage<R1, H1, false>(sB, sT, sA, taps.k[1], dst1, w, h, x0, y0,
-                                 dec_stage == 1 ? dec : nullptr);
-      chain_stage<(R2 ? R2 : 1), 0, true>(sA, sT, sB, taps.k[2], dst2, w, h, x0, y0,
-                                          dec_stage == 2 ? dec : nullptr);
-    }
-    else
-      chain_stage<R1, 0, true>(sB, sT, sA, taps.k[1], dst1, w, h, x0, y0,
-                               dec_stage == 1 ? dec : nullptr);
-  }
-
-  template <int R0, int R1, int R2>
-  static bool launch_chain(const float* src, size_t src_stride, float* const* dst,
-                           size_t dst_stride, int w, int h, int batch,
-                           const Taps* const* taps, hipStream_t stream, float* dec,
-                           size_t dec_stride, int dec_stage)
-  {
-    constexpr int HIN = R0 + R1 + R2, H0 = R1 + R2;
-    constexpr int SZ_A = (TY + 2 * HIN) * chain_pitch(TX + 2 * HIN);
-    constexpr int SZ_T = (TY + 2 * HIN + 8) * (((TX + 2 * H0 + 3) / 4) * 4);
-    constexpr int SZ_B = (TY + 2 * H0) * chain_pitch(TX + 2 * H0);
-    const size_t lds = sizeof(float) * size_t(SZ_A + SZ_T + SZ_B);
-    static std::atomic<bool> allowed[64];
-    int dev = 0;
-    (void) hipGetDevice(&dev);
-    if (lds > 64 * 1024 && !allowed[dev & 63].load(std::memory_order_acquire))
-    {
-      (void) hipFuncSetAttribute(
-          reinterpret_cast<const void*>(gaussian_blur_chain_kernel<R0, R1, R2>),
-          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-      allowed[dev & 63].store(true, std::memory_order_release);
-    }
-    ChainTaps ct;
-    const int n = R2 ? 3 : 2;
-    for (int s = 0; s < n; ++s)
-      for (int j = 0; j < taps[s]->size; ++j)
-        ct.k[s][j] = taps[s]->k[j];
-    const dim3 grid((w + TX - 1) / TX, (h + TY - 1) / TY, batch);
-    hipLaunchKernelGGL((gaussian_blur_chain_kernel<R0, R1, R2>), grid, dim3(NT), lds,
-                       stream, src, src_stride, dst[0], dst[1], n == 3 ? dst[2] : nullptr,
-                       dst_stride, w, h, ct, dec, dec_stride, dec_stage);
-    return true;
-  }
-
-  //! OFF by default (SARA_HIP_BLUR_CHAIN=1 enables).  Measured on one 1080p
-  //! frame (profiles/r03b_single_frame_timeline_chain.txt): a chain workgroup
-  //! is a serial sequence of three row / column passes with five barriers on a
-  //! 70 KB LDS footprint (two workgroups per CU), and the halo of the whole
-  //! chain is staged and filtered by every neighbour: <6, 5, 6> on octave 0
-  //! takes 50.8 us against 14.4 + 12.2 + 12.4 us for the three separate
-  //! launches (1013 tiles = two rounds of 25 us), <5, 6> 29.9 against 26.6 on
-  //! octave 1, 13.3 against 25.2 on octave 2, <10, 12> 32.5 against 18 on
-  //! octave 3; one call 0.544 ms against 0.518.  The dependent-launch chain is
-  //! shorter, every link is longer: no gain, kept for the record and the test.
-  static const bool g_blur_chain = [] {
-    const char* e = getenv("SARA_HIP_BLUR_CHAIN");
-    return e && std::string(e) == "1";
-  }();
-
-  bool gaussian_blur_chain_available(const Taps* const* taps, int n, int w, int h,
-                                     int batch)
-  {
-    if (!g_blur_chain || n < 2 || n > 3)
-      return false;
-    // only where a launch cannot fill the chip anyway (see g_march_min_pixels)
-    if (size_t(w) * h * batch >= g_march_min_pixels)
-      return false;
-    const int r0 = taps[0]->size / 2, r1 = taps[1]->size / 2;
-    const int r2 = n == 3 ? taps[2]->size / 2 : 0;
-    return (r0 == 6 && r1 == 5 && r2 == 6) || (r0 == 5 && r1 == 6 && r2 == 0) ||
-           (r0 == 5 && r1 == 6 && r2 == 8) || (r0 == 10 && r1 == 12 && r2 == 0) ||
-           (r0 == 8 && r1 == 10 && r2 == 0);
-  }
-
-  bool launch_gaussian_blur_chain(const float* src, size_t src_stride,
-                                  float* const* dst, size_t dst_stride, int w, int h,
-                                  int batch, const Taps* const* taps, int n,
-                                  hipStream_t stream, float* dec, size_t dec_stride,
-                                  int dec_stage)
-  {
-    if (!gaussian_blur_chain_available(taps, n, w, h, batch))
-      return false;
-    const int r0 = taps[0]->size / 2, r1 = taps[1]->size / 2;
-    const int r2 = n == 3 ? taps[2]->size / 2 : 0;
-#define SARA_CHAIN(a, b, c)                                                    \
-  if (r0 == a && r1 == b && r2 == c)                                           \
-    return launch_chain<a, b, c>(src, src_stride, dst, dst_stride, w, h, batch,  \
-                                 taps, stream, dec, dec_stride, dec_stage);
-    SARA_CHAIN(6, 5, 6)
-    SARA_CHAIN(5, 6, 0)
-    SARA_CHAIN(5, 6, 8)
-    SARA_CHAIN(10, 12, 0)
-    SARA_CHAIN(8, 10, 0)
-#undef SARA_CHAIN
-    return false;
   }
 
   bool launch_gaussian_blur_gray8(const unsigned char* src, size_t src_stride,
@@ -1202,13 +913,11 @@ namespace sara_hip {
     const bool base_ok = big_enough && dog == nullptr;
     const bool march4_ok = base_ok && ((w % 4 == 0 && w >= 4) || w >= 256);
     const bool march2_ok = base_ok && ((w % 4 == 0 && w >= 4) || w >= 128);
-    if (!g_fuse_decimate)
-      dec = nullptr;
     // the hand-scheduled kernel shares the products of mirrored taps
     bool symmetric = true;
     for (int j = 0; j < R; ++j)
       symmetric &= std::memcmp(&taps.k[j], &taps.k[2 * R - j], sizeof(float)) == 0;
-    if (march2_ok && g_use_march && g_use_march2 && dec == nullptr && symmetric)
+    if (march2_ok && g_use_march && dec == nullptr && symmetric)
     {
       switch (R)
       {
@@ -1382,51 +1091,6 @@ namespace sara_hip {
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count;
          i += size_t(gridDim.x) * blockDim.x)
       dst[b * dst_stride + i] = src[b * src_stride + i];
-  }
-
-  //! Byte copy by the shader cores (16 bytes per lane and iteration).  An
-  //! experiment for the result read-back into pinned host memory
-  //! (SARA_HIP_D2H=kernel): the copy engines serialise host-to-device and
-  //! device-to-host copies on this platform (measured with two streams: 9.3 ms
-  //! + 2.5 ms = 11.8 ms when both are in flight), and a kernel writing over
-  //! PCIe could run beside an upload.  Measured: float frames 12.96 -> 11.94
-  //! ms per step, but 8-bit frames 8.4 -> 11.3 ms (the copy kernel queues
-  //! behind the next batch's launches whatever its grid and stream priority),
-  //! so the copy engine stays the default.
-  __global__ __launch_bounds__(256) void blit_kernel(const uint4* __restrict__ src,
-                                                     uint4* __restrict__ dst,
-                                                     size_t n16,
-                                                     const unsigned char* src_tail,
-                                                     unsigned char* dst_tail,
-                                                     int tail)
-  {
-    const size_t stride = size_t(gridDim.x) * blockDim.x;
-    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += stride)
-      dst[i] = src[i];
-    if (blockIdx.x == 0 && int(threadIdx.x) < tail)
-      dst_tail[threadIdx.x] = src_tail[threadIdx.x];
-  }
-
-  void launch_blit(const void* src, void* dst, size_t bytes, hipStream_t stream,
-                   int nblocks)
-  {
-    if (bytes == 0)
-      return;
-    const size_t n16 = bytes / 16;
-    const int tail = int(bytes - n16 * 16);
-    const unsigned char* s = static_cast<const unsigned char*>(src);
-    unsigned char* d = static_cast<unsigned char*>(dst);
-    // a PCIe link needs few waves to stay full; a small grid leaves the CUs to
-    // the pipeline of the next batch
-    static const int max_blocks = [] {
-      const char* e = getenv("SARA_HIP_BLIT_BLOCKS");
-      return e ? std::max(1, atoi(e)) : 64;
-    }();
-    const int blocks = int(std::min<size_t>(size_t(nblocks > 0 ? nblocks : max_blocks),
-                                            (n16 + 255) / 256 + 1));
-    hipLaunchKernelGGL(blit_kernel, dim3(blocks), dim3(256), 0, stream,
-                       reinterpret_cast<const uint4*>(s), reinterpret_cast<uint4*>(d),
-                       n16, s + n16 * 16, d + n16 * 16, tail);
   }
 
   void launch_copy_planes(const float* src, size_t src_stride, float* dst,

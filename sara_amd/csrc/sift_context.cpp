@@ -371,19 +371,12 @@ struct sara_hip_sift
     float* h_desc = nullptr;
     int32_t* h_so = nullptr;
     size_t h_cap = 0;            // keypoints the pinned arrays hold
-    // read-back enqueued by submit() itself, sized from the previous batch
-    // (collect() copies what is missing): rows already on their way to the
-    // pinned arrays, 0 = none
-    size_t spec_rows = 0;
-    bool spec_desc = false;
   } ring[2];
-  size_t last_total = 0;        // keypoints of the batch collected last
   // detect_staged(): recorded by detect() as soon as the last kernel that
   // reads the input frames has been enqueued (the staging buffer is free for
   // the next upload long before the batch is complete)
   hipEvent_t consumed_event = nullptr;
   bool consumed_recorded = false;
-  bool speculative_d2h = false;  // SARA_HIP_SPEC_D2H=1 (experiment, see submit())
   hipStream_t d2h_stream = nullptr;
   int next_ticket = 0;
   sara_oeregion* d_ex_regions = nullptr;
@@ -395,7 +388,6 @@ struct sara_hip_sift
   int* d_grouped = nullptr;        // [max_batch][cap]
   int bucket_stride = 0;
   RowBuckets row_buckets{};        // of the current schedule
-  bool bucketed_rank = true;       // SARA_HIP_RANK=count restores the O(n^2) kernel
   int* h_counts = nullptr;  // pinned, 3*max_batch+2
   // Small batches are launch-bound (about 60 launches in 0.7 ms for one 1080p
   // frame): the enqueue sequence of detect() is captured once per (size,
@@ -415,19 +407,12 @@ struct sara_hip_sift
   // remembered per slot; when the caller's pointer changes, their argument is
   // rewritten in the executable graph (hipGraphExecKernelNodeSetParams)
   // instead of copying the frames to a fixed address first (8.3 MB and one
-  // more enqueue per 1080p call).  SARA_HIP_GRAPH_INPLACE=0 restores the copy.
+  // more enqueue per 1080p call); cleared for good when the runtime cannot
+  // rewrite a captured kernel's argument (the copy comes back).
   bool graph_inplace = true;
   const void* graph_src_s[2] = {nullptr, nullptr};     // pointer baked into the slot's graph
   size_t graph_src_stride_s[2] = {0, 0};
   std::vector<hipGraphNode_t> graph_src_nodes_s[2];    // kernels reading it
-  // Round 3: the replay is a sequence of LINEAR graphs (detect() says why)
-  struct GraphSegment
-  {
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-  };
-  GraphSegment seg_s[2][4];
-  bool graph_segments = false;  // SARA_HIP_GRAPH_SEGMENTS=1 (experiment, see detect())
   hipEvent_t ev[SARA_HIP_TIME_COUNT + 1] = {};
   bool ev_recorded[SARA_HIP_TIME_COUNT + 1] = {};
   // SARA_HIP_OPT_LAUNCH_TIMERS: one event pair around every launch of the
@@ -539,40 +524,10 @@ namespace {
                           std::string(#expr) + ": " + hipGetErrorString(e_))); \
   } while (0)
 
-    // SARA_HIP_CU_COUNT=n (experiment): the pipeline's streams may only use n
-    // of the 256 CUs (hipExtStreamCreateWithCUMask, every (256/n)-th CU
-    // pattern spread over the XCDs) - measures how each stage scales with CUs,
-    // which decides whether a CU-partitioned overlap of one batch's
-    // per-keypoint kernels with the next batch's pyramid can pay (DESIGN.md
-    // section 4, round 3).
-    static const int cu_count = [] {
-      const char* e = getenv("SARA_HIP_CU_COUNT");
-      return e ? std::max(8, std::min(256, atoi(e))) : 0;
-    }();
     auto make_stream = [&](hipStream_t* st) -> hipError_t {
-      if (cu_count <= 0 || cu_count >= 256)
-        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      // Bresenham: cu_count bits set, evenly spaced over 256
-      for (int i = 0, acc = 0; i < 256; ++i)
-      {
-        acc += cu_count;
-        if (acc >= 256)
-        {
-          acc -= 256;
-          mask[i >> 5] |= 1u << (i & 31);
-        }
-      }
-      return hipExtStreamCreateWithCUMask(st, 8, mask);
+      return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
     };
     TRY_HIP(make_stream(&c->own_stream));
-    for (auto& r : c->launch_rec)
-  {
-    if (r.begin)
-      (void) hipEventDestroy(r.begin);
-    if (r.end)
-      (void) hipEventDestroy(r.end);
-  }
   for (auto& e : c->ev)
       TRY_HIP(hipEventCreate(&e));
     for (int o = 0; o < 16; ++o)
@@ -601,12 +556,6 @@ namespace {
       c->use_graph = std::string(e) != "0";
     if (const char* e = getenv("SARA_HIP_GRAPH_MAX_BATCH"))
       c->graph_max_batch = atoi(e);
-    if (const char* e = getenv("SARA_HIP_GRAPH_SEGMENTS"))
-      c->graph_segments = std::string(e) != "0";
-    if (const char* e = getenv("SARA_HIP_GRAPH_INPLACE"))
-      c->graph_inplace = std::string(e) != "0";
-    if (const char* e = getenv("SARA_HIP_SPEC_D2H"))
-      c->speculative_d2h = std::string(e) != "0";
 
     // ---- taps and tables (host arithmetic as in GaussianPyramid.hpp:106-121)
     const float k = pyr.scale_geometric_factor;
@@ -711,8 +660,6 @@ namespace {
       TRY_ST(c->alloc(c->d_bucket_hist, size_t(max_batch) * c->bucket_stride));
       TRY_ST(c->alloc(c->d_bucket_cursor, size_t(max_batch) * c->bucket_stride));
       TRY_ST(c->alloc(c->d_grouped, rows));
-      if (const char* e = getenv("SARA_HIP_RANK"))
-        c->bucketed_rank = std::string(e) != "count";
     }
     c->sites.cap = 4 * c->cap;
     TRY_ST(c->alloc(c->sites.key, size_t(max_batch) * c->sites.cap));
@@ -908,6 +855,13 @@ sara_hip_status sara_hip_sift_destroy(sara_hip_sift* c)
   for (auto& e : c->ev)
     if (e)
       (void) hipEventDestroy(e);
+  for (auto& r : c->launch_rec)
+  {
+    if (r.begin)
+      (void) hipEventDestroy(r.begin);
+    if (r.end)
+      (void) hipEventDestroy(r.end);
+  }
   for (int o = 0; o < 16; ++o)
   {
     if (c->oct_stream[o])
@@ -940,13 +894,6 @@ sara_hip_status sara_hip_sift_destroy(sara_hip_sift* c)
       (void) hipGraphExecDestroy(c->graph_exec_s[k]);
     if (c->graph_s[k])
       (void) hipGraphDestroy(c->graph_s[k]);
-    for (auto& g : c->seg_s[k])
-    {
-      if (g.exec)
-        (void) hipGraphExecDestroy(g.exec);
-      if (g.graph)
-        (void) hipGraphDestroy(g.graph);
-    }
     sara_hip_sift::RingSlot& r = c->ring[k];
     if (r.done)
       (void) hipEventDestroy(r.done);
@@ -1119,20 +1066,8 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   const bool graph_mode = c->use_graph && !c->graph_broken && !hip_stream &&
                           graph_thread_ok() &&
                           batch <= c->graph_max_batch && !debug_sync;
-  // Small images under graph replay: everything on ONE stream.  A graph captured
-  // from one stream is submitted in ~15 us whatever its length, a forked one
-  // costs the host 3.3 us per node (tools/ubench/graph_launch_cost.hip); when
-  // the kernels are so small that the call is the host's enqueue time anyway,
-  // running them one after the other is faster than running them side by side
-  // late.  SARA_HIP_LINEAR_GRAPH_PIXELS (pixels x batch; 0 = never).
-  static const long long linear_pixels = [] {
-    const char* e = getenv("SARA_HIP_LINEAR_GRAPH_PIXELS");
-    return e ? atoll(e) : 0ll;
-  }();
-  const bool linear_graph =
-      graph_mode && (long long) width * height * batch <= linear_pixels;
-  const bool multi_stream = c->multi_stream && !linear_graph;
-  const bool side_gradient = c->side_gradient && !linear_graph;
+  const bool multi_stream = c->multi_stream;
+  const bool side_gradient = c->side_gradient;
   const bool timing = c->timers && !graph_mode;
   // 8-bit gray frames not converted yet (detect_u8): the first blur of the
   // pyramid reads them directly when it is the marching blur of octave 0 and
@@ -1188,8 +1123,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     src = c->d_input;
     src_stride = in_plane;
   }
-  else if (graph_mode && images != c->d_input && c->graph_inplace &&
-           !c->graph_segments && !gray8)
+  else if (graph_mode && images != c->d_input && c->graph_inplace && !gray8)
   {
     // the graph reads the caller's frames where they are (see graph_inplace)
     src_in_place = true;
@@ -1237,34 +1171,17 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       (void) hipEventRecord(c->launch_rec[size_t(rec)].end, st);
   };
 
-  static const bool fuse_gradient_env = [] {
-    const char* e = getenv("SARA_HIP_FUSE_GRADIENT");
-    return e && std::string(e) == "1";
-  }();
-  // Segment replay (see the end of this function): enqueue() is then called
-  // once per segment and emits only that segment's launches on seg_stream.
-  //   0: octave 0 up to G(downscale_index, 0) (+ the base of octave 1)
-  //   1: octaves 1.. : blurs, scans, gradients   (second stream)
-  //   2: the rest of octave 0, its scan and gradients
-  //   3: refinement, ordering, orientations, descriptors
-  int seg_phase = -1;
-  hipStream_t seg_stream = nullptr;
-  bool seg_base_ready = false;  // base_ready handed from segment 0 to 1
-
   auto enqueue = [&]() -> sara_hip_status {
 
   const bool want_gradients = last_stage >= SARA_HIP_STAGE_GRADIENT;
-  const bool side = side_gradient && want_gradients && !fuse_gradient_env &&
-                    !debug_sync;
+  const bool side = side_gradient && want_gradients && !debug_sync;
   // see SiftContext::octave_pipeline
-  const bool pipe = seg_phase >= 0 ||
-                    (multi_stream && sc.num_octaves > 1 &&
-                     last_stage >= SARA_HIP_STAGE_EXTREMA && !fuse_gradient_env &&
-                     !debug_sync && (!want_gradients || side) &&
-                     (c->octave_pipeline < 0 ? graph_mode : c->octave_pipeline != 0));
-  bool grad_fused[16] = {};
+  const bool pipe = multi_stream && sc.num_octaves > 1 &&
+                    last_stage >= SARA_HIP_STAGE_EXTREMA && !debug_sync &&
+                    (!want_gradients || side) &&
+                    (c->octave_pipeline < 0 ? graph_mode : c->octave_pipeline != 0);
   // the stream the extrema .. descriptor stages are enqueued on
-  hipStream_t tail = seg_phase >= 0 ? seg_stream : stream;
+  hipStream_t tail = stream;
 
   // polar gradients of one octave (the planes the later stages read)
   auto enqueue_gradient = [&](int o, hipStream_t gs) -> sara_hip_status {
@@ -1272,8 +1189,6 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     const int s_n = c->all_gradient_scales ? S : S - 3;
     const int w = sc.oct[o].w, h = sc.oct[o].h;
     const size_t pl = size_t(w) * h;
-    if (grad_fused[o])
-      return SARA_HIP_OK;  // written by the extremum scan
     const size_t cpl = size_t((w + 15) / 16) * ((h + 15) / 16);
     if (gradient_polar_needs_zeroed_cmax(c->G[o] + pl * s_lo, pl * S,
                                          c->GR[o] + pl * 2 * s_lo, pl * 2 * S,
@@ -1300,47 +1215,22 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     dv.scales = S;
     dv.plane = size_t(dv.w) * dv.h;
     dv.frame_stride = dv.plane * S;
-    // With the gradient stage requested, the scan of the fast path also
-    // emits the polar gradients of the planes it has in registers.
-    const bool want_grad = want_gradients && !c->all_gradient_scales && !side;
-    const size_t cpl = size_t((dv.w + 15) / 16) * ((dv.h + 15) / 16);
-    grad_fused[o] = false;
-    if (want_grad)
-      HIP_TRY(hipMemsetAsync(c->CM[o], 0, cpl * S * batch * sizeof(unsigned), ss));
     // the Halide-branch classifier looks at every pixel, whatever the padding
     if (c->signed_type || (dv.w > 2 * c->img_padding && dv.h > 2 * c->img_padding))
-      grad_fused[o] = launch_extrema_scan(
-          dv, o, batch, ep, c->d_tab, c->cand, c->sites, ss,
-          want_grad ? c->GR[o] : nullptr, dv.plane * 2 * S,
-          want_grad ? c->CM[o] : nullptr, cpl * S);
+      launch_extrema_scan(dv, o, batch, ep, c->d_tab, c->cand, c->sites, ss);
     return SARA_HIP_OK;
   };
-  if (pipe && seg_phase <= 0)  // the scans start before the pyramid is complete
+  if (pipe)  // the scans start before the pyramid is complete
     HIP_TRY(hipMemsetAsync(c->d_counters, 0,
                            sizeof(int) * counters_padded(c->max_batch), tail));
 
   // ---- Gaussian pyramid + fused DoG ---------------------------------------
-  if (sc.num_octaves > 0 && seg_phase != 3)
+  if (sc.num_octaves > 0)
   {
-    hipStream_t stream = tail;  // segment replay: this segment's stream
     const size_t pl0 = size_t(sc.oct[0].w) * sc.oct[0].h;
     float* G00 = c->G[0];
     const size_t g_stride0 = pl0 * S;
-    // Launch-chain-bound regime (octave pipelining = small batches): the blurs
-    // of the spine go out as chains of two or three per launch where the radii
-    // have a fused kernel (launch_gaussian_blur_chain).  Octave 0's chain
-    // starts from the source frame: initial blur, s = 1, s = 2.
-    const Taps* chain0_taps[3] = {&c->init_taps, &c->taps[1], &c->taps[2]};
-    const bool chain0 =
-        pipe && seg_phase < 0 && c->pyr.first_octave_index == 0 && sc.init_blur &&
-        !gray8_fused &&
-        !c->fma_blur && sc.downscale_index == 2 && S > 3 && !time_launches &&
-        gaussian_blur_chain_available(chain0_taps, 3, sc.oct[0].w, sc.oct[0].h, batch);
-    if (seg_phase > 0)
-    {
-      // G(0, 0) belongs to segment 0
-    }
-    else if (c->pyr.first_octave_index < 0)
+    if (c->pyr.first_octave_index < 0)
     {
       launch_enlarge(src, src_stride, width, height, G00, g_stride0, sc.oct[0].w,
                      sc.oct[0].h, batch, stream);
@@ -1359,10 +1249,6 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       }
       launch_scale(blurred, bstride, width, height, G00, g_stride0, sc.oct[0].w,
                    sc.oct[0].h, batch, stream);
-    }
-    else if (sc.init_blur && chain0)
-    {
-      // G(0, 0) .. G(2, 0) come out of one launch on the spine (below)
     }
     else if (sc.init_blur)
     {
@@ -1388,7 +1274,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     }
 
     // nothing reads the caller's / staged frames beyond this point
-    if (c->consumed_event && !graph_mode && !chain0 && seg_phase < 0)
+    if (c->consumed_event && !graph_mode)
     {
       HIP_TRY(hipEventRecord(c->consumed_event, stream));
       c->consumed_recorded = true;
@@ -1436,102 +1322,11 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       }
       base_ready = false;
     };
-    // blurs s_lo .. s_hi of octave o, fused where a chain kernel exists
     auto enqueue_blurs = [&](int o, int s_lo, int s_hi, hipStream_t st) {
-      const int w = sc.oct[o].w, h = sc.oct[o].h;
-      const size_t pl = size_t(w) * h;
-      const size_t gs = pl * S;
-      int s = s_lo;
-      while (s <= s_hi)
-      {
-        bool fused = false;
-        for (int n = std::min(3, s_hi - s + 1); n >= 2 && !fused && !c->fma_blur &&
-                                                !time_launches && seg_phase < 0;
-             --n)
-        {
-          const Taps* tp[3] = {&c->taps[s], &c->taps[s + 1],
-                               n == 3 ? &c->taps[s + 2] : nullptr};
-          if (!gaussian_blur_chain_available(tp, n, w, h, batch))
-            continue;
-          float* dst[3] = {c->G[o] + pl * s, c->G[o] + pl * (s + 1),
-                           n == 3 ? c->G[o] + pl * (s + 2) : nullptr};
-          float* dec = nullptr;
-          size_t dec_stride = 0;
-          int dec_stage = -1;
-          if (o < last && dsi >= s && dsi < s + n)
-          {
-            dec = c->G[o + 1];
-            dec_stride = size_t(sc.oct[o + 1].w) * sc.oct[o + 1].h * S;
-            dec_stage = dsi - s;
-          }
-          fused = launch_gaussian_blur_chain(c->G[o] + pl * (s - 1), gs, dst, gs, w, h,
-                                             batch, tp, n, st, dec, dec_stride,
-                                             dec_stage);
-          if (fused)
-          {
-            if (dec)
-              base_ready = true;
-            s += n;
-          }
-        }
-        if (!fused)
-        {
-          enqueue_blur(o, s, st);
-          ++s;
-        }
-      }
+      for (int s = s_lo; s <= s_hi; ++s)
+        enqueue_blur(o, s, st);
     };
-    if (seg_phase >= 0)
-    {
-      const bool scans = last_stage >= SARA_HIP_STAGE_EXTREMA;
-      if (seg_phase == 0)
-      {
-        enqueue_base(0, stream);
-        for (int s = 1; s <= dsi && s < S; ++s)
-          enqueue_blur(0, s, stream);
-        seg_base_ready = base_ready;
-      }
-      else if (seg_phase == 1)
-      {
-        base_ready = seg_base_ready;
-        for (int o = 1; o <= last; ++o)
-        {
-          enqueue_base(o, stream);
-          for (int s = 1; s < S; ++s)
-            enqueue_blur(o, s, stream);
-          if (scans)
-          {
-            const sara_hip_status sst = enqueue_scan(o, stream);
-            if (sst != SARA_HIP_OK)
-              return sst;
-          }
-        }
-        for (int o = 1; o <= last && want_gradients; ++o)
-        {
-          const sara_hip_status gst = enqueue_gradient(o, stream);
-          if (gst != SARA_HIP_OK)
-            return gst;
-        }
-      }
-      else
-      {
-        for (int s = dsi + 1; s < S; ++s)
-          enqueue_blur(0, s, stream);
-        if (scans)
-        {
-          const sara_hip_status sst = enqueue_scan(0, stream);
-          if (sst != SARA_HIP_OK)
-            return sst;
-        }
-        if (want_gradients)
-        {
-          const sara_hip_status gst = enqueue_gradient(0, stream);
-          if (gst != SARA_HIP_OK)
-            return gst;
-        }
-      }
-    }
-    else if (pipe)
+    if (pipe)
     {
       // Small batches are bound by the chain of dependent launches, and a
       // dependency that crosses hardware queues costs ~12 us against ~0 on
@@ -1551,21 +1346,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       // a queue of its own.  With plain streams the same order simply works.
       hipStream_t side0 = c->oct_stream[1];
       enqueue_base(0, stream);
-      if (chain0)
-      {
-        float* dst[3] = {G00, G00 + pl0, G00 + 2 * pl0};
-        float* dec = last > 0 ? c->G[1] : nullptr;
-        const size_t dec_stride =
-            last > 0 ? size_t(sc.oct[1].w) * sc.oct[1].h * S : 0;
-        (void) launch_gaussian_blur_chain(src, src_stride, dst, g_stride0,
-                                          sc.oct[0].w, sc.oct[0].h, batch,
-                                          chain0_taps, 3, stream, dec, dec_stride,
-                                          last > 0 ? 2 : -1);
-        if (dec)
-          base_ready = true;
-      }
-      else
-        enqueue_blurs(0, 1, dsi, stream);
+      enqueue_blurs(0, 1, dsi, stream);
       HIP_TRY(hipEventRecord(c->oct_ready[0], stream));
       // the last octave's gradients go behind the side chain of octave last-2
       // (done early, and not the queue finish_sites is waiting for)
@@ -1590,23 +1371,6 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
         if (st0 != SARA_HIP_OK)
           return st0;
       }
-      // Octaves whose side chain is captured BEFORE the spine goes on (bit o):
-      // under graph replay the runtime hands the nodes to the queues depth
-      // first, so a side chain captured after the whole spine reaches its
-      // queue last - octave 1's, the heaviest of them, started 80 us after
-      // its input was ready.  Captured first it keeps the spine's queue and
-      // the spine hops to the next one (one more cross-queue dependency,
-      // ~12 us, on a path that has the slack).
-      static const int side_first_env = [] {
-        const char* e = getenv("SARA_HIP_SIDE_FIRST");
-        return e ? atoi(e) : 0;
-      }();
-      // Measured on one 1080p frame (tools/b1_bench.py, no profiler): mask 0
-      // 0.204 / 0.292 ms (extrema only / full), mask 2 (octave 1) 0.204 / 0.312,
-      // mask 6 0.207 / 0.315 - although the profiler's timeline, whose dispatch
-      // interception slows the host side down, shows the opposite (span 320 ->
-      // 293 us).  Off.
-      const int side_first = graph_mode ? side_first_env : 0;
       // the spine
       for (int o = 1; o <= last; ++o)
       {
@@ -1615,14 +1379,6 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
         enqueue_blurs(o, 1, s_hi, tail);
         if (o < last)
           HIP_TRY(hipEventRecord(c->oct_ready[o], tail));
-        if (o < last && ((side_first >> o) & 1))
-        {
-          hipStream_t so = c->oct_stream[o + 1];
-          HIP_TRY(hipStreamWaitEvent(so, c->oct_ready[o], 0));
-          const sara_hip_status sto = enqueue_side(o, so);
-          if (sto != SARA_HIP_OK)
-            return sto;
-        }
       }
       HIP_TRY(hipEventRecord(c->aux_fork, tail));  // the last octave's planes
       {
@@ -1642,8 +1398,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       {
         hipStream_t so = c->oct_stream[o + 1];
         int fillers = 0;
-        const bool captured = ((side_first >> o) & 1) != 0;
-        if (graph_mode && !captured)
+        if (graph_mode)
           for (; fillers < last - 1 - o && fillers < 3; ++fillers)
           {
             hipStream_t fs = c->filler_stream[fillers];
@@ -1653,7 +1408,6 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
                 sizeof(int), fs));
             HIP_TRY(hipEventRecord(c->filler_done[fillers], fs));
           }
-        if (!captured)
         {
           HIP_TRY(hipStreamWaitEvent(so, c->oct_ready[o], 0));
           const sara_hip_status sto = enqueue_side(o, so);
@@ -1699,11 +1453,6 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     }
   }
   HIP_TRY(mark(2));
-  if (seg_phase >= 0 && seg_phase != 3)
-  {
-    HIP_TRY(hipGetLastError());
-    return SARA_HIP_OK;
-  }
 
   // ---- polar gradients on the side stream, next to the extrema stage --------
   auto enqueue_gradients = [&](hipStream_t gs) -> sara_hip_status {
@@ -1752,22 +1501,15 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       }
       launch_finish_sites(pv, batch, ep, c->d_tab, c->sites, c->cand, tail);
     }
-    if (c->bucketed_rank && c->row_buckets.total < c->bucket_stride &&
-        sc.num_octaves <= 16)
-      launch_rank_candidates_bucketed(c->cand, c->row_buckets, c->d_bucket_hist,
-                                      c->d_bucket_cursor, c->d_grouped, batch,
-                                      tail);
-    else
-      launch_rank_candidates(c->cand, batch, tail);
+    // row_buckets.total <= bucket_stride - 1 by construction (the buckets of
+    // the current schedule are a subset of the largest one's)
+    launch_rank_candidates_bucketed(c->cand, c->row_buckets, c->d_bucket_hist,
+                                    c->d_bucket_cursor, c->d_grouped, batch, tail);
   }
   HIP_TRY(mark(3));
 
   // ---- polar gradients ----------------------------------------------------
-  if (pipe && seg_phase >= 0)
-  {
-    // the segments are ordered by events between their launches
-  }
-  else if (pipe)
+  if (pipe)
   {
     // join the side chains (their gradients follow their scans)
     for (int o = 0; o + 1 < sc.num_octaves; ++o)
@@ -1798,12 +1540,6 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     launch_descriptors(*c->h_grad, c->cand, c->ori, batch, c->d_feat, c->d_so,
                        c->d_desc, last_stage >= SARA_HIP_STAGE_DESCRIPTOR ? 1 : 0,
                        c->root_sift ? 1 : 0, tail);
-  if (tail != stream && seg_phase < 0)
-  {
-    // back to the caller's stream
-    HIP_TRY(hipEventRecord(c->aux_join, tail));
-    HIP_TRY(hipStreamWaitEvent(stream, c->aux_join, 0));
-  }
   HIP_TRY(mark(6));
   HIP_TRY(hipGetLastError());
   return SARA_HIP_OK;
@@ -1819,130 +1555,6 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   }
   std::lock_guard<std::recursive_mutex> graph_lock(runtime_mutex());
   const int gs = c->write_slot;
-  static const bool trace_graph = getenv("SARA_HIP_TRACE_GRAPH") != nullptr;
-
-  // ---- Round 3 experiment (SARA_HIP_GRAPH_SEGMENTS=1, off by default): replay
-  // as a sequence of LINEAR graphs.
-  // hipGraphLaunch of a graph with forks hands its nodes to the queues one by
-  // one, 3.3 us each on the host (the ~42 nodes of a 4-octave call: 75-130 us
-  // inside the launch call, and a branch that comes late in the runtime's order
-  // starts that late), while a graph captured from ONE stream is submitted in
-  // 7-9 us whatever its length (tools/ubench/graph_launch_cost.hip: 32 kernels
-  // 8.6 us linear, 107 us forked, 106 us as plain launches).  Here the call is
-  // cut into four linear graphs on two streams, launched in the order of the
-  // critical path, with two event hand-offs between them:
-  //   stream:     [0: octave 0 up to G(downscale_index)]  [2: rest of octave 0,
-  //               its scan and gradients]   (wait)  [3: refinement .. descriptors]
-  //   aux_stream: (wait 0)  [1: octaves 1.., their scans and gradients]
-  // Measured on one 1080p frame: the host leaves detect() after 20-45 us instead
-  // of 75-90, but the call takes 0.29 / 0.46 ms (extrema only / full) against
-  // 0.20 / 0.32 ms for the forked graph in the same run - two-way concurrency
-  // and 13-19 us per hand-off between graphs (tools/ubench/graph_sched.hip)
-  // lose more than the host gains; the forked graph keeps four queues busy.
-  // Kept for the next look at this regime, not selected.
-  const bool seg_ok = c->graph_segments && !fuse_gradient_env &&
-                      (last_stage < SARA_HIP_STAGE_GRADIENT || c->side_gradient) &&
-                      sc.num_octaves > 0;
-  if (seg_ok)
-  {
-    sara_hip_sift::GraphSegment* seg = c->seg_s[gs];
-    const int last = sc.num_octaves - 1;
-    const bool have[4] = {true, last >= 1, true,
-                          last_stage >= SARA_HIP_STAGE_EXTREMA};
-    hipStream_t seg_streams[4] = {stream, c->aux_stream, stream, stream};
-    bool cached = c->graph_w_s[gs] == width && c->graph_h_s[gs] == height &&
-                  c->graph_batch_s[gs] == batch &&
-                  c->graph_stage_s[gs] == int(last_stage);
-    for (int k = 0; k < 4 && cached; ++k)
-      cached = !have[k] || seg[k].exec != nullptr;
-    bool ok = true;
-    if (!cached)
-    {
-      for (int k = 0; k < 4; ++k)
-      {
-        if (seg[k].exec)
-          (void) hipGraphExecDestroy(seg[k].exec);
-        if (seg[k].graph)
-          (void) hipGraphDestroy(seg[k].graph);
-        seg[k].exec = nullptr;
-        seg[k].graph = nullptr;
-      }
-      // the forked graph of this slot (if any) is stale as well
-      if (c->graph_exec_s[gs])
-        (void) hipGraphExecDestroy(c->graph_exec_s[gs]);
-      if (c->graph_s[gs])
-        (void) hipGraphDestroy(c->graph_s[gs]);
-      c->graph_exec_s[gs] = nullptr;
-      c->graph_s[gs] = nullptr;
-      c->graph_stage_s[gs] = -1;
-      for (int k = 0; k < 4 && ok; ++k)
-      {
-        if (!have[k])
-          continue;
-        seg_phase = k;
-        seg_stream = seg_streams[k];
-        ok = hipStreamBeginCapture(seg_stream, hipStreamCaptureModeRelaxed) ==
-             hipSuccess;
-        if (!ok)
-          break;
-        const sara_hip_status est = enqueue();
-        const hipError_t ee = hipStreamEndCapture(seg_stream, &seg[k].graph);
-        ok = est == SARA_HIP_OK && ee == hipSuccess && seg[k].graph != nullptr;
-        if (ok)
-          ok = hipGraphInstantiate(&seg[k].exec, seg[k].graph, nullptr, nullptr, 0) ==
-               hipSuccess;
-        if (trace_graph)
-          std::fprintf(stderr, "[sara_hip] segment %d captured: %d\n", k, int(ok));
-      }
-      seg_phase = -1;
-      if (!ok)
-      {
-        // fall back to the forked graph for good; clear the sticky error
-        (void) hipGetLastError();
-        for (int k = 0; k < 4; ++k)
-        {
-          if (seg[k].exec)
-            (void) hipGraphExecDestroy(seg[k].exec);
-          if (seg[k].graph)
-            (void) hipGraphDestroy(seg[k].graph);
-          seg[k].exec = nullptr;
-          seg[k].graph = nullptr;
-        }
-        c->graph_segments = false;
-      }
-      else
-      {
-        c->graph_w_s[gs] = width;
-        c->graph_h_s[gs] = height;
-        c->graph_batch_s[gs] = batch;
-        c->graph_stage_s[gs] = int(last_stage);
-      }
-    }
-    if (ok)
-    {
-      HIP_TRY(hipGraphLaunch(seg[0].exec, stream));
-      if (have[1])
-      {
-        HIP_TRY(hipEventRecord(c->oct_ready[0], stream));
-        HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->oct_ready[0], 0));
-        HIP_TRY(hipGraphLaunch(seg[1].exec, c->aux_stream));
-        HIP_TRY(hipEventRecord(c->aux_join, c->aux_stream));
-      }
-      HIP_TRY(hipGraphLaunch(seg[2].exec, stream));
-      if (have[1])
-        HIP_TRY(hipStreamWaitEvent(stream, c->aux_join, 0));
-      if (have[3])
-        HIP_TRY(hipGraphLaunch(seg[3].exec, stream));
-      if (c->timers)
-      {
-        c->ev_recorded[SARA_HIP_TIME_TOTAL] = true;
-        HIP_TRY(hipEventRecord(c->ev[SARA_HIP_TIME_TOTAL], stream));
-      }
-      c->has_result = true;
-      return SARA_HIP_OK;
-    }
-  }
-
   hipGraph_t& graph = c->graph_s[gs];
   hipGraphExec_t& graph_exec = c->graph_exec_s[gs];
   // a graph captured on the caller's frames serves other frames after an
@@ -1981,8 +1593,6 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       return sara_hip_sift_detect(c, images, frame_stride, batch, width, height,
                                   images_on_device, last_stage, hip_stream);
     }
-    if (trace_graph)
-      std::fprintf(stderr, "[sara_hip] frame address rewritten in the graph\n");
     c->graph_src_s[gs] = src;
   }
   if (!cached)
@@ -1995,22 +1605,17 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       (void) hipGraphDestroy(graph);
     graph_exec = nullptr;
     graph = nullptr;
-    const bool trace = trace_graph;
     bool ok = hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed) ==
               hipSuccess;
-    if (trace) std::fprintf(stderr, "[sara_hip] capture begun: %d\n", int(ok));
     if (ok)
     {
       const sara_hip_status est = enqueue();
-      if (trace) std::fprintf(stderr, "[sara_hip] enqueued: %d\n", int(est));
       const hipError_t ee = hipStreamEndCapture(stream, &graph);
-      if (trace) std::fprintf(stderr, "[sara_hip] capture ended: %s\n", hipGetErrorString(ee));
       ok = est == SARA_HIP_OK && ee == hipSuccess && graph != nullptr;
     }
     if (ok)
       ok = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0) ==
            hipSuccess;
-    if (trace) std::fprintf(stderr, "[sara_hip] instantiated: %d\n", int(ok));
     if (!ok)
     {
       // fall back to plain launches for good; clear the sticky error
@@ -2057,9 +1662,6 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       (void) hipGetLastError();
       // no such node found: the graph stays valid for this address only, and
       // the next address makes src_kind_ok false -> fall back to the copy
-      if (trace_graph)
-        std::fprintf(stderr, "[sara_hip] frames read in place by %zu kernel node(s)\n",
-                     c->graph_src_nodes_s[gs].size());
       if (c->graph_src_nodes_s[gs].empty())
         c->graph_inplace = false;
     }
@@ -2119,11 +1721,7 @@ sara_hip_status sara_hip_sift_detect_u8(sara_hip_sift* c, const uint8_t* images,
     src = c->d_u8;
     src_stride = px * channels;
   }
-  static const bool fuse_gray8 = [] {
-    const char* e = getenv("SARA_HIP_FUSE_GRAY8");
-    return !(e && e[0] == '0' && e[1] == 0);
-  }();
-  if (channels == 1 && fuse_gray8)
+  if (channels == 1)
   {
     // gray8: detect() lets the first blur read the bytes itself when it can
     // (and converts into d_input otherwise)
@@ -2145,11 +1743,7 @@ sara_hip_status sara_hip_sift_detect_u8(sara_hip_sift* c, const uint8_t* images,
 }
 
 namespace {
-  //! The read-back stream.  SARA_HIP_D2H_FIRST=1 (experiment, off) also makes
-  //! it copy 8 MB device -> host right away, i.e. before the upload stream's
-  //! first copy - a guess at how the runtime binds streams to copy engines
-  //! that did not hold: the float32 host -> host step got worse under the 7.0.2
-  //! runtime (9.3 -> 12.6 ms) and no more predictable under 7.2.
+  //! The read-back stream.
   sara_hip_status ensure_d2h_stream(sara_hip_sift* c)
   {
     if (c->d2h_stream)
@@ -2160,28 +1754,6 @@ namespace {
     std::lock_guard<std::recursive_mutex> runtime_lock(runtime_mutex());
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIP_TRY(hipStreamCreateWithPriority(&c->d2h_stream, hipStreamNonBlocking, hi));
-    static const bool first = [] {
-      const char* e = getenv("SARA_HIP_D2H_FIRST");
-      return e && e[0] == '1';
-    }();
-    if (first && c->d_input)
-    {
-      // a copy large enough to go through a copy engine (small ones do not)
-      static const size_t prime_bytes = [] {
-        const char* e = getenv("SARA_HIP_D2H_PRIME_BYTES");
-        return e ? size_t(atoll(e)) : size_t(8) << 20;
-      }();
-      const size_t bytes = std::min(prime_bytes, size_t(c->max_w) * c->max_h *
-                                                     sizeof(float) * c->max_batch);
-      void* tmp = nullptr;
-      HIP_TRY(hipHostMalloc(&tmp, bytes));
-      const hipError_t e1 = hipMemcpyAsync(tmp, c->d_input, bytes,
-                                           hipMemcpyDeviceToHost, c->d2h_stream);
-      const hipError_t e2 = hipStreamSynchronize(c->d2h_stream);
-      (void) hipHostFree(tmp);
-      HIP_TRY(e1);
-      HIP_TRY(e2);
-    }
     return SARA_HIP_OK;
   }
 }  // namespace
@@ -2251,35 +1823,7 @@ sara_hip_status sara_hip_sift_stage(sara_hip_sift* c, const void* images,
   // the pipeline that last read this buffer must be done with it
   if (c->stage_used[k])
     HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->stage_free[k], 0));
-  // SARA_HIP_H2D=kernel (experiment, off): upload by a copy KERNEL when the
-  // frames are in pinned (device-visible) host memory.  Why it was tried: the
-  // float32 host -> host step flips between 9.1 and 12.5 ms from process to
-  // process (both HIP runtimes) - when the upload and the read-back of the
-  // batch before end up behind one another on the copy engines instead of side
-  // by side.  A kernel reading host memory and a copy engine writing it cannot
-  // collide, and alone they overlap perfectly (tools/ubench/pcie_duplex.hip:
-  // 9.44 ms for 0.53 GB up with 32 workgroups + 0.14 GB down, 9.25 ms for the
-  // upload alone).  Next to the pipeline's kernels, however, the copy kernel
-  // is starved: 11.8-12.1 ms per float32 step in every run, gray8 7.1 -> 7.3.
-  static const bool h2d_kernel = [] {
-    const char* e = getenv("SARA_HIP_H2D");
-    return e && std::string(e) == "kernel";
-  }();
-  bool pinned = false;
-  if (h2d_kernel && stride_bytes == px * elem)
-  {
-    hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, images) == hipSuccess)
-      pinned = attr.type == hipMemoryTypeHost;
-    else
-      (void) hipGetLastError();  // pageable memory: not an error
-  }
-  if (pinned)
-  {
-    launch_blit(images, c->d_stage[k], px * elem * batch, c->copy_stream, 32);
-    HIP_TRY(hipGetLastError());
-  }
-  else if (stride_bytes == px * elem)  // contiguous frames: one linear copy
+  if (stride_bytes == px * elem)  // contiguous frames: one linear copy
     HIP_TRY(hipMemcpyAsync(c->d_stage[k], images, px * elem * batch,
                            hipMemcpyHostToDevice, c->copy_stream));
   else
@@ -2330,7 +1874,7 @@ sara_hip_status sara_hip_sift_detect_staged(sara_hip_sift* c,
   c->consumed_event = nullptr;
   if (st != SARA_HIP_OK)
     return st;
-  if (!c->consumed_recorded)  // graph replay, fused chains: at the end of the batch
+  if (!c->consumed_recorded)  // graph replay: at the end of the batch
     HIP_TRY(hipEventRecord(c->stage_free[k], stream));
   c->stage_used[k] = true;
   return SARA_HIP_OK;
@@ -2447,32 +1991,6 @@ sara_hip_status submit_impl(sara_hip_sift* c, const void* images,
                          sizeof(int) * (4 * size_t(c->max_batch) + 1),
                          hipMemcpyDeviceToHost, c->last_stream));
   HIP_TRY(hipEventRecord(r.done, c->last_stream));
-  // Speculative read-back (round 3 experiment, SARA_HIP_SPEC_D2H=1, off).
-  // collect() waits for the batch, reads its size and only then starts the
-  // copies; here they are enqueued at once, behind the batch on the read-back
-  // stream, for 1.15 x the keypoints of the batch collected last, and collect()
-  // adds the rows that are missing.  Measured: 64 x 1080p float32 host -> host
-  // 10.9 -> 21.7 ms per step - hipMemcpyAsync of a device-to-host copy behind
-  // an event that has not fired yet keeps the HOST inside the call until the
-  // batch is done (ROCm 7.0 and 7.2 alike), so submit() no longer returns
-  // early and upload, kernels and read-back run one after the other.
-  r.spec_rows = 0;
-  if (c->speculative_d2h && c->last_total > 0 && r.h_cap > 0)
-  {
-    const size_t rows = std::min(
-        r.h_cap, std::min(size_t(c->max_batch) * c->cap,
-                          c->last_total + c->last_total / 7 + 256));
-    HIP_TRY(hipStreamWaitEvent(c->d2h_stream, r.done, 0));
-    HIP_TRY(hipMemcpyAsync(r.h_feat, c->d_feat_s[slot], sizeof(sara_oeregion) * rows,
-                           hipMemcpyDeviceToHost, c->d2h_stream));
-    HIP_TRY(hipMemcpyAsync(r.h_so, c->d_so_s[slot], sizeof(int32_t) * 2 * rows,
-                           hipMemcpyDeviceToHost, c->d2h_stream));
-    r.spec_desc = last_stage >= SARA_HIP_STAGE_DESCRIPTOR;
-    if (r.spec_desc)
-      HIP_TRY(hipMemcpyAsync(r.h_desc, c->d_desc_s[slot], sizeof(float) * 128 * rows,
-                             hipMemcpyDeviceToHost, c->d2h_stream));
-    r.spec_rows = rows;
-  }
   r.ticket = c->next_ticket;
   r.pending = true;
   r.batch = batch;
@@ -2513,9 +2031,6 @@ sara_hip_status sara_hip_sift_collect(sara_hip_sift* c, int ticket,
                     "max_keypoints: the lists are truncated");
   if (size_t(n) > r.h_cap)
   {
-    if (r.spec_rows)  // a speculative read-back is writing the arrays
-      HIP_TRY(hipStreamSynchronize(c->d2h_stream));
-    r.spec_rows = 0;
     if (r.h_feat)
       (void) hipHostFree(r.h_feat);
     if (r.h_desc)
@@ -2540,48 +2055,6 @@ sara_hip_status sara_hip_sift_collect(sara_hip_sift* c, int ticket,
   {
     // the batch is complete (event): the copies need no further ordering and
     // run beside the next batch's kernels
-    // SARA_HIP_D2H=kernel: read-back through a copy kernel instead of the copy
-    // engine (experiment, off: see launch_blit)
-    static const bool by_kernel = [] {
-      const char* e = getenv("SARA_HIP_D2H");
-      return e && std::string(e) == "kernel";
-    }();
-    // rows [0, have) were copied by submit()'s speculative read-back
-    const size_t have = std::min(r.spec_rows, size_t(n));
-    const bool desc_have = have > 0 && r.spec_desc;
-    if (have > 0)
-    {
-      const size_t m = size_t(n) - have;
-      if (m > 0)
-      {
-        HIP_TRY(hipMemcpyAsync(r.h_feat + have, c->d_feat_s[slot] + have,
-                               sizeof(sara_oeregion) * m, hipMemcpyDeviceToHost,
-                               c->d2h_stream));
-        HIP_TRY(hipMemcpyAsync(r.h_so + 2 * have, c->d_so_s[slot] + 2 * have,
-                               sizeof(int32_t) * 2 * m, hipMemcpyDeviceToHost,
-                               c->d2h_stream));
-      }
-      if (descriptors)
-      {
-        const size_t from = desc_have ? have : 0;
-        if (size_t(n) > from)
-          HIP_TRY(hipMemcpyAsync(r.h_desc + 128 * from, c->d_desc_s[slot] + 128 * from,
-                                 sizeof(float) * 128 * (size_t(n) - from),
-                                 hipMemcpyDeviceToHost, c->d2h_stream));
-      }
-    }
-    else if (by_kernel)
-    {
-      launch_blit(c->d_feat_s[slot], r.h_feat, sizeof(sara_oeregion) * size_t(n),
-                  c->d2h_stream);
-      launch_blit(c->d_so_s[slot], r.h_so, sizeof(int32_t) * 2 * size_t(n),
-                  c->d2h_stream);
-      if (descriptors)
-        launch_blit(c->d_desc_s[slot], r.h_desc, sizeof(float) * 128 * size_t(n),
-                    c->d2h_stream);
-      HIP_TRY(hipGetLastError());
-    }
-    else
     {
       HIP_TRY(hipMemcpyAsync(r.h_feat, c->d_feat_s[slot], sizeof(sara_oeregion) * n,
                              hipMemcpyDeviceToHost, c->d2h_stream));
@@ -2594,10 +2067,6 @@ sara_hip_status sara_hip_sift_collect(sara_hip_sift* c, int ticket,
     }
     HIP_TRY(hipStreamSynchronize(c->d2h_stream));
   }
-  else if (r.spec_rows)
-    HIP_TRY(hipStreamSynchronize(c->d2h_stream));
-  r.spec_rows = 0;
-  c->last_total = size_t(n);
   r.pending = false;
   if (features)
     *features = r.h_feat;
@@ -2706,9 +2175,6 @@ namespace sara_hip {
     sara_hip_sift::RingSlot& r = c->ring[ticket & 1];
     if (r.pending && r.ticket == ticket)
     {
-      if (r.spec_rows && c->d2h_stream)  // the device arrays are still being read
-        (void) hipStreamSynchronize(c->d2h_stream);
-      r.spec_rows = 0;
       r.pending = false;
     }
   }

@@ -169,18 +169,6 @@ namespace sara_hip {
   //! on the fly as float(v) / 255.f.  Returns false (nothing launched) when the
   //! marching kernel cannot take the shape / radius: the caller then converts
   //! into a float plane first.
-  //! Two or three consecutive blurs of one plane chain in ONE launch (small
-  //! launches only: a chain of dependent launches, not bandwidth, bounds them).
-  //! taps[s] / dst[s]: stage s; dec: nearest-neighbour half of stage dec_stage's
-  //! output (the next octave's first plane), or NULL.  false = not available
-  //! for these radii / this size: launch the blurs one by one.
-  bool gaussian_blur_chain_available(const Taps* const* taps, int n, int w, int h,
-                                     int batch);
-  bool launch_gaussian_blur_chain(const float* src, size_t src_stride,
-                                  float* const* dst, size_t dst_stride, int w, int h,
-                                  int batch, const Taps* const* taps, int n,
-                                  hipStream_t stream, float* dec, size_t dec_stride,
-                                  int dec_stage);
   bool launch_gaussian_blur_gray8(const unsigned char* src, size_t src_stride,
                                   float* dst, size_t dst_stride, int w, int h,
                                   int batch, const Taps& taps, hipStream_t stream);
@@ -195,10 +183,6 @@ namespace sara_hip {
                       float* dst, size_t dst_stride, int dw, int dh, int batch,
                       hipStream_t stream);
 
-  //! Byte copy by the shader cores (pinned host memory on either side);
-  //! blocks = 0: SARA_HIP_BLIT_BLOCKS (64).
-  void launch_blit(const void* src, void* dst, size_t bytes, hipStream_t stream,
-                   int blocks = 0);
   void launch_copy_planes(const float* src, size_t src_stride, float* dst,
                           size_t dst_stride, size_t count, int batch,
                           hipStream_t stream);
@@ -234,17 +218,10 @@ namespace sara_hip {
   //! classifies and appends to `sites` (finish with launch_finish_sites once
   //! all octaves are scanned); the general path refines and appends to `cand`
   //! directly.
-  //! When `grad`/`cmax` are given and the fast path runs, the same pass also
-  //! writes the polar gradients of planes 1..S-3 (octave base
-  //! [frame][scale][h][w][2], frame stride in floats) and their coarse maxima
-  //! (cmax must be zeroed), and the function returns true; otherwise the
-  //! caller runs launch_gradient_polar itself.
-  bool launch_extrema_scan(const OctaveView& gauss, int octave, int batch,
+  void launch_extrema_scan(const OctaveView& gauss, int octave, int batch,
                            const ExtremaParams& p, const ScaleTable* tab,
                            const CandidateLists& cand, const SiteLists& sites,
-                           hipStream_t stream, float* grad = nullptr,
-                           size_t grad_frame_stride = 0, unsigned* cmax = nullptr,
-                           size_t cmax_stride = 0);
+                           hipStream_t stream);
 
   //! Edge test + refinement + contrast test of the classified sites.
   void launch_finish_sites(const OctavePyramidView& pyr, int batch,
@@ -263,8 +240,6 @@ namespace sara_hip {
                                        const RowBuckets& rb, int* hist,
                                        int* cursor, int* grouped, int batch,
                                        hipStream_t stream);
-  void launch_rank_candidates(const CandidateLists& cand, int batch,
-                              hipStream_t stream);
 
   // ---- orientation / descriptors ----------------------------------------------
   struct GradPyramidView

@@ -144,12 +144,6 @@ namespace {
     hipEvent_t done = nullptr;
     hipError_t wait(hipStream_t stream)
     {
-      static const bool spin = [] {
-        const char* e = getenv("SARA_HIP_MATCH_WAIT");
-        return !(e && std::string(e) == "block");
-      }();
-      if (!spin)
-        return hipStreamSynchronize(stream);
       if (!done)
       {
         const hipError_t e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
@@ -482,11 +476,7 @@ namespace {
       r.radius[1] = list ? list + cap[0] : nullptr;
       if (mfma)
       {
-        static const int radius_slots = [] {
-          const char* e = getenv("SARA_HIP_MATCH_SLOTS");
-          return e && atoi(e) == 64 ? 64 : 32;  // 64: fewer fall-backs, same time
-        }();
-        const int slots = radius_on ? radius_slots : 8;
+        const int slots = radius_on ? 32 : 8;  // 64 radius slots: fewer fall-backs, same time
         float* fs = nullptr;
         int* is = nullptr;
         HIPM_TRY(ws.get(Workspace::kAux1, match_mfma_scratch_floats(n1, n2), fs));

@@ -200,12 +200,11 @@ def test_default_small_launch_threshold(oracle, tmp_path):
     assert np.max(np.abs(got["kdesc"][off:off + len(rk)] - rdesc)) <= 2e-3
 
 
-def test_single_frame_schedule_with_blur_chains(oracle, tmp_path):
+def test_single_frame_schedule_as_shipped(oracle, tmp_path):
     """The one-frame-per-call schedule (HIP-graph replay, octave pipelining,
     small octaves through the tiled blur) in a fresh process with the shipped
-    launch rules, once as shipped and once with SARA_HIP_BLUR_CHAIN=1 (two or
-    three consecutive blurs per launch, gaussian_blur_chain_kernel): every
-    Gaussian plane bit-identical to the oracle's, keypoints at the usual bars."""
+    launch rules: every Gaussian plane bit-identical to the oracle's, keypoints
+    at the usual bars."""
     import os
     import subprocess
     import sys
@@ -231,9 +230,9 @@ def test_single_frame_schedule_with_blur_chains(oracle, tmp_path):
         "         **{'g%%d' %% i: a for i, a in enumerate(g)})\n"
         % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
            str(tmp_path / "img.npy"), noct, w, h, noct))
-    for chain in ("0", "1"):
+    for chain in ("0",):
         out = tmp_path / ("out%s.npz" % chain)
-        env = dict(os.environ, SARA_HIP_BLUR_CHAIN=chain)
+        env = dict(os.environ)
         env.pop("SARA_HIP_MARCH_MIN_PIXELS", None)   # the shipped launch rules
         subprocess.run([sys.executable, str(script), str(out)], check=True, env=env)
         got = np.load(out)

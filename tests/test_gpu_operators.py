@@ -313,20 +313,31 @@ def test_extremum_map_halide_seam(oracle):
     assert got[0, 5] == 1 and got[h - 1, 0] == -1 and np.count_nonzero(got) > 20
 
 
+def _tile_geometry(h, w, batch=1):
+    """launch_blur_r (pyramid_kernels.hip): geometry from the number of 64 x 32
+    tiles - 0: 64 x 32 / 512 threads, 1: 64 x 16 / 256, 2: 32 x 16 / 128."""
+    tiles = ((w + 63) // 64) * ((h + 31) // 32) * batch
+    return 0 if tiles >= 200 else (1 if tiles >= 48 else 2)
+
+
 @pytest.mark.parametrize("geom", [0, 1, 2])
 def test_tiled_blur_geometries_bit_exact(oracle, tmp_path, geom):
     """The tiled blur (what launches too small for the marching kernels use, and
     every launch of a one-frame call) has three tile geometries, picked from the
     number of tiles (64 x 32 / 512 threads, 64 x 16 / 256, 32 x 16 / 128).  Each
-    is forced in a fresh process (SARA_HIP_BLUR=tile, SARA_HIP_TILE_GEOM) on
-    shapes with borders in every position of a tile, interior tiles (16-byte
-    staging) and odd widths, for every radius of the pyramid and a few others;
-    the fused half-size output is checked through a 3-octave pyramid."""
+    is reached in a fresh process (SARA_HIP_BLUR=tile) through shapes of the
+    matching tile count, with borders in every position of a tile, interior
+    tiles (16-byte staging) and odd widths, for every radius of the pyramid and
+    a few others; the fused half-size output is checked through a 3-octave
+    pyramid."""
     import os
     import subprocess
     import sys
-    shapes = [(3, 3), (5, 64), (33, 65), (97, 131), (135, 240), (70, 517),
-              (41, 129), (50, 124), (66, 300), (17, 1366)]
+    shapes = {2: [(3, 3), (5, 64), (33, 65), (97, 131), (135, 240), (70, 517),
+                  (41, 129), (50, 124), (66, 300), (17, 1366)],
+              1: [(300, 517), (222, 1366), (270, 480), (129, 1027)],
+              0: [(400, 1366), (517, 1027), (540, 960)]}[geom]
+    assert all(_tile_geometry(h, w) == geom for h, w in shapes)
     sigmas = [0.5, 1.2262735, 1.5198685, 1.946588, 2.4525296, 3.0900156, 4.1, 0.9,
               2.2, 3.6]
     rng = np.random.default_rng(11 + geom)
@@ -358,7 +369,6 @@ def test_tiled_blur_geometries_bit_exact(oracle, tmp_path, geom):
            sigmas, str(out)))
     env = dict(os.environ)
     env["SARA_HIP_BLUR"] = "tile"
-    env["SARA_HIP_TILE_GEOM"] = str(geom)
     subprocess.run([sys.executable, str(script)], check=True, env=env)
     got = np.load(out)
     for i, src in enumerate(srcs):

@@ -9,7 +9,5 @@ for l in sys.stdin:
 "; }
 run SARA_HIP_BLUR=tile
 for w in 1024 2048 3072 4096 6144; do run SARA_HIP_MARCH_WAVES=$w SARA_HIP_MARCH2_WAVES=$w; done
-run SARA_HIP_MARCH_MINROWS=2
-run SARA_HIP_MARCH_MINROWS=8
 run SARA_HIP_STREAMS=1
 run A=1
