@@ -1600,11 +1600,75 @@ namespace sara_hip {
     }
   }
 
+  //! The same ordering for a call on one or two frames, where the single
+  //! 1024-thread workgroup per frame of the fused counting sort is a 19 us link
+  //! in a chain of dependent launches (9 us here): rank = number of smaller
+  //! keys, counted directly.  A workgroup ranks 16 keys with 16 lanes each; the frame's keys
+  //! pass through LDS in chunks of 4096 (a 1080p frame has ~3 500: one chunk,
+  //! ~220 comparisons per lane).  O(n^2 / lanes): only where n is a few
+  //! thousand and the chip is otherwise idle.
+  __global__ __launch_bounds__(256) void rank_small_kernel(CandidateLists cand)
+  {
+    constexpr int kChunk = 4096;
+    __shared__ unsigned long long s_keys[kChunk];
+    const int b = blockIdx.y;
+    const int n = min(cand.count[b], cand.cap);
+    if (int(blockIdx.x) * 16 >= n)
+      return;
+    const size_t row = size_t(b) * cand.cap;
+    const unsigned long long* keys = cand.key + row;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * 16 + (tid >> 4), sub = tid & 15;
+    const unsigned long long mine = i < n ? keys[i] : ~0ull;
+    int rank = 0;
+    for (int base = 0; base < n; base += kChunk)
+    {
+      const int m = min(kChunk, n - base);
+      if (base > 0)
+        __syncthreads();
+      for (int j = tid; j < m; j += 256)
+        s_keys[j] = keys[base + j];
+      __syncthreads();
+      // eight independent LDS reads in flight per lane (a plain loop waits
+      // for each read: 220 x the LDS latency)
+      int j = sub;
+      for (; j + 16 * 7 < m; j += 16 * 8)
+      {
+        unsigned long long k[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          k[q] = s_keys[j + 16 * q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          rank += (k[q] < mine);
+      }
+      for (; j < m; j += 16)
+        rank += (s_keys[j] < mine);
+    }
+    // sum over the 16 lanes of a key (one DPP row)
+    rank += __builtin_amdgcn_update_dpp(0, rank, 0x111, 0xf, 0xf, false);  // row_shr:1
+    rank += __builtin_amdgcn_update_dpp(0, rank, 0x112, 0xf, 0xf, false);  // row_shr:2
+    rank += __builtin_amdgcn_update_dpp(0, rank, 0x114, 0xf, 0xf, false);  // row_shr:4
+    rank += __builtin_amdgcn_update_dpp(0, rank, 0x118, 0xf, 0xf, false);  // row_shr:8
+    if (sub == 15 && i < n)
+    {
+      cand.order[row + rank] = i;
+      cand.skey[row + rank] = mine;
+      cand.sdata[row + rank] = cand.data[row + i];
+    }
+  }
+
   void launch_rank_candidates_bucketed(const CandidateLists& cand,
                                        const RowBuckets& rb, int* hist,
                                        int* cursor, int* grouped, int batch,
                                        hipStream_t stream)
   {
+    if (batch <= 2 && cand.cap <= 32768)
+    {
+      hipLaunchKernelGGL(rank_small_kernel, dim3((cand.cap + 15) / 16, batch), dim3(256),
+                         0, stream, cand);
+      return;
+    }
     // fused form when the buckets fit in LDS (images up to about 6000 rows
     // per octave-0 plane set), four launches beyond that (8K frames)
     const size_t lds = sizeof(int) * (size_t(rb.total) + 1 + 1024);

@@ -13,7 +13,12 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <limits>
 #include <mutex>
 #include <string>
@@ -44,33 +49,152 @@ namespace sara_hip {
 
 namespace {
 
-  //! HIP-graph replay is reserved to ONE host thread of the process: the first
-  //! one that asks.  With graphs captured and launched from several host
-  //! threads the ROCm 7 runtime crashed in hip::Graph::UpdateStreams (under
-  //! hipGraphLaunch) even with every graph call of the process serialised by
-  //! runtime_mutex() and every graph used only by the thread that captured it
-  //! (rocgdb backtrace; tests/test_gpu_pipeline.py::
-  //! test_compute_sift_keypoints_keeps_its_context is the reproducer).  Other
-  //! threads run the same enqueue sequence as plain launches: about 0.15 ms
-  //! more per 1080p frame, same results.  SARA_HIP_GRAPH_ANY_THREAD=1 lifts it.
-  bool graph_thread_ok()
+  //! Every HIP-graph call of the process - capture, instantiation, argument
+  //! update, hipGraphLaunch - runs on ONE thread, the graph launcher.  With
+  //! graphs captured and launched from several host threads the ROCm 7 runtime
+  //! crashed in hip::Graph::UpdateStreams (under hipGraphLaunch) even with every
+  //! graph call serialised by runtime_mutex() and every graph used only by the
+  //! thread that captured it (rocgdb backtrace; tests/test_gpu_pipeline.py::
+  //! test_compute_sift_keypoints_keeps_its_context was the reproducer).  Round 3
+  //! therefore gave graph replay to the first thread that asked and left every
+  //! other thread on plain launches (+ 0.15 ms per 1080p frame).  Now a caller
+  //! of any thread hands the graph part of its detect() to the launcher and
+  //! waits for it: the caller is blocked for the duration anyway (the host side
+  //! of a replay is what detect() consists of), so nothing is lost but the
+  //! hand-over - a spin on an atomic in both directions while calls keep coming
+  //! (the launcher keeps polling for 200 us after a job before it sleeps on
+  //! its condition variable; a caller polls for 2 ms before it does).
+  class GraphLauncher
   {
-    static const bool any = [] {
-      const char* e = getenv("SARA_HIP_GRAPH_ANY_THREAD");
-      return e && e[0] == '1';
-    }();
-    if (any)
-      return true;
-    static std::mutex m;
-    static bool claimed = false;
-    static std::thread::id owner;
-    std::lock_guard<std::mutex> lock(m);
-    if (!claimed)
+  public:
+    //! Runs fn() on the launcher thread and returns when it has finished.
+    template <typename F>
+    void run(F&& fn)
     {
-      owner = std::this_thread::get_id();
-      claimed = true;
+      if (std::this_thread::get_id() == thread_id_.load(std::memory_order_acquire))
+      {
+        fn();  // a nested call from inside a job
+        return;
+      }
+      Job job;
+      job.fn = [&fn] { fn(); };
+      {
+        std::lock_guard<std::mutex> lock(m_);
+        if (!started_)
+        {
+          started_ = true;
+          worker_ = std::thread([this] { loop(); });
+        }
+        queue_.push_back(&job);
+        ++posted_;
+      }
+      if (sleeping_.load(std::memory_order_acquire))
+        cv_.notify_one();
+      // the job is tens of microseconds of host work: poll first
+      const auto t0 = std::chrono::steady_clock::now();
+      while (!job.done.load(std::memory_order_acquire))
+      {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
+        {
+          std::unique_lock<std::mutex> lock(job.m);
+          job.waiting = true;
+          job.cv.wait(lock, [&] { return job.done.load(std::memory_order_acquire); });
+          break;
+        }
+      }
+      // the launcher may still be inside the notification of job.cv
+      std::lock_guard<std::mutex> lock(job.m);
     }
-    return owner == std::this_thread::get_id();
+
+    ~GraphLauncher()
+    {
+      {
+        std::lock_guard<std::mutex> lock(m_);
+        stop_ = true;
+      }
+      cv_.notify_all();
+      if (worker_.joinable())
+        worker_.join();
+    }
+
+  private:
+    struct Job
+    {
+      std::function<void()> fn;
+      std::atomic<bool> done{false};
+      std::mutex m;
+      std::condition_variable cv;
+      bool waiting = false;
+    };
+
+    void loop()
+    {
+      thread_id_.store(std::this_thread::get_id(), std::memory_order_release);
+      for (;;)
+      {
+        Job* job = nullptr;
+        {
+          std::unique_lock<std::mutex> lock(m_);
+          if (queue_.empty())
+          {
+            // keep polling for a while: a caller's next detect() is usually a
+            // few hundred microseconds away
+            lock.unlock();
+            const auto t0 = std::chrono::steady_clock::now();
+            bool found = false;
+            while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(200))
+            {
+              if (posted_.load(std::memory_order_acquire) != taken_)
+              {
+                found = true;
+                break;
+              }
+            }
+            lock.lock();
+            if (!found && queue_.empty())
+            {
+              sleeping_.store(true, std::memory_order_release);
+              cv_.wait(lock, [&] { return stop_ || !queue_.empty(); });
+              sleeping_.store(false, std::memory_order_release);
+            }
+          }
+          if (queue_.empty())
+          {
+            if (stop_)
+              return;
+            continue;
+          }
+          job = queue_.front();
+          queue_.pop_front();
+          ++taken_;
+        }
+        job->fn();
+        {
+          std::lock_guard<std::mutex> lock(job->m);
+          job->done.store(true, std::memory_order_release);
+          if (job->waiting)
+            job->cv.notify_one();
+        }
+      }
+    }
+
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<Job*> queue_;
+    std::atomic<unsigned long long> posted_{0};
+    unsigned long long taken_ = 0;  // launcher thread only
+    std::atomic<bool> sleeping_{false};
+    std::atomic<std::thread::id> thread_id_{std::thread::id()};
+    std::thread worker_;
+    bool started_ = false, stop_ = false;
+  };
+
+  GraphLauncher& graph_launcher()
+  {
+    // leaked on purpose: at process exit the HIP runtime may already be gone
+    // when static destructors run, and the launcher only ever sleeps by then
+    static GraphLauncher* g = new GraphLauncher;
+    return *g;
   }
 
   thread_local std::string g_error = "";
@@ -840,12 +964,29 @@ sara_hip_status sara_hip_sift_destroy(sara_hip_sift* c)
 {
   if (!c)
     return SARA_HIP_OK;
-  std::lock_guard<std::recursive_mutex> runtime_lock(runtime_mutex());
   (void) hipSetDevice(c->device);
   if (c->last_stream)
     (void) hipStreamSynchronize(c->last_stream);
   if (c->own_stream)
     (void) hipStreamSynchronize(c->own_stream);
+  // Graph calls belong to the launcher thread.  NOT under runtime_mutex(): the
+  // launcher may be inside another thread's replay, which takes that mutex - a
+  // caller that waits for the launcher while holding it would deadlock.
+  if (c->graph_exec_s[0] || c->graph_s[0] || c->graph_exec_s[1] || c->graph_s[1])
+    graph_launcher().run([&] {
+      (void) hipSetDevice(c->device);
+      std::lock_guard<std::recursive_mutex> lock(runtime_mutex());
+      for (int k = 0; k < 2; ++k)
+      {
+        if (c->graph_exec_s[k])
+          (void) hipGraphExecDestroy(c->graph_exec_s[k]);
+        if (c->graph_s[k])
+          (void) hipGraphDestroy(c->graph_s[k]);
+        c->graph_exec_s[k] = nullptr;
+        c->graph_s[k] = nullptr;
+      }
+    });
+  std::lock_guard<std::recursive_mutex> runtime_lock(runtime_mutex());
   for (void* p : c->allocations)
     (void) hipFree(p);
   if (c->h_grad)
@@ -890,10 +1031,6 @@ sara_hip_status sara_hip_sift_destroy(sara_hip_sift* c)
   }
   for (int k = 0; k < 2; ++k)
   {
-    if (c->graph_exec_s[k])
-      (void) hipGraphExecDestroy(c->graph_exec_s[k]);
-    if (c->graph_s[k])
-      (void) hipGraphDestroy(c->graph_s[k]);
     sara_hip_sift::RingSlot& r = c->ring[k];
     if (r.done)
       (void) hipEventDestroy(r.done);
@@ -1064,7 +1201,6 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
 
   // Graph replay: own stream, small batch, no stage timers inside a capture.
   const bool graph_mode = c->use_graph && !c->graph_broken && !hip_stream &&
-                          graph_thread_ok() &&
                           batch <= c->graph_max_batch && !debug_sync;
   const bool multi_stream = c->multi_stream;
   const bool side_gradient = c->side_gradient;
@@ -1553,6 +1689,9 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     c->has_result = true;
     return SARA_HIP_OK;
   }
+  // everything below touches graphs: on the launcher thread (GraphLauncher)
+  auto graph_section = [&]() -> sara_hip_status {
+  HIP_TRY(hipSetDevice(c->device));
   std::lock_guard<std::recursive_mutex> graph_lock(runtime_mutex());
   const int gs = c->write_slot;
   hipGraph_t& graph = c->graph_s[gs];
@@ -1673,6 +1812,17 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     HIP_TRY(hipEventRecord(c->ev[SARA_HIP_TIME_TOTAL], stream));
   }
   c->has_result = true;
+  return SARA_HIP_OK;
+  };
+  sara_hip_status gst = SARA_HIP_OK;
+  std::string gmsg;
+  graph_launcher().run([&] {
+    gst = graph_section();
+    if (gst != SARA_HIP_OK)
+      gmsg = g_error;  // the launcher thread's message
+  });
+  if (gst != SARA_HIP_OK)
+    return fail(gst, gmsg);
   return SARA_HIP_OK;
 }
 

@@ -273,3 +273,75 @@ def test_benchmark_batch_geometry_against_oracle(oracle):
         common.assert_regions_equal(kreg[sl], rk, rtol_shape=1e-6,
                                     atol_theta=1e-6)
         assert np.max(np.abs(kdesc[sl] - rdesc)) <= 2e-3
+
+
+def test_four_threads_each_with_its_own_context_replay_graphs(oracle):
+    """compute_sift_keypoints' call pattern from several host threads (one
+    context per thread, OdometryPipeline::detect_keypoints per camera,
+    SfM/Odometry/OdometryPipeline.cpp:82-90): every thread gets the HIP-graph
+    replay - the graph calls of all of them run on the library's launcher
+    thread - so a call costs what it costs a single-threaded caller, and the
+    results are the single-thread results.  Bar: wall time / total calls <=
+    0.35 ms per 1080p call (HBM-resident frame, keypoints left on the device)."""
+    import threading
+    import time
+    W, H, T, CALLS = 1920, 1080, 4, 60
+    frames = synth_batch(W, H, T, first_index=500)
+    p = params(4)
+    want = []
+    with sara_amd.SiftContext(W, H, 1, p) as c:
+        for i in range(T):
+            c.detect(frames[i:i + 1])
+            want.append(c.fetch())
+    ctxs = [sara_amd.SiftContext(W, H, 1, p) for _ in range(T)]
+    devs = [sara_amd.DeviceArray(frames[i:i + 1]) for i in range(T)]
+    got, errors = [None] * T, []
+    start = threading.Barrier(T + 1)
+
+    def work(k):
+        try:
+            c = ctxs[k]
+            for _ in range(5):                    # capture + warm-up
+                c.detect_device(devs[k].ptr, 1, W, H)
+                c.synchronize()
+            start.wait()
+            for _ in range(CALLS):
+                c.detect_device(devs[k].ptr, 1, W, H)
+                c.synchronize()
+            start.wait()
+            got[k] = c.fetch()
+        except Exception as e:  # noqa: BLE001 - reported below
+            errors.append(e)
+            try:
+                start.abort()
+            except Exception:
+                pass
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(T)]
+    for t in ts:
+        t.start()
+    start.wait()
+    t0 = time.perf_counter()
+    start.wait()
+    per_call = (time.perf_counter() - t0) / (T * CALLS)
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for k in range(T):
+        for a, b in zip(got[k], want[k]):
+            assert np.ascontiguousarray(a).tobytes() == np.ascontiguousarray(b).tobytes()
+    # one thread alone, for the record
+    c = ctxs[0]
+    t0 = time.perf_counter()
+    for _ in range(CALLS):
+        c.detect_device(devs[0].ptr, 1, W, H)
+        c.synchronize()
+    alone = (time.perf_counter() - t0) / CALLS
+    print("1080p call: %.3f ms alone, %.3f ms per call with %d threads"
+          % (1e3 * alone, 1e3 * per_call, T))
+    for c in ctxs:
+        c.close()
+    for d in devs:
+        d.close()
+    assert per_call <= 0.35e-3, per_call
+    assert alone <= 0.45e-3, alone
