@@ -915,14 +915,44 @@ namespace sara_hip {
                  (diag[2] * scale) * t) >= 0.f;
   }
 
+  //! The 19 DoG values refine_extremum and on_edge read around (x, y, s), in
+  //! the order of SiteLists::nb.
+  struct SiteNeighbourhood
+  {
+    float v[kSiteNb];
+    // layer s: v[3 * (dy + 1) + (dx + 1)]; layers s -+ 1: centre, left, right,
+    // up, down at v[9..13] / v[14..18]
+    __device__ float mid(int dx, int dy) const { return v[3 * (dy + 1) + dx + 1]; }
+    __device__ float below(int i) const { return v[9 + i]; }   // layer s - 1
+    __device__ float above(int i) const { return v[14 + i]; }  // layer s + 1
+    __device__ void load(const DogOctave& I, int x, int y, int s)
+    {
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx)
+          v[3 * (dy + 1) + dx + 1] = I.at(x + dx, y + dy, s);
+      const int ox[5] = {0, -1, 1, 0, 0}, oy[5] = {0, 0, 0, -1, 1};
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+      {
+        v[9 + i] = I.at(x + ox[i], y + oy[i], s - 1);
+        v[14 + i] = I.at(x + ox[i], y + oy[i], s + 1);
+      }
+      v[19] = 0.f;
+    }
+  };
+
   //! refine_extremum.  type: 1 maximum, 255 minimum (the reference's uint8
   //! map stores -1 as 255, so minima are never refined), or -1 minimum with
   //! SARA_HIP_OPT_SIGNED_EXTREMUM_TYPE (the int8 map of RefineExtremum.cpp:246).
-  //! pos = (x, y, sigma).
+  //! pos = (x, y, sigma).  nb (optional): the neighbourhood of the start site
+  //! as the scan captured it - the same floats I.at() would return.
   __device__ inline void refine_extremum(const DogOctave& I, int x, int y, int s,
                                          int type, float pos[3], float& val,
                                          int border_sz, int num_iter,
-                                         const ScaleTable& tab, float kfactor)
+                                         const ScaleTable& tab, float kfactor,
+                                         const SiteNeighbourhood* nb = nullptr)
   {
     float D_prime[3] = {0.f, 0.f, 0.f};
     float H[3][3];
@@ -932,29 +962,31 @@ namespace sara_hip {
     pos[1] = float(y);
     pos[2] = tab.sigma[s];
 
+    SiteNeighbourhood n;
+    bool n_valid = false;  // n holds the neighbourhood of the current (x, y)
     for (int i = 0; i < num_iter; ++i)
     {
       if (x < border_sz || x >= I.w - border_sz || y < border_sz ||
           y >= I.h - border_sz || s < 1 || s >= I.layers - 1)
         break;
 
-      const float c = I.at(x, y, s);
-      D_prime[0] = (I.at(x + 1, y, s) - I.at(x - 1, y, s)) / 2.f;
-      D_prime[1] = (I.at(x, y + 1, s) - I.at(x, y - 1, s)) / 2.f;
-      D_prime[2] = (I.at(x, y, s + 1) - I.at(x, y, s - 1)) / 2.f;
+      if (i == 0 && nb)
+        n = *nb;
+      else
+        n.load(I, x, y, s);
+      n_valid = true;
+      const float c = n.mid(0, 0);
+      D_prime[0] = (n.mid(1, 0) - n.mid(-1, 0)) / 2.f;
+      D_prime[1] = (n.mid(0, 1) - n.mid(0, -1)) / 2.f;
+      D_prime[2] = (n.above(0) - n.below(0)) / 2.f;
 
-      H[0][0] = I.at(x + 1, y, s) - 2.f * c + I.at(x - 1, y, s);
-      H[1][1] = I.at(x, y + 1, s) - 2.f * c + I.at(x, y - 1, s);
-      H[2][2] = I.at(x, y, s + 1) - 2.f * c + I.at(x, y, s - 1);
-      H[0][1] = H[1][0] = (I.at(x + 1, y + 1, s) - I.at(x - 1, y + 1, s) -
-                           I.at(x + 1, y - 1, s) + I.at(x - 1, y - 1, s)) /
-                          4.f;
-      H[0][2] = H[2][0] = (I.at(x + 1, y, s + 1) - I.at(x - 1, y, s + 1) -
-                           I.at(x + 1, y, s - 1) + I.at(x - 1, y, s - 1)) /
-                          4.f;
-      H[1][2] = H[2][1] = (I.at(x, y + 1, s + 1) - I.at(x, y - 1, s + 1) -
-                           I.at(x, y + 1, s - 1) + I.at(x, y - 1, s - 1)) /
-                          4.f;
+      H[0][0] = n.mid(1, 0) - 2.f * c + n.mid(-1, 0);
+      H[1][1] = n.mid(0, 1) - 2.f * c + n.mid(0, -1);
+      H[2][2] = n.above(0) - 2.f * c + n.below(0);
+      H[0][1] = H[1][0] =
+          (n.mid(1, 1) - n.mid(-1, 1) - n.mid(1, -1) + n.mid(-1, -1)) / 4.f;
+      H[0][2] = H[2][0] = (n.above(2) - n.above(1) - n.below(2) + n.below(1)) / 4.f;
+      H[1][2] = H[2][1] = (n.above(4) - n.above(3) - n.below(4) + n.below(3)) / 4.f;
 
       // (lambda * float(type)).maxCoeff() >= 0: with type in {1, 255} the
       // Newton step is taken only when H is negative definite, with type -1
@@ -993,6 +1025,7 @@ namespace sara_hip {
       {
         x += hh[0] > 0 ? 1 : -1;
         y += hh[1] > 0 ? 1 : -1;
+        n_valid = false;
         continue;
       }
       break;
@@ -1001,7 +1034,7 @@ namespace sara_hip {
     pos[0] = float(x);
     pos[1] = float(y);
     pos[2] = tab.sigma[s];
-    const float oldval = I.at(x, y, s);
+    const float oldval = n_valid ? n.mid(0, 0) : I.at(x, y, s);
     const float newval = oldval + 0.5f * sum3(D_prime[0] * hh[0],
                                               D_prime[1] * hh[1],
                                               D_prime[2] * hh[2]);
@@ -1061,16 +1094,18 @@ namespace sara_hip {
                                           int type, int octave, int frame,
                                           const ExtremaParams& p,
                                           const ScaleTable& tab,
-                                          const CandidateLists& cand)
+                                          const CandidateLists& cand,
+                                          const SiteNeighbourhood* nb = nullptr)
   {
-    const float v = I.at(x, y, s);
+    auto at = [&](int dx, int dy) {
+      return nb ? nb->mid(dx, dy) : I.at(x + dx, y + dy, s);
+    };
+    const float v = at(0, 0);
     if (!p.signed_type)  // the Halide classifier has done its own edge test
     {
-      const float hxx = I.at(x + 1, y, s) - 2.f * v + I.at(x - 1, y, s);
-      const float hyy = I.at(x, y + 1, s) - 2.f * v + I.at(x, y - 1, s);
-      const float hxy = (I.at(x + 1, y + 1, s) - I.at(x - 1, y + 1, s) -
-                         I.at(x + 1, y - 1, s) + I.at(x - 1, y - 1, s)) /
-                        4.f;
+      const float hxx = at(1, 0) - 2.f * v + at(-1, 0);
+      const float hyy = at(0, 1) - 2.f * v + at(0, -1);
+      const float hxy = (at(1, 1) - at(-1, 1) - at(1, -1) + at(-1, -1)) / 4.f;
       const float tr = hxx + hyy;
       const float det = hxx * hyy - hxy * hxy;
       const float er = p.edge_ratio_thres;
@@ -1082,7 +1117,7 @@ namespace sara_hip {
     float val = v;
     refine_extremum(I, x, y, s, type == 1 ? 1 : (p.signed_type ? -1 : 255), pos,
                     val, p.img_padding_sz, p.refine_iters, tab,
-                    p.scale_geometric_factor);
+                    p.scale_geometric_factor, nb);
     if (fabsf(val) < p.extremum_thres)
       return;
     if (p.signed_type)
@@ -1170,18 +1205,27 @@ namespace sara_hip {
   //! the per-layer 3x3 maxima are shared by the ND-2 scales scanned.  The rare
   //! classified sites go through finish_candidate().
   //! HBM traffic: 4*(ND+1) B read per pixel, nothing written but candidates.
-  //! Moves `qn` (<= 128) queued keys of one wave to the frame's site list.
-  __device__ inline void flush_sites(const unsigned long long* queue, int qn,
-                                     int lane, int frame, const SiteLists& sites)
+  //! A queued site: key (2 words) + neighbourhood (kSiteNb words) + 2 pad.
+  constexpr int kSiteQueueWords = 24;
+  constexpr int kSiteQueueCap = 64;  // entries per wave (6 KB of LDS): any
+                                     // iteration's hits fit an empty queue
+  //! Moves `qn` (<= kSiteQueueCap) queued sites of one wave to the frame's list.
+  __device__ inline void flush_sites(const unsigned* queue, int qn, int lane,
+                                     int frame, const SiteLists& sites)
   {
     int base = 0;
     if (lane == 0)
       base = atomicAdd(&sites.count[frame], qn);
     base = __builtin_amdgcn_readfirstlane(base);
     __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < qn; i += 64)
-      if (base + i < sites.cap)
-        sites.key[size_t(frame) * sites.cap + base + i] = queue[i];
+    const int room = min(qn, max(sites.cap - base, 0));
+    if (lane < room)
+      sites.key[size_t(frame) * sites.cap + base + lane] =
+          (unsigned long long) queue[lane * kSiteQueueWords] |
+          ((unsigned long long) queue[lane * kSiteQueueWords + 1] << 32);
+    float* nb = sites.nb + (size_t(frame) * sites.cap + base) * kSiteNb;
+    for (int w = lane; w < room * kSiteNb; w += 64)
+      nb[w] = __uint_as_float(queue[(w / kSiteNb) * kSiteQueueWords + 2 + w % kSiteNb]);
     __builtin_amdgcn_wave_barrier();
   }
 
@@ -1194,7 +1238,7 @@ namespace sara_hip {
       int seg_rows, int nstrips, int nseg, int xcd_total)
   {
     static_assert(PF == 3, "the row loop is unrolled 3x");
-    __shared__ unsigned long long s_queue[128];
+    __shared__ unsigned s_queue[kSiteQueueCap * kSiteQueueWords];
     int qn = 0;  // wave-uniform fill of the queue
     constexpr int NG = ND + 1;
     constexpr int STRIDE = 126;
@@ -1296,16 +1340,70 @@ namespace sara_hip {
             const unsigned long long hits = __ballot(hit);
             if (hits != 0ull)
             {
+              // Classified sites go to a wave-local LDS queue first and reach
+              // the frame's list in batches: one returning atomic per batch
+              // instead of one per site (every wave of a frame hits the same
+              // counter, and that serialisation was the kernel's bottleneck).
+              // The edge test / refinement run later in finish_sites_kernel.
+              const int nh = __popcll(hits);
+              if (qn + nh > kSiteQueueCap)
+              {
+                flush_sites(s_queue, qn, lane, b, sites);
+                qn = 0;
+              }
+              unsigned* e = s_queue + (qn + __popcll(hits & ((1ull << lane) - 1ull))) *
+                                          kSiteQueueWords;
               if (hit)
-                s_queue[qn + __popcll(hits & ((1ull << lane) - 1ull))] =
+              {
+                const unsigned long long key =
                     ((((unsigned long long) (octave * kMaxScales + s) << 20 |
                        (unsigned) y)
                       << 20 |
                       (unsigned) x)
                      << 1) |
                     (unsigned) is_max;
-              qn += __popcll(hits);
-              if (qn >= 64)
+                e[0] = unsigned(key);
+                e[1] = unsigned(key >> 32);
+              }
+              // The site's DoG neighbourhood (SiteLists::nb), from the rows in
+              // registers, written value by value (an array of 20 would spill):
+              // the whole wave executes the lane shifts - column x-1 / x+1 of a
+              // lane's first / second pixel sit in the neighbouring lane - and
+              // the lanes with a hit store.  ~4 % of the iterations get here.
+              // (no array of row indices: indexing the register ring through
+              // one sends the whole ring to scratch memory)
+              auto put_row = [&](int r, const float2 m2) {
+                const float side = c == 0 ? shift_from_prev(m2.y) : shift_from_next(m2.x);
+                if (hit)
+                {
+                  e[2 + 3 * r + 0] = __float_as_uint(c == 0 ? side : m2.x);
+                  e[2 + 3 * r + 1] = __float_as_uint(c == 0 ? m2.x : m2.y);
+                  e[2 + 3 * r + 2] = __float_as_uint(c == 0 ? m2.y : side);
+                }
+              };
+              put_row(0, ring[ia][s]);
+              put_row(1, ring[ib][s]);
+              put_row(2, ring[ic][s]);
+#pragma unroll
+              for (int dl = 0; dl < 2; ++dl)
+              {
+                const int l = dl == 0 ? s - 1 : s + 1;
+                const float2 m2 = ring[ib][l];
+                const float side = c == 0 ? shift_from_prev(m2.y) : shift_from_next(m2.x);
+                if (hit)
+                {
+                  unsigned* o = e + 2 + 9 + 5 * dl;
+                  o[0] = __float_as_uint(c == 0 ? m2.x : m2.y);                    // centre
+                  o[1] = __float_as_uint(c == 0 ? side : m2.x);                    // left
+                  o[2] = __float_as_uint(c == 0 ? m2.y : side);                    // right
+                  o[3] = __float_as_uint(c == 0 ? ring[ia][l].x : ring[ia][l].y);  // up
+                  o[4] = __float_as_uint(c == 0 ? ring[ic][l].x : ring[ic][l].y);  // down
+                }
+              }
+              if (hit)
+                e[2 + 19] = 0u;
+              qn += nh;
+              if (qn >= kSiteQueueCap / 2)
               {
                 flush_sites(s_queue, qn, lane, b, sites);
                 qn = 0;
@@ -1336,7 +1434,19 @@ namespace sara_hip {
     const int x = int((key >> 1) & 0xfffff);
     const DogOctave I{pyr.base[o] + size_t(b) * pyr.frame_stride[o], pyr.w[o],
                       pyr.h[o], pyr.plane[o], pyr.scales - 1};
-    finish_candidate(I, x, y, s, (key & 1ull) ? 1 : -1, o, b, p, *tabp, cand);
+    SiteNeighbourhood nb;
+    const float4* r =
+        reinterpret_cast<const float4*>(sites.nb + (size_t(b) * sites.cap + i) * kSiteNb);
+#pragma unroll
+    for (int q = 0; q < kSiteNb / 4; ++q)
+    {
+      const float4 t = r[q];
+      nb.v[4 * q] = t.x;
+      nb.v[4 * q + 1] = t.y;
+      nb.v[4 * q + 2] = t.z;
+      nb.v[4 * q + 3] = t.w;
+    }
+    finish_candidate(I, x, y, s, (key & 1ull) ? 1 : -1, o, b, p, *tabp, cand, &nb);
   }
 
   void launch_finish_sites(const OctavePyramidView& pyr, int batch,

@@ -787,6 +787,7 @@ namespace {
     }
     c->sites.cap = 4 * c->cap;
     TRY_ST(c->alloc(c->sites.key, size_t(max_batch) * c->sites.cap));
+    TRY_ST(c->alloc(c->sites.nb, size_t(max_batch) * c->sites.cap * kSiteNb));
     TRY_ST(c->alloc(c->ori.peak_count, rows));
     TRY_ST(c->alloc(c->ori.peak_theta, rows * kMaxPeaks));
     TRY_ST(c->alloc(c->ori.offset, rows));

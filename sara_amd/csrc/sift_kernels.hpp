@@ -112,9 +112,18 @@ namespace sara_hip {
 
   //! Classified extremum sites of the marching scan, before the edge test and
   //! the refinement (same key layout as CandidateLists::key).
+  //! nb: what the edge test and the first refinement step of a site read - the
+  //! DoG values around it, captured by the scan from the rows it holds in
+  //! registers (kSiteNb floats per site: layer s as a 3 x 3 block, row-major
+  //! (y-1, y, y+1) x (x-1, x, x+1); then centre, left, right, up, down of layer
+  //! s-1 and the same of layer s+1; one pad).  finish_sites_kernel then reads
+  //! 88 contiguous bytes per site instead of gathering 36 Gaussian values
+  //! through the planes (0.87 GB per 64 x 1080p step in round 3).
+  constexpr int kSiteNb = 20;
   struct SiteLists
   {
     unsigned long long* key;  // [frame][cap]
+    float* nb;                // [frame][cap][kSiteNb]
     int* count;               // [frame] (may exceed cap)
     int cap;
   };
