@@ -625,8 +625,56 @@ namespace sara_hip {
                  : "v"(t0), "v"(t1), "v"(k0), "v"(kr));
   }
 
+  // The same two passes with fused multiply-adds (SARA_HIP_OPT_FMA_BLUR: NOT
+  // bit-exact), in the same hand-written form and at the same occupancy as the
+  // exact kernel - 50 instead of 88 arithmetic instructions per pixel (no
+  // product can be shared between outputs any more).  It exists to answer one
+  // question: is the exact kernel bound by the number of instructions it
+  // issues?  (Round 2's FMA variant was compiler-scheduled at another
+  // occupancy and proved nothing either way.)
+  __device__ __forceinline__ void rowf4(float& s0, float& s1, float va, float vb,
+                                        float vc, float vd, float ve, float k0,
+                                        float k1, float k2, float k3)
+  {
+    asm volatile("v_fma_f32 %0, %2, %7, %0\n\tv_fma_f32 %1, %3, %7, %1\n\t"
+                 "v_fma_f32 %0, %3, %8, %0\n\tv_fma_f32 %1, %4, %8, %1\n\t"
+                 "v_fma_f32 %0, %4, %9, %0\n\tv_fma_f32 %1, %5, %9, %1\n\t"
+                 "v_fma_f32 %0, %5, %10, %0\n\tv_fma_f32 %1, %6, %10, %1"
+                 : "+v"(s0), "+v"(s1)
+                 : "v"(va), "v"(vb), "v"(vc), "v"(vd), "v"(ve), "v"(k0), "v"(k1),
+                   "v"(k2), "v"(k3));
+  }
+  __device__ __forceinline__ void rowf1(float& s0, float& s1, float va, float vb,
+                                        float k0)
+  {
+    asm volatile("v_fma_f32 %0, %2, %4, %0\n\tv_fma_f32 %1, %3, %4, %1"
+                 : "+v"(s0), "+v"(s1)
+                 : "v"(va), "v"(vb), "v"(k0));
+  }
+  //! taps j .. j+3 of two columns into the four outputs that are j .. j+3 steps old
+  __device__ __forceinline__ void colf4(float& a0, float& a1, float& b0, float& b1,
+                                        float& c0, float& c1, float& d0, float& d1,
+                                        float t0, float t1, float ka, float kb,
+                                        float kc, float kd)
+  {
+    asm volatile("v_fma_f32 %0, %8, %10, %0\n\tv_fma_f32 %1, %9, %10, %1\n\t"
+                 "v_fma_f32 %2, %8, %11, %2\n\tv_fma_f32 %3, %9, %11, %3\n\t"
+                 "v_fma_f32 %4, %8, %12, %4\n\tv_fma_f32 %5, %9, %12, %5\n\t"
+                 "v_fma_f32 %6, %8, %13, %6\n\tv_fma_f32 %7, %9, %13, %7"
+                 : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1),
+                   "+v"(d0), "+v"(d1)
+                 : "v"(t0), "v"(t1), "v"(ka), "v"(kb), "v"(kc), "v"(kd));
+  }
+  __device__ __forceinline__ void colf1(float& a0, float& a1, float t0, float t1,
+                                        float ka)
+  {
+    asm volatile("v_fma_f32 %0, %2, %4, %0\n\tv_fma_f32 %1, %3, %4, %1"
+                 : "+v"(a0), "+v"(a1)
+                 : "v"(t0), "v"(t1), "v"(ka));
+  }
+
   template <int R, int PF, bool FMA = false>
-  __global__ __launch_bounds__(64, (FMA && R < 12) ? 4 : 1) void gaussian_blur_march2_kernel(
+  __global__ __launch_bounds__(64, 1) void gaussian_blur_march2_kernel(
       const float* __restrict__ src, size_t src_stride,
       float* __restrict__ dst, size_t dst_stride, int w, int h, int seg_rows,
       int nstrips, int nseg, int xcd_total, Taps taps)
@@ -720,29 +768,36 @@ namespace sara_hip {
         float t0 = 0.f, t1 = 0.f;
         if constexpr (FMA)
         {
-          // opt-in fused form: one v_fma per tap and output (no product is
-          // shared between outputs any more), compiler-scheduled
+          // opt-in fused form: one v_fma per tap and output, hand-written
+          // like the exact form below
+          constexpr int NB = K / 4;
 #pragma unroll
-          for (int j = 0; j < K; ++j)
+          for (int q = 0; q < NB; ++q)
           {
-            t0 = __builtin_fmaf(v[D + j], SARA_TK(j), t0);
-            t1 = __builtin_fmaf(v[D + j + 1], SARA_TK(j), t1);
+            const int j = 4 * q;
+            rowf4(t0, t1, v[D + j], v[D + j + 1], v[D + j + 2], v[D + j + 3],
+                  v[D + j + 4], SARA_TK(j), SARA_TK(j + 1), SARA_TK(j + 2),
+                  SARA_TK(j + 3));
           }
 #pragma unroll
-          for (int j = 0; j < K; ++j)
+          for (int j = 4 * NB; j < K; ++j)
+            rowf1(t0, t1, v[D + j], v[D + j + 1], SARA_TK(j));
+#define SARA_SLF(j) ((i + K - 1 - (j)) % K)
+          // tap 0 opens a new output: 0.f + t k[0]
+          A[SARA_SLF(0)][0] = 0.f;
+          A[SARA_SLF(0)][1] = 0.f;
+          colf1(A[SARA_SLF(0)][0], A[SARA_SLF(0)][1], t0, t1, SARA_TK(0));
+#pragma unroll
+          for (int q = 0; q < (K - 1) / 4; ++q)
           {
-            const int sl = (i + K - 1 - j) % K;
-            if (j == 0)
-            {
-              A[sl][0] = 0.f + t0 * SARA_TK(0);
-              A[sl][1] = 0.f + t1 * SARA_TK(0);
-            }
-            else
-            {
-              A[sl][0] = __builtin_fmaf(t0, SARA_TK(j), A[sl][0]);
-              A[sl][1] = __builtin_fmaf(t1, SARA_TK(j), A[sl][1]);
-            }
+            const int j = 1 + 4 * q;
+            colf4(A[SARA_SLF(j)][0], A[SARA_SLF(j)][1], A[SARA_SLF(j + 1)][0],
+                  A[SARA_SLF(j + 1)][1], A[SARA_SLF(j + 2)][0], A[SARA_SLF(j + 2)][1],
+                  A[SARA_SLF(j + 3)][0], A[SARA_SLF(j + 3)][1], t0, t1, SARA_TK(j),
+                  SARA_TK(j + 1), SARA_TK(j + 2), SARA_TK(j + 3));
           }
+          static_assert((K - 1) % 4 == 0, "radii 8, 10, 12: K - 1 is a multiple of 4");
+#undef SARA_SLF
         }
         else
         {
