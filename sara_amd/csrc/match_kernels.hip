@@ -320,33 +320,37 @@ namespace sara_hip {
     __shared__ unsigned long long s_k1[256];
     __shared__ int s_k2[256];
     const int n = *count;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    const int base = blockIdx.y * 256;
-    if (int(blockIdx.x) * 256 >= n || base >= n)
-      return;
-    const int f = base + threadIdx.x;
-    unsigned long long o1 = ~0ull;
-    int o2 = 0x7fffffff;
-    if (f < n)
-      match_key(in[f], o1, o2);
-    s_k1[threadIdx.x] = o1;
-    s_k2[threadIdx.x] = o2;
-    __syncthreads();
-    if (e >= n)
-      return;
-    unsigned long long k1;
-    int k2;
-    match_key(in[e], k1, k2);
-    int before = 0;
-    const int m = min(256, n - base);
+    // (the grid may be smaller than the list: tiles are walked with its stride)
+    for (int tx = blockIdx.x; tx * 256 < n; tx += gridDim.x)
+      for (int ty = blockIdx.y; ty * 256 < n; ty += gridDim.y)
+      {
+        const int e = tx * 256 + threadIdx.x;
+        const int base = ty * 256;
+        const int f = base + threadIdx.x;
+        unsigned long long o1 = ~0ull;
+        int o2 = 0x7fffffff;
+        if (f < n)
+          match_key(in[f], o1, o2);
+        __syncthreads();  // the previous tile has been consumed
+        s_k1[threadIdx.x] = o1;
+        s_k2[threadIdx.x] = o2;
+        __syncthreads();
+        if (e >= n)
+          continue;
+        unsigned long long k1;
+        int k2;
+        match_key(in[e], k1, k2);
+        int before = 0;
+        const int m = min(256, n - base);
 #pragma unroll 8
-    for (int k = 0; k < m; ++k)
-    {
-      const unsigned long long p1 = s_k1[k];
-      before += (p1 < k1 || (p1 == k1 && s_k2[k] < k2)) ? 1 : 0;
-    }
-    if (before)
-      atomicAdd(rank + e, before);
+        for (int k = 0; k < m; ++k)
+        {
+          const unsigned long long p1 = s_k1[k];
+          before += (p1 < k1 || (p1 == k1 && s_k2[k] < k2)) ? 1 : 0;
+        }
+        if (before)
+          atomicAdd(rank + e, before);
+      }
   }
 
   __global__ void rank_scatter_kernel(const sara_match* __restrict__ in,
@@ -354,8 +358,8 @@ namespace sara_hip {
                                       const int* __restrict__ rank,
                                       sara_match* __restrict__ out)
   {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < *count)
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < *count;
+         e += gridDim.x * blockDim.x)
       out[rank[e]] = in[e];
   }
 
@@ -375,6 +379,204 @@ namespace sara_hip {
                        scratch, count, rank_scratch);
     hipLaunchKernelGGL(rank_scatter_kernel, dim3(tiles), dim3(256), 0, stream,
                        scratch, count, rank_scratch, out);
+  }
+
+  // ------------------------------------------------------------------------ //
+  // compute_matches' tail for squared ratios > 1 (the reference's DEFAULT,
+  // sift_ratio_thres = 1.2f) on the device.  Input: the radius members of both
+  // directions as unordered (query, index, distance) triples - what rerank /
+  // fallback / radius_kernel append - and the knnSearch(3) tables.  Per member
+  // (AnnMatcher.cpp:141-170): rank = its position in the query's members
+  // ordered by (distance, index); score = d_top1 / d_next for rank 0, distance
+  // / d_top1 behind it (0 when d_top1 == 0); the reference's loop stops at the
+  // first score above the threshold, and scores do not decrease along a run, so
+  // a member is emitted iff its own score passes.  Then :239-258: of a pair
+  // (x, y) found from both sides the lower score survives (direction 0 on a
+  // tie), and the list is ordered by (score, x, y).  A few thousand members per
+  // direction: ranks and twins are found by comparing every member with every
+  // other one, tile against tile.
+  // ------------------------------------------------------------------------ //
+  //! grid (tiles, tiles, 4): z = 2 * dir + role.  role 0: members of direction
+  //! `dir` count their predecessors in the same run; role 1: they look for
+  //! their twin (query and index swapped) among the other direction's members.
+  __global__ __launch_bounds__(256) void radius_pair_kernel(
+      const MatchNeighbour* __restrict__ m0, const int* __restrict__ c0, int cap0,
+      const MatchNeighbour* __restrict__ m1, const int* __restrict__ c1, int cap1,
+      int* __restrict__ rank0, int* __restrict__ rank1, int* __restrict__ twin0,
+      int* __restrict__ twin1)
+  {
+    __shared__ int s_q[256], s_i[256];
+    __shared__ float s_d[256];
+    const int dir = blockIdx.z >> 1, role = blockIdx.z & 1;
+    const MatchNeighbour* mine = dir == 0 ? m0 : m1;
+    const int n_mine = min(dir == 0 ? *c0 : *c1, dir == 0 ? cap0 : cap1);
+    const bool same = role == 0;
+    const MatchNeighbour* other = (dir == 0) == same ? m0 : m1;
+    const int n_other = (dir == 0) == same ? min(*c0, cap0) : min(*c1, cap1);
+    // the grid is sized for typical lists; longer ones are walked with its stride
+    for (int tx = blockIdx.x; tx * 256 < n_mine; tx += gridDim.x)
+      for (int ty = blockIdx.y; ty * 256 < n_other; ty += gridDim.y)
+      {
+        const int e = tx * 256 + threadIdx.x;
+        const int base = ty * 256;
+        const int f = base + threadIdx.x;
+        MatchNeighbour o{-1, -1, 0.f};
+        if (f < n_other)
+          o = other[f];
+        __syncthreads();  // the previous tile has been consumed
+        s_q[threadIdx.x] = o.query;
+        s_i[threadIdx.x] = o.index;
+        s_d[threadIdx.x] = o.distance;
+        __syncthreads();
+        if (e >= n_mine)
+          continue;
+        const MatchNeighbour me = mine[e];
+        const int m = min(256, n_other - base);
+        if (same)
+        {
+          int before = 0;
+#pragma unroll 8
+          for (int k = 0; k < m; ++k)
+            before += (s_q[k] == me.query &&
+                       (s_d[k] < me.distance ||
+                        (s_d[k] == me.distance && s_i[k] < me.index)))
+                          ? 1
+                          : 0;
+          if (before)
+            atomicAdd((dir == 0 ? rank0 : rank1) + e, before);
+        }
+        else
+        {
+          int twin = -1;
+#pragma unroll 8
+          for (int k = 0; k < m; ++k)
+            if (s_q[k] == me.index && s_i[k] == me.query)
+              twin = base + k;
+          if (twin >= 0)
+            (dir == 0 ? twin0 : twin1)[e] = twin + 1;  // 0 = none (zero-filled)
+        }
+      }
+  }
+
+  //! score of every member (-1: not emitted) from its rank.
+  __global__ void radius_score_kernel(const MatchNeighbour* __restrict__ m0,
+                                      const int* __restrict__ c0, int cap0,
+                                      const MatchNeighbour* __restrict__ m1,
+                                      const int* __restrict__ c1, int cap1,
+                                      const float* __restrict__ top_d0, int n1,
+                                      const float* __restrict__ top_d1, int n2,
+                                      float squared_ratio_thres,
+                                      const int* __restrict__ rank0,
+                                      const int* __restrict__ rank1,
+                                      float* __restrict__ score0,
+                                      float* __restrict__ score1)
+  {
+    const int dir = blockIdx.y;
+    const int n = min(dir == 0 ? *c0 : *c1, dir == 0 ? cap0 : cap1);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n;
+         e += gridDim.x * blockDim.x)
+    {
+    const MatchNeighbour me = (dir == 0 ? m0 : m1)[e];
+    const float* td = dir == 0 ? top_d0 : top_d1;
+    const int nq = dir == 0 ? n1 : n2;
+    const int rank = (dir == 0 ? rank0 : rank1)[e];
+    const float d_top1 = td[me.query], d_next = td[nq + me.query];
+    float score = 0.f;
+    if (rank == 0)
+      score = d_next > 0.f ? d_top1 / d_next : 0.f;
+    else if (d_top1)
+      score = me.distance / d_top1;
+    (dir == 0 ? score0 : score1)[e] = score > squared_ratio_thres ? -1.f : score;
+    }
+  }
+
+  //! Appends the surviving members as matches (any order; *count counts).
+  __global__ void radius_emit_kernel(const MatchNeighbour* __restrict__ m0,
+                                     const int* __restrict__ c0, int cap0,
+                                     const MatchNeighbour* __restrict__ m1,
+                                     const int* __restrict__ c1, int cap1,
+                                     const int* __restrict__ rank0,
+                                     const int* __restrict__ rank1,
+                                     const int* __restrict__ twin0,
+                                     const int* __restrict__ twin1,
+                                     const float* __restrict__ score0,
+                                     const float* __restrict__ score1,
+                                     sara_match* __restrict__ out, int capacity,
+                                     int* __restrict__ count, int* __restrict__ overflow)
+  {
+    const int dir = blockIdx.y;
+    const int found = dir == 0 ? *c0 : *c1;
+    const int cap = dir == 0 ? cap0 : cap1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && found > cap)
+      *overflow = 1;  // members were dropped: the caller redoes the search
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < min(found, cap);
+         e += gridDim.x * blockDim.x)
+    {
+    const float score = (dir == 0 ? score0 : score1)[e];
+    if (score < 0.f)
+      continue;
+    const int twin = (dir == 0 ? twin0 : twin1)[e] - 1;
+    if (twin >= 0)
+    {
+      const float st = (dir == 0 ? score1 : score0)[twin];
+      if (st >= 0.f && (dir == 0 ? st < score : st <= score))
+        continue;
+    }
+    const MatchNeighbour me = (dir == 0 ? m0 : m1)[e];
+    sara_match m;
+    m.x_index = dir == 0 ? me.query : me.index;
+    m.y_index = dir == 0 ? me.index : me.query;
+    m.score = score;
+    m.rank = (dir == 0 ? rank0 : rank1)[e] + 1;
+    m.direction = dir;
+    const int at = atomicAdd(count, 1);
+    if (at < capacity)
+      out[at] = m;
+    else
+      *overflow = 1;
+    }
+  }
+
+  size_t finish_radius_scratch_ints(int cap0, int cap1)
+  {
+    // rank, twin, score per member of both directions, then the match ranks
+    return 4 * (size_t(cap0) + cap1) + 16;
+  }
+
+  void launch_finish_radius_matches(const MatchNeighbour* m0, const int* c0, int cap0,
+                                    const MatchNeighbour* m1, const int* c1, int cap1,
+                                    const float* top_d0, int n1, const float* top_d1,
+                                    int n2, float squared_ratio_thres, int* iscratch,
+                                    sara_match* scratch, int* header, sara_match* out,
+                                    hipStream_t stream)
+  {
+    const size_t n = size_t(cap0) + cap1;
+    int* rank0 = iscratch;
+    int* rank1 = rank0 + cap0;
+    int* twin0 = rank1 + cap1;
+    int* twin1 = twin0 + cap0;
+    int* mrank = twin1 + cap1;  // n ints
+    float* score0 = reinterpret_cast<float*>(mrank + n);
+    float* score1 = score0 + cap0;
+    // ranks, twins (index + 1) and match ranks start at 0: one fill
+    (void) hipMemsetAsync(rank0, 0, sizeof(int) * 3 * n, stream);
+    // a key has a handful of members: grids for 2 per key, strided beyond that
+    const int tiles = std::max(1, std::min(int((std::max(cap0, cap1) + 255) / 256),
+                                           (2 * std::max(n1, n2) + 255) / 256));
+    hipLaunchKernelGGL(radius_pair_kernel, dim3(tiles, tiles, 4), dim3(256), 0, stream,
+                       m0, c0, cap0, m1, c1, cap1, rank0, rank1, twin0, twin1);
+    hipLaunchKernelGGL(radius_score_kernel, dim3(tiles, 2), dim3(256), 0, stream, m0, c0,
+                       cap0, m1, c1, cap1, top_d0, n1, top_d1, n2, squared_ratio_thres,
+                       rank0, rank1, score0, score1);
+    hipLaunchKernelGGL(radius_emit_kernel, dim3(tiles, 2), dim3(256), 0, stream, m0, c0,
+                       cap0, m1, c1, cap1, rank0, rank1, twin0, twin1, score0, score1,
+                       scratch, int(n), header, header + 1);
+    const int mtiles = std::max(1, std::min(int((n + 255) / 256),
+                                            (4 * std::max(n1, n2) + 255) / 256));
+    hipLaunchKernelGGL(rank_count_kernel, dim3(mtiles, mtiles), dim3(256), 0, stream,
+                       scratch, header, mrank);
+    hipLaunchKernelGGL(rank_scatter_kernel, dim3(mtiles), dim3(256), 0, stream, scratch,
+                       header, mrank, out);
   }
 
   void match_chunking(int nq, int nt, int* chunk, int* nchunks)

@@ -192,7 +192,7 @@ namespace sara_hip {
     //! The contraction runs in chunks of 64 k: both operand panels of a chunk
     //! take 68 KB of LDS, so two workgroups share a CU (with the whole k range
     //! staged at once - 133 KB - it is one).  Measured per pass over 4.3 k x
-    //! 4.3 k keys (SARA_HIP_MATCH_SKIP): contraction alone 40 us (78 % of the
+    //! 4.3 k keys (timing builds with a phase removed): contraction alone 40 us (78 % of the
     //! f32 MFMA peak), staging alone 23, minima epilogue alone 16 - and 80
     //! together: co-resident workgroups fall into step (the contraction is the
     //! longest phase and the one they share a unit for), so the phases add up;
@@ -215,9 +215,6 @@ namespace sara_hip {
         int with_cols_and_debug)
     {
       extern __shared__ __attribute__((aligned(16))) float lds[];
-      // timing experiments (SARA_HIP_MATCH_SKIP, bits: 1 no staging, 2 no
-      // contraction, 4 no epilogue); 0 in production
-      const int debug = with_cols_and_debug >> 8;
       const int with_cols = with_cols_and_debug & 1;
       float* sA = lds;
       float* sB = lds + kTile * kPanelStride;
@@ -236,9 +233,7 @@ namespace sara_hip {
         if (k0 > 0)
           __syncthreads();  // the previous chunk's panels have been consumed
         // ---- stage the two panels of this chunk (zero-padded) ----------------
-        if (debug & 1)
-          ;
-        else if (vec4)
+        if (vec4)
         {
           // 16 float4 per row and panel, 8 per thread: every load is in flight
           // before the first LDS write
@@ -298,7 +293,6 @@ namespace sara_hip {
         const float4* qb1 = reinterpret_cast<const float4*>(
             sB + (wn * 64 + 32 + li) * kPanelStride + 32 * half);
         float4 a0 = qa0[0], a1 = qa1[0], b0 = qb0[0], b1 = qb1[0];
-        if (!(debug & 2))
 #pragma unroll
         for (int t = 0; t < 8; ++t)
         {
@@ -323,12 +317,6 @@ namespace sara_hip {
         }
       }
       __syncthreads();  // the panels are dead: their LDS is reused below
-      if (debug & 4)
-      {
-        if (acc00[0] + acc01[1] + acc10[2] + acc11[3] == 12345.f && rowmin)
-          rowmin[0] = 0.f;  // keeps the contraction alive
-        return;
-      }
 
       // squared norms of this tile's rows / columns (>= FLT_MAX for the padding:
       // a row or column past the end can never be anyone's neighbour)
@@ -523,16 +511,33 @@ namespace sara_hip {
     //! Global three smallest approximations of every query -> its threshold.
     //! top1: rank of the best real neighbour (1 when a set is matched against
     //! itself: rank 0 is the query).
-    __global__ void thresholds_kernel(const float* __restrict__ partial, int ntiles,
-                                      int n, const float* __restrict__ norms,
-                                      const unsigned* __restrict__ other_max_bits,
-                                      int dim, float squared_ratio_thres, int top1,
-                                      float* __restrict__ tau)
+    //! blockIdx.y = direction (rows / columns of the tiles): one launch.
+    struct ThresholdDir
     {
+      const float* partial;
+      int ntiles, n;
+      const float* norms;
+      const unsigned* other_max_bits;
+      float* tau;
+    };
+    struct ThresholdArgs
+    {
+      ThresholdDir d[2];
+    };
+    __global__ void thresholds_kernel(ThresholdArgs args, int dim,
+                                      float squared_ratio_thres, int top1)
+    {
+      const ThresholdDir& a = args.d[blockIdx.y];
+      const float* __restrict__ partial = a.partial;
+      const int ntiles = a.ntiles, n = a.n;
+      const float* __restrict__ norms = a.norms;
+      const unsigned* __restrict__ other_max_bits = a.other_max_bits;
+      float* __restrict__ tau = a.tau;
       const int i = blockIdx.x * blockDim.x + threadIdx.x;
       if (i >= n)
         return;
       float m1 = FLT_MAX, m2 = FLT_MAX, m3 = FLT_MAX;
+#pragma unroll 4
       for (int t = 0; t < ntiles; ++t)
       {
         const float* p = partial + (size_t(t) * n + i) * 3;
@@ -631,16 +636,53 @@ namespace sara_hip {
       }
     }
 
-    //! Exact distances of every query's candidate slots; CAP lanes per query.
-    template <int CAP>
-    __global__ __launch_bounds__(256) void rerank_kernel(
-        const float* __restrict__ q, int nq, const float* __restrict__ t, int dim,
-        const int* __restrict__ cand, const int* __restrict__ cnt,
-        float squared_ratio_thres, int top1, float* __restrict__ top_d,
-        int* __restrict__ top_i, MatchNeighbour* __restrict__ radius_out,
-        int radius_cap, int* __restrict__ radius_count, int* __restrict__ flagged,
-        int* __restrict__ flagged_count)
+    __device__ __forceinline__ int wave_max_int(int v)
     {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+        v = max(v, __shfl_xor(v, o));
+      return v;
+    }
+
+    //! Exact distances of every query's candidate slots; CAP lanes per query.
+    //! blockIdx.y = direction: one launch for both.
+    struct RerankDir
+    {
+      const float* q;
+      int nq;
+      const float* t;
+      const int* cand;
+      const int* cnt;
+      float* top_d;
+      int* top_i;
+      MatchNeighbour* radius_out;
+      int radius_cap;
+      int* radius_count;
+      int* flagged;
+      int* flagged_count;
+    };
+    struct RerankArgs
+    {
+      RerankDir d[2];
+    };
+    template <int CAP>
+    __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs args, int dim,
+                                                         float squared_ratio_thres,
+                                                         int top1)
+    {
+      const RerankDir& a = args.d[blockIdx.y];
+      const float* __restrict__ q = a.q;
+      const int nq = a.nq;
+      const float* __restrict__ t = a.t;
+      const int* __restrict__ cand = a.cand;
+      const int* __restrict__ cnt = a.cnt;
+      float* __restrict__ top_d = a.top_d;
+      int* __restrict__ top_i = a.top_i;
+      MatchNeighbour* __restrict__ radius_out = a.radius_out;
+      const int radius_cap = a.radius_cap;
+      int* __restrict__ radius_count = a.radius_count;
+      int* __restrict__ flagged = a.flagged;
+      int* __restrict__ flagged_count = a.flagged_count;
       const int gid = blockIdx.x * blockDim.x + threadIdx.x;
       const int qi = gid / CAP, slot = gid % CAP;
       const int lane = threadIdx.x & 63;
@@ -658,18 +700,23 @@ namespace sara_hip {
         idx = cand[size_t(qi) * CAP + slot];
         d = flann_l2_rows(q + size_t(qi) * dim, t + size_t(idx) * dim, dim);
       }
-      // rank by (distance, index) inside the group; d of rank top1
+      // rank by (distance, index) inside the group; d of rank top1.  Slots
+      // from the group's count on are empty (FLT_MAX, INT_MAX: they precede
+      // nothing), so the loops stop at the fullest group of the wave - a query
+      // has 3-4 candidates, CAP is 32 for the radius search.
       int rank = 0;
       float d_top1 = FLT_MAX;
+      const int used = __builtin_amdgcn_readfirstlane(
+          wave_max_int(valid ? min(c, CAP) : 0));
       // first the ranks ...
-      for (int k = 0; k < CAP; ++k)
+      for (int k = 0; k < used; ++k)
       {
         const float od = __shfl(d, base + k);
         const int oi = __shfl(idx, base + k);
         rank += (od < d || (od == d && oi < idx)) ? 1 : 0;
       }
       // ... then the distance the radius is built from
-      for (int k = 0; k < CAP; ++k)
+      for (int k = 0; k < used; ++k)
       {
         const float od = __shfl(d, base + k);
         const int orank = __shfl(rank, base + k);
@@ -725,12 +772,39 @@ namespace sara_hip {
     //! of computing 4-5 distances per thread one after the other, twice (top-3
     //! pass and radius pass): with 33 flagged queries of 8 600 it ran on 33
     //! workgroups for 130 us per direction - a latency chain, not work.
-    __global__ __launch_bounds__(256) void fallback_distances_kernel(
-        const float* __restrict__ q, const float* __restrict__ t, int nt, int dim,
-        const int* __restrict__ flagged, const int* __restrict__ flagged_count,
-        float* __restrict__ staged)
+    //! Both directions in one launch (blockIdx.z): they are independent, and a
+    //! fall-back is a latency chain on a few dozen workgroups - run one after
+    //! the other the two cost 120 us of the default-ratio call's 350.
+    struct FallbackDir
     {
-      const int n = min(*flagged_count, kFallbackSlots);
+      const float* q;
+      int nq;
+      const float* t;
+      int nt;
+      const int* flagged;
+      const int* flagged_count;
+      float* top_d;
+      int* top_i;
+      MatchNeighbour* radius_out;
+      int radius_cap;
+      int* radius_count;
+      float* staged;  // [kFallbackSlots][nt], or NULL
+    };
+    struct FallbackArgs
+    {
+      FallbackDir d[2];
+    };
+
+    __global__ __launch_bounds__(256) void fallback_distances_kernel(FallbackArgs args,
+                                                                     int dim)
+    {
+      const FallbackDir& a = args.d[blockIdx.z];
+      const float* __restrict__ q = a.q;
+      const float* __restrict__ t = a.t;
+      const int nt = a.nt;
+      const int* __restrict__ flagged = a.flagged;
+      float* __restrict__ staged = a.staged;
+      const int n = min(*a.flagged_count, kFallbackSlots);
       const int per = (nt + kFallbackParts - 1) / kFallbackParts;
       for (int k = blockIdx.y; k < n; k += gridDim.y)
       {
@@ -744,19 +818,27 @@ namespace sara_hip {
     //! Queries whose candidate slots overflowed: exhaustive search, one
     //! 1024-thread workgroup per query (a single wave per query spent 0.3 ms on
     //! its 67 dependent row reads per lane).
-    __global__ __launch_bounds__(1024) void fallback_kernel(
-        const float* __restrict__ q, int nq, const float* __restrict__ t, int nt,
-        int dim, const int* __restrict__ flagged,
-        const int* __restrict__ flagged_count, float squared_ratio_thres, int top1,
-        float* __restrict__ top_d, int* __restrict__ top_i,
-        MatchNeighbour* __restrict__ radius_out, int radius_cap,
-        int* __restrict__ radius_count, const float* __restrict__ staged)
+    __global__ __launch_bounds__(1024) void fallback_kernel(FallbackArgs args, int dim,
+                                                            float squared_ratio_thres,
+                                                            int top1)
     {
+      const FallbackDir& a = args.d[blockIdx.z];
+      const float* __restrict__ q = a.q;
+      const int nq = a.nq;
+      const float* __restrict__ t = a.t;
+      const int nt = a.nt;
+      const int* __restrict__ flagged = a.flagged;
+      float* __restrict__ top_d = a.top_d;
+      int* __restrict__ top_i = a.top_i;
+      MatchNeighbour* __restrict__ radius_out = a.radius_out;
+      const int radius_cap = a.radius_cap;
+      int* __restrict__ radius_count = a.radius_count;
+      const float* __restrict__ staged = a.staged;
       __shared__ float s_d[1024 * 3];
       __shared__ int s_i[1024 * 3];
       __shared__ float s_radius;
       const int tid = threadIdx.x;
-      const int n = *flagged_count;
+      const int n = *a.flagged_count;
       for (int k = blockIdx.x; k < n; k += gridDim.x)
       {
         const int qi = flagged[k];
@@ -856,7 +938,7 @@ namespace sara_hip {
     const size_t tm = (size_t(n1) + kTile - 1) / kTile, tn = (size_t(n2) + kTile - 1) / kTile;
     // norms (n1 + n2 + 2), tau (n1 + n2), row minima [tn][n1][3], column minima [tm][n2][3]
     return 2 * (size_t(n1) + n2) + 16 + 4 * (tn * n1 + tm * n2) + 8 +
-           size_t(kFallbackSlots) * size_t(std::max(n1, n2));  // staged distances
+           2 * size_t(kFallbackSlots) * size_t(std::max(n1, n2));  // staged distances
   }
 
   size_t match_mfma_scratch_ints(int n1, int n2, int cap)
@@ -927,11 +1009,7 @@ namespace sara_hip {
     allow_big_lds<kMinima>(mfma_tiles_kernel<kMinima>);
     allow_big_lds<kEmit>(mfma_tiles_kernel<kEmit>);
     const dim3 grid(tn, tm);
-    static const int skip = [] {
-      const char* e = getenv("SARA_HIP_MATCH_SKIP");
-      return e ? atoi(e) : 0;
-    }();
-    const int cols_arg = (with_dir1 ? 1 : 0) | (skip << 8);
+    const int cols_arg = with_dir1 ? 1 : 0;
     // Round 3, ratios <= 1 (only the three nearest neighbours matter): ONE pass
     // over the tiles that keeps, per row and column of a tile, the four smallest
     // approximations together with where they are (kPacked), and the candidates
@@ -967,54 +1045,60 @@ namespace sara_hip {
                        n1, d2, n2, dim, na, nb, rowmin, colmin, nullptr, nullptr,
                        nullptr, nullptr, nullptr, nullptr, cap, cols_arg);
     tick();  // 2: minima
-    hipLaunchKernelGGL(thresholds_kernel, dim3((n1 + 255) / 256), dim3(256), 0, stream,
-                       rowmin, tn, n1, na, maxbits + 1, dim, squared_ratio_thres,
-                       top1, tau_r);
-    if (with_dir1)
-      hipLaunchKernelGGL(thresholds_kernel, dim3((n2 + 255) / 256), dim3(256), 0,
-                         stream, colmin, tm, n2, nb, maxbits, dim,
-                         squared_ratio_thres, top1, tau_c);
+    {
+      ThresholdArgs ta;
+      ta.d[0] = ThresholdDir{rowmin, tn, n1, na, maxbits + 1, tau_r};
+      ta.d[1] = ThresholdDir{colmin, tm, n2, nb, maxbits, tau_c};
+      const int nmax = std::max(n1, with_dir1 ? n2 : 0);
+      hipLaunchKernelGGL(thresholds_kernel, dim3((nmax + 255) / 256, with_dir1 ? 2 : 1),
+                         dim3(256), 0, stream, ta, dim, squared_ratio_thres, top1);
+    }
     tick();  // 3: thresholds
     hipLaunchKernelGGL(mfma_tiles_kernel<kEmit>, grid, dim3(256), lds, stream, d1, n1,
                        d2, n2, dim, na, nb, nullptr, nullptr, tau_r, tau_c, cand_r,
                        cnt_r, cand_c, cnt_c, cap, cols_arg);
     tick();  // 4: emit
     }
-    auto rerank = [&](const float* q, int nq, const float* t, int nt, const int* cand,
-                      const int* cnt, float* td, int* ti, MatchNeighbour* ro, int rcap,
-                      int* rcount, int* flagged, int* fcount) {
-      const size_t threads = size_t(nq) * cap;
-      const dim3 g(unsigned((threads + 255) / 256));
+    {
+      RerankArgs ra;
+      ra.d[0] = RerankDir{d1, n1, d2, cand_r, cnt_r, top12_d, top12_i, radius12,
+                          radius12_cap, radius12_count, flag_r, scal};
+      ra.d[1] = RerankDir{d2, n2, d1, cand_c, cnt_c, top21_d, top21_i, radius21,
+                          radius21_cap, radius21_count, flag_c, scal + 1};
+      const size_t threads = size_t(std::max(n1, with_dir1 ? n2 : 0)) * cap;
+      const dim3 g(unsigned((threads + 255) / 256), with_dir1 ? 2 : 1);
       if (cap == 8)
-        hipLaunchKernelGGL(rerank_kernel<8>, g, dim3(256), 0, stream, q, nq, t, dim,
-                           cand, cnt, squared_ratio_thres, top1, td, ti, ro, rcap,
-                           rcount, flagged, fcount);
+        hipLaunchKernelGGL(rerank_kernel<8>, g, dim3(256), 0, stream, ra, dim,
+                           squared_ratio_thres, top1);
       else if (cap == 64)
-        hipLaunchKernelGGL(rerank_kernel<64>, g, dim3(256), 0, stream, q, nq, t, dim,
-                           cand, cnt, squared_ratio_thres, top1, td, ti, ro, rcap,
-                           rcount, flagged, fcount);
+        hipLaunchKernelGGL(rerank_kernel<64>, g, dim3(256), 0, stream, ra, dim,
+                           squared_ratio_thres, top1);
       else
-        hipLaunchKernelGGL(rerank_kernel<32>, g, dim3(256), 0, stream, q, nq, t, dim,
-                           cand, cnt, squared_ratio_thres, top1, td, ti, ro, rcap,
-                           rcount, flagged, fcount);
-      // (the two directions share `staged`: they run one after the other)
-      // staged only for the radius search, where overflowing queries are the
-      // rule (ratio <= 1: a handful of candidates per query, no query flagged
-      // on the benchmark pair - not worth a launch)
+        hipLaunchKernelGGL(rerank_kernel<32>, g, dim3(256), 0, stream, ra, dim,
+                           squared_ratio_thres, top1);
+    }
+    {
+      // Queries whose candidate slots overflowed.  Their distances are staged
+      // only for the radius search, where overflowing queries are the rule
+      // (ratio <= 1: a handful of candidates per query, no query flagged on the
+      // benchmark pair - not worth a launch).
       const bool stage = squared_ratio_thres > 1.f;
+      FallbackArgs fa;
+      fa.d[0] = FallbackDir{d1, n1, d2, n2, flag_r, scal, top12_d, top12_i, radius12,
+                            radius12_cap, radius12_count, stage ? staged : nullptr};
+      fa.d[1] = FallbackDir{d2, n2, d1, n1, flag_c, scal + 1, top21_d, top21_i,
+                            radius21, radius21_cap, radius21_count,
+                            stage ? staged + size_t(kFallbackSlots) * std::max(n1, n2)
+                                  : nullptr};
+      const int ndir = with_dir1 ? 2 : 1;
+      const int nq_max = std::max(n1, with_dir1 ? n2 : 0);
       if (stage)
         hipLaunchKernelGGL(fallback_distances_kernel,
-                           dim3(kFallbackParts, std::min(nq, kFallbackSlots)), dim3(256),
-                           0, stream, q, t, nt, dim, flagged, fcount, staged);
-      hipLaunchKernelGGL(fallback_kernel, dim3(std::min(nq, 256)), dim3(1024), 0, stream,
-                         q, nq, t, nt, dim, flagged, fcount, squared_ratio_thres,
-                         top1, td, ti, ro, rcap, rcount, stage ? staged : nullptr);
-    };
-    rerank(d1, n1, d2, n2, cand_r, cnt_r, top12_d, top12_i, radius12, radius12_cap,
-           radius12_count, flag_r, scal);
-    if (with_dir1)
-      rerank(d2, n2, d1, n1, cand_c, cnt_c, top21_d, top21_i, radius21, radius21_cap,
-             radius21_count, flag_c, scal + 1);
+                           dim3(kFallbackParts, std::min(nq_max, kFallbackSlots), ndir),
+                           dim3(256), 0, stream, fa, dim);
+      hipLaunchKernelGGL(fallback_kernel, dim3(std::min(nq_max, 256), 1, ndir),
+                         dim3(1024), 0, stream, fa, dim, squared_ratio_thres, top1);
+    }
     tick();  // 5: rerank + fallback
     if (prof)
     {
@@ -1026,27 +1110,6 @@ namespace sara_hip {
         (void) hipEventElapsedTime(&ms, pev[k], pev[k + 1]);
         std::fprintf(stderr, "[match prof]   %-10s %8.1f us\n", names[k], 1e3 * ms);
       }
-    }
-    static const bool debug = getenv("SARA_HIP_MATCH_DEBUG") != nullptr;
-    if (debug)
-    {
-      int h[2] = {0, 0};
-      std::vector<int> hc(size_t(n1) + n2);
-      (void) hipStreamSynchronize(stream);
-      (void) hipMemcpy(h, scal, sizeof(h), hipMemcpyDeviceToHost);
-      (void) hipMemcpy(hc.data(), cnt_r, sizeof(int) * hc.size(), hipMemcpyDeviceToHost);
-      long long sum = 0;
-      int mx = 0;
-      for (int v : hc)
-      {
-        sum += v;
-        mx = std::max(mx, v);
-      }
-      std::fprintf(stderr,
-                   "[sara_hip match] cap %d thres2 %.3f: flagged %d / %d of %d / %d "
-                   "queries; candidates %.2f per query, max %d\n",
-                   cap, squared_ratio_thres, h[0], h[1], n1, n2,
-                   double(sum) / double(hc.size()), mx);
     }
   }
 

@@ -330,6 +330,19 @@ namespace sara_hip {
                              int have0, int have1, float squared_ratio_thres,
                              sara_match* scratch, int* rank_scratch, int* count,
                              sara_match* out, hipStream_t stream);
+  //! compute_matches' tail for squared ratios > 1 on the device: the radius
+  //! members of both directions (unordered triples, counts on the device, lists
+  //! of cap0 / cap1 entries) -> matches ordered by (score, x, y) in `out`
+  //! (cap0 + cap1 entries), header[0] = their number, header[1] != 0 when a
+  //! member list overflowed (nothing delivered is trustworthy then).  iscratch:
+  //! finish_radius_scratch_ints() ints, scratch: cap0 + cap1 records.
+  size_t finish_radius_scratch_ints(int cap0, int cap1);
+  void launch_finish_radius_matches(const MatchNeighbour* m0, const int* c0, int cap0,
+                                    const MatchNeighbour* m1, const int* c1, int cap1,
+                                    const float* top_d0, int n1, const float* top_d1,
+                                    int n2, float squared_ratio_thres, int* iscratch,
+                                    sara_match* scratch, int* header, sara_match* out,
+                                    hipStream_t stream);
   //! radiusSearch of every query: neighbours with distance <
   //! top_d[top1][query] * squared_ratio_thres, appended in no particular order.
   void launch_radius_exhaustive(const float* q, int nq, const float* t, int nt,

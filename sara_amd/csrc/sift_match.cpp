@@ -64,6 +64,7 @@ namespace {
       kAux1,
       kAux2,
       kAux3,
+      kFinish,
       kSlots
     };
     int device = -1;
@@ -432,13 +433,19 @@ namespace {
     int* top_i[2] = {nullptr, nullptr};
     MatchNeighbour* radius[2] = {nullptr, nullptr};
     int radius_found[2] = {0, 0};
+    int* count = nullptr;       // device: members found per direction
+    size_t cap[2] = {0, 0};     // entries of radius[dir]
     int nq[2] = {0, 0}, nt[2] = {0, 0};
     bool have[2] = {false, false};
   };
 
+  //! keep_on_device: the radius members stay on the device and their counts
+  //! are not read back (the caller finishes there, see
+  //! launch_finish_radius_matches); r.count points at the two device counters.
   sara_hip_status device_search(Workspace& ws, const float* d1, int n1,
                                 const float* d2, int n2, int dim, float thres2,
-                                int top1, bool self_matching, DeviceSearch* out)
+                                int top1, bool self_matching, DeviceSearch* out,
+                                bool keep_on_device = false, size_t min_cap = 0)
   {
     DeviceSearch& r = *out;
     r.nq[0] = n1;
@@ -463,7 +470,12 @@ namespace {
     size_t cap[2] = {0, 0};
     if (radius_on)
       for (int dir = 0; dir < 2; ++dir)
-        cap[dir] = r.have[dir] ? std::max<size_t>(8 * size_t(r.nq[dir]), 1 << 15) : 1;
+        cap[dir] = r.have[dir] ? std::max<size_t>(std::max<size_t>(8 * size_t(r.nq[dir]),
+                                                                    1 << 15), min_cap)
+                               : 1;
+    r.count = d_count;
+    r.cap[0] = cap[0];
+    r.cap[1] = cap[1];
     for (int attempt = 0; attempt < 2; ++attempt)
     {
       MatchNeighbour* list = nullptr;
@@ -508,7 +520,7 @@ namespace {
                                      ws.stream);
         }
       HIPM_TRY(hipGetLastError());
-      if (!radius_on)
+      if (!radius_on || keep_on_device)
         break;
       int found[2] = {0, 0};
       HIPM_TRY(ws.wait(ws.stream));  // the copies below use the NULL stream
@@ -686,6 +698,78 @@ sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,
   }
   std::vector<sara_match> m;
   DeviceSearch ds;
+  // Default ratio (squared threshold > 1), both sets with something to rank:
+  // the members of the radius searches never leave the device - ranks, scores,
+  // the (x, y) duplicates of the two directions and the final order are worked
+  // out there (launch_finish_radius_matches) and ONE copy brings the finished
+  // list back.  (Round 3 read the member lists back and finished on the host:
+  // 0.37 of the call's 0.79 ms for a 4.3 k x 4.3 k pair.)  A member list that
+  // overflows its capacity is reported by the device; the call then falls
+  // through to the host path below, which retries with exact capacities.
+  if (thres2 > 1.f && n1 >= 3 && n2 >= 3)
+  {
+    struct Header
+    {
+      int count, overflow, pad[2];
+    };
+    for (int attempt = 0; attempt < 2; ++attempt)
+    {
+      const sara_hip_status ss = device_search(ws, d1, n1, d2, n2, dim, thres2, 0, false,
+                                               &ds, true, attempt ? size_t(1) << 19 : 0);
+      if (ss != SARA_HIP_OK)
+        return ss;
+      const int cap0 = int(ds.cap[0]), cap1 = int(ds.cap[1]);
+      const size_t total = size_t(cap0) + cap1;
+      unsigned char *d_out = nullptr, *d_tmp = nullptr;
+      int* d_int = nullptr;
+      const size_t list_bytes = sizeof(sara_match) * total;
+      const size_t out_bytes = sizeof(Header) + list_bytes;
+      HIPM_TRY(ws.get(Workspace::kOut, out_bytes, d_out));
+      HIPM_TRY(ws.get(Workspace::kAux3, list_bytes, d_tmp));
+      HIPM_TRY(ws.get(Workspace::kFinish, finish_radius_scratch_ints(cap0, cap1), d_int));
+      HIPM_TRY(hipMemsetAsync(d_out, 0, sizeof(Header), ws.stream));
+      launch_finish_radius_matches(ds.radius[0], ds.count, cap0, ds.radius[1],
+                                   ds.count + 1, cap1, ds.top_d[0], n1, ds.top_d[1], n2,
+                                   thres2, d_int, reinterpret_cast<sara_match*>(d_tmp),
+                                   reinterpret_cast<int*>(d_out),
+                                   reinterpret_cast<sara_match*>(d_out + sizeof(Header)),
+                                   ws.stream);
+      HIPM_TRY(hipGetLastError());
+      // the header first (a few hundred bytes would do, but the list's length
+      // is only known from it): header + as many records as a pair of sets
+      // with a few members per key has, the rest in a second copy if needed
+      void* h = nullptr;
+      HIPM_TRY(ws.host(out_bytes, h));
+      const size_t first = std::min(total, 3 * (size_t(n1) + n2));
+      HIPM_TRY(hipMemcpyAsync(h, d_out, sizeof(Header) + sizeof(sara_match) * first,
+                              hipMemcpyDeviceToHost, ws.stream));
+      HIPM_TRY(ws.wait(ws.stream));
+      const Header hd = *static_cast<Header*>(h);
+      if (hd.overflow)
+        continue;  // once more with room for 2^19 members per direction
+      const size_t found = size_t(std::max(hd.count, 0));
+      if (found > first)
+      {
+        HIPM_TRY(hipMemcpyAsync(static_cast<unsigned char*>(h) + sizeof(Header) +
+                                    sizeof(sara_match) * first,
+                                d_out + sizeof(Header) + sizeof(sara_match) * first,
+                                sizeof(sara_match) * (found - first),
+                                hipMemcpyDeviceToHost, ws.stream));
+        HIPM_TRY(ws.wait(ws.stream));
+      }
+      lap("device finish");
+      *count = int(found);
+      if (found > size_t(capacity))
+        return set_error(SARA_HIP_CAPACITY_EXCEEDED,
+                         "more matches than `capacity` (*count holds the number "
+                         "needed)");
+      std::memcpy(matches, static_cast<unsigned char*>(h) + sizeof(Header),
+                  sizeof(sara_match) * found);
+      return SARA_HIP_OK;
+    }
+    // both attempts overflowed (more than half a million radius members per
+    // direction): the host path below sizes the lists exactly
+  }
   const sara_hip_status ss =
       device_search(ws, d1, n1, d2, n2, dim, thres2, 0, false, &ds);
   if (ss != SARA_HIP_OK)
