@@ -387,6 +387,34 @@ def match_config(torch, dev):
             call(ratio)
             t = timed(lambda: call(ratio), 50, 5)
             out[name] = {"ms_per_pair": 1e3 * t, "matches": int(cnt.value)}
+        # The consumer's unit of work (SfM/Helpers/KeypointMatching.cpp:19-25 after
+        # OdometryPipeline::detect_keypoints): detect two frames, match them.  The
+        # frames are resident in HBM, the keypoints never leave the device between
+        # the two steps; the match list ends on the host.
+        d_frames = torch.from_numpy(frames).to(dev)
+
+        def pair(ratio):
+            c.detect_device(d_frames.data_ptr(), 2, W, H)
+            cts, _ = c.counts()                    # also orders the matcher behind detect
+            o1 = int(cts[0])
+            _, dd, _, _ = c.device_results()
+            capi.check(lib.sara_hip_match_descriptors(
+                dd, o1, dd + o1 * 512, int(cts[1]), 128, ratio, 1, buf.ctypes.data, cap,
+                C.byref(cnt), dev.index or 0))
+
+        fe = {}
+        for name, ratio in (("ratio_0.6", 0.6), ("ratio_1.2_default", 1.2)):
+            pair(ratio)
+            fe[name] = {"ms_per_pair": 1e3 * timed(lambda: pair(ratio), 50, 5),
+                        "matches": int(cnt.value)}
+        t_det = timed(lambda: (c.detect_device(d_frames.data_ptr(), 2, W, H), c.counts()),
+                      50, 5)
+        fe["ms_detect_two_frames"] = 1e3 * t_det
+        fe["workload"] = ("detect (one call, batch of two 1080p frames resident in HBM) "
+                          "+ counts + AnnMatcher on the device-resident descriptors, "
+                          "match list on the host: the front-end's work per image pair")
+        out["front_end_pair"] = fe
+        del d_frames
     out["workload"] = ("AnnMatcher::compute_matches on %d x %d SIFT descriptors "
                        "(two 1080p frames), both directions, descriptors in HBM, "
                        "match list on the host" % (n1, n2))
@@ -399,6 +427,9 @@ def match_config(torch, dev):
     flop = 2.0 * n1 * n2 * 128
     out["mfma_flop_per_pass"] = flop
     out["mfma_passes"] = {"ratio_0.6": 1, "ratio_1.2_default": 2}
+    out["default_ratio_tail"] = ("ranks, scores, (x, y) duplicates of the two "
+                                 "directions and the final order on the device; one "
+                                 "read-back of the finished list")
     out["mfma_time_at_peak_us_per_pass"] = flop / 157.3e12 * 1e6
     out["producer"] = ("MFMA prefilter (v_mfma_f32_32x32x2_f32, both directions from "
                        "one contraction, rigorous error guard; tile minima carry "
