@@ -280,12 +280,17 @@ def test_four_threads_each_with_its_own_context_replay_graphs(oracle):
     context per thread, OdometryPipeline::detect_keypoints per camera,
     SfM/Odometry/OdometryPipeline.cpp:82-90): every thread gets the HIP-graph
     replay - the graph calls of all of them run on the library's launcher
-    thread - so a call costs what it costs a single-threaded caller, and the
-    results are the single-thread results.  Bar: wall time / total calls <=
-    0.35 ms per 1080p call (HBM-resident frame, keypoints left on the device)."""
+    thread - and the results are the single-thread results.  The timing runs in
+    a fresh process with the shipped launch rules (tools/thread_calls.py; this
+    process forces the marching kernels onto small launches, conftest.py): wall
+    time / total calls <= 0.35 ms per 1080p call with 4 threads (HBM-resident
+    frame, keypoints left on the device)."""
+    import os
+    import re
+    import subprocess
+    import sys
     import threading
-    import time
-    W, H, T, CALLS = 1920, 1080, 4, 60
+    W, H, T, CALLS = 1920, 1080, 4, 12
     frames = synth_batch(W, H, T, first_index=500)
     p = params(4)
     want = []
@@ -296,52 +301,42 @@ def test_four_threads_each_with_its_own_context_replay_graphs(oracle):
     ctxs = [sara_amd.SiftContext(W, H, 1, p) for _ in range(T)]
     devs = [sara_amd.DeviceArray(frames[i:i + 1]) for i in range(T)]
     got, errors = [None] * T, []
-    start = threading.Barrier(T + 1)
 
     def work(k):
         try:
             c = ctxs[k]
-            for _ in range(5):                    # capture + warm-up
+            for _ in range(CALLS):                # capture, then replays
                 c.detect_device(devs[k].ptr, 1, W, H)
                 c.synchronize()
-            start.wait()
-            for _ in range(CALLS):
-                c.detect_device(devs[k].ptr, 1, W, H)
-                c.synchronize()
-            start.wait()
             got[k] = c.fetch()
         except Exception as e:  # noqa: BLE001 - reported below
             errors.append(e)
-            try:
-                start.abort()
-            except Exception:
-                pass
 
     ts = [threading.Thread(target=work, args=(k,)) for k in range(T)]
     for t in ts:
         t.start()
-    start.wait()
-    t0 = time.perf_counter()
-    start.wait()
-    per_call = (time.perf_counter() - t0) / (T * CALLS)
     for t in ts:
         t.join()
-    assert not errors, errors
-    for k in range(T):
-        for a, b in zip(got[k], want[k]):
-            assert np.ascontiguousarray(a).tobytes() == np.ascontiguousarray(b).tobytes()
-    # one thread alone, for the record
-    c = ctxs[0]
-    t0 = time.perf_counter()
-    for _ in range(CALLS):
-        c.detect_device(devs[0].ptr, 1, W, H)
-        c.synchronize()
-    alone = (time.perf_counter() - t0) / CALLS
-    print("1080p call: %.3f ms alone, %.3f ms per call with %d threads"
-          % (1e3 * alone, 1e3 * per_call, T))
     for c in ctxs:
         c.close()
     for d in devs:
         d.close()
-    assert per_call <= 0.35e-3, per_call
-    assert alone <= 0.45e-3, alone
+    assert not errors, errors
+    for k in range(T):
+        for a, b in zip(got[k], want[k]):
+            assert np.ascontiguousarray(a).tobytes() == np.ascontiguousarray(b).tobytes()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("SARA_HIP_MARCH_MIN_PIXELS", None)   # the shipped launch rules
+    per_call = {}
+    for n in (1, 4):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "thread_calls.py"),
+                              str(n), "100"], capture_output=True, text=True, env=env,
+                             timeout=300, check=True).stdout
+        m = re.search(r"(\d+) thread\(s\): ([0-9.]+) ms per call", out)
+        assert m and int(m.group(1)) == n, out
+        per_call[n] = float(m.group(2))
+    print("1080p call: %.3f ms alone, %.3f ms per call with 4 threads"
+          % (per_call[1], per_call[4]))
+    assert per_call[4] <= 0.35, per_call
+    assert per_call[1] <= 0.40, per_call
