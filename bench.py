@@ -893,7 +893,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if gather_mode == "rccl":
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            # (gloo only ships the communicator id, the checksums and the timing
+            # reduction; a bounded timeout, so that a rank that dies in one of
+            # the secondary measurements cannot hang the others for half an hour)
+            import datetime
+            dist.init_process_group("gloo", rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=240))
             from sara_amd.distributed import Comm
             ident = [Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ident, src=0)
@@ -1068,9 +1073,16 @@ def main():
         gather_check = verify_gather(ctx, comm, frames, args, dist, rank, world)
     if world > 1 and args.stage >= 5:
         if not args.no_extras:
-            h2h_multi = host_to_host_multi(
-                ctx, frames_host, args, torch, dist, rank, world,
-                kp_total / max(args.steps, 1) / world)
+            # a secondary measurement: whatever goes wrong in it (shared memory,
+            # host registration across processes - untested on a real node) must
+            # not cost the line
+            try:
+                h2h_multi = host_to_host_multi(
+                    ctx, frames_host, args, torch, dist, rank, world,
+                    kp_total / max(args.steps, 1) / world)
+            except Exception as e:  # noqa: BLE001
+                h2h_multi = None
+                sys.stderr.write("rank %d: host_to_host_multi failed: %r\n" % (rank, e))
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -1222,8 +1234,11 @@ def main():
         comm.close()
     ctx.close()
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:  # noqa: BLE001 - the line is out already
+            sys.stderr.write("rank %d: shutdown: %r\n" % (rank, e))
 
 
 if __name__ == "__main__":

@@ -50,9 +50,20 @@ def main():
         "workload": "bench.py defaults (64 x 1920x1080 frames, 4 octaves)",
         "stage": "Gaussian pyramid (all gaussian_blur* + scale kernels)",
         "hbm_read_bytes_per_step": rd, "hbm_write_bytes_per_step": wr,
-        "hbm_bytes_per_step": rd + wr, "kernels": kernels}, open(out, "w"),
+        "hbm_bytes_per_step": rd + wr,
+        "whole_step_read_bytes": sum(v["hbm_read_bytes_per_step"] for v in kernels.values()),
+        "whole_step_write_bytes": sum(v["hbm_write_bytes_per_step"] for v in kernels.values()),
+        "kernels": kernels}, open(out, "w"),
         indent=1)
     print("pyramid stage: read %.3f GB + write %.3f GB per step" % (rd / 1e9, wr / 1e9))
+    print("whole step: read %.3f GB + write %.3f GB" %
+          (sum(v["hbm_read_bytes_per_step"] for v in kernels.values()) / 1e9,
+           sum(v["hbm_write_bytes_per_step"] for v in kernels.values()) / 1e9))
+    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_read_bytes_per_step"]
+                       - kv[1]["hbm_write_bytes_per_step"])[:14]:
+        print("  %-58s %5.1f launches  read %6.3f GB  write %6.3f GB" %
+              (k[:58], v["launches_per_step"], v["hbm_read_bytes_per_step"] / 1e9,
+               v["hbm_write_bytes_per_step"] / 1e9))
 
 
 if __name__ == "__main__":
