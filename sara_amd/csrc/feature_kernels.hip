@@ -1315,6 +1315,9 @@ namespace sara_hip {
           m[l] = make_float2(fmaxf(fmaxf(vl, vx), vy), fmaxf(fmaxf(vx, vy), vr));
           mn[l] = make_float2(fminf(fminf(ul, ux), uy), fminf(fminf(ux, uy), ur));
         }
+        // bit 2 (s - 1) + c: (scale s, pixel c of this lane) is a classified
+        // site; the same bit of maxbits: it is a maximum
+        unsigned hitbits = 0u, maxbits = 0u;
 #pragma unroll
         for (int s = 1; s <= ND - 2; ++s)
         {
@@ -1331,83 +1334,100 @@ namespace sara_hip {
             const bool mine = (c == 0 ? lane > 0 : lane < 63) && x >= pad &&
                               x < w - pad;
             const bool is_max = (v == M), is_min = (v == N);
-            // Classified sites go to a wave-local LDS queue first and reach
-            // the frame's list in batches: one returning atomic per ~64 sites
-            // instead of one per site (every wave of a frame hits the same
-            // counter, and that serialisation was the kernel's bottleneck).
-            // The edge test / refinement run later in finish_sites_kernel.
             const bool hit = mine && !(fabsf(v) < thr8) && (is_max || is_min);
+            hitbits |= hit ? 1u << (2 * (s - 1) + c) : 0u;
+            maxbits |= is_max ? 1u << (2 * (s - 1) + c) : 0u;
+          }
+        }
+        // Classified sites go to a wave-local LDS queue first and reach the
+        // frame's list in batches: one returning atomic per batch instead of
+        // one per site (every wave of a frame hits the same counter, and that
+        // serialisation was the kernel's bottleneck).  The edge test and the
+        // refinement run later in finish_sites_kernel, from the site's DoG
+        // neighbourhood (SiteLists::nb), which is written here from the rows in
+        // registers.  ONE copy of this code per row step, behind a rolled loop
+        // over the (scale, pixel) slots with the layer picked by selects: inside
+        // the unrolled classification loops above it stood 18 times in the
+        // kernel, which then no longer fitted the instruction cache (11.5 k
+        // instructions; scan 827 -> 914 us per 64 x 1080p step).  About 4 % of
+        // the row steps get here.
+        if (__builtin_expect(__ballot(hitbits != 0u) != 0ull, 0))
+        {
+#pragma clang loop unroll(disable)
+          for (int k = 0; k < 2 * (ND - 2); ++k)
+          {
+            const bool hit = ((hitbits >> k) & 1u) != 0u;
             const unsigned long long hits = __ballot(hit);
-            if (hits != 0ull)
+            if (hits == 0ull)
+              continue;
+            const int s = 1 + (k >> 1), c = k & 1;  // wave-uniform
+            const int nh = __popcll(hits);
+            if (qn + nh > kSiteQueueCap)
             {
-              // Classified sites go to a wave-local LDS queue first and reach
-              // the frame's list in batches: one returning atomic per batch
-              // instead of one per site (every wave of a frame hits the same
-              // counter, and that serialisation was the kernel's bottleneck).
-              // The edge test / refinement run later in finish_sites_kernel.
-              const int nh = __popcll(hits);
-              if (qn + nh > kSiteQueueCap)
-              {
-                flush_sites(s_queue, qn, lane, b, sites);
-                qn = 0;
-              }
-              unsigned* e = s_queue + (qn + __popcll(hits & ((1ull << lane) - 1ull))) *
-                                          kSiteQueueWords;
-              if (hit)
-              {
-                const unsigned long long key =
-                    ((((unsigned long long) (octave * kMaxScales + s) << 20 |
-                       (unsigned) y)
-                      << 20 |
-                      (unsigned) x)
-                     << 1) |
-                    (unsigned) is_max;
-                e[0] = unsigned(key);
-                e[1] = unsigned(key >> 32);
-              }
-              // The site's DoG neighbourhood (SiteLists::nb), from the rows in
-              // registers, written value by value (an array of 20 would spill):
-              // the whole wave executes the lane shifts - column x-1 / x+1 of a
-              // lane's first / second pixel sit in the neighbouring lane - and
-              // the lanes with a hit store.  ~4 % of the iterations get here.
-              // (no array of row indices: indexing the register ring through
-              // one sends the whole ring to scratch memory)
-              auto put_row = [&](int r, const float2 m2) {
-                const float side = c == 0 ? shift_from_prev(m2.y) : shift_from_next(m2.x);
-                if (hit)
-                {
-                  e[2 + 3 * r + 0] = __float_as_uint(c == 0 ? side : m2.x);
-                  e[2 + 3 * r + 1] = __float_as_uint(c == 0 ? m2.x : m2.y);
-                  e[2 + 3 * r + 2] = __float_as_uint(c == 0 ? m2.y : side);
-                }
-              };
-              put_row(0, ring[ia][s]);
-              put_row(1, ring[ib][s]);
-              put_row(2, ring[ic][s]);
+              flush_sites(s_queue, qn, lane, b, sites);
+              qn = 0;
+            }
+            unsigned* e = s_queue + (qn + __popcll(hits & ((1ull << lane) - 1ull))) *
+                                        kSiteQueueWords;
+            if (hit)
+            {
+              const unsigned long long key =
+                  ((((unsigned long long) (octave * kMaxScales + s) << 20 |
+                     (unsigned) y)
+                    << 20 |
+                    (unsigned) (col + c))
+                   << 1) |
+                  ((maxbits >> k) & 1u);
+              e[0] = unsigned(key);
+              e[1] = unsigned(key >> 32);
+            }
+            // layer l of ring row r (l is wave-uniform; the register ring cannot
+            // be indexed at run time without going to scratch)
+            auto layer = [&](int r, int l) {
+              float2 v2 = ring[r][0];
 #pragma unroll
-              for (int dl = 0; dl < 2; ++dl)
-              {
-                const int l = dl == 0 ? s - 1 : s + 1;
-                const float2 m2 = ring[ib][l];
-                const float side = c == 0 ? shift_from_prev(m2.y) : shift_from_next(m2.x);
-                if (hit)
-                {
-                  unsigned* o = e + 2 + 9 + 5 * dl;
-                  o[0] = __float_as_uint(c == 0 ? m2.x : m2.y);                    // centre
-                  o[1] = __float_as_uint(c == 0 ? side : m2.x);                    // left
-                  o[2] = __float_as_uint(c == 0 ? m2.y : side);                    // right
-                  o[3] = __float_as_uint(c == 0 ? ring[ia][l].x : ring[ia][l].y);  // up
-                  o[4] = __float_as_uint(c == 0 ? ring[ic][l].x : ring[ic][l].y);  // down
-                }
-              }
+              for (int q = 1; q < ND; ++q)
+                v2 = l == q ? ring[r][q] : v2;
+              return v2;
+            };
+            // the whole wave executes the lane shifts - column x-1 / x+1 of a
+            // lane's first / second pixel sit in the neighbouring lane - and
+            // the lanes with a hit store, value by value
+            auto put_row = [&](int slot, const float2 m2) {
+              const float sp = shift_from_prev(m2.y), sn = shift_from_next(m2.x);
               if (hit)
-                e[2 + 19] = 0u;
-              qn += nh;
-              if (qn >= kSiteQueueCap / 2)
               {
-                flush_sites(s_queue, qn, lane, b, sites);
-                qn = 0;
+                e[2 + slot + 0] = __float_as_uint(c == 0 ? sp : m2.x);
+                e[2 + slot + 1] = __float_as_uint(c == 0 ? m2.x : m2.y);
+                e[2 + slot + 2] = __float_as_uint(c == 0 ? m2.y : sn);
               }
+            };
+            put_row(0, layer(ia, s));
+            put_row(3, layer(ib, s));
+            put_row(6, layer(ic, s));
+#pragma unroll
+            for (int dl = 0; dl < 2; ++dl)
+            {
+              const int l = dl == 0 ? s - 1 : s + 1;
+              const float2 m2 = layer(ib, l), up = layer(ia, l), dn = layer(ic, l);
+              const float sp = shift_from_prev(m2.y), sn = shift_from_next(m2.x);
+              if (hit)
+              {
+                unsigned* o = e + 2 + 9 + 5 * dl;
+                o[0] = __float_as_uint(c == 0 ? m2.x : m2.y);  // centre
+                o[1] = __float_as_uint(c == 0 ? sp : m2.x);    // left
+                o[2] = __float_as_uint(c == 0 ? m2.y : sn);    // right
+                o[3] = __float_as_uint(c == 0 ? up.x : up.y);  // up
+                o[4] = __float_as_uint(c == 0 ? dn.x : dn.y);  // down
+              }
+            }
+            if (hit)
+              e[2 + 19] = 0u;
+            qn += nh;
+            if (qn >= kSiteQueueCap / 2)
+            {
+              flush_sites(s_queue, qn, lane, b, sites);
+              qn = 0;
             }
           }
         }
