@@ -1945,9 +1945,10 @@ namespace sara_hip {
   //! area 1 : 2.5 between scales): with 4 waves per group the others idle.
   //! Measured (64 x 1080p): descriptor kernel 2.67 / 2.45 / 2.36 ms with
   //! 4 / 2 / 1 waves per group; the orientation kernel shares its weight
-  //! tables in LDS across the group and prefers 4 (1.04 against 1.17 ms).
+  //! tables in LDS across the group and prefers 4 (round 4, same box: 0.75 /
+  //! 0.81 / 0.89 ms with 4 / 2 / 1, 0.81 with 8).
 #ifndef SARA_ORI_WAVES
-#define SARA_ORI_WAVES 2
+#define SARA_ORI_WAVES 4
 #endif
 #ifndef SARA_DESC_WAVES
 #define SARA_DESC_WAVES 1
@@ -2010,7 +2011,8 @@ namespace sara_hip {
       int n_weights, CandidateLists cand, OrientationLists ori, int xcd_run)
   {
     __shared__ unsigned long long s_mask[kOriWaves][kOriGroup * kOriBins];
-    __shared__ double s_contrib[kOriWaves][64 * kOriGroup];
+    // a bin's segment is followed by one slot that holds 0. (see the replay)
+    __shared__ double s_contrib[kOriWaves][64 * kOriGroup + 64];
     __shared__ int s_segoff[kOriWaves][kOriGroup * kOriBins];
     extern __shared__ __attribute__((aligned(16))) double s_weights[];
     const GradPyramidView& grad = *gradp;
@@ -2020,6 +2022,44 @@ namespace sara_hip {
     __shared__ float s_thr[40];
     if (threadIdx.x < 40)
       s_thr[threadIdx.x] = tab.ori_bin_thr[threadIdx.x];
+    // What an item needs of its octave and scale, in LDS: from global memory
+    // these are a second round trip (key -> table entries -> first gather) at
+    // the head of every item.  The patch geometry comes with it: D = 2R + 1,
+    // 64 / D and 64 % D (a lane's pixel advances by 64 per chunk) and
+    // ceil(2^16 / D), with which lane / D is one multiplication and a shift
+    // (exact for lane < 64: the error of lane * magic / 2^16 stays below
+    // 64 / 2^16 < 1 / D).
+    struct OctaveEntry
+    {
+      unsigned long long base, frame_stride, plane;
+      int w, h;
+    };
+    struct ScaleEntry
+    {
+      int radius, woff, dv64, du64, magic, pad[3];
+    };
+    __shared__ __attribute__((aligned(16))) OctaveEntry s_oct[16];
+    __shared__ __attribute__((aligned(16))) ScaleEntry s_scale[kMaxScales];
+    if (threadIdx.x < 16)
+    {
+      const int o_ = threadIdx.x;
+      s_oct[o_].base = reinterpret_cast<unsigned long long>(grad.base[o_]);
+      s_oct[o_].frame_stride = grad.frame_stride[o_];
+      s_oct[o_].plane = grad.plane[o_];
+      s_oct[o_].w = grad.w[o_];
+      s_oct[o_].h = grad.h[o_];
+    }
+    if (threadIdx.x >= 32 && threadIdx.x < 32 + kMaxScales)
+    {
+      const int s_ = threadIdx.x - 32;
+      const int R_ = tab.ori_radius[s_];
+      const int D_ = max(2 * R_ + 1, 1);
+      s_scale[s_].radius = R_;
+      s_scale[s_].woff = tab.ori_woff[s_];
+      s_scale[s_].dv64 = 64 / D_;
+      s_scale[s_].du64 = 64 % D_;
+      s_scale[s_].magic = (65536 + D_ - 1) / D_;
+    }
     if (WLDS)
     {
       for (int i = threadIdx.x; i < n_weights; i += 64 * kOriWaves)
@@ -2059,16 +2099,18 @@ namespace sara_hip {
 
     const int rx = int(roundf(d.x));
     const int ry = int(roundf(d.y));
-    const int R = tab.ori_radius[s];
-    const int woff = tab.ori_woff[s];
-    const int w = grad.w[o], h = grad.h[o];
+    const OctaveEntry oe = s_oct[o];
+    const ScaleEntry se = s_scale[s];
+    const int R = se.radius;
+    const int woff = se.woff;
+    const int w = oe.w, h = oe.h;
     // explicitly a global-memory pointer: through a generic pointer these
     // gathers become flat_load, which counts on lgkmcnt as well, so waiting
     // for a sample would also wait for every LDS atomic still in flight
     const global_float2_ptr g =
         (global_float2_ptr) reinterpret_cast<const f32x2*>(
-            grad.base[o] + size_t(b) * grad.frame_stride[o]) +
-        size_t(s) * grad.plane[o];
+            reinterpret_cast<const float*>(oe.base) + size_t(b) * oe.frame_stride) +
+        size_t(s) * oe.plane;
     // a pixel that is always inside the image (idle lanes gather it)
     const size_t center = size_t(min(max(ry, 0), h - 1)) * w +
                           size_t(min(max(rx, 0), w - 1));
@@ -2077,7 +2119,9 @@ namespace sara_hip {
     const int npx = D * D;
     float hist = 0.f;
 
-    const int dv64 = 64 / D, du64 = 64 % D;
+    const int dv64 = se.dv64, du64 = se.du64;
+    // lane = lrow * D + lcol
+    const int lrow = (lane * se.magic) >> 16, lcol = lane - lrow * D;
     unsigned long long* bin_mask = s_mask[wave];
     double* contrib = s_contrib[wave];
     int* seg_off = s_segoff[wave];
@@ -2096,7 +2140,7 @@ namespace sara_hip {
         v_ += 1;
       }
     };
-    int iu = lane % D - R, iv = lane / D - R;  // issue side
+    int iu = lcol - R, iv = lrow - R;  // issue side
     auto issue = [&](int base_, float2& mo_, bool& ok_) {
       const int xx = rx + iu, yy = ry + iv;
       ok_ = (base_ + lane < npx) && xx >= 0 && xx < w && yy >= 0 && yy < h;
@@ -2110,7 +2154,7 @@ namespace sara_hip {
     for (int q = 0; q < kOriAhead; ++q)
       issue(64 * q, ring[q], ring_ok[q]);
     __builtin_amdgcn_s_waitcnt(0x0f70 | (kOriAhead - 1));  // see descriptor_kernel
-    int u = lane % D - R, v = lane / D - R;  // consumer side
+    int u = lcol - R, v = lrow - R;  // consumer side
 
     // Chunks are processed in groups of kOriGroup: the samples of a group are
     // sorted by (bin, chunk, lane) and each bin's segment is replayed once per
@@ -2190,7 +2234,11 @@ namespace sara_hip {
         cnt += __popcll(own);
       }
       const int incl = wave_inclusive_scan(cnt);
-      const int seg_begin = incl - cnt;
+      // segment of lane l: slots [seg_begin, seg_end), then a slot that stays
+      // 0. - lane l's segment is shifted by l slots to make room for them
+      const int seg_begin = incl - cnt + lane;
+      const int seg_end = seg_begin + cnt;
+      contrib[seg_end] = 0.;
       if (lane < kOriBins)
       {
 #pragma unroll
@@ -2211,17 +2259,22 @@ namespace sara_hip {
       SARA_OPROF_T(t_c2);
       SARA_OPROF_ADD(2, t_c1, t_c2);
       {
-        int i = seg_begin;
-        const int end = lane < kOriBins ? incl : seg_begin;
-        double nxt = i < end ? contrib[i] : 0.;
-        while (__ballot(i < end) != 0ull)
+        // Lock step over the fullest bin's count, without predication: a lane
+        // whose segment is exhausted keeps reading the 0. behind it, and
+        // float(double(hist) + 0.) is hist (hist >= +0: the contributions are
+        // weight * magnitude).  Per step: index, LDS read of the next
+        // contribution, and the three dependent conversions / addition.
+        const int steps = wave_max_dpp(cnt);
+        const double* p = contrib + seg_begin;
+        const double* const p_end = contrib + seg_end;
+        double cur = *p;
+#pragma unroll 2
+        for (int st = 0; st < steps; ++st)
         {
-          const double cur = nxt;
-          if (i + 1 < end)
-            nxt = contrib[i + 1];
-          if (i < end)
-            hist = float(double(hist) + cur);
-          ++i;
+          p = p + 1 < p_end ? p + 1 : p_end;
+          const double nxt = *p;
+          hist = float(double(hist) + cur);
+          cur = nxt;
         }
       }
       __builtin_amdgcn_wave_barrier();
