@@ -197,6 +197,35 @@ namespace {
     return *g;
   }
 
+  //! ROCm runtimes before 7.2 (the 7.0 runtime bundled with torch 2.10 is what
+  //! a Python caller that imported torch first runs on) crash in
+  //! hip::Graph::UpdateStreams - hipGraphLaunch reads a stale entry of the
+  //! executable's parallel-stream list - once contexts with graphs are
+  //! created, replayed and destroyed by several host threads, even with every
+  //! graph call on the launcher thread; serialising every call of the library
+  //! does not prevent it, a wide dummy graph launched first does not either
+  //! (tools/churn_repro.py: 3 of 3 runs die; none on ROCm 7.2).  On those
+  //! runtimes graph replay therefore stays with the first host thread that
+  //! asks for it, as in round 3, and the other threads' contexts run plain
+  //! launches (+ 0.15 ms of host time per 1080p frame); on ROCm >= 7.2 every
+  //! thread replays graphs through the launcher.
+  bool graphs_need_one_thread()
+  {
+    static const bool old_runtime = [] {
+      int v = 0;
+      return hipRuntimeGetVersion(&v) == hipSuccess && v < 70200000;
+    }();
+    return old_runtime;
+  }
+  bool first_graph_thread()
+  {
+    static std::atomic<std::thread::id> first{std::thread::id()};
+    std::thread::id none, me = std::this_thread::get_id();
+    if (first.compare_exchange_strong(none, me))
+      return true;
+    return first.load() == me;
+  }
+
   thread_local std::string g_error = "";
 
   sara_hip_status fail(sara_hip_status code, const std::string& msg)
@@ -1202,7 +1231,8 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
 
   // Graph replay: own stream, small batch, no stage timers inside a capture.
   const bool graph_mode = c->use_graph && !c->graph_broken && !hip_stream &&
-                          batch <= c->graph_max_batch && !debug_sync;
+                          batch <= c->graph_max_batch && !debug_sync &&
+                          (!graphs_need_one_thread() || first_graph_thread());
   const bool multi_stream = c->multi_stream;
   const bool side_gradient = c->side_gradient;
   const bool timing = c->timers && !graph_mode;
