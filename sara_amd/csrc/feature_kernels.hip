@@ -1130,7 +1130,7 @@ namespace sara_hip {
     }
 
     const int slot = atomicAdd(&cand.count[frame], 1);
-    if (slot < cand.cap)
+    if (unsigned(slot) < unsigned(cand.cap))
     {
       const size_t i = size_t(frame) * cand.cap + slot;
       cand.key[i] =
@@ -1218,7 +1218,9 @@ namespace sara_hip {
       base = atomicAdd(&sites.count[frame], qn);
     base = __builtin_amdgcn_readfirstlane(base);
     __builtin_amdgcn_wave_barrier();
-    const int room = min(qn, max(sites.cap - base, 0));
+    // (unsigned: a counter that was not zeroed must not turn into a negative
+    // offset - seen with a single-stream graph on the ROCm 7.0 runtime)
+    const int room = unsigned(base) < unsigned(sites.cap) ? min(qn, sites.cap - base) : 0;
     if (lane < room)
       sites.key[size_t(frame) * sites.cap + base + lane] =
           (unsigned long long) queue[lane * kSiteQueueWords] |

@@ -57,9 +57,11 @@ namespace {
   //! thread that captured it (rocgdb backtrace; tests/test_gpu_pipeline.py::
   //! test_compute_sift_keypoints_keeps_its_context was the reproducer).  Round 3
   //! therefore gave graph replay to the first thread that asked and left every
-  //! other thread on plain launches (+ 0.15 ms per 1080p frame).  Now a caller
-  //! of any thread hands the graph part of its detect() to the launcher and
-  //! waits for it: the caller is blocked for the duration anyway (the host side
+  //! other thread on plain launches (+ 0.15 ms per 1080p frame).  Now - on
+  //! ROCm 7.2 and later; older runtimes keep round 3's rule, see
+  //! graphs_need_one_thread() below - a caller of any thread hands the graph
+  //! part of its detect() to the launcher and waits for it: the caller is
+  //! blocked for the duration anyway (the host side
   //! of a replay is what detect() consists of), so nothing is lost but the
   //! hand-over - a spin on an atomic in both directions while calls keep coming
   //! (the launcher keeps polling for 200 us after a job before it sleeps on

@@ -846,3 +846,23 @@ def test_fma_blur_option_within_tolerance(oracle):
         back = ctx.fetch()
         assert back[1].tobytes() == exact[1].tobytes()
         assert np.array_equal(back[2], exact[2])
+
+
+@pytest.mark.gpu
+def test_context_churn_from_several_threads_next_to_a_replaying_thread():
+    """tools/churn_repro.py in a fresh process WITH torch imported first (the
+    ROCm 7.0 runtime torch bundles becomes the process's HIP runtime): six
+    threads create, use once and destroy contexts while the main thread keeps
+    replaying its graph.  That runtime crashed in hip::Graph::UpdateStreams
+    when several threads replayed graphs (3 of 3 runs of this script); the
+    library now keeps graph replay with one thread there
+    (sift_context.cpp: graphs_need_one_thread)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "churn_repro.py"),
+                        "--main-busy", "--reps", "3"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-400:], r.stderr[-400:])
+    assert "errors: []" in r.stdout, r.stdout[-400:]
