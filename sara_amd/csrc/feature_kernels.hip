@@ -249,7 +249,9 @@ namespace sara_hip {
         ring[i % 3].x = tailA ? ring[i % 3].y : ring[i % 3].x;
         ring[i % 3].z = tailB ? ring[i % 3].w : ring[i % 3].z;
         ering[i % 3] = pe[i % PF];
-        load_row(yy + PF, pm[i % PF], pe[i % PF]);
+        // (rows behind the segment's last one, y1, are never consumed: ask
+        // for y1 again - a cache hit - instead of streaming them from HBM)
+        load_row(min(yy + PF, y1), pm[i % PF], pe[i % PF]);
 
         const int y = yy - 1;  // output row: needs rows y-1, y, y+1
         if (n >= 2 && y < y1)
@@ -1297,7 +1299,7 @@ namespace sara_hip {
 #pragma unroll
         for (int l = 0; l < ND; ++l)
           ring[i][l] = make_float2(cur[l + 1].x - cur[l].x, cur[l + 1].y - cur[l].y);
-        load_row(yy + PF, pg[i]);
+        load_row(min(yy + PF, y1), pg[i]);  // see gradient_polar_march_kernel
 
         const int y = yy - 1;
         const int ia = (i + 1) % 3, ib = (i + 2) % 3, ic = i;  // y-1, y, y+1

@@ -388,7 +388,9 @@ namespace sara_hip {
         *reinterpret_cast<float4*>(rowbuf + RP + CPL * lane) = pm[i % PF];
         if (lane < 2 * R)
           rowbuf[hslot] = phv[i % PF];
-        load_row(yy + PF, pm[i % PF], phv[i % PF]);
+        // (the last source row a segment consumes is y1 + R - 1: rows behind it
+        // are asked for as that row again, a cache hit, not streamed from HBM)
+        load_row(min(yy + PF, y1 + R - 1), pm[i % PF], phv[i % PF]);
 
         // row pass on source row n
         float t[CPL];
@@ -750,7 +752,9 @@ namespace sara_hip {
         *reinterpret_cast<float2*>(rowbuf + RP + CPL * lane) = pm[i % PF];
         if (lane < 2 * R)
           rowbuf[hslot] = phv[i % PF];
-        load_row(yy + PF, pm[i % PF], phv[i % PF]);
+        // (the last source row a segment consumes is y1 + R - 1: rows behind it
+        // are asked for as that row again, a cache hit, not streamed from HBM)
+        load_row(min(yy + PF, y1 + R - 1), pm[i % PF], phv[i % PF]);
 
         float v[NQ * 2];
         {
