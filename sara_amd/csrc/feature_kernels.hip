@@ -1236,21 +1236,30 @@ namespace sara_hip {
 #ifndef SARA_EXTREMA_WAVES_PER_EU
 #define SARA_EXTREMA_WAVES_PER_EU 4
 #endif
-  template <int ND, int PF>
-  __global__ __launch_bounds__(64, SARA_EXTREMA_WAVES_PER_EU) void extrema_march_kernel(
+  //! NW: waves per workgroup = adjacent strips of the same rows, kept within a
+  //! dozen rows of each other by a barrier.  A row segment of 128 columns starts
+  //! anywhere in a cache line, so neighbouring strips share the line at their
+  //! seam; single-wave workgroups drift apart by more rows than the L2 keeps
+  //! and fetched those lines twice (FETCH_SIZE 4.77 GB per 64 x 1080p step for
+  //! 4.23 GB of planes; launched together but unsynchronised: no change; with
+  //! the barrier 4.38 GB, the kernel 1 % faster).
+  template <int ND, int PF, int NW>
+  __global__ __launch_bounds__(64 * NW, SARA_EXTREMA_WAVES_PER_EU) void extrema_march_kernel(
       OctaveView gauss, int octave, ExtremaParams p, SiteLists sites,
       int seg_rows, int nstrips, int nseg, int xcd_total)
   {
     static_assert(PF == 3, "the row loop is unrolled 3x");
-    __shared__ unsigned s_queue[kSiteQueueCap * kSiteQueueWords];
+    __shared__ unsigned s_queue_all[NW][kSiteQueueCap * kSiteQueueWords];
+    unsigned* s_queue = s_queue_all[threadIdx.x >> 6];
     int qn = 0;  // wave-uniform fill of the queue
     constexpr int NG = ND + 1;
     constexpr int STRIDE = 126;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     int strip, seg;
     size_t bb;
-    if (!march_work_item(nstrips, nseg, xcd_total, strip, seg, bb))
+    if (!march_work_item(nstrips / NW, nseg, xcd_total, strip, seg, bb))
       return;
+    strip = strip * NW + int(threadIdx.x >> 6);
     const int b = int(bb);
     const int w = gauss.w, h = gauss.h;
     const int pad = p.img_padding_sz;
@@ -1287,6 +1296,8 @@ namespace sara_hip {
 
     for (int n0 = 0; n0 < T; n0 += 3)
     {
+      if (NW > 1 && (n0 % 12) == 0)
+        __builtin_amdgcn_s_barrier();  // the strips stay within a dozen rows
 #pragma unroll
       for (int i = 0; i < 3; ++i)
       {
@@ -1503,10 +1514,26 @@ namespace sara_hip {
       nseg = std::max(1, std::min(nseg, (gauss.h + min_rows - 1) / min_rows));
       const int seg_rows = (gauss.h + nseg - 1) / nseg;
       nseg = (gauss.h + seg_rows - 1) / seg_rows;
-      const int total = xcd_map_enabled() ? nstrips * nseg * batch : 0;
-      const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(nstrips * nseg, batch);
-      hipLaunchKernelGGL((extrema_march_kernel<5, 3>), grid, dim3(64), 0, stream,
-                         gauss, octave, p, sites, seg_rows, nstrips, nseg, total);
+      // workgroups of 8 / 4 adjacent strips where the count divides (see the
+      // kernel's NW) and the launch fills the chip anyway: a small launch (one
+      // frame per call) keeps single-wave workgroups, which spread over all CUs
+      const int waves = nstrips * nseg * batch;
+      const int NW = (nstrips % 8 == 0 && waves >= 4096) ? 8
+                     : ((nstrips % 4 == 0 && waves >= 2048) ? 4 : 1);
+      const int gstrips = nstrips / NW;
+      const int total = xcd_map_enabled() ? gstrips * nseg * batch : 0;
+      const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(gstrips * nseg, batch);
+#define SARA_SCAN(NW_)                                                         \
+  hipLaunchKernelGGL((extrema_march_kernel<5, 3, NW_>), grid, dim3(64 * NW_),  \
+                     0, stream, gauss, octave, p, sites, seg_rows, nstrips,    \
+                     nseg, total)
+      if (NW == 8)
+        SARA_SCAN(8);
+      else if (NW == 4)
+        SARA_SCAN(4);
+      else
+        SARA_SCAN(1);
+#undef SARA_SCAN
       return;
     }
     const dim3 block(64, 4);
