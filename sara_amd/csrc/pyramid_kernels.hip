@@ -293,8 +293,8 @@ namespace sara_hip {
   //! is converted as it is loaded, float(v) / 255.f (ChannelConversion.hpp:40-54)
   //! - the first blur of the pyramid then reads the uploaded frame itself and
   //! the separate conversion pass (1 B read + 4 B written per pixel) is gone.
-  template <int R, int PF, bool DEC, bool FMA = false, bool U8 = false>
-  __global__ __launch_bounds__(64, R <= 6 ? 4 : 1) void gaussian_blur_march_kernel(
+  template <int R, int PF, bool DEC, bool FMA = false, bool U8 = false, int NW = 1>
+  __global__ __launch_bounds__(64 * NW, R <= 6 ? 4 : 1) void gaussian_blur_march_kernel(
       const float* __restrict__ src, size_t src_stride,
       float* __restrict__ dst, size_t dst_stride, float* __restrict__ dec,
       size_t dec_stride, int w, int h, int seg_rows, int nstrips, int nseg,
@@ -307,13 +307,15 @@ namespace sara_hip {
     constexpr int D = RP - R;
     constexpr int ROWF = RP + W + RP;      // floats per LDS row slot
     constexpr int NQ = (D + CPL + 2 * R + 3) / 4;  // b128 reads per window
-    __shared__ __attribute__((aligned(16))) float s_row[2 * ROWF];
+    __shared__ __attribute__((aligned(16))) float s_row_all[NW][2 * ROWF];
+    float* s_row = s_row_all[threadIdx.x >> 6];
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     int strip, seg;
     size_t b;
-    if (!march_work_item(nstrips, nseg, xcd_total, strip, seg, b))
+    if (!march_work_item(nstrips / NW, nseg, xcd_total, strip, seg, b))
       return;
+    strip = strip * NW + int(threadIdx.x >> 6);
     const unsigned char* src8 =
         reinterpret_cast<const unsigned char*>(src) + b * src_stride;
     src += b * src_stride;
@@ -376,6 +378,8 @@ namespace sara_hip {
 
     for (int n0 = 0; n0 < T; n0 += K)
     {
+      if (NW > 1)
+        __builtin_amdgcn_s_barrier();  // the strips of a workgroup stay within K rows
 #pragma unroll
       for (int i = 0; i < K; ++i)
       {
@@ -504,8 +508,36 @@ namespace sara_hip {
     nseg = std::max(1, std::min(nseg, (h + min_rows - 1) / min_rows));
     const int seg_rows = (h + nseg - 1) / nseg;
     nseg = (h + seg_rows - 1) / seg_rows;
-    const int total = xcd_map_enabled() ? nstrips * nseg * batch : 0;
-    const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(nstrips * nseg, batch);
+    // Workgroups of 8 / 4 adjacent strips, kept within K rows of each other by
+    // a barrier per round (the NW of the kernel), when the launch fills the
+    // chip anyway: the halo columns a strip reads from its neighbours' lines
+    // are then L2 hits.  64 x 1080p: R = 5 338 -> 308 us per step, R = 6 + half
+    // size 392 -> 367 (8 waves; 4 are neutral); a small launch (one frame per
+    // call) keeps single-wave workgroups, which spread over all CUs.
+    const int waves = nstrips * nseg * batch;
+    const int NW = (!src_is_u8 && !fma && nstrips % 8 == 0 && waves >= 4096) ? 8
+                   : ((!src_is_u8 && !fma && nstrips % 4 == 0 && waves >= 2048) ? 4 : 1);
+    const int gstrips = nstrips / NW;
+    const int total = xcd_map_enabled() ? gstrips * nseg * batch : 0;
+    const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(gstrips * nseg, batch);
+    if (NW == 8 || NW == 4)
+    {
+#define SARA_MARCH_NW(DEC_, NW_)                                               \
+  hipLaunchKernelGGL((gaussian_blur_march_kernel<R, PF, DEC_, false, false, NW_>), \
+                     grid, dim3(64 * NW_), 0, stream, src, src_stride, dst,    \
+                     dst_stride, dec, dec_stride, w, h, seg_rows, nstrips,     \
+                     nseg, total, taps)
+      if (NW == 8 && dec)
+        SARA_MARCH_NW(true, 8);
+      else if (NW == 8)
+        SARA_MARCH_NW(false, 8);
+      else if (dec)
+        SARA_MARCH_NW(true, 4);
+      else
+        SARA_MARCH_NW(false, 4);
+#undef SARA_MARCH_NW
+      return;
+    }
 #define SARA_MARCH_LAUNCH(DEC_, FMA_)                                          \
   hipLaunchKernelGGL((gaussian_blur_march_kernel<R, PF, DEC_, FMA_>), grid,    \
                      dim3(64), 0, stream, src, src_stride, dst, dst_stride,    \
@@ -876,6 +908,8 @@ namespace sara_hip {
     nseg = std::max(1, std::min(nseg, (h + min_rows - 1) / min_rows));
     const int seg_rows = (h + nseg - 1) / nseg;
     nseg = (h + seg_rows - 1) / seg_rows;
+    // (workgroups of several strips, as in launch_blur_march, slow these
+    // issue-bound kernels down: R = 10 435 -> 573 us per step with 5 / 8 waves)
     const int total = xcd_map_enabled() ? nstrips * nseg * batch : 0;
     const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(nstrips * nseg, batch);
     if (fma)
