@@ -1517,9 +1517,12 @@ namespace sara_hip {
       // workgroups of 8 / 4 adjacent strips where the count divides (see the
       // kernel's NW) and the launch fills the chip anyway: a small launch (one
       // frame per call) keeps single-wave workgroups, which spread over all CUs
+      // (the parity tests set SARA_HIP_MARCH_MIN_PIXELS to 0 and take the
+      // groups at every size)
       const int waves = nstrips * nseg * batch;
-      const int NW = (nstrips % 8 == 0 && waves >= 4096) ? 8
-                     : ((nstrips % 4 == 0 && waves >= 2048) ? 4 : 1);
+      const bool any = march_min_pixels() == 0;
+      const int NW = (nstrips % 8 == 0 && (any || waves >= 4096)) ? 8
+                     : ((nstrips % 4 == 0 && (any || waves >= 2048)) ? 4 : 1);
       const int gstrips = nstrips / NW;
       const int total = xcd_map_enabled() ? gstrips * nseg * batch : 0;
       const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(gstrips * nseg, batch);

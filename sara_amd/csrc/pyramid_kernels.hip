@@ -68,6 +68,8 @@ namespace sara_hip {
     const char* e = getenv("SARA_HIP_MARCH_MIN_PIXELS");
     return e ? size_t(atoll(e)) : size_t(4) << 20;
   }();
+  size_t march_min_pixels() { return g_march_min_pixels; }
+
   // Round 3: the tile geometry is a template parameter and the window is staged
   // with 16-byte loads.  One frame per call is a chain of dependent launches of
   // 3-17 MB each; tools/ubench/tile_blur_b1.hip times such chains: an empty
@@ -514,9 +516,13 @@ namespace sara_hip {
     // are then L2 hits.  64 x 1080p: R = 5 338 -> 308 us per step, R = 6 + half
     // size 392 -> 367 (8 waves; 4 are neutral); a small launch (one frame per
     // call) keeps single-wave workgroups, which spread over all CUs.
+    // (launches this function gets are >= g_march_min_pixels; the wave counts
+    // keep the groups to launches that fill the chip - the parity tests, which
+    // set the pixel threshold to 0, take the groups at every size)
     const int waves = nstrips * nseg * batch;
-    const int NW = (!src_is_u8 && !fma && nstrips % 8 == 0 && waves >= 4096) ? 8
-                   : ((!src_is_u8 && !fma && nstrips % 4 == 0 && waves >= 2048) ? 4 : 1);
+    const bool big = g_march_min_pixels == 0 || waves >= 2048;
+    const int NW = (!src_is_u8 && !fma && nstrips % 8 == 0 && big && (g_march_min_pixels == 0 || waves >= 4096)) ? 8
+                   : ((!src_is_u8 && !fma && nstrips % 4 == 0 && big) ? 4 : 1);
     const int gstrips = nstrips / NW;
     const int total = xcd_map_enabled() ? gstrips * nseg * batch : 0;
     const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(gstrips * nseg, batch);

@@ -265,6 +265,9 @@ namespace sara_hip {
     size_t cmax_frame_stride[16];  // in uint32
   };
 
+  //! SARA_HIP_MARCH_MIN_PIXELS (pyramid_kernels.hip): launches below it are small.
+  size_t march_min_pixels();
+
   //! grad / tab are device pointers (indexed per wave, so they live in HBM
   //! rather than in the kernel argument segment).
   void launch_orientations(const GradPyramidView* grad, const ScaleTable* tab,

@@ -202,6 +202,27 @@ def test_thresholds(oracle):
             compare_lists(run_lists(ctx), ref, 0)
 
 
+@pytest.mark.parametrize("w,h,noct,b", [
+    # strip groups (round 4): workgroups of 8 / 4 adjacent strips in the extremum
+    # scan (126 columns per strip) and the R <= 6 marching blurs (256 columns),
+    # the last blur strip moved left where the width is no multiple of 256
+    (1008, 72, 2, 1),    # scan 8 strips, blur 4 (the last one moved left)
+    (2016, 48, 2, 1),    # scan 16, blur 8 (moved left); octave 1: scan 8, blur 4
+    (2048, 40, 1, 2),    # blur 8 full strips, scan 17 (single-wave workgroups)
+    (504, 90, 1, 3),     # scan 4 strips, blur 2
+    (1024, 64, 2, 2)])   # blur 4, scan 9; octave 1: scan 5, blur 2
+def test_strip_groups_against_the_oracle(oracle, w, h, noct, b):
+    frames = synth_batch(w, h, b, first_index=40)
+    with sara_amd.SiftContext(w, h, b, hip_params(0, noct)) as ctx:
+        ctx.detect(frames)
+        lists = run_lists(ctx)
+        for i in range(b):
+            ref = oracle.RefSift(frames[i], ref_params(oracle, 0, noct))
+            compare_full(ctx, ref, frame=i)
+            ne, nk = compare_lists(lists, ref, i)
+            assert ne > 0
+
+
 def test_batch_of_distinct_frames(oracle):
     """Each frame of a batch equals the single-frame oracle result; frames are
     concatenated in order."""
