@@ -2557,7 +2557,9 @@ namespace sara_hip {
   {
     // parts per frame: ~1 extremum per thread at the list sizes of a video
     // frame when the batch alone cannot fill the chip
-    const int parts = batch <= 2 ? 4 : (batch <= 8 ? 2 : 1);
+    // (64 frames: 41 / 31 / 29 us with 1 / 2 / 4 parts - one workgroup per
+    // frame leaves three quarters of the CUs idle)
+    const int parts = (batch <= 2 || batch > 8) ? 4 : 2;
     hipLaunchKernelGGL(scan_peaks_kernel, dim3(parts, batch), dim3(1024), 0, stream,
                        cand, ori, done_counter, batch);
   }
