@@ -546,6 +546,21 @@ namespace DO::Sara {
       return raw;
     }
 
+    //! The reference keeps its extrema in std::vectors (reserve(10000), then
+    //! push_back: FeatureDetectors/RefineExtremum.cpp:496-514), so no image has
+    //! "too many" keypoints.  The context's lists have a capacity; when a frame
+    //! overflows them, the callers below grow the lists to twice what the frame
+    //! asked for and run it again (a list that overflowed starves the ones
+    //! behind it, hence a loop; every step at least doubles).  The grown
+    //! context stays where it is cached: a video pays for the growth once.
+    constexpr int kMaxGrowthSteps = 8;
+    inline void grow_for_last_batch(sara_hip_sift* ctx)
+    {
+      int cap = 0, need = 0;
+      check(sara_hip_sift_capacity(ctx, &cap, &need));
+      check(sara_hip_sift_reserve(ctx, 2 * std::max(cap, need)));
+    }
+
   }  // namespace hip_detail
 
   static_assert(sizeof(Rgb8) == 3, "Rgb8 must be three packed bytes");
@@ -594,15 +609,24 @@ namespace DO::Sara {
         hip_detail::ContextKey{p, image.width(), image.height(), device});
     // submit / collect: upload, kernels, and the read-back into pinned memory
     // owned by the context; one copy from there into the returned containers
-    int ticket = -1;
-    hip_detail::check(sara_hip_sift_submit(ctx, image.data(), 0, 0, 1,
-                                           image.width(), image.height(), 0,
-                                           SARA_HIP_STAGE_DESCRIPTOR, &ticket));
     const sara_oeregion* f = nullptr;
     const float* d = nullptr;
     int total = 0;
-    hip_detail::check(
-        sara_hip_sift_collect(ctx, ticket, &f, &d, nullptr, nullptr, &total));
+    for (int step = 0;; ++step)
+    {
+      int ticket = -1;
+      hip_detail::check(sara_hip_sift_submit(ctx, image.data(), 0, 0, 1,
+                                             image.width(), image.height(), 0,
+                                             SARA_HIP_STAGE_DESCRIPTOR, &ticket));
+      const sara_hip_status st =
+          sara_hip_sift_collect(ctx, ticket, &f, &d, nullptr, nullptr, &total);
+      if (st != SARA_HIP_CAPACITY_EXCEEDED || step + 1 >= hip_detail::kMaxGrowthSteps)
+      {
+        hip_detail::check(st);
+        break;
+      }
+      hip_detail::grow_for_last_batch(ctx);
+    }
 #ifndef SARA_HIP_WITH_SARA_HEADERS
     // the stand-in containers are filled in one pass (no value-initialisation
     // in front of the copy: 0.25 -> 0.2 ms of a 0.8 ms call)
@@ -806,18 +830,34 @@ namespace DO::Sara {
                                      std::vector<Point2i>* scale_octave_pairs = 0)
     {
       const auto cp = hip_detail::to_c(_pyramid_params);
-      sara_hip_sift* raw = nullptr;
-      hip_detail::check(sara_hip_sift_create_dog(
-          &cp, _gauss_truncate, _extremum_thres, _edge_ratio_thres,
-          _img_padding_sz, _extremum_refinement_iter, I.width(), I.height(), 1,
-          0, _device, &raw));
-      _ctx.reset(raw);
+      if (!_ctx || _ctx_w != I.width() || _ctx_h != I.height())
+      {
+        sara_hip_sift* raw = nullptr;
+        hip_detail::check(sara_hip_sift_create_dog(
+            &cp, _gauss_truncate, _extremum_thres, _edge_ratio_thres,
+            _img_padding_sz, _extremum_refinement_iter, I.width(), I.height(), 1,
+            0, _device, &raw));
+        _ctx.reset(raw);
+        _ctx_w = I.width();
+        _ctx_h = I.height();
+      }
       _have_g = _have_d = false;
-      hip_detail::check(sara_hip_sift_detect(_ctx.get(), I.data(), 0, 1, I.width(),
-                                             I.height(), 0,
-                                             SARA_HIP_STAGE_EXTREMA, nullptr));
       int total = 0;
-      hip_detail::check(sara_hip_sift_extrema_counts(_ctx.get(), nullptr, &total));
+      for (int step = 0;; ++step)
+      {
+        hip_detail::check(sara_hip_sift_detect(_ctx.get(), I.data(), 0, 1,
+                                               I.width(), I.height(), 0,
+                                               SARA_HIP_STAGE_EXTREMA, nullptr));
+        const sara_hip_status st =
+            sara_hip_sift_extrema_counts(_ctx.get(), nullptr, &total);
+        if (st != SARA_HIP_CAPACITY_EXCEEDED ||
+            step + 1 >= hip_detail::kMaxGrowthSteps)
+        {
+          hip_detail::check(st);
+          break;
+        }
+        hip_detail::grow_for_last_batch(_ctx.get());
+      }
       auto extrema = std::vector<OERegion>(size_t(total));
       auto xyso = std::vector<int32_t>(size_t(total) * 5);
       if (total > 0)
@@ -895,6 +935,7 @@ namespace DO::Sara {
     float _gauss_truncate, _extremum_thres, _edge_ratio_thres;
     int _img_padding_sz, _extremum_refinement_iter, _device;
     hip_detail::Context _ctx;
+    int _ctx_w = 0, _ctx_h = 0;  // size the context was created for
     mutable ImagePyramid<float> _gaussians, _diff_of_gaussians;
     mutable bool _have_g = false, _have_d = false;
     std::vector<std::vector<OERegion>> _extrema;

@@ -229,6 +229,33 @@ SARA_HIP_API sara_hip_status sara_hip_sift_counts(sara_hip_sift* ctx,
                                                  int* per_frame_counts,
                                                  int* total);
 
+/* Keypoint-list capacity.  The reference has none: it reserves 10000 extrema  */
+/* per scale and push_backs beyond (FeatureDetectors/RefineExtremum.cpp:        */
+/* 496-514), so compute_sift_keypoints() returns whatever an image produces.    */
+/* The context's lists hold max_keypoints entries per frame (4 * max_keypoints */
+/* classified sites); a frame that needs more is reported - never silently      */
+/* truncated - as SARA_HIP_CAPACITY_EXCEEDED by counts() / collect() /          */
+/* extrema_counts(), and the caller grows the lists and runs the frame again:   */
+/*   capacity(): *max_keypoints = the current per-frame capacity, *required =   */
+/*     the capacity the last batch whose counts were read asked for (largest    */
+/*     per-frame max(extrema, keypoints, sites / 4)).  A list that overflowed   */
+/*     starves the lists behind it, so after an overflow `required` is a lower  */
+/*     bound: reserve more (the shims take 2 x) and loop.                       */
+/*   reserve(): grows the per-frame capacity to max_keypoints (never shrinks;   */
+/*     a no-op when it is already that large), waits for the context's work,    */
+/*     re-allocates the list and result arrays in HBM, forgets the captured     */
+/*     graph and the last result.  SARA_HIP_NOT_READY while a ticket is         */
+/*     pending; SARA_HIP_CAPACITY_EXCEEDED when HBM cannot hold the request     */
+/*     (the old capacity stays in place).                                       */
+/* This is what DO::Sara::compute_sift_keypoints / ComputeDoGExtrema of         */
+/* include/DO/Sara/HipSift.hpp and sara_amd do on their callers' behalf; the    */
+/* grown context stays cached, so a video pays for the growth once.             */
+SARA_HIP_API sara_hip_status sara_hip_sift_capacity(const sara_hip_sift* ctx,
+                                                   int* max_keypoints,
+                                                   int* required);
+SARA_HIP_API sara_hip_status sara_hip_sift_reserve(sara_hip_sift* ctx,
+                                                  int max_keypoints);
+
 /* Copies the keypoints of the whole batch, frames concatenated in order:      */
 /*   features     : total x sara_oeregion (rescaled by the octave factor,      */
 /*                  SIFT.cpp:92-98)                                            */

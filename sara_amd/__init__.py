@@ -166,6 +166,7 @@ class SiftContext:
                 max_height, max_batch, max_keypoints, device, C.byref(self._h))
         capi.check(st)
         self.device = device
+        self.max_width, self.max_height = max_width, max_height
         self.max_batch = max_batch
         self.batch = 0
         self._keepalive = None
@@ -264,6 +265,27 @@ class SiftContext:
 
     def synchronize(self):
         capi.check(capi.load().sara_hip_sift_synchronize(self._h))
+
+    # -- keypoint-list capacity ------------------------------------------------ #
+    def capacity(self):
+        """-> (max_keypoints per frame, capacity the last examined batch asked
+        for); sara_hip_sift_capacity."""
+        cap, need = C.c_int(0), C.c_int(0)
+        capi.check(capi.load().sara_hip_sift_capacity(self._h, C.byref(cap),
+                                                      C.byref(need)))
+        return cap.value, need.value
+
+    def reserve(self, max_keypoints):
+        """Grow the per-frame list capacity (sara_hip_sift_reserve)."""
+        capi.check(capi.load().sara_hip_sift_reserve(self._h, int(max_keypoints)))
+        return self
+
+    def grow_for_last_batch(self):
+        """After a SARA_HIP_CAPACITY_EXCEEDED: reserve twice what the batch
+        asked for (a list that overflowed starves the ones behind it, so the
+        figure is a lower bound and the caller loops)."""
+        cap, need = self.capacity()
+        return self.reserve(2 * max(cap, need))
 
     # -- pipelined host-to-host operation ------------------------------------- #
     def submit(self, images, last_stage=STAGE_DESCRIPTOR):
@@ -565,9 +587,23 @@ def compute_sift_keypoints(image, pyramid_params=None, gauss_truncate=4.0,
     params = pyramid_params or ImagePyramidParams()
     ctx = _cached_context(w, h, params, gauss_truncate, extremum_thres,
                           edge_ratio_thres, extremum_refinement_iter, device)
-    ticket = ctx.submit(img)
-    _, regions, desc, so = ctx.collect(ticket, copy=True)
-    return KeypointList(regions, desc, so)
+    # The reference's lists are std::vectors (RefineExtremum.cpp:496-514): an
+    # image never has "too many" keypoints.  The context's lists are sized for
+    # ordinary frames; one that overflows them is run again on grown lists, and
+    # the grown context stays cached (a video pays once).
+    for _ in range(_MAX_GROWTH_STEPS):
+        ticket = ctx.submit(img)
+        try:
+            _, regions, desc, so = ctx.collect(ticket, copy=True)
+        except capi.SaraHipError as e:
+            if e.status != capi.CAPACITY_EXCEEDED:
+                raise
+            ctx.grow_for_last_batch()
+            continue
+        return KeypointList(regions, desc, so)
+    raise capi.SaraHipError(capi.CAPACITY_EXCEEDED,
+                            "keypoint lists still overflow after %d growth steps"
+                            % _MAX_GROWTH_STEPS)
 
 
 #: contexts of compute_sift_keypoints(), most recently used first, ONE LIST PER
@@ -577,6 +613,8 @@ def compute_sift_keypoints(image, pyramid_params=None, gauss_truncate=4.0,
 #: with.  Creating a context allocates the pyramid / gradient / list buffers
 #: in HBM (tens of milliseconds); a detection takes less than one.
 _CONTEXT_CACHE_MAX = 4
+#: every step at least doubles the lists: 16 200 -> over 4 M entries per frame
+_MAX_GROWTH_STEPS = 8
 
 
 class _ThreadContexts(threading.local):
@@ -638,13 +676,26 @@ class ComputeDoGExtrema:
         img = np.ascontiguousarray(image, dtype=np.float32)
         h, w = img.shape
         gt, et, er, pad, it, dev = self._args
-        if self._ctx is not None:
-            self._ctx.close()
-        self._ctx = SiftContext(w, h, 1, self.params, gt, et, er,
-                                dog_args=(pad, it), device=dev)
-        self._ctx.detect(img, last_stage=STAGE_EXTREMA)
-        _, regions, xyso = self._ctx.extrema()
-        return regions, xyso[:, 2:4].copy()
+        if self._ctx is None or (self._ctx.max_width, self._ctx.max_height) != (w, h):
+            if self._ctx is not None:
+                self._ctx.close()
+            self._ctx = SiftContext(w, h, 1, self.params, gt, et, er,
+                                    dog_args=(pad, it), device=dev)
+        # no capacity in the reference (RefineExtremum.cpp:496-514): grow and
+        # run again when a frame overflows the lists
+        for _ in range(_MAX_GROWTH_STEPS):
+            self._ctx.detect(img, last_stage=STAGE_EXTREMA)
+            try:
+                _, regions, xyso = self._ctx.extrema()
+            except capi.SaraHipError as e:
+                if e.status != capi.CAPACITY_EXCEEDED:
+                    raise
+                self._ctx.grow_for_last_batch()
+                continue
+            return regions, xyso[:, 2:4].copy()
+        raise capi.SaraHipError(capi.CAPACITY_EXCEEDED,
+                                "extremum lists still overflow after %d growth "
+                                "steps" % _MAX_GROWTH_STEPS)
 
     def gaussians(self, s, o):
         return self._ctx.gaussian(s, o)

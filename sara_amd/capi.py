@@ -109,6 +109,7 @@ EXPORTS = [
     "sara_hip_sift_group_transport", "sara_hip_self_match_descriptors",
     "sara_hip_match_release_workspace", "sara_hip_sift_pyramid_launches",
     "sara_hip_comm_size", "sara_hip_rccl_version",
+    "sara_hip_sift_capacity", "sara_hip_sift_reserve",
 ]
 
 _f32p = C.POINTER(C.c_float)
@@ -151,6 +152,9 @@ def _declare(lib):
                                          C.c_int, C.c_int, C.c_int, _vp]
     lib.sara_hip_sift_synchronize.argtypes = [_vp]
     lib.sara_hip_sift_counts.argtypes = [_vp, _i32p, _i32p]
+    lib.sara_hip_sift_capacity.argtypes = [_vp, C.POINTER(C.c_int),
+                                           C.POINTER(C.c_int)]
+    lib.sara_hip_sift_reserve.argtypes = [_vp, C.c_int]
     lib.sara_hip_sift_fetch.argtypes = [_vp, _vp, _vp, _vp, C.c_int]
     lib.sara_hip_sift_device_results.argtypes = [_vp, C.POINTER(_vp),
                                                  C.POINTER(_vp), C.POINTER(_vp),

@@ -514,6 +514,10 @@ struct sara_hip_sift
   int32_t* d_so_s[2] = {nullptr, nullptr};
   float* d_desc_s[2] = {nullptr, nullptr};
   int write_slot = 0;
+  bool has_slot1 = false;  // the second result slot exists (first submit())
+  // largest per-frame list length, in units of max_keypoints, that the last
+  // examined batch asked for (sara_hip_sift_capacity)
+  int required_cap = 0;
   struct RingSlot
   {
     int ticket = -1;
@@ -603,6 +607,85 @@ struct sara_hip_sift
 };
 
 namespace {
+
+  //! Everything whose size is a multiple of the per-frame list capacity
+  //! `c->cap` (sara_hip_sift_reserve re-allocates exactly this set).
+  sara_hip_status alloc_lists(sara_hip_sift* c)
+  {
+    const size_t rows = size_t(c->max_batch) * c->cap;
+#define TRY_ST(expr)                                                           \
+  do                                                                           \
+  {                                                                            \
+    const sara_hip_status st_ = (expr);                                        \
+    if (st_ != SARA_HIP_OK)                                                    \
+      return st_;                                                              \
+  } while (0)
+    c->cand.cap = c->cap;
+    TRY_ST(c->alloc(c->cand.key, rows));
+    TRY_ST(c->alloc(c->cand.data, rows));
+    TRY_ST(c->alloc(c->cand.order, rows));
+    TRY_ST(c->alloc(c->cand.skey, rows));
+    TRY_ST(c->alloc(c->cand.sdata, rows));
+    TRY_ST(c->alloc(c->d_grouped, rows));
+    c->sites.cap = 4 * c->cap;
+    TRY_ST(c->alloc(c->sites.key, size_t(c->max_batch) * c->sites.cap));
+    TRY_ST(c->alloc(c->sites.nb, size_t(c->max_batch) * c->sites.cap * kSiteNb));
+    TRY_ST(c->alloc(c->ori.peak_count, rows));
+    TRY_ST(c->alloc(c->ori.peak_theta, rows * kMaxPeaks));
+    TRY_ST(c->alloc(c->ori.offset, rows));
+    TRY_ST(c->alloc(c->ori.record, rows));
+    TRY_ST(c->alloc(c->ori.item, rows));
+    for (int k = 0; k < (c->has_slot1 ? 2 : 1); ++k)
+    {
+      TRY_ST(c->alloc(c->d_feat_s[k], rows));
+      TRY_ST(c->alloc(c->d_so_s[k], rows * 2));
+      TRY_ST(c->alloc(c->d_desc_s[k], rows * 128));
+    }
+    c->d_feat = c->d_feat_s[c->write_slot];
+    c->d_so = c->d_so_s[c->write_slot];
+    c->d_desc = c->d_desc_s[c->write_slot];
+    TRY_ST(c->alloc(c->d_ex_regions, rows));
+    TRY_ST(c->alloc(c->d_ex_xyso, rows * 5));
+#undef TRY_ST
+    return SARA_HIP_OK;
+  }
+
+  //! Frees what alloc_lists() allocated (pointers that are still null are
+  //! skipped).
+  void free_lists(sara_hip_sift* c)
+  {
+    auto drop = [&](auto*& p) {
+      if (!p)
+        return;
+      auto it = std::find(c->allocations.begin(), c->allocations.end(),
+                          static_cast<void*>(p));
+      if (it != c->allocations.end())
+        c->allocations.erase(it);
+      (void) hipFree(p);
+      p = nullptr;
+    };
+    drop(c->cand.key);
+    drop(c->cand.data);
+    drop(c->cand.order);
+    drop(c->cand.skey);
+    drop(c->cand.sdata);
+    drop(c->d_grouped);
+    drop(c->sites.key);
+    drop(c->sites.nb);
+    drop(c->ori.peak_count);
+    drop(c->ori.peak_theta);
+    drop(c->ori.offset);
+    drop(c->ori.record);
+    drop(c->ori.item);
+    for (int k = 0; k < 2; ++k)
+    {
+      drop(c->d_feat_s[k]);
+      drop(c->d_so_s[k]);
+      drop(c->d_desc_s[k]);
+    }
+    drop(c->d_ex_regions);
+    drop(c->d_ex_xyso);
+  }
 
   sara_hip_status create_impl(const sara_pyramid_params& pyr, float gauss_truncate,
                               float extremum_thres, float edge_ratio_thres,
@@ -790,10 +873,6 @@ namespace {
       TRY_ST(c->alloc(c->d_full, size_t(max_w) * max_h * max_batch));
 
     // ---- candidate / keypoint lists
-    const size_t rows = size_t(max_batch) * c->cap;
-    c->cand.cap = c->cap;
-    TRY_ST(c->alloc(c->cand.key, rows));
-    TRY_ST(c->alloc(c->cand.data, rows));
     // the four per-frame counters share one block: one memset per detect()
     // + 1 for frame_offset[batch], + 1 arrival counter of the peak scan
     // padded to whole 256-byte blocks: the runtime then zeroes it with one
@@ -803,9 +882,6 @@ namespace {
     c->sites.count = c->d_counters + max_batch;
     c->ori.kp_count = c->d_counters + 2 * size_t(max_batch);
     c->ori.frame_offset = c->d_counters + 3 * size_t(max_batch);  // max_batch + 1
-    TRY_ST(c->alloc(c->cand.order, rows));
-    TRY_ST(c->alloc(c->cand.skey, rows));
-    TRY_ST(c->alloc(c->cand.sdata, rows));
     {
       // one bucket per image row of every plane of the largest schedule
       int total = 0;
@@ -814,25 +890,9 @@ namespace {
       c->bucket_stride = total + 1;
       TRY_ST(c->alloc(c->d_bucket_hist, size_t(max_batch) * c->bucket_stride));
       TRY_ST(c->alloc(c->d_bucket_cursor, size_t(max_batch) * c->bucket_stride));
-      TRY_ST(c->alloc(c->d_grouped, rows));
     }
-    c->sites.cap = 4 * c->cap;
-    TRY_ST(c->alloc(c->sites.key, size_t(max_batch) * c->sites.cap));
-    TRY_ST(c->alloc(c->sites.nb, size_t(max_batch) * c->sites.cap * kSiteNb));
-    TRY_ST(c->alloc(c->ori.peak_count, rows));
-    TRY_ST(c->alloc(c->ori.peak_theta, rows * kMaxPeaks));
-    TRY_ST(c->alloc(c->ori.offset, rows));
-    TRY_ST(c->alloc(c->ori.record, rows));
-    TRY_ST(c->alloc(c->ori.item, rows));
     TRY_ST(c->alloc(c->d_ex_offset, size_t(max_batch) + 1));
-    TRY_ST(c->alloc(c->d_feat_s[0], rows));
-    TRY_ST(c->alloc(c->d_so_s[0], rows * 2));
-    TRY_ST(c->alloc(c->d_desc_s[0], rows * 128));
-    c->d_feat = c->d_feat_s[0];
-    c->d_so = c->d_so_s[0];
-    c->d_desc = c->d_desc_s[0];
-    TRY_ST(c->alloc(c->d_ex_regions, rows));
-    TRY_ST(c->alloc(c->d_ex_xyso, rows * 5));
+    TRY_ST(alloc_lists(c));
 #undef TRY_ST
 #undef TRY_HIP
     *out = c;
@@ -849,6 +909,26 @@ namespace {
       return fail(SARA_HIP_NOT_READY,
                   "the last detect() stopped before the requested stage");
     return SARA_HIP_OK;
+  }
+
+  //! Remembers what list capacity a batch asked for: per frame the largest of
+  //! the extremum count, the keypoint count and a quarter of the classified
+  //! sites (their list holds 4 * max_keypoints).  A list that overflowed
+  //! starves the ones behind it, so the figure is a lower bound then.
+  void note_required(sara_hip_sift* c, const int* h_ex, const int* h_sites,
+                     const int* h_kp, int batch)
+  {
+    int need = 0;
+    for (int b = 0; b < batch; ++b)
+    {
+      if (h_ex)
+        need = std::max(need, h_ex[b]);
+      if (h_sites)
+        need = std::max(need, (h_sites[b] + 3) / 4);
+      if (h_kp)
+        need = std::max(need, h_kp[b]);
+    }
+    c->required_cap = need;
   }
 
 }  // namespace
@@ -1152,6 +1232,63 @@ sara_hip_status sara_hip_sift_set_option(sara_hip_sift* c, int option, int value
   default:
     return fail(SARA_HIP_INVALID_PARAMS, "unknown option");
   }
+}
+
+sara_hip_status sara_hip_sift_capacity(const sara_hip_sift* c, int* max_keypoints,
+                                       int* required)
+{
+  if (!c)
+    return fail(SARA_HIP_INVALID_PARAMS, "null context");
+  if (max_keypoints)
+    *max_keypoints = c->cap;
+  if (required)
+    *required = c->required_cap;
+  return SARA_HIP_OK;
+}
+
+sara_hip_status sara_hip_sift_reserve(sara_hip_sift* c, int max_keypoints)
+{
+  if (!c)
+    return fail(SARA_HIP_INVALID_PARAMS, "null context");
+  if (max_keypoints <= c->cap)
+    return SARA_HIP_OK;  // the lists never shrink
+  if (c->ring[0].pending || c->ring[1].pending)
+    return fail(SARA_HIP_NOT_READY,
+                "reserve() with a batch in flight: collect() its ticket first");
+  if (max_keypoints > INT_MAX / 4 - 1)  // sites.cap = 4 * cap is an int
+    return fail(SARA_HIP_CAPACITY_EXCEEDED, "max_keypoints too large");
+  HIP_TRY(hipSetDevice(c->device));
+  std::lock_guard<std::recursive_mutex> runtime_lock(runtime_mutex());
+  for (hipStream_t st : {c->last_stream, c->own_stream, c->aux_stream,
+                         c->d2h_stream, c->copy_stream})
+    if (st)
+      HIP_TRY(hipStreamSynchronize(st));
+  const int old_cap = c->cap;
+  free_lists(c);
+  c->cap = max_keypoints;
+  sara_hip_status st = alloc_lists(c);
+  if (st != SARA_HIP_OK)
+  {
+    // out of HBM: back to the old lists, which fitted before.  The failed
+    // hipMalloc also left its code in the thread's sticky last-error slot,
+    // where the next hipGetLastError() after a launch would find it
+    (void) hipGetLastError();
+    free_lists(c);
+    c->cap = old_cap;
+    const std::string why = g_error;
+    if (alloc_lists(c) != SARA_HIP_OK)
+      return fail(SARA_HIP_RUNTIME_ERROR,
+                  "reserve(): the keypoint lists could not be re-allocated; "
+                  "the context is unusable (" + why + ")");
+    return fail(SARA_HIP_CAPACITY_EXCEEDED,
+                "reserve(): not enough device memory for max_keypoints (" + why +
+                    ")");
+  }
+  // the list pointers and capacities are kernel arguments baked into a
+  // captured graph: capture again on the next detect()
+  c->graph_stage_s[0] = c->graph_stage_s[1] = -1;
+  c->has_result = false;
+  return SARA_HIP_OK;
 }
 
 sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
@@ -2078,6 +2215,8 @@ namespace {
         st = c->alloc(c->d_desc_s[slot], rows * 128);
       if (st != SARA_HIP_OK)
         return st;
+      if (slot == 1)
+        c->has_slot1 = true;
     }
     c->write_slot = slot;
     c->d_feat = c->d_feat_s[slot];
@@ -2207,6 +2346,7 @@ sara_hip_status sara_hip_sift_collect(sara_hip_sift* c, int ticket,
                 "descriptors requested, but the ticket was submitted with "
                 "last_stage < DESCRIPTOR (collect it with descriptors = NULL)");
   sara_hip_status status = SARA_HIP_OK;
+  note_required(c, h_ex, h_sites, h_kp, r.batch);
   for (int b = 0; b < r.batch && status == SARA_HIP_OK; ++b)
     if (h_kp[b] > c->cap || h_ex[b] > c->cap || h_sites[b] > c->sites.cap)
       status = fail(SARA_HIP_CAPACITY_EXCEEDED,
@@ -2344,6 +2484,8 @@ namespace sara_hip {
     out->d_so = c->d_so_s[ticket & 1];
     out->capacity_exceeded = false;
     out->last_stage = r.stage;
+    note_required(c, r.h_counters, r.h_counters + mb,
+                  r.h_counters + 2 * size_t(mb), r.batch);
     for (int b = 0; b < r.batch; ++b)
       if (r.h_counters[2 * size_t(mb) + b] > c->cap || r.h_counters[b] > c->cap ||
           r.h_counters[mb + b] > c->sites.cap)
@@ -2390,6 +2532,7 @@ sara_hip_status sara_hip_sift_counts(sara_hip_sift* c, int* per_frame, int* tota
                          sizeof(int) * 3 * size_t(c->max_batch),
                          hipMemcpyDeviceToHost, c->last_stream));
   HIP_TRY(hipStreamSynchronize(c->last_stream));
+  note_required(c, h_ex, h_sites, h_kp, c->cur_batch);
   int sum = 0;
   bool overflow = false;
   for (int b = 0; b < c->cur_batch; ++b)
@@ -2564,14 +2707,19 @@ sara_hip_status sara_hip_sift_extrema_counts(sara_hip_sift* c, int* per_frame,
   if (st != SARA_HIP_OK)
     return st;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipMemcpyAsync(c->h_counts, c->cand.count, sizeof(int) * c->cur_batch,
+  // cand.count | sites.count are contiguous in d_counters
+  int* h_ex = c->h_counts;
+  int* h_sites = c->h_counts + c->max_batch;
+  HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counters,
+                         sizeof(int) * 2 * size_t(c->max_batch),
                          hipMemcpyDeviceToHost, c->last_stream));
   HIP_TRY(hipStreamSynchronize(c->last_stream));
+  note_required(c, h_ex, h_sites, nullptr, c->cur_batch);
   int sum = 0;
   bool overflow = false;
   for (int b = 0; b < c->cur_batch; ++b)
   {
-    const int n = c->h_counts[b];
+    const int n = h_ex[b];
     overflow = overflow || n > c->cap;
     if (per_frame)
       per_frame[b] = std::min(n, c->cap);
@@ -2582,10 +2730,8 @@ sara_hip_status sara_hip_sift_extrema_counts(sara_hip_sift* c, int* per_frame,
   if (overflow)
     return fail(SARA_HIP_CAPACITY_EXCEEDED,
                 "a frame produced more extrema than max_keypoints");
-  HIP_TRY(hipMemcpy(c->h_counts, c->sites.count, sizeof(int) * c->cur_batch,
-                    hipMemcpyDeviceToHost));
   for (int b = 0; b < c->cur_batch; ++b)
-    if (c->h_counts[b] > c->sites.cap)
+    if (h_sites[b] > c->sites.cap)
       return fail(SARA_HIP_CAPACITY_EXCEEDED,
                   "a frame produced more classified sites than 4*max_keypoints");
   return SARA_HIP_OK;

@@ -71,11 +71,20 @@ def test_in_sara_mode_returns_the_standalone_results(tmp_path):
 
 
 @pytest.mark.gpu
-def test_shim_matches_oracle(oracle, tmp_path):
+@pytest.mark.parametrize("kind", ["synth", "dots"])
+def test_shim_matches_oracle(oracle, tmp_path, kind):
+    """`dots`: a frame that overflows the default keypoint lists (6 000 extrema
+    against a capacity of 3 750) - DO::Sara::compute_sift_keypoints and
+    ComputeDoGExtrema grow their contexts and return what the reference, which
+    has no limit (RefineExtremum.cpp:496-514), returns."""
     from sara_amd.synth import synth
     exe = _build()
-    w, h, noct = 320, 240, 3
-    img = synth(w, h, 4321)
+    if kind == "synth":
+        w, h, noct = 320, 240, 3
+        img = synth(w, h, 4321)
+    else:
+        w, h, noct = 800, 600, 3
+        img = common.dot_grid(w, h)
     fin, fout = tmp_path / "in.f32", tmp_path / "out.bin"
     img.tofile(fin)
     res = subprocess.run([exe, str(fin), str(w), str(h), str(noct), str(fout)],
@@ -88,6 +97,8 @@ def test_shim_matches_oracle(oracle, tmp_path):
     raw = np.fromfile(fout, dtype=np.uint8)
     n, ne = np.frombuffer(raw[:8].tobytes(), dtype=np.int32)
     assert (n, ne) == (len(rk), len(rext)) == (info["keypoints"], info["extrema"])
+    if kind == "dots":
+        assert ne > w * h // 128
     assert info["octaves"] == noct and info["factor1"] == 2
     off = 8
     feats = common.regions_from_bytes(raw[off:off + 48 * n])
