@@ -1132,6 +1132,8 @@ namespace sara_hip {
     }
 
     const int slot = atomicAdd(&cand.count[frame], 1);
+    if (slot < 0)
+      *cand.error = 1;  // the counter was not zeroed for this step
     if (unsigned(slot) < unsigned(cand.cap))
     {
       const size_t i = size_t(frame) * cand.cap + slot;
@@ -1221,7 +1223,10 @@ namespace sara_hip {
     base = __builtin_amdgcn_readfirstlane(base);
     __builtin_amdgcn_wave_barrier();
     // (unsigned: a counter that was not zeroed must not turn into a negative
-    // offset - seen with a single-stream graph on the ROCm 7.0 runtime)
+    // offset - seen with a single-stream graph on the ROCm 7.0 runtime; the
+    // step is then reported as failed, see SiteLists::error)
+    if (base < 0 && lane == 0)
+      *sites.error = 1;
     const int room = unsigned(base) < unsigned(sites.cap) ? min(qn, sites.cap - base) : 0;
     if (lane < room)
       sites.key[size_t(frame) * sites.cap + base + lane] =
@@ -1517,12 +1522,10 @@ namespace sara_hip {
       // workgroups of 8 / 4 adjacent strips where the count divides (see the
       // kernel's NW) and the launch fills the chip anyway: a small launch (one
       // frame per call) keeps single-wave workgroups, which spread over all CUs
-      // (the parity tests set SARA_HIP_MARCH_MIN_PIXELS to 0 and take the
-      // groups at every size)
-      const int waves = nstrips * nseg * batch;
-      const bool any = march_min_pixels() == 0;
-      const int NW = (nstrips % 8 == 0 && (any || waves >= 4096)) ? 8
-                     : ((nstrips % 4 == 0 && (any || waves >= 2048)) ? 4 : 1);
+      // (SARA_HIP_STRIP_GROUP forces the groups for the parity tests)
+      const int limit = strip_group_limit(nstrips * nseg * batch);
+      const int NW = (nstrips % 8 == 0 && limit >= 8) ? 8
+                     : ((nstrips % 4 == 0 && limit >= 4) ? 4 : 1);
       const int gstrips = nstrips / NW;
       const int total = xcd_map_enabled() ? gstrips * nseg * batch : 0;
       const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(gstrips * nseg, batch);

@@ -69,6 +69,20 @@ namespace sara_hip {
     return e ? size_t(atoll(e)) : size_t(4) << 20;
   }();
   size_t march_min_pixels() { return g_march_min_pixels; }
+  //! SARA_HIP_STRIP_GROUP (tests only): 0 / unset = the production rule -
+  //! strip-group workgroups (NW = 8 / 4) only for launches of >= 4096 / 2048
+  //! waves; 1, 4, 8 = the largest group taken at EVERY launch size, so that
+  //! the parity tests, whose images are small, run the grouped kernels.
+  static const int g_strip_group = [] {
+    const char* e = getenv("SARA_HIP_STRIP_GROUP");
+    return e ? atoi(e) : 0;
+  }();
+  int strip_group_limit(int waves)
+  {
+    if (g_strip_group > 0)
+      return g_strip_group;
+    return waves >= 4096 ? 8 : (waves >= 2048 ? 4 : 1);
+  }
 
   // Round 3: the tile geometry is a template parameter and the window is staged
   // with 16-byte loads.  One frame per call is a chain of dependent launches of
@@ -516,13 +530,11 @@ namespace sara_hip {
     // are then L2 hits.  64 x 1080p: R = 5 338 -> 308 us per step, R = 6 + half
     // size 392 -> 367 (8 waves; 4 are neutral); a small launch (one frame per
     // call) keeps single-wave workgroups, which spread over all CUs.
-    // (launches this function gets are >= g_march_min_pixels; the wave counts
-    // keep the groups to launches that fill the chip - the parity tests, which
-    // set the pixel threshold to 0, take the groups at every size)
-    const int waves = nstrips * nseg * batch;
-    const bool big = g_march_min_pixels == 0 || waves >= 2048;
-    const int NW = (!src_is_u8 && !fma && nstrips % 8 == 0 && big && (g_march_min_pixels == 0 || waves >= 4096)) ? 8
-                   : ((!src_is_u8 && !fma && nstrips % 4 == 0 && big) ? 4 : 1);
+    // (the wave counts keep the groups to launches that fill the chip;
+    // SARA_HIP_STRIP_GROUP forces them for the parity tests)
+    const int limit = (src_is_u8 || fma) ? 1 : strip_group_limit(nstrips * nseg * batch);
+    const int NW = (nstrips % 8 == 0 && limit >= 8) ? 8
+                   : ((nstrips % 4 == 0 && limit >= 4) ? 4 : 1);
     const int gstrips = nstrips / NW;
     const int total = xcd_map_enabled() ? gstrips * nseg * batch : 0;
     const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(gstrips * nseg, batch);
@@ -1208,6 +1220,18 @@ namespace sara_hip {
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count;
          i += size_t(gridDim.x) * blockDim.x)
       out[i] = a[i] - b[i];
+  }
+
+  __global__ void zero_counters_kernel(int4* p)
+  {
+    p[blockIdx.x * 16 + threadIdx.x] = make_int4(0, 0, 0, 0);
+  }
+
+  void launch_zero_counters(int* counters, size_t count, hipStream_t stream)
+  {
+    // whole 256-byte blocks (counters_padded): 16 lanes x 16 bytes each
+    hipLaunchKernelGGL(zero_counters_kernel, dim3(unsigned(count / 64)), dim3(16), 0,
+                       stream, reinterpret_cast<int4*>(counters));
   }
 
   void launch_subtract(const float* a, const float* b, float* out, size_t count,

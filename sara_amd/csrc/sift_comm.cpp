@@ -685,12 +685,23 @@ namespace {
           rmsg = sara_hip_last_error();
       }
       st = exchange_header(c, rs == SARA_HIP_OK ? 0 : -1, 0);
-      if (st == SARA_HIP_OK && c->h_hdr[size_t(kHdr) * root] < 0)
+      // every entry, as in step 1: a rank whose header upload failed sent the
+      // constant -1 entry and is about to return its local error - peers that
+      // only looked at the root's entry would go on to the transfers and block
+      // on that rank's send / recv
+      int bad = -1;
+      if (st == SARA_HIP_OK)
+        for (int k = 0; k < c->nranks && bad < 0; ++k)
+          if (c->h_hdr[size_t(kHdr) * k] < 0)
+            bad = k;
+      if (bad == root)
         st = rs != SARA_HIP_OK
                  ? set_error(rs, rmsg.c_str())
                  : set_error(SARA_HIP_RCCL_ERROR,
                              "gather abandoned: the root could not allocate "
                              "its receive buffers");
+      else if (bad >= 0)
+        st = peer_failed(c, l, bad);
       if (st != SARA_HIP_OK)
       {
         release();

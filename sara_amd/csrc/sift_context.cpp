@@ -21,6 +21,7 @@
 #include <functional>
 #include <limits>
 #include <mutex>
+#include <pthread.h>
 #include <string>
 #include <thread>
 #include <vector>
@@ -63,9 +64,15 @@ namespace {
   //! part of its detect() to the launcher and waits for it: the caller is
   //! blocked for the duration anyway (the host side
   //! of a replay is what detect() consists of), so nothing is lost but the
-  //! hand-over - a spin on an atomic in both directions while calls keep coming
-  //! (the launcher keeps polling for 200 us after a job before it sleeps on
-  //! its condition variable; a caller polls for 2 ms before it does).
+  //! hand-over.  Both sides wait cooperatively: a short run of `pause`
+  //! instructions (the answer is usually microseconds away), then
+  //! sched_yield() between looks - so that a process with more threads than
+  //! cores hands the core to whoever it is waiting for - then a condition
+  //! variable.  The launcher only polls at all while calls keep coming (the
+  //! previous job arrived within a millisecond of the one before: a video
+  //! loop); an occasional caller finds it asleep and pays one wake-up.
+  //! After fork() the child has no launcher thread: a pthread_atfork handler
+  //! gives it a fresh launcher (graph_launcher()).
   class GraphLauncher
   {
   public:
@@ -92,17 +99,13 @@ namespace {
       }
       if (sleeping_.load(std::memory_order_acquire))
         cv_.notify_one();
-      // the job is tens of microseconds of host work: poll first
-      const auto t0 = std::chrono::steady_clock::now();
-      while (!job.done.load(std::memory_order_acquire))
+      // the job is tens of microseconds of host work: look before sleeping
+      if (!wait_briefly([&] { return job.done.load(std::memory_order_acquire); },
+                        std::chrono::microseconds(2000)))
       {
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
-        {
-          std::unique_lock<std::mutex> lock(job.m);
-          job.waiting = true;
-          job.cv.wait(lock, [&] { return job.done.load(std::memory_order_acquire); });
-          break;
-        }
+        std::unique_lock<std::mutex> lock(job.m);
+        job.waiting = true;
+        job.cv.wait(lock, [&] { return job.done.load(std::memory_order_acquire); });
       }
       // the launcher may still be inside the notification of job.cv
       std::lock_guard<std::mutex> lock(job.m);
@@ -139,19 +142,15 @@ namespace {
           std::unique_lock<std::mutex> lock(m_);
           if (queue_.empty())
           {
-            // keep polling for a while: a caller's next detect() is usually a
-            // few hundred microseconds away
+            // in a hot loop the caller's next detect() is a few hundred
+            // microseconds away: look for it before sleeping
             lock.unlock();
-            const auto t0 = std::chrono::steady_clock::now();
-            bool found = false;
-            while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(200))
-            {
-              if (posted_.load(std::memory_order_acquire) != taken_)
-              {
-                found = true;
-                break;
-              }
-            }
+            const bool found =
+                hot_ && wait_briefly(
+                            [&] {
+                              return posted_.load(std::memory_order_acquire) != taken_;
+                            },
+                            std::chrono::microseconds(200));
             lock.lock();
             if (!found && queue_.empty())
             {
@@ -170,6 +169,11 @@ namespace {
           queue_.pop_front();
           ++taken_;
         }
+        {
+          const auto now = std::chrono::steady_clock::now();
+          hot_ = now - last_job_ < std::chrono::milliseconds(1);
+          last_job_ = now;
+        }
         job->fn();
         {
           std::lock_guard<std::mutex> lock(job->m);
@@ -180,9 +184,34 @@ namespace {
       }
     }
 
+    //! Waits for ready() for at most `limit` without monopolising a core:
+    //! ~2 us of pause instructions, then sched_yield() between looks.
+    template <typename Ready>
+    static bool wait_briefly(Ready ready, std::chrono::microseconds limit)
+    {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < 64; ++i)
+      {
+        if (ready())
+          return true;
+        __builtin_ia32_pause();
+      }
+      while (!ready())
+      {
+        if (std::chrono::steady_clock::now() - t0 > limit)
+          return false;
+        std::this_thread::yield();
+      }
+      return true;
+    }
+
     std::mutex m_;
     std::condition_variable cv_;
     std::deque<Job*> queue_;
+    // launcher thread only: arrival of the previous job, and whether the one
+    // before it was less than a millisecond earlier
+    std::chrono::steady_clock::time_point last_job_{};
+    bool hot_ = false;
     std::atomic<unsigned long long> posted_{0};
     unsigned long long taken_ = 0;  // launcher thread only
     std::atomic<bool> sleeping_{false};
@@ -191,12 +220,24 @@ namespace {
     bool started_ = false, stop_ = false;
   };
 
+  std::atomic<GraphLauncher*> g_launcher{nullptr};
+
   GraphLauncher& graph_launcher()
   {
     // leaked on purpose: at process exit the HIP runtime may already be gone
     // when static destructors run, and the launcher only ever sleeps by then
-    static GraphLauncher* g = new GraphLauncher;
-    return *g;
+    static const bool once = [] {
+      g_launcher.store(new GraphLauncher, std::memory_order_release);
+      // fork(): the child inherits the launcher's state (started, perhaps a
+      // locked mutex) but not its thread - the first run() would wait for
+      // ever.  The child gets a fresh launcher; the old one is abandoned.
+      pthread_atfork(nullptr, nullptr, [] {
+        g_launcher.store(new GraphLauncher, std::memory_order_release);
+      });
+      return true;
+    }();
+    (void) once;
+    return *g_launcher.load(std::memory_order_acquire);
   }
 
   //! ROCm runtimes before 7.2 (the 7.0 runtime bundled with torch 2.10 is what
@@ -213,9 +254,10 @@ namespace {
   //! thread replays graphs through the launcher.
   bool graphs_need_one_thread()
   {
+    // fail closed: a runtime that does not say what it is counts as old
     static const bool old_runtime = [] {
       int v = 0;
-      return hipRuntimeGetVersion(&v) == hipSuccess && v < 70200000;
+      return hipRuntimeGetVersion(&v) != hipSuccess || v < 70200000;
     }();
     return old_runtime;
   }
@@ -410,10 +452,21 @@ static void orientation_bin_thresholds(float thr_out[40])
   }
 }
 
-//! Ints in d_counters (4 * max_batch + 2 used), in whole 256-byte blocks.
+//! Ints in d_counters (4 * max_batch + 3 used: the per-frame counters, the
+//! frame offsets, the peak scan's arrival counter, the error flag), in whole
+//! 256-byte blocks; the last three ints are the graph's filler targets.
 static inline size_t counters_padded(int max_batch)
 {
   return (4 * size_t(max_batch) + 2 + 8 + 63) / 64 * 64;  // >= 8 spare ints
+}
+//! Ints of d_counters that travel to the host with a batch's counts.
+static inline size_t counters_read(int max_batch)
+{
+  return 4 * size_t(max_batch) + 3;
+}
+static inline size_t error_flag_index(int max_batch)
+{
+  return 4 * size_t(max_batch) + 2;
 }
 
 struct sara_hip_sift
@@ -525,7 +578,7 @@ struct sara_hip_sift
     int batch = 0;
     sara_hip_stage stage = SARA_HIP_STAGE_DESCRIPTOR;  // last_stage of the submit()
     hipEvent_t done = nullptr;   // counters of the batch are in h_counters
-    int* h_counters = nullptr;   // pinned copy of d_counters (4 * max_batch + 1)
+    int* h_counters = nullptr;   // pinned copy of d_counters (counters_read())
     sara_oeregion* h_feat = nullptr;  // pinned result arrays, grown on demand
     float* h_desc = nullptr;
     int32_t* h_so = nullptr;
@@ -547,7 +600,7 @@ struct sara_hip_sift
   int* d_grouped = nullptr;        // [max_batch][cap]
   int bucket_stride = 0;
   RowBuckets row_buckets{};        // of the current schedule
-  int* h_counts = nullptr;  // pinned, 3*max_batch+2
+  int* h_counts = nullptr;  // pinned, counters_read(max_batch)
   // Small batches are launch-bound (about 60 launches in 0.7 ms for one 1080p
   // frame): the enqueue sequence of detect() is captured once per (size,
   // batch, stage) into a HIP graph and replayed (SARA_HIP_GRAPH=0 disables,
@@ -850,7 +903,7 @@ namespace {
     std::memset(c->h_grad, 0, sizeof(GradPyramidView));
     TRY_ST(c->alloc(c->d_grad, 1));
     TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_counts),
-                          sizeof(int) * (3 * size_t(max_batch) + 2)));
+                          sizeof(int) * counters_read(max_batch)));
 
     // ---- HBM: pyramids [frame][scale][h][w] per octave
     const int no = c->max_sched.num_octaves;
@@ -882,6 +935,7 @@ namespace {
     c->sites.count = c->d_counters + max_batch;
     c->ori.kp_count = c->d_counters + 2 * size_t(max_batch);
     c->ori.frame_offset = c->d_counters + 3 * size_t(max_batch);  // max_batch + 1
+    c->cand.error = c->sites.error = c->d_counters + error_flag_index(max_batch);
     {
       // one bucket per image row of every plane of the largest schedule
       int total = 0;
@@ -909,6 +963,28 @@ namespace {
       return fail(SARA_HIP_NOT_READY,
                   "the last detect() stopped before the requested stage");
     return SARA_HIP_OK;
+  }
+
+  //! A list counter the step did not zero (seen once, with a graph
+  //! captured from one stream on the ROCm 7.0 runtime, before the counters were
+  //! cleared by a kernel of the library): a kernel met a negative counter and
+  //! raised the flag, or a counter is negative now.  The lists of such a step
+  //! are incomplete - the call fails instead of returning them.
+  bool counters_corrupt(const int* h, int mb, int batch, int lists)
+  {
+    if (h[error_flag_index(mb)] != 0)
+      return true;
+    for (int l = 0; l < lists; ++l)
+      for (int b = 0; b < batch; ++b)
+        if (h[size_t(l) * mb + b] < 0)
+          return true;
+    return false;
+  }
+  sara_hip_status corrupt_counters_error()
+  {
+    return fail(SARA_HIP_RUNTIME_ERROR,
+                "a keypoint-list counter was not cleared before this batch ran "
+                "(negative counter): the lists are incomplete");
   }
 
   //! Remembers what list capacity a batch asked for: per frame the largest of
@@ -1225,6 +1301,7 @@ sara_hip_status sara_hip_sift_set_option(sara_hip_sift* c, int option, int value
     if (c->last_stream)
       HIP_TRY(hipStreamSynchronize(c->last_stream));
     c->downscale_at_double_sigma = on;
+    c->max_sched = make_schedule(c->pyr, c->max_w, c->max_h, on);  // same sizes
     c->cur_w = c->cur_h = -1;  // rebuild the schedule on the next detect
     c->graph_stage_s[0] = c->graph_stage_s[1] = -1;
     return SARA_HIP_OK;
@@ -1338,6 +1415,17 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
         }
       rb.total = at;
       rb.stride = c->bucket_stride;
+      // the fused counting sort writes rb.total + 1 ints per frame into rows
+      // of bucket_stride: the current schedule's buckets must be a subset of
+      // the largest schedule's (they are for every image <= max_width x
+      // max_height; checked, not assumed)
+      if (rb.total >= c->bucket_stride || c->cur.num_octaves > 16)
+      {
+        c->cur_w = c->cur_h = -1;
+        return fail(SARA_HIP_CAPACITY_EXCEEDED,
+                    "the image's pyramid has more rows than the context's "
+                    "largest schedule");
+      }
     }
     GradPyramidView& gv = *c->h_grad;
     std::memset(&gv, 0, sizeof(gv));
@@ -1527,8 +1615,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     return SARA_HIP_OK;
   };
   if (pipe)  // the scans start before the pyramid is complete
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0,
-                           sizeof(int) * counters_padded(c->max_batch), tail));
+    launch_zero_counters(c->d_counters, counters_padded(c->max_batch), tail);
 
   // ---- Gaussian pyramid + fused DoG ---------------------------------------
   if (sc.num_octaves > 0)
@@ -1782,8 +1869,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
 
   // ---- extrema ------------------------------------------------------------
   if (!pipe)
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0,
-                           sizeof(int) * counters_padded(c->max_batch), stream));
+    launch_zero_counters(c->d_counters, counters_padded(c->max_batch), stream);
   if (last_stage >= SARA_HIP_STAGE_EXTREMA)
   {
     if (!pipe)
@@ -1807,8 +1893,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       }
       launch_finish_sites(pv, batch, ep, c->d_tab, c->sites, c->cand, tail);
     }
-    // row_buckets.total <= bucket_stride - 1 by construction (the buckets of
-    // the current schedule are a subset of the largest one's)
+    // row_buckets.total < bucket_stride: checked where the schedule is built
     launch_rank_candidates_bucketed(c->cand, c->row_buckets, c->d_bucket_hist,
                                     c->d_bucket_cursor, c->d_grouped, batch, tail);
   }
@@ -2278,7 +2363,7 @@ sara_hip_status submit_impl(sara_hip_sift* c, const void* images,
   {
     HIP_TRY(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r.h_counters),
-                          sizeof(int) * (4 * size_t(c->max_batch) + 1)));
+                          sizeof(int) * counters_read(c->max_batch)));
   }
   {
     const sara_hip_status ds = ensure_d2h_stream(c);
@@ -2310,7 +2395,7 @@ sara_hip_status submit_impl(sara_hip_sift* c, const void* images,
   // the counters of this batch travel to pinned memory in stream order: the
   // next batch may reset them before collect() looks
   HIP_TRY(hipMemcpyAsync(r.h_counters, c->d_counters,
-                         sizeof(int) * (4 * size_t(c->max_batch) + 1),
+                         sizeof(int) * counters_read(c->max_batch),
                          hipMemcpyDeviceToHost, c->last_stream));
   HIP_TRY(hipEventRecord(r.done, c->last_stream));
   r.ticket = c->next_ticket;
@@ -2346,6 +2431,11 @@ sara_hip_status sara_hip_sift_collect(sara_hip_sift* c, int ticket,
                 "descriptors requested, but the ticket was submitted with "
                 "last_stage < DESCRIPTOR (collect it with descriptors = NULL)");
   sara_hip_status status = SARA_HIP_OK;
+  if (counters_corrupt(r.h_counters, mb, r.batch, 3))
+  {
+    r.pending = false;
+    return corrupt_counters_error();
+  }
   note_required(c, h_ex, h_sites, h_kp, r.batch);
   for (int b = 0; b < r.batch && status == SARA_HIP_OK; ++b)
     if (h_kp[b] > c->cap || h_ex[b] > c->cap || h_sites[b] > c->sites.cap)
@@ -2474,6 +2564,11 @@ namespace sara_hip {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(r.done));
     const int mb = c->max_batch;
+    if (counters_corrupt(r.h_counters, mb, r.batch, 3))
+    {
+      r.pending = false;
+      return corrupt_counters_error();
+    }
     const int* h_off = r.h_counters + 3 * size_t(mb);
     out->device = c->device;
     out->batch = r.batch;
@@ -2529,9 +2624,11 @@ sara_hip_status sara_hip_sift_counts(sara_hip_sift* c, int* per_frame, int* tota
   int* h_sites = c->h_counts + c->max_batch;
   int* h_kp = c->h_counts + 2 * size_t(c->max_batch);
   HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counters,
-                         sizeof(int) * 3 * size_t(c->max_batch),
+                         sizeof(int) * counters_read(c->max_batch),
                          hipMemcpyDeviceToHost, c->last_stream));
   HIP_TRY(hipStreamSynchronize(c->last_stream));
+  if (counters_corrupt(c->h_counts, c->max_batch, c->cur_batch, 3))
+    return corrupt_counters_error();
   note_required(c, h_ex, h_sites, h_kp, c->cur_batch);
   int sum = 0;
   bool overflow = false;
@@ -2711,9 +2808,11 @@ sara_hip_status sara_hip_sift_extrema_counts(sara_hip_sift* c, int* per_frame,
   int* h_ex = c->h_counts;
   int* h_sites = c->h_counts + c->max_batch;
   HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counters,
-                         sizeof(int) * 2 * size_t(c->max_batch),
+                         sizeof(int) * counters_read(c->max_batch),
                          hipMemcpyDeviceToHost, c->last_stream));
   HIP_TRY(hipStreamSynchronize(c->last_stream));
+  if (counters_corrupt(c->h_counts, c->max_batch, c->cur_batch, 2))
+    return corrupt_counters_error();
   note_required(c, h_ex, h_sites, nullptr, c->cur_batch);
   int sum = 0;
   bool overflow = false;

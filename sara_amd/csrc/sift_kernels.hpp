@@ -73,6 +73,7 @@ namespace sara_hip {
     unsigned long long* skey;  // [frame][cap]
     float4* sdata;             // [frame][cap]
     int cap;
+    int* error;                // see SiteLists::error
   };
 
   //! Everything the descriptor kernel needs to know about one extremum, in
@@ -126,6 +127,10 @@ namespace sara_hip {
     float* nb;                // [frame][cap][kSiteNb]
     int* count;               // [frame] (may exceed cap)
     int cap;
+    int* error;               // one int per context: set to 1 by a kernel that
+                              // meets a NEGATIVE list counter (a counter the
+                              // step did not zero); counts() / collect() then
+                              // fail instead of returning truncated lists
   };
 
   //! Gaussian pyramid of the batch: octave o at base[o], planes
@@ -196,6 +201,13 @@ namespace sara_hip {
                           size_t dst_stride, size_t count, int batch,
                           hipStream_t stream);
 
+  //! Zeroes `count` ints (count a multiple of 64).  The per-step counters are
+  //! cleared by a kernel of the library, not by hipMemsetAsync: inside a graph
+  //! captured from ONE stream the ROCm 7.0 runtime let the scan run on counters
+  //! its memset node had not cleared yet (round 4; the lists then came back
+  //! truncated with status OK).  A kernel node is ordered like every other
+  //! kernel of the chain.
+  void launch_zero_counters(int* counters, size_t count, hipStream_t stream);
   void launch_subtract(const float* a, const float* b, float* out, size_t count,
                        hipStream_t stream);
 
@@ -267,6 +279,10 @@ namespace sara_hip {
 
   //! SARA_HIP_MARCH_MIN_PIXELS (pyramid_kernels.hip): launches below it are small.
   size_t march_min_pixels();
+  //! Largest strip-group workgroup (1, 4 or 8 waves) a marching launch of
+  //! `waves` waves may use: 8 from 4096 waves, 4 from 2048 (the launch fills the
+  //! chip anyway), else 1; SARA_HIP_STRIP_GROUP overrides it for tests.
+  int strip_group_limit(int waves);
 
   //! grad / tab are device pointers (indexed per wave, so they live in HBM
   //! rather than in the kernel argument segment).

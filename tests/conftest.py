@@ -9,6 +9,12 @@ import pytest
 # pair, hand-scheduled - under test; test_gpu_full_size.py::test_default_small_
 # launch_threshold re-runs one case in a subprocess with the shipped default.
 os.environ.setdefault("SARA_HIP_MARCH_MIN_PIXELS", "0")
+# Strip-group workgroups (8 / 4 adjacent strips under a barrier) are taken in
+# production only by launches that fill the chip (>= 4096 / 2048 waves); the
+# tests force them at every size for the same reason.  The shipped selection
+# runs in test_gpu_full_size.py::test_shipped_kernel_selection_* (fresh
+# processes without either variable).
+os.environ.setdefault("SARA_HIP_STRIP_GROUP", "8")
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -139,6 +139,7 @@ def test_shim_per_frame_call_1080p(tmp_path):
     synth(w, h, 1234).tofile(fin)
     env = dict(os.environ)
     env.pop("SARA_HIP_MARCH_MIN_PIXELS", None)   # the shipped launch rules
+    env.pop("SARA_HIP_STRIP_GROUP", None)
     res = subprocess.run([exe, str(fin), str(w), str(h), str(noct), str(fout)],
                          capture_output=True, text=True, env=env)
     assert res.returncode == 0, (res.returncode, res.stderr)

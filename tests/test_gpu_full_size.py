@@ -181,6 +181,7 @@ def test_default_small_launch_threshold(oracle, tmp_path):
         % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(out)))
     env = dict(os.environ)
     env.pop("SARA_HIP_MARCH_MIN_PIXELS", None)
+    env.pop("SARA_HIP_STRIP_GROUP", None)
     subprocess.run([sys.executable, str(script)], check=True, env=env)
     got = np.load(out)
     frames = synth_batch(640, 480, 12)
@@ -234,6 +235,7 @@ def test_single_frame_schedule_as_shipped(oracle, tmp_path):
         out = tmp_path / ("out%s.npz" % chain)
         env = dict(os.environ)
         env.pop("SARA_HIP_MARCH_MIN_PIXELS", None)   # the shipped launch rules
+        env.pop("SARA_HIP_STRIP_GROUP", None)
         subprocess.run([sys.executable, str(script), str(out)], check=True, env=env)
         got = np.load(out)
         i = 0
@@ -328,6 +330,7 @@ def test_four_threads_each_with_its_own_context_replay_graphs(oracle):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     env.pop("SARA_HIP_MARCH_MIN_PIXELS", None)   # the shipped launch rules
+    env.pop("SARA_HIP_STRIP_GROUP", None)
     per_call = {}
     for n in (1, 4):
         out = subprocess.run([sys.executable, os.path.join(root, "tools", "thread_calls.py"),
@@ -338,5 +341,57 @@ def test_four_threads_each_with_its_own_context_replay_graphs(oracle):
         per_call[n] = float(m.group(2))
     print("1080p call: %.3f ms alone, %.3f ms per call with 4 threads"
           % (per_call[1], per_call[4]))
-    assert per_call[4] <= 0.35, per_call
-    assert per_call[1] <= 0.40, per_call
+    # (the bars are the forked graph's; a graph captured from one stream -
+    # SARA_HIP_STREAMS=1, a profiling mode of tools/test_modes.sh - is a chain)
+    slack = 1.5 if os.environ.get("SARA_HIP_STREAMS") == "1" else 1.0
+    assert per_call[4] <= 0.35 * slack, per_call
+    assert per_call[1] <= 0.40 * slack, per_call
+
+
+def test_shipped_kernel_selection_at_the_benchmark_batch(oracle, tmp_path):
+    """The kernel shapes production picks for 64 x 1080p - strip groups of 8 / 4
+    / 1 by wave count, tiled blur for the small octaves - in a fresh process
+    WITHOUT the test switches of conftest.py (SARA_HIP_MARCH_MIN_PIXELS,
+    SARA_HIP_STRIP_GROUP): frames 0 and 63 against the oracle."""
+    import os
+    import subprocess
+    import sys
+    B = 64
+    script = tmp_path / "run.py"
+    out = tmp_path / "out.npz"
+    script.write_text(
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import sara_amd\n"
+        "from sara_amd.synth import synth_batch\n"
+        "frames = synth_batch(1920, 1080, %d)\n"
+        "p = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=4)\n"
+        "with sara_amd.SiftContext(1920, 1080, %d, p) as ctx:\n"
+        "    ctx.detect(frames)\n"
+        "    kc, kreg, kdesc, kso = ctx.fetch()\n"
+        "    g = {'g%%d_%%d_%%d' %% (f, s, o): ctx.gaussian(s, o, f)\n"
+        "         for f in (0, 63) for o in range(4) for s in (1, 3, 5)}\n"
+        "np.savez(%r, kc=kc, kreg=kreg.view(np.uint8), kdesc=kdesc, kso=kso, **g)\n"
+        % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), B, B,
+           str(out)))
+    env = dict(os.environ)
+    env.pop("SARA_HIP_MARCH_MIN_PIXELS", None)
+    env.pop("SARA_HIP_STRIP_GROUP", None)
+    subprocess.run([sys.executable, str(script)], check=True, env=env)
+    got = np.load(out)
+    kc = got["kc"]
+    off = np.concatenate([[0], np.cumsum(kc)]).astype(np.int64)
+    allreg = common.regions_from_bytes(got["kreg"])
+    for f in (0, 63):
+        ref = oracle.RefSift(synth(1920, 1080, 1234 + f),
+                             oracle.PyramidParams(0, 6, None, 1, 0.5, 1.6, 4))
+        for o in range(4):
+            for s in (1, 3, 5):
+                assert np.array_equal(got["g%d_%d_%d" % (f, s, o)],
+                                      ref.gaussian(s, o)), (f, s, o)
+        rk, rso, rdesc = ref.keypoints()
+        assert int(kc[f]) == len(rk)
+        sl = slice(int(off[f]), int(off[f + 1]))
+        common.assert_regions_equal(allreg[sl], rk, rtol_shape=1e-6, atol_theta=1e-6)
+        assert np.array_equal(got["kso"][sl], rso)
+        assert np.max(np.abs(got["kdesc"][sl] - rdesc)) <= 2e-3

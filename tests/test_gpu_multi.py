@@ -278,6 +278,7 @@ def _bench(*argv, timeout=900):
     env = dict(os.environ)
     env.pop("SARA_HIP_COMM_TRANSPORT", None)
     env.pop("SARA_HIP_MARCH_MIN_PIXELS", None)     # the shipped kernel selection
+    env.pop("SARA_HIP_STRIP_GROUP", None)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv),

@@ -4,6 +4,7 @@ batches, gauss_truncate, 8-bit input and the matcher).
   python tools/fuzz_more.py [n_cases] [seed] [size_factor]"""
 import os, sys
 os.environ.setdefault("SARA_HIP_MARCH_MIN_PIXELS", "0")
+os.environ.setdefault("SARA_HIP_STRIP_GROUP", "8")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 sys.path.insert(0, os.path.join(root, "tests"))

@@ -4,6 +4,7 @@ an empty pyramid, ImagePyramid.hpp:292-295) must come back empty.  python tools/
 import os, sys, faulthandler
 faulthandler.enable()
 os.environ.setdefault("SARA_HIP_MARCH_MIN_PIXELS", "0")
+os.environ.setdefault("SARA_HIP_STRIP_GROUP", "8")
 root = os.getcwd()
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np

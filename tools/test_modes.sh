@@ -3,6 +3,7 @@
 for mode in "A=1" "SARA_HIP_GRAPH=0" "SARA_HIP_STREAMS=1" "SARA_HIP_BLUR=tile" \
             "SARA_HIP_FEATURES=tile" "SARA_HIP_SIDE_GRADIENT=0" \
             "SARA_HIP_MARCH_MIN_PIXELS=4194304" "SARA_HIP_XCD_MAP=0" \
+            "SARA_HIP_STRIP_GROUP=0" "SARA_HIP_STRIP_GROUP=4" "SARA_HIP_STRIP_GROUP=1" \
             "SARA_HIP_OCTAVE_PIPELINE=0" "SARA_HIP_OCTAVE_PIPELINE=1" \
             "SARA_HIP_GRAPH=0 SARA_HIP_OCTAVE_PIPELINE=1" \
             "SARA_HIP_GRAD_TILE_PIXELS=0" "SARA_HIP_GRAD_TILE_PIXELS=100000000000" \
