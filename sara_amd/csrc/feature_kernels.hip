@@ -2612,7 +2612,7 @@ namespace sara_hip {
 #define SARA_DESC_WAVES_PER_EU 6
 #endif
 #ifndef SARA_DESC_PAD
-#define SARA_DESC_PAD 1
+#define SARA_DESC_PAD 4
 #endif
   constexpr int kDescCopies = SARA_DESC_COPIES;  // histogram replicas per wave
   // cell stride in 64-bit words; the padding moves neighbouring cells off the
@@ -2637,15 +2637,21 @@ namespace sara_hip {
   constexpr int kDescChunk = SARA_DESC_CHUNK;        // pixels per chunk (16 or 8)
   constexpr int kDescGroups = 64 / kDescChunk;       // chunks per step of a wave
   constexpr int kDescChunksPerPhase = 8;  // chunks of one row per table fill
-  constexpr int kDescTableCap = kDescRowsPerBlock * kDescChunksPerPhase;
 #ifndef SARA_DESC_AHEAD
 #define SARA_DESC_AHEAD 4
 #endif
   constexpr int kDescAhead = SARA_DESC_AHEAD;  // gathers in flight per lane
+  // The chunk list is kept as one segment per group, each followed by idle
+  // entries as far as the software pipeline looks ahead (3 * kDescAhead - 1
+  // steps past the last one): the stream needs no bounds checks
+  constexpr int kDescSegIdle = 3 * kDescAhead;
+  constexpr int kDescSeg = kDescRowsPerBlock * kDescChunksPerPhase / kDescGroups + kDescSegIdle;
+  constexpr int kDescTableCap = kDescGroups * kDescSeg;
 
   constexpr int kDescWaves = SARA_DESC_WAVES;
   //! constants of sincos_reduced_f64 (device_math.hpp), read with scalar loads
   __constant__ double g_sincos_coef[kSincosCoefCount] = SARA_SINCOS_COEF_INIT;
+
 
   __global__ __launch_bounds__(64 * kDescWaves, SARA_DESC_WAVES_PER_EU) void descriptor_kernel(
       GradPyramidView grad, CandidateLists cand, OrientationLists ori,
@@ -2881,9 +2887,15 @@ namespace sara_hip {
                     p11 = wy1 * wx1;
         const unsigned dxo = x_ok ? unsigned(kDescCellStride) : 0u;
         const unsigned dyo = y_ok ? unsigned(kDescGrid * kDescCellStride) : 0u;
-        const unsigned cell = __umul24(unsigned(yi), unsigned(kDescGrid)) + unsigned(xi);
-        const unsigned h0 =
-            __umul24(cell, unsigned(kDescCellStride)) + unsigned(copy);
+        // word index of (cell, copy) through the float pipe: yi, xi are small
+        // integers held in floats already, the two fused multiply-adds are
+        // exact, and one conversion replaces two conversions, a 64-bit
+        // multiply-add and a 24-bit multiply
+        (void) xi;
+        (void) yi;
+        const unsigned h0 = unsigned(int(__builtin_fmaf(
+            __builtin_fmaf(yif, float(kDescGrid), xif), float(kDescCellStride),
+            float(copy))));
         const unsigned ia = h0 + unsigned((oi & 7) * kDescCopies);
         const unsigned ib = h0 + unsigned(((oi + 1) & 7) * kDescCopies);
         // the eight contributions, rounded to nearest (ties up) in one block
@@ -2954,32 +2966,58 @@ namespace sara_hip {
           const int incl = wave_inclusive_scan(nch);
           const int C = __builtin_amdgcn_readlane(incl, 63);
           __builtin_amdgcn_wave_barrier();  // the previous list is consumed
+          // entry j of the list goes to segment j / per, slot j % per; an entry
+          // carries its pixel count (1..8; 0 = idle) instead of `last`.
+          // j / per as (j * M) >> 16 with M = ceil(2^16 / per): exact for
+          // j < 512, per <= 64 (the error term j e / (per 2^16) < 1 / 128 is
+          // below the smallest distance 1 / 64 of frac(j / per) from 1)
+          const int per_grp = (C + kDescGroups - 1) / kDescGroups;
+          const unsigned magic = (65536u + unsigned(per_grp) - 1u) / unsigned(max(per_grp, 1));
           for (int c = 0; c < nch; ++c)
           {
             const int u0rel = u_first - u_min + kDescChunk * (c_lo + c);
-            const int last = min(kDescChunk - 1, len - 1 - kDescChunk * (c_lo + c));
-            tab[incl - nch + c] =
-                unsigned(lane) | (unsigned(last) << 6) | (unsigned(u0rel) << 10);
+            const int cnt = min(kDescChunk, len - kDescChunk * (c_lo + c));
+            const unsigned j = unsigned(incl - nch + c);
+            const unsigned gq = (j * magic) >> 16;
+            tab[gq * kDescSeg + (j - gq * unsigned(per_grp))] =
+                unsigned(lane) | (unsigned(cnt) << 6) | (unsigned(u0rel) << 10);
+          }
+          {
+            // idle entries behind every segment (8 lanes per segment, 3 each:
+            // the segments are short of at most 7 entries in total, and the
+            // pipeline reads kDescSegIdle - 1 past the last step)
+            const int cnt_g = min(max(C - grp * per_grp, 0), per_grp);
+            static_assert(kDescChunk == 8 && kDescSegIdle + 7 <= 24, "idle cover");
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+            {
+              const int k = cnt_g + l16 + 8 * q;
+              if (k < kDescSeg)
+                tab[grp * kDescSeg + k] = 0u;
+            }
           }
           __builtin_amdgcn_wave_barrier();
           SARA_PROF_T(t_tab);
           SARA_PROF_ADD(2, t_blk, t_tab);
 
-          // ---- stream the chunks: group g takes chunk kDescGroups * step + g --
+          // ---- stream the chunks: group g walks its own segment of the list --
+          // (the g-th contiguous eighth: the chunks a wave works on at one time
+          // are then rows apart - about one histogram cell - and the eight
+          // ds_add of a step hit different cells instead of one; same-address
+          // atomics serialise.  Round 5: 1.50 -> 1.39 ms per 64 x 1080p step,
+          // SQ_WAIT_INST_LDS halved.)
           // kDescAhead stages in flight per lane.  A stage holds the chunk
           // entry it is working on, the gathered pair, and the entry fetched
           // for its next use; the loop is unrolled over the stages so that
-          // nothing is copied (a copy would wait for the gather).
-          auto fetch = [&](int step) -> unsigned {
-            const int j = kDescGroups * step + grp;
-            return j < C ? tab[j] : 0x3c0u;  // idle: last = 15 never matches
-          };
-          auto gather = [&](int step, unsigned e) -> float2 {
-            const int j = kDescGroups * step + grp;
-            const int last = int((e >> 6) & 15u);
+          // nothing is copied (a copy would wait for the gather).  Entries
+          // behind a segment's end are idle (pixel count 0): no bounds checks.
+          const unsigned* seg = tab + grp * kDescSeg;
+          auto fetch = [&](int step) -> unsigned { return seg[step]; };
+          auto gather = [&](unsigned e) -> float2 {
+            const int last = int((e >> 6) & 15u) - 1;  // idle entries: -1
             const int vv = vb + int(e & 63u);
             const int uu = u_min + int(e >> 10) + l16;
-            const bool act = (j < C) && (l16 <= last);
+            const bool act = l16 <= last;
             // Unconditional gather (idle lanes read the keypoint's own pixel):
             // with the load under a branch the compiler cannot count it and
             // waits for vmcnt(0), i.e. also for the gathers it has just issued.
@@ -2988,7 +3026,7 @@ namespace sara_hip {
                                             unsigned(rx + uu)
                                       : unsigned(center));
           };
-          const int nsteps = (C + kDescGroups - 1) / kDescGroups;
+          const int nsteps = (C + kDescGroups - 1) / kDescGroups;  // == per_grp
           unsigned ent[kDescAhead], ent_next[kDescAhead];
           float2 data[kDescAhead];
 #pragma unroll
@@ -2999,7 +3037,7 @@ namespace sara_hip {
           }
 #pragma unroll
           for (int q = 0; q < kDescAhead; ++q)
-            data[q] = gather(q, ent[q]);
+            data[q] = gather(ent[q]);
           // everything older than these gathers has landed: the compiler's
           // wait-count bookkeeping enters the loop with exactly kDescAhead
           // loads pending and can wait for vmcnt(kDescAhead - 1) per step
@@ -3012,11 +3050,11 @@ namespace sara_hip {
             {
               const int step = step0 + q;  // steps >= nsteps find idle entries
               const unsigned e = ent[q];
-              const int last = int((e >> 6) & 15u);
-              if (kDescGroups * step + grp < C && l16 <= last)
+              const int last = int((e >> 6) & 15u) - 1;
+              if (l16 <= last)
                 accumulate(u_min + int(e >> 10) + l16, vb + int(e & 63u), data[q]);
               ent[q] = ent_next[q];
-              data[q] = gather(step + kDescAhead, ent[q]);
+              data[q] = gather(ent[q]);
               ent_next[q] = fetch(step + 2 * kDescAhead);
             }
           }

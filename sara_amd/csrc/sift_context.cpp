@@ -703,6 +703,18 @@ namespace {
     return SARA_HIP_OK;
   }
 
+  //! Bytes alloc_lists() allocates per list entry (= per keypoint of capacity)
+  //! and frame.
+  size_t list_bytes_per_entry(const sara_hip_sift* c)
+  {
+    const size_t cand = 8 + 16 + 4 + 8 + 16 + 4;              // key data order skey sdata grouped
+    const size_t sites = 4 * (8 + sizeof(float) * kSiteNb);   // 4 sites per entry
+    const size_t ori = 4 + 4 * kMaxPeaks + 4 + sizeof(KeypointRecord) + sizeof(KeypointItem);
+    const size_t results = (c->has_slot1 ? 2 : 1) * (sizeof(sara_oeregion) + 8 + 512);
+    const size_t extrema = sizeof(sara_oeregion) + 20;
+    return cand + sites + ori + results + extrema;
+  }
+
   //! Frees what alloc_lists() allocated (pointers that are still null are
   //! skipped).
   void free_lists(sara_hip_sift* c)
@@ -1341,6 +1353,22 @@ sara_hip_status sara_hip_sift_reserve(sara_hip_sift* c, int max_keypoints)
     if (st)
       HIP_TRY(hipStreamSynchronize(st));
   const int old_cap = c->cap;
+  {
+    // Refuse what cannot fit BEFORE touching anything: the lists take
+    // list_bytes_per_entry() bytes per keypoint and frame (the old ones are
+    // freed first), and a request of hundreds of gigabytes that fails half-way
+    // would first have taken most of the device's memory from everybody else.
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const size_t per = list_bytes_per_entry(c) * size_t(c->max_batch);
+    const size_t have = per * size_t(old_cap);
+    const size_t want = per * size_t(max_keypoints);
+    if (want > free_b + have)
+      return fail(SARA_HIP_CAPACITY_EXCEEDED,
+                  "reserve(): not enough device memory for max_keypoints (" +
+                      std::to_string(want >> 20) + " MiB of lists, " +
+                      std::to_string((free_b + have) >> 20) + " MiB available)");
+  }
   free_lists(c);
   c->cap = max_keypoints;
   sara_hip_status st = alloc_lists(c);
