@@ -30,6 +30,7 @@
 // N x M x 128 subtract/multiply/add at VALU rate: exact float32 semantics.
 #include "sift_kernels.hpp"
 
+#include <algorithm>
 #include <cfloat>
 
 namespace sara_hip {
@@ -363,15 +364,40 @@ namespace sara_hip {
       out[rank[e]] = in[e];
   }
 
+  __global__ __launch_bounds__(256) void zero_ranges_kernel(ZeroRanges r)
+  {
+    int* p = r.p[blockIdx.y];
+    const unsigned n = r.n[blockIdx.y];
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+      p[i] = 0;
+  }
+
+  void launch_zero_ranges(const ZeroRanges& r, hipStream_t stream)
+  {
+    if (r.count == 0)
+      return;
+    unsigned longest = 0;
+    for (int k = 0; k < r.count; ++k)
+      longest = std::max(longest, r.n[k]);
+    const unsigned blocks = std::min(512u, (longest + 1023) / 1024);
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3(std::max(blocks, 1u), r.count), dim3(256),
+                       0, stream, r);
+  }
+
   void launch_finish_matches(const float* top_d0, const int* top_i0, int n1,
                              const float* top_d1, const int* top_i1, int n2,
                              int have0, int have1, float squared_ratio_thres,
                              sara_match* scratch, int* rank_scratch, int* count,
-                             sara_match* out, hipStream_t stream)
+                             sara_match* out, hipStream_t stream, bool scratch_cleared)
   {
     const int n = n1 + n2;
     const int tiles = (n + 255) / 256;
-    (void) hipMemsetAsync(rank_scratch, 0, sizeof(int) * size_t(n), stream);
+    if (!scratch_cleared)
+    {
+      ZeroRanges z;
+      z.add(rank_scratch, size_t(n));
+      launch_zero_ranges(z, stream);
+    }
     hipLaunchKernelGGL(mutual_filter_kernel, dim3(tiles), dim3(256), 0, stream,
                        top_d0, top_i0, n1, top_d1, top_i1, n2, have0, have1,
                        squared_ratio_thres, scratch, count);
@@ -543,12 +569,18 @@ namespace sara_hip {
     return 4 * (size_t(cap0) + cap1) + 16;
   }
 
+  size_t finish_radius_cleared_ints(int cap0, int cap1)
+  {
+    // ranks, twins (index + 1) and match ranks start at 0
+    return 3 * (size_t(cap0) + cap1);
+  }
+
   void launch_finish_radius_matches(const MatchNeighbour* m0, const int* c0, int cap0,
                                     const MatchNeighbour* m1, const int* c1, int cap1,
                                     const float* top_d0, int n1, const float* top_d1,
                                     int n2, float squared_ratio_thres, int* iscratch,
                                     sara_match* scratch, int* header, sara_match* out,
-                                    hipStream_t stream)
+                                    hipStream_t stream, bool scratch_cleared)
   {
     const size_t n = size_t(cap0) + cap1;
     int* rank0 = iscratch;
@@ -559,7 +591,12 @@ namespace sara_hip {
     float* score0 = reinterpret_cast<float*>(mrank + n);
     float* score1 = score0 + cap0;
     // ranks, twins (index + 1) and match ranks start at 0: one fill
-    (void) hipMemsetAsync(rank0, 0, sizeof(int) * 3 * n, stream);
+    if (!scratch_cleared)
+    {
+      ZeroRanges z;
+      z.add(rank0, finish_radius_cleared_ints(cap0, cap1));
+      launch_zero_ranges(z, stream);
+    }
     // a key has a handful of members: grids for 2 per key, strided beyond that
     const int tiles = std::max(1, std::min(int((std::max(cap0, cap1) + 255) / 256),
                                            (2 * std::max(n1, n2) + 255) / 256));

@@ -958,7 +958,7 @@ namespace sara_hip {
                          float* top12_d, int* top12_i, float* top21_d, int* top21_i,
                          MatchNeighbour* radius12, int radius12_cap, int* radius12_count,
                          MatchNeighbour* radius21, int radius21_cap, int* radius21_count,
-                         hipStream_t stream)
+                         hipStream_t stream, const ZeroRanges* also_clear)
   {
     const int tm = (n1 + kTile - 1) / kTile, tn = (n2 + kTile - 1) / kTile;
     // ---- carve the scratch
@@ -995,8 +995,16 @@ namespace sara_hip {
       (void) hipEventRecord(pev[pk++], stream);
     };
     tick();
-    (void) hipMemsetAsync(maxbits, 0, 16 * sizeof(float), stream);
-    (void) hipMemsetAsync(cnt_r, 0, sizeof(int) * (size_t(n1) + n2 + 16), stream);
+    {
+      // one launch clears what this search and - when the caller says so -
+      // its tail expect to be zero
+      ZeroRanges z;
+      if (also_clear)
+        z = *also_clear;
+      z.add(maxbits, 16);
+      z.add(cnt_r, size_t(n1) + n2 + 16);
+      launch_zero_ranges(z, stream);
+    }
     hipLaunchKernelGGL(row_norms_kernel, dim3((n1 + n2 + 63) / 64), dim3(1024), 0,
                        stream, d1, n1, d2, n2, dim, na, nb, maxbits);
     // panels of one chunk, or the distance tile + norms / thresholds (minima),

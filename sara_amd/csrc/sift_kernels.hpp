@@ -327,6 +327,27 @@ namespace sara_hip {
     int32_t index;
     float distance;
   };
+  //! Up to six int arrays cleared by ONE launch (launch_zero_ranges): the
+  //! matcher's counters, flags and rank arrays of a call.  Round 4 cleared them
+  //! with a hipMemsetAsync each, which the runtime turns into up to three fill
+  //! kernels per call site - 17 fills per match call, a fifth of its GPU time.
+  struct ZeroRanges
+  {
+    int* p[6] = {};
+    unsigned n[6] = {};  // ints
+    int count = 0;
+    void add(void* ptr, size_t ints)
+    {
+      if (ptr && ints && count < 6)
+      {
+        p[count] = static_cast<int*>(ptr);
+        n[count] = unsigned(ints);
+        ++count;
+      }
+    }
+  };
+  void launch_zero_ranges(const ZeroRanges& r, hipStream_t stream);
+
   //! (query block, candidate chunk) decomposition of an exhaustive search.
   void match_chunking(int nq, int nt, int* chunk, int* nchunks);
   //! knnSearch(3) of every row of `q` in `t` (exhaustive, FLANN's squared L2,
@@ -348,7 +369,8 @@ namespace sara_hip {
                              const float* top_d1, const int* top_i1, int n2,
                              int have0, int have1, float squared_ratio_thres,
                              sara_match* scratch, int* rank_scratch, int* count,
-                             sara_match* out, hipStream_t stream);
+                             sara_match* out, hipStream_t stream,
+                             bool scratch_cleared = false);
   //! compute_matches' tail for squared ratios > 1 on the device: the radius
   //! members of both directions (unordered triples, counts on the device, lists
   //! of cap0 / cap1 entries) -> matches ordered by (score, x, y) in `out`
@@ -361,7 +383,9 @@ namespace sara_hip {
                                     const float* top_d0, int n1, const float* top_d1,
                                     int n2, float squared_ratio_thres, int* iscratch,
                                     sara_match* scratch, int* header, sara_match* out,
-                                    hipStream_t stream);
+                                    hipStream_t stream, bool scratch_cleared = false);
+  //! The ints of `iscratch` launch_finish_radius_matches() expects to be zero.
+  size_t finish_radius_cleared_ints(int cap0, int cap1);
   //! radiusSearch of every query: neighbours with distance <
   //! top_d[top1][query] * squared_ratio_thres, appended in no particular order.
   void launch_radius_exhaustive(const float* q, int nq, const float* t, int nt,
@@ -379,7 +403,7 @@ namespace sara_hip {
                          float* top12_d, int* top12_i, float* top21_d, int* top21_i,
                          MatchNeighbour* radius12, int radius12_cap, int* radius12_count,
                          MatchNeighbour* radius21, int radius21_cap, int* radius21_count,
-                         hipStream_t stream);
+                         hipStream_t stream, const ZeroRanges* also_clear = nullptr);
 
   // ---- hand-off between the context and the RCCL gather (sift_comm.cpp) ------
   //! Device-resident results of one submit() ticket.

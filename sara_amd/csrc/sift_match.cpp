@@ -439,13 +439,21 @@ namespace {
     bool have[2] = {false, false};
   };
 
+  //! Entries of a direction's radius-member list.
+  size_t radius_list_capacity(int nq, bool have, size_t min_cap)
+  {
+    return have ? std::max<size_t>(std::max<size_t>(8 * size_t(nq), 1 << 15), min_cap)
+                : 1;
+  }
+
   //! keep_on_device: the radius members stay on the device and their counts
   //! are not read back (the caller finishes there, see
   //! launch_finish_radius_matches); r.count points at the two device counters.
   sara_hip_status device_search(Workspace& ws, const float* d1, int n1,
                                 const float* d2, int n2, int dim, float thres2,
                                 int top1, bool self_matching, DeviceSearch* out,
-                                bool keep_on_device = false, size_t min_cap = 0)
+                                bool keep_on_device = false, size_t min_cap = 0,
+                                const ZeroRanges* also_clear = nullptr)
   {
     DeviceSearch& r = *out;
     r.nq[0] = n1;
@@ -470,9 +478,7 @@ namespace {
     size_t cap[2] = {0, 0};
     if (radius_on)
       for (int dir = 0; dir < 2; ++dir)
-        cap[dir] = r.have[dir] ? std::max<size_t>(std::max<size_t>(8 * size_t(r.nq[dir]),
-                                                                    1 << 15), min_cap)
-                               : 1;
+        cap[dir] = radius_list_capacity(r.nq[dir], r.have[dir], min_cap);
     r.count = d_count;
     r.cap[0] = cap[0];
     r.cap[1] = cap[1];
@@ -482,8 +488,14 @@ namespace {
       if (radius_on)
       {
         HIPM_TRY(ws.get(Workspace::kRadius, cap[0] + cap[1], list));
-        HIPM_TRY(hipMemsetAsync(d_count, 0, 4 * sizeof(int), ws.stream));
       }
+      // everything the call expects to be zero, in one launch (the MFMA
+      // producer adds its own arrays to the same launch)
+      ZeroRanges zr;
+      if (also_clear && attempt == 0)
+        zr = *also_clear;
+      if (radius_on)
+        zr.add(d_count, 4);
       r.radius[0] = list;
       r.radius[1] = list ? list + cap[0] : nullptr;
       if (mfma)
@@ -496,9 +508,11 @@ namespace {
         launch_match_mfma(d1, n1, d2, n2, dim, thres2, top1, r.have[1] ? 1 : 0, fs,
                           is, slots, r.top_d[0], r.top_i[0], r.top_d[1], r.top_i[1],
                           r.radius[0], int(cap[0]), d_count, r.radius[1],
-                          int(cap[1]), d_count + 1, ws.stream);
+                          int(cap[1]), d_count + 1, ws.stream, &zr);
       }
       else
+      {
+        launch_zero_ranges(zr, ws.stream);
         for (int dir = 0; dir < 2; ++dir)
         {
           if (!r.have[dir])
@@ -519,6 +533,7 @@ namespace {
                                      r.radius[dir], int(cap[dir]), d_count + dir,
                                      ws.stream);
         }
+      }
       HIPM_TRY(hipGetLastError());
       if (!radius_on || keep_on_device)
         break;
@@ -714,11 +729,11 @@ sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,
     };
     for (int attempt = 0; attempt < 2; ++attempt)
     {
-      const sara_hip_status ss = device_search(ws, d1, n1, d2, n2, dim, thres2, 0, false,
-                                               &ds, true, attempt ? size_t(1) << 19 : 0);
-      if (ss != SARA_HIP_OK)
-        return ss;
-      const int cap0 = int(ds.cap[0]), cap1 = int(ds.cap[1]);
+      // the tail's buffers first: their zero-initialised parts are cleared by
+      // the same launch as the search's counters
+      const size_t min_cap = attempt ? size_t(1) << 19 : 0;
+      const int cap0 = int(radius_list_capacity(n1, n2 >= 2, min_cap));
+      const int cap1 = int(radius_list_capacity(n2, n1 >= 2, min_cap));
       const size_t total = size_t(cap0) + cap1;
       unsigned char *d_out = nullptr, *d_tmp = nullptr;
       int* d_int = nullptr;
@@ -727,13 +742,21 @@ sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,
       HIPM_TRY(ws.get(Workspace::kOut, out_bytes, d_out));
       HIPM_TRY(ws.get(Workspace::kAux3, list_bytes, d_tmp));
       HIPM_TRY(ws.get(Workspace::kFinish, finish_radius_scratch_ints(cap0, cap1), d_int));
-      HIPM_TRY(hipMemsetAsync(d_out, 0, sizeof(Header), ws.stream));
+      ZeroRanges tail;
+      tail.add(d_out, sizeof(Header) / sizeof(int));
+      tail.add(d_int, finish_radius_cleared_ints(cap0, cap1));
+      const sara_hip_status ss = device_search(ws, d1, n1, d2, n2, dim, thres2, 0, false,
+                                               &ds, true, min_cap, &tail);
+      if (ss != SARA_HIP_OK)
+        return ss;
+      if (int(ds.cap[0]) != cap0 || int(ds.cap[1]) != cap1)
+        return set_error(SARA_HIP_RUNTIME_ERROR, "radius list capacities disagree");
       launch_finish_radius_matches(ds.radius[0], ds.count, cap0, ds.radius[1],
                                    ds.count + 1, cap1, ds.top_d[0], n1, ds.top_d[1], n2,
                                    thres2, d_int, reinterpret_cast<sara_match*>(d_tmp),
                                    reinterpret_cast<int*>(d_out),
                                    reinterpret_cast<sara_match*>(d_out + sizeof(Header)),
-                                   ws.stream);
+                                   ws.stream, true);
       HIPM_TRY(hipGetLastError());
       // the header first (a few hundred bytes would do, but the list's length
       // is only known from it): header + as many records as a pair of sets
@@ -770,34 +793,45 @@ sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,
     // both attempts overflowed (more than half a million radius members per
     // direction): the host path below sizes the lists exactly
   }
-  const sara_hip_status ss =
-      device_search(ws, d1, n1, d2, n2, dim, thres2, 0, false, &ds);
+  // Ratios <= 1: only the best neighbour can pass (K = 1, AnnMatcher.cpp:131):
+  // the ratio test of both directions, the removal of (x, y) duplicates and the
+  // sort by score all run on the device; one copy brings the finished list
+  // back.  The tail's buffers exist before the search, so that ONE launch
+  // clears the counters of both.
+  struct Header1
+  {
+    int count, pad[3];
+  };
+  const int cap_dev = n1 + n2;
+  unsigned char *d_out1 = nullptr, *d_tmp1 = nullptr;
+  const size_t list_bytes1 = sizeof(sara_match) * size_t(cap_dev);
+  const size_t out_bytes1 = sizeof(Header1) + list_bytes1;
+  ZeroRanges tail1;
+  if (!(thres2 > 1.f))
+  {
+    HIPM_TRY(ws.get(Workspace::kOut, out_bytes1, d_out1));
+    HIPM_TRY(ws.get(Workspace::kAux3, list_bytes1 + sizeof(int) * size_t(cap_dev), d_tmp1));
+    tail1.add(d_out1, sizeof(Header1) / sizeof(int));
+    tail1.add(d_tmp1 + list_bytes1, size_t(cap_dev));
+  }
+  const sara_hip_status ss = device_search(ws, d1, n1, d2, n2, dim, thres2, 0, false,
+                                           &ds, false, 0, &tail1);
   if (ss != SARA_HIP_OK)
     return ss;
   lap("search");
   if (!(thres2 > 1.f))
   {
-    // Only the best neighbour can pass (K = 1, AnnMatcher.cpp:131): the ratio
-    // test of both directions, the removal of (x, y) duplicates and the sort by
-    // score all run on the device; one copy brings the finished list back.
-    struct Header
-    {
-      int count, pad[3];
-    };
-    const int cap_dev = n1 + n2;
-    unsigned char *d_out = nullptr, *d_tmp = nullptr;
-    const size_t list_bytes = sizeof(sara_match) * size_t(cap_dev);
-    const size_t out_bytes = sizeof(Header) + list_bytes;
-    HIPM_TRY(ws.get(Workspace::kOut, out_bytes, d_out));
-    HIPM_TRY(ws.get(Workspace::kAux3, list_bytes + sizeof(int) * size_t(cap_dev), d_tmp));
-    HIPM_TRY(hipMemsetAsync(d_out, 0, sizeof(Header), ws.stream));
+    using Header = Header1;
+    unsigned char *d_out = d_out1, *d_tmp = d_tmp1;
+    const size_t list_bytes = list_bytes1;
+    const size_t out_bytes = out_bytes1;
     launch_finish_matches(ds.top_d[0], ds.top_i[0], n1, ds.top_d[1], ds.top_i[1], n2,
                           ds.have[0] ? 1 : 0, ds.have[1] ? 1 : 0, thres2,
                           reinterpret_cast<sara_match*>(d_tmp),
                           reinterpret_cast<int*>(d_tmp + list_bytes),
                           reinterpret_cast<int*>(d_out),
                           reinterpret_cast<sara_match*>(d_out + sizeof(Header)),
-                          ws.stream);
+                          ws.stream, true);
     HIPM_TRY(hipGetLastError());
     void* h = nullptr;
     HIPM_TRY(ws.host(out_bytes, h));
