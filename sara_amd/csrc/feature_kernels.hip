@@ -112,30 +112,13 @@ namespace sara_hip {
   //! register ring (loop unrolled 3x), horizontal neighbours come from the
   //! adjacent lane through ds_bpermute and, at the strip edges, from one extra
   //! scalar load.  HBM traffic: 4 B read + 8 B written per pixel.
-#ifndef SARA_GRAD_WAVES_PER_EU
-#define SARA_GRAD_WAVES_PER_EU 6
-#endif
-#ifndef SARA_DEFINITENESS_SHORTCUT
-#define SARA_DEFINITENESS_SHORTCUT 1
-#endif
-#ifndef SARA_GRAD_EXP
-#define SARA_GRAD_EXP 0
-#endif
-#ifndef SARA_GRAD_ROLLED
-#define SARA_GRAD_ROLLED 0
-#endif
-#ifndef SARA_GRAD_PF
-#define SARA_GRAD_PF 2
-#endif
-#ifndef SARA_GRAD_EDGE_UNCOND
-#define SARA_GRAD_EDGE_UNCOND 0
-#endif
-#ifndef SARA_ATAN_TABLE
-#define SARA_ATAN_TABLE 2
-#endif
-  // 0: select chains, 1: 5-row table + IEEE division and sqrt, 2 (default):
-  // look-up table + the short sqrt / division sequences of device_math.hpp
-  constexpr int g_atan_table = SARA_ATAN_TABLE;
+  // Settled by the sweeps of rounds 2-4 (docs/experiments.md):
+  constexpr int kGradWavesPerEu = 6;  // 4-8 waves per SIMD: within 5 %
+  constexpr int kGradPrefetch = 2;    // rows in flight; 3-4 no faster
+  // atanf reduction: 0 select chains, 1 5-row table + IEEE division and sqrt,
+  // 2 look-up table + the short sqrt / division sequences of device_math.hpp
+  // (1.97 -> 1.85 -> 1.63 ms per step)
+  constexpr int g_atan_table = 2;
 
   //! Fills the look-up form of the atanf reduction table (device_math.hpp).
   __device__ inline void fill_atan_lut(float* lut, int tid, int nthreads)
@@ -150,7 +133,7 @@ namespace sara_hip {
     }
   }
   template <int PF>
-  __global__ __launch_bounds__(64, SARA_GRAD_WAVES_PER_EU) void gradient_polar_march_kernel(
+  __global__ __launch_bounds__(64, kGradWavesPerEu) void gradient_polar_march_kernel(
       const float* __restrict__ src, size_t src_stride,
       float* __restrict__ dst, size_t dst_stride, int w, int h, int nscales,
       int seg_rows, int nstrips, int nseg, int xcd_total,
@@ -607,7 +590,7 @@ namespace sara_hip {
       nseg = (h + seg_rows - 1) / seg_rows;
       const int total = xcd_map_enabled() ? nstrips * nseg * planes : 0;
       const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(nstrips * nseg, planes);
-      hipLaunchKernelGGL((gradient_polar_march_kernel<SARA_GRAD_PF>), grid, dim3(64), 0,
+      hipLaunchKernelGGL((gradient_polar_march_kernel<kGradPrefetch>), grid, dim3(64), 0,
                          stream, src, src_stride, dst, dst_stride, w, h, nscales,
                          seg_rows, nstrips, nseg, total, cmax, cmax_stride);
       return;
@@ -790,7 +773,6 @@ namespace sara_hip {
                         fmaxf(fabsf(m21), fabsf(m22)));
     if (scale == 0.f)
       scale = 1.f;
-#if SARA_DEFINITENESS_SHORTCUT
     // The answer is the sign of an extreme eigenvalue as the float solver
     // computes it.  The solver is backward stable: its eigenvalues of the
     // scaled matrix (largest |coefficient| = 1) are off by a few tens of
@@ -814,7 +796,6 @@ namespace sara_hip {
       if (!positive_definite3(a00, a10, a11, a20, a21, a22, sg, delta))
         return true;   // an eigenvalue is beyond delta on the wrong side
     }
-#endif
     m00 /= scale;
     m10 /= scale;
     m11 /= scale;
@@ -1238,9 +1219,7 @@ namespace sara_hip {
     __builtin_amdgcn_wave_barrier();
   }
 
-#ifndef SARA_EXTREMA_WAVES_PER_EU
-#define SARA_EXTREMA_WAVES_PER_EU 4
-#endif
+  constexpr int kExtremaWavesPerEu = 4;  // 112 VGPRs: the register ring of 5 DoG layers
   //! NW: waves per workgroup = adjacent strips of the same rows, kept within a
   //! dozen rows of each other by a barrier.  A row segment of 128 columns starts
   //! anywhere in a cache line, so neighbouring strips share the line at their
@@ -1249,7 +1228,7 @@ namespace sara_hip {
   //! 4.23 GB of planes; launched together but unsynchronised: no change; with
   //! the barrier 4.38 GB, the kernel 1 % faster).
   template <int ND, int PF, int NW>
-  __global__ __launch_bounds__(64 * NW, SARA_EXTREMA_WAVES_PER_EU) void extrema_march_kernel(
+  __global__ __launch_bounds__(64 * NW, kExtremaWavesPerEu) void extrema_march_kernel(
       OctaveView gauss, int octave, ExtremaParams p, SiteLists sites,
       int seg_rows, int nstrips, int nseg, int xcd_total)
   {
@@ -1984,12 +1963,6 @@ namespace sara_hip {
   //! 4 / 2 / 1 waves per group; the orientation kernel shares its weight
   //! tables in LDS across the group and prefers 4 (round 4, same box: 0.75 /
   //! 0.81 / 0.89 ms with 4 / 2 / 1, 0.81 with 8).
-#ifndef SARA_ORI_WAVES
-#define SARA_ORI_WAVES 4
-#endif
-#ifndef SARA_DESC_WAVES
-#define SARA_DESC_WAVES 1
-#endif
 
   //! Inclusive prefix sum over the 64 lanes (DPP row shifts, then the row
   //! broadcasts of gfx9: 6 steps, no LDS).
@@ -2029,20 +2002,13 @@ namespace sara_hip {
   //! global memory each look-up is a vector load that shares the in-order
   //! vmcnt counter with the gathers: waiting for a weight then also waits for
   //! every gather issued ahead of it, which defeats the prefetch ring below.
-    constexpr int kOriWaves = SARA_ORI_WAVES;
-#ifndef SARA_ORI_AHEAD
-#define SARA_ORI_AHEAD 2
-#endif
-#ifndef SARA_ORI_GROUP
-#define SARA_ORI_GROUP 2
-#endif
-  constexpr int kOriGroup = SARA_ORI_GROUP;  // chunks sorted and replayed together
-  static_assert(SARA_ORI_GROUP % SARA_ORI_AHEAD == 0, "ring slots are static");
-#ifndef SARA_ORI_BLOCKS_PER_EU
-#define SARA_ORI_BLOCKS_PER_EU 1
-#endif
+  constexpr int kOriWaves = 4;       // waves per workgroup (2: 0.73 -> 0.74 ms)
+  constexpr int kOriBlocksPerEu = 1;
+  constexpr int kOriGroup = 2;  // chunks sorted and replayed together (4 / 6 / 8: 1.02 / 1.02 / 1.22 ms vs 0.92)
+  constexpr int kOriAheadRing = 2;  // gathers in flight per lane (4 / 6 / 8 slower)
+  static_assert(kOriGroup % kOriAheadRing == 0, "ring slots are static");
   template <bool WLDS>
-  __global__ __launch_bounds__(64 * kOriWaves, SARA_ORI_BLOCKS_PER_EU) void orientation_kernel(
+  __global__ __launch_bounds__(64 * kOriWaves, kOriBlocksPerEu) void orientation_kernel(
       const GradPyramidView* __restrict__ gradp,
       const ScaleTable* __restrict__ tabp, const double* __restrict__ weights,
       int n_weights, CandidateLists cand, OrientationLists ori, int xcd_run)
@@ -2167,7 +2133,7 @@ namespace sara_hip {
     // a ring of kOriAhead chunks (64 pixels each) of unconditional gathers runs
     // ahead of the histogram work.  (u, v) of this lane's pixel advances by 64
     // pixels per chunk, once on the issue side and once on the consumer side.
-    constexpr int kOriAhead = SARA_ORI_AHEAD;
+    constexpr int kOriAhead = kOriAheadRing;
     auto advance = [&](int& u_, int& v_) {
       u_ += du64;
       v_ += dv64;
@@ -2605,42 +2571,24 @@ namespace sara_hip {
   // one chunk each per step: no per-row lockstep, equal work for the groups,
   // and a software pipeline that runs across row boundaries (chunk entry read
   // three steps ahead, gather issued two steps ahead).
-#ifndef SARA_DESC_COPIES
-#define SARA_DESC_COPIES 4
-#endif
-#ifndef SARA_DESC_WAVES_PER_EU
-#define SARA_DESC_WAVES_PER_EU 6
-#endif
-#ifndef SARA_DESC_PAD
-#define SARA_DESC_PAD 4
-#endif
-  constexpr int kDescCopies = SARA_DESC_COPIES;  // histogram replicas per wave
-  // cell stride in 64-bit words; the padding moves neighbouring cells off the
-  // same LDS bank
-#ifndef SARA_DESC_FX32
-#define SARA_DESC_FX32 1
-#endif
-  // SARA_DESC_FX32: 32-bit accumulators on a 5 x 5 cell grid.  The fifth row
-  // and column are dump cells: the dx / dy = 1 neighbours of cells 3 always
-  // exist, so the eight addresses of a sample are two registers plus
-  // immediates and the weights need no selects; the fixed-point scale is
-  // chosen per keypoint so that no bin can overflow (see fx_scale).
-  constexpr bool kDescFx32 = SARA_DESC_FX32 != 0;
-  constexpr int kDescGrid = kDescFx32 ? 5 : 4;  // cells per row of the LDS grid
-  constexpr int kDescCellStride = 8 * kDescCopies + SARA_DESC_PAD;
+  constexpr int kDescCopies = 4;  // histogram replicas per wave (2: +0.6 ms; 8 do not fit)
+  // 32-bit fixed-point accumulators on a 5 x 5 cell grid.  The fifth row and
+  // column are dump cells: the dx / dy = 1 neighbours of cells 3 always exist,
+  // so the eight addresses of a sample are two registers plus immediates and
+  // the weights need no selects; the fixed-point scale is chosen per keypoint
+  // so that no bin can overflow (see fx_scale).  (Round 2a: 64-bit
+  // accumulators on 4 x 4 cells, 2.04 vs 1.60 ms; in git history.)
+  constexpr int kDescGrid = 5;  // cells per row of the LDS grid
+  // pad 4: a neighbouring cell starts four banks on (0 / 1 / 3 / 4 / 5 / 7 words:
+  // 1.396 / 1.412 / 1.386 / 1.376 / 1.389 / 1.400 ms per step)
+  constexpr int kDescCellStride = 8 * kDescCopies + 4;
   constexpr int kDescHistWords = kDescGrid * kDescGrid * kDescCellStride;
-  using desc_acc_t = std::conditional_t<kDescFx32, int, unsigned long long>;
+  using desc_acc_t = int;
   constexpr int kDescRowsPerBlock = 64;   // one row per lane
-#ifndef SARA_DESC_CHUNK
-#define SARA_DESC_CHUNK 8
-#endif
-  constexpr int kDescChunk = SARA_DESC_CHUNK;        // pixels per chunk (16 or 8)
+  constexpr int kDescChunk = 8;        // pixels per chunk (16: 1.60 vs 1.53 ms)
   constexpr int kDescGroups = 64 / kDescChunk;       // chunks per step of a wave
   constexpr int kDescChunksPerPhase = 8;  // chunks of one row per table fill
-#ifndef SARA_DESC_AHEAD
-#define SARA_DESC_AHEAD 4
-#endif
-  constexpr int kDescAhead = SARA_DESC_AHEAD;  // gathers in flight per lane
+  constexpr int kDescAhead = 4;  // gathers in flight per lane (2 / 6 / 8: slower)
   // The chunk list is kept as one segment per group, each followed by idle
   // entries as far as the software pipeline looks ahead (3 * kDescAhead - 1
   // steps past the last one): the stream needs no bounds checks
@@ -2648,12 +2596,13 @@ namespace sara_hip {
   constexpr int kDescSeg = kDescRowsPerBlock * kDescChunksPerPhase / kDescGroups + kDescSegIdle;
   constexpr int kDescTableCap = kDescGroups * kDescSeg;
 
-  constexpr int kDescWaves = SARA_DESC_WAVES;
+  constexpr int kDescWaves = 1;       // waves per workgroup (2 / 4: 2.45 / 2.67 vs 2.36 ms)
+  constexpr int kDescWavesPerEu = 6;  // 7 / 8: no change (round 5)
   //! constants of sincos_reduced_f64 (device_math.hpp), read with scalar loads
   __constant__ double g_sincos_coef[kSincosCoefCount] = SARA_SINCOS_COEF_INIT;
 
 
-  __global__ __launch_bounds__(64 * kDescWaves, SARA_DESC_WAVES_PER_EU) void descriptor_kernel(
+  __global__ __launch_bounds__(64 * kDescWaves, kDescWavesPerEu) void descriptor_kernel(
       GradPyramidView grad, CandidateLists cand, OrientationLists ori,
       sara_oeregion* __restrict__ features, int32_t* __restrict__ scale_octave,
       float* __restrict__ descriptors, int with_descriptors, int root_sift,
@@ -2733,9 +2682,7 @@ namespace sara_hip {
     // Fixed-point scale of the accumulation.  Every contribution is bounded by
     // |wy*wx*wo*weight*mag| < 2*2*1*1*max(mag); max(mag) over a superset of
     // the patch comes from the coarse 16x16 magnitude maxima written by the
-    // gradient kernel.  64-bit accumulators: with max(mag) < 2^e the products
-    // scaled by 2^(25-e) stay below 2^29 and convert to int32 with one
-    // rounding of 2^-(26-e).  32-bit accumulators: see below.
+    // gradient kernel.
     float fx_scale = 1.f;
     double fx_inv = 1.;
     if (with_descriptors)
@@ -2752,33 +2699,21 @@ namespace sara_hip {
       // magnitudes are >= 0: their bit patterns order like the floats
       mxb = unsigned(wave_max_dpp(int(mxb)));
       const float mx = __uint_as_float(mxb);
-      int e = 0;
-      (void) frexpf(mx, &e);  // mx < 2^e
-      if (!(mx > 0.f) || !(mx < 3.0e38f))
-        e = 0;
-      if (kDescFx32)
-      {
-        // 32-bit accumulators: the scale is as large as the worst case allows.
-        // A bin collects the samples whose patch coordinates (px, py) lie in a
-        // 2 x 2 cell box.  Each of its four cell-sized quadrants (side l
-        // pixels) holds at most (l + 2)^2 pixels (area + perimeter / 2 + 1 of
-        // a convex region), and |wy wx| <= 4, 2, 2, 1 there (the weights
-        // exceed 1 only where modf() hands out a negative fraction, for
-        // coordinates in (-1, 0)); wo <= 1, weight <= 1, mag <= mx.  Hence
-        // sum |contribution| <= 9 (l + 2)^2 mx scale, kept below 2^31.
-        const float bound = 9.f * (l + 2.f) * (l + 2.f);
-        if (mx > 0.f && mx < 3.0e38f)
-          fx_scale = (2147483648.f * 0.999f) / (bound * mx);
-        // a scale outside the normal range (absurd magnitudes) falls back to 1
-        if (!(fx_scale > 1e-30f && fx_scale < 1e30f))
-          fx_scale = 1.f;
-        fx_inv = 1. / double(fx_scale);
-      }
-      else
-      {
-        fx_scale = ldexpf(1.f, 25 - e);
-        fx_inv = ldexp(1., e - 25);
-      }
+      // 32-bit accumulators: the scale is as large as the worst case allows.
+      // A bin collects the samples whose patch coordinates (px, py) lie in a
+      // 2 x 2 cell box.  Each of its four cell-sized quadrants (side l
+      // pixels) holds at most (l + 2)^2 pixels (area + perimeter / 2 + 1 of
+      // a convex region), and |wy wx| <= 4, 2, 2, 1 there (the weights
+      // exceed 1 only where modf() hands out a negative fraction, for
+      // coordinates in (-1, 0)); wo <= 1, weight <= 1, mag <= mx.  Hence
+      // sum |contribution| <= 9 (l + 2)^2 mx scale, kept below 2^31.
+      const float bound = 9.f * (l + 2.f) * (l + 2.f);
+      if (mx > 0.f && mx < 3.0e38f)
+        fx_scale = (2147483648.f * 0.999f) / (bound * mx);
+      // a scale outside the normal range (absurd magnitudes) falls back to 1
+      if (!(fx_scale > 1e-30f && fx_scale < 1e30f))
+        fx_scale = 1.f;
+      fx_inv = 1. / double(fx_scale);
     }
 
     SARA_PROF_T(t_setup);
@@ -2804,21 +2739,13 @@ namespace sara_hip {
       if (!with_descriptors)
         return;
 
-      if (kDescFx32)
       {
         // 16 bytes per lane and store (the array is padded to a multiple of 4)
         int4* h4 = reinterpret_cast<int4*>(hist);
-#pragma unroll
+  #pragma unroll
         for (int q = 0; q < (kDescHistWords + 255) / 256; ++q)
           if (q * 64 + lane < (kDescHistWords + 3) / 4)
             h4[q * 64 + lane] = make_int4(0, 0, 0, 0);
-      }
-      else
-      {
-#pragma unroll
-        for (int q = 0; q < (kDescHistWords + 63) / 64; ++q)
-          if (q * 64 + lane < kDescHistWords)
-            hist[q * 64 + lane] = desc_acc_t(0);
       }
 
       SARA_PROF_T(t_zero);
@@ -2877,16 +2804,14 @@ namespace sara_hip {
         const float xfrac = px - xif, yfrac = py - yif, ofrac = a - oif;
         const int xi = int(xif), yi = int(yif), oi = int(oif);
         const float w1 = ofrac * wm, w0 = wm - w1;
-        // xi, yi are in 0..3 (p in (-1, 4), truncation): the dx / dy = 1
-        // neighbours exist when xi / yi < 3; otherwise their weight is zeroed
-        // and their address falls back on the dx / dy = 0 cell
-        const bool x_ok = kDescFx32 || xi < 3, y_ok = kDescFx32 || yi < 3;
-        const float wx1 = x_ok ? xfrac : 0.f, wy1 = y_ok ? yfrac : 0.f;
+        // xi, yi are in 0..3 (p in (-1, 4), truncation): on the 5 x 5 grid the
+        // dx / dy = 1 neighbours always exist (dump row / column)
+        const float wx1 = xfrac, wy1 = yfrac;
         const float wy0 = 1.f - yfrac, wx0 = 1.f - xfrac;
         const float p00 = wy0 * wx0, p01 = wy0 * wx1, p10 = wy1 * wx0,
                     p11 = wy1 * wx1;
-        const unsigned dxo = x_ok ? unsigned(kDescCellStride) : 0u;
-        const unsigned dyo = y_ok ? unsigned(kDescGrid * kDescCellStride) : 0u;
+        const unsigned dxo = unsigned(kDescCellStride);
+        const unsigned dyo = unsigned(kDescGrid * kDescCellStride);
         // word index of (cell, copy) through the float pipe: yi, xi are small
         // integers held in floats already, the two fused multiply-adds are
         // exact, and one conversion replaces two conversions, a 64-bit
@@ -2909,7 +2834,7 @@ namespace sara_hip {
             : "v"(p00 * w0), "v"(p00 * w1), "v"(p01 * w0), "v"(p01 * w1),
               "v"(p10 * w0), "v"(p10 * w1), "v"(p11 * w0), "v"(p11 * w1));
 #define SARA_DESC_ADD(i, val)                                                  \
-  atomicAdd(&hist[i], desc_acc_t(kDescFx32 ? (long long) (val) : (long long) (val)))
+  atomicAdd(&hist[i], desc_acc_t(val))
         SARA_DESC_ADD(ia, c0);
         SARA_DESC_ADD(ib, c1);
         SARA_DESC_ADD(ia + dxo, c2);
@@ -3081,7 +3006,6 @@ namespace sara_hip {
         const desc_acc_t* q0 = hist + (cy * kDescGrid + cx) * kDescCellStride +
                                (lane & 7) * kDescCopies;
         const desc_acc_t* q1 = q0 + 2 * kDescGrid * kDescCellStride;
-        if (kDescFx32)
         {
           long long s0 = 0, s1 = 0;
 #pragma unroll
@@ -3092,15 +3016,6 @@ namespace sara_hip {
           }
           a0 = double(s0) * fx_inv;
           a1 = double(s1) * fx_inv;
-        }
-        else
-        {
-#pragma unroll
-          for (int c = 0; c < kDescCopies; ++c)
-          {
-            a0 += double((long long) q0[c]) * fx_inv;
-            a1 += double((long long) q1[c]) * fx_inv;
-          }
         }
       }
       float h0 = float(a0), h1 = float(a1);
