@@ -7,8 +7,10 @@
 // exhaustive kernels compute all n1 x n2 x 128 subtract/multiply/add triples
 // in FLANN's order on the vector ALUs.  Here the n1 x n2 squared distances are
 // first APPROXIMATED as |a|^2 + |b|^2 - 2 a.b with the dot products on the
-// matrix cores (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulation,
-// one contraction for both matching directions), with a rigorous bound E on
+// matrix cores (round 5: v_mfma_f32_32x32x16_bf16 on a hi / lo split of the
+// rows, three products per pair, f32 accumulation; rounds 3-4:
+// v_mfma_f32_32x32x2_f32; one contraction for both matching directions), with
+// a rigorous bound E on
 // |approximation - true distance|; only the few candidates per query that the
 // bound cannot exclude are then evaluated in FLANN's exact arithmetic.  The
 // results (top-3 lists, radius members) are therefore the SAME floats and
@@ -19,7 +21,19 @@
 //   |a|^2, |b|^2 summed in float32          <= 1.01 (dim + 1) u s
 //   dot product, any order of dim fma/adds  <= 1.01 dim u |a||b| <= .. dim u s / 2 * 2
 //   the two final additions                 <= 4 u s
-// => |approx - d| <= E := kGuard (2 dim + 8) u (|a|^2 + max_j |b_j|^2), and
+// => |approx - d| <= E := kGuard (2 dim + 8) u (|a|^2 + max_j |b_j|^2) for the
+// f32 contraction of rounds 3-4.  Round 5 contracts on the bf16 matrix cores
+// (16 x the f32 MFMA rate) with a split representation x = hi + lo + e,
+// hi = bf16(x), lo = bf16(x - hi), |e| <= 2^-16 |x| (|x - hi| <= 2^-8 |x|,
+// |lo| <= 2^-8 (1 + 2^-8) |x|), and three products per pair:
+//   a.b ~ sum hi hi + hi lo + lo hi      (bf16 x bf16 is exact in float32)
+//   dropped: |lo lo| + |e_a b| + |a e_b| <= 3.03 2^-16 |a_i||b_i| per term
+//   float32 accumulation of 3 dim terms  <= 1.01 (3 dim) u sum |terms|
+//                                        <= 1.02 (3 dim) u |a||b|
+//   |a||b| <= s / 2, and the approximation uses 2 a.b:
+// => |approx - d| <= E := kGuard ((4.1 dim + 8) u + 3.03 2^-16) s, about four
+// times the f32 bound (for SIFT rows: 40 squared-distance units at distances of
+// 10^4..10^5) - the candidate lists grow by a few per cent.  And
 // FLANN's float32 distance d_f = d (1 + theta), |theta| <= (dim + 4) u.
 // A candidate list built as { j : approx(j) <= tau } with
 //   tau = m3 + |m3| 1e-4 + 2.01 E        (m3: third smallest approximation)
@@ -55,13 +69,32 @@ namespace sara_hip {
   namespace {
     constexpr int kTile = 128;         // rows and columns of a macro tile
     constexpr int kChunk = 64;         // k staged per chunk
-    constexpr int kPanelStride = 68;   // floats per staged row (16-byte aligned)
     constexpr int kQueue = 3072;       // LDS queue of the emit pass, in hits
     constexpr int kDStride = 129;      // floats per row of the distance tile
     constexpr float kGuard = 1.25f;    // slack on the error bound
     constexpr int kFallbackSlots = 128;  // flagged queries whose distances are staged
     constexpr int kFallbackParts = 8;    // workgroups per staged query
     constexpr float kUnit = 5.9604645e-8f;  // 2^-24
+    // bf16 panels: 64 k of a row = 128 bytes, rows 144 bytes apart (the 16-byte
+    // fragment reads of 16 consecutive rows then fall on distinct banks)
+    constexpr int kPanelBytes = 144;
+    constexpr int kMaxDimPadded = 128;  // dim <= 128 (sara_hip_sift.h), padded to 64
+    //! E / (|a|^2 + max |b|^2), see the header of this file.
+    __host__ __device__ inline float guard_coeff(int dim)
+    {
+      return kGuard * ((4.1f * float(dim) + 8.f) * kUnit + 3.03f / 65536.f);
+    }
+    using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+    //! Round to nearest even; finite inputs.
+    __device__ inline unsigned short to_bf16(float v)
+    {
+      const unsigned u = __float_as_uint(v);
+      return (unsigned short) ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+    __device__ inline float from_bf16(unsigned short h)
+    {
+      return __uint_as_float(unsigned(h) << 16);
+    }
 
     using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -111,7 +144,8 @@ namespace sara_hip {
     __global__ __launch_bounds__(1024) void row_norms_kernel(
         const float* __restrict__ x1, int n1, const float* __restrict__ x2, int n2,
         int dim, float* __restrict__ norms1, float* __restrict__ norms2,
-        unsigned* __restrict__ max_bits)
+        unsigned* __restrict__ max_bits, unsigned short* __restrict__ split1,
+        unsigned short* __restrict__ split2, int dimp)
     {
       const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;  // row of both
       const int sub = threadIdx.x & 15;
@@ -125,6 +159,17 @@ namespace sara_hip {
         const float* r = x + size_t(i) * dim;
         for (int k = sub; k < dim; k += 16)
           s += r[k] * r[k];
+        // the row as hi / lo bf16 halves (hi: [i][0..dimp), lo: the same array
+        // n rows further), zero-padded to dimp
+        unsigned short* hi = (second ? split2 : split1) + size_t(i) * dimp;
+        unsigned short* lo = hi + size_t(n) * dimp;
+        for (int k = sub; k < dimp; k += 16)
+        {
+          const float v = k < dim ? r[k] : 0.f;
+          const unsigned short h = to_bf16(v);
+          hi[k] = h;
+          lo[k] = to_bf16(v - from_bf16(h));
+        }
       }
       for (int o = 8; o > 0; o >>= 1)
         s += __shfl_xor(s, o);
@@ -189,23 +234,19 @@ namespace sara_hip {
     //! One 128 x 128 tile of approximate squared distances between rows
     //! [row0, row0 + 128) of A and [col0, col0 + 128) of B.  256 threads = 4
     //! waves, each a 64 x 64 quadrant = 2 x 2 MFMA blocks of 32 x 32.
-    //! The contraction runs in chunks of 64 k: both operand panels of a chunk
-    //! take 68 KB of LDS, so two workgroups share a CU (with the whole k range
-    //! staged at once - 133 KB - it is one).  Measured per pass over 4.3 k x
-    //! 4.3 k keys (timing builds with a phase removed): contraction alone 40 us (78 % of the
-    //! f32 MFMA peak), staging alone 23, minima epilogue alone 16 - and 80
-    //! together: co-resident workgroups fall into step (the contraction is the
-    //! longest phase and the one they share a unit for), so the phases add up;
-    //! a persistent variant that started every second workgroup of a CU a
-    //! staging phase late changed nothing.  What would: prefetching the next
-    //! chunk's panels into registers under the contraction.
-    //! Inside a chunk row the k are stored even ones first, odd ones second:
-    //! the 32 x 32 x 2 instruction wants k = 2 s + (lane >> 5) in lane, so each
-    //! half of the wave reads ITS 32 values of a row as 8 x ds_read_b128.
+    //! The contraction runs in chunks of 64 k: the hi / lo panels of both
+    //! operands take 72 KB of LDS, so two workgroups share a CU.  Per pass over
+    //! 4.3 k x 4.3 k keys: 42 us (minima) / 54 us (emit) - with the f32
+    //! instruction of rounds 3-4 80 us each, of which the contraction alone was
+    //! 40 (timing builds with a phase removed: staging 23, minima epilogue 16;
+    //! co-resident workgroups fall into step, so the phases add up).  The bf16
+    //! contraction is 12 MFMA per 16 k and quadrant at 16 x the f32 rate: what
+    //! is left is staging and the epilogue.
     template <int MODE>
     __global__ __launch_bounds__(256, 2) void mfma_tiles_kernel(
-        const float* __restrict__ A, int n1, const float* __restrict__ B, int n2,
-        int dim, const float* __restrict__ na, const float* __restrict__ nb,
+        const unsigned short* __restrict__ Ah, int n1,
+        const unsigned short* __restrict__ Bh, int n2, int dimp,
+        const float* __restrict__ na, const float* __restrict__ nb,
         // MINIMA: [tiles along the other axis][n][3]
         float* __restrict__ rowmin, float* __restrict__ colmin,
         // EMIT
@@ -216,104 +257,80 @@ namespace sara_hip {
     {
       extern __shared__ __attribute__((aligned(16))) float lds[];
       const int with_cols = with_cols_and_debug & 1;
-      float* sA = lds;
-      float* sB = lds + kTile * kPanelStride;
+      // hi / lo panels of A and B for one chunk of 64 k (bf16, rows kPanelBytes apart)
+      unsigned char* sAh = reinterpret_cast<unsigned char*>(lds);
+      unsigned char* sAl = sAh + kTile * kPanelBytes;
+      unsigned char* sBh = sAl + kTile * kPanelBytes;
+      unsigned char* sBl = sBh + kTile * kPanelBytes;
+      const unsigned short* Al = Ah + size_t(n1) * dimp;
+      const unsigned short* Bl = Bh + size_t(n2) * dimp;
       const int tid = threadIdx.x;
       const int row0 = blockIdx.y * kTile, col0 = blockIdx.x * kTile;
       const int lane = tid & 63, wave = tid >> 6;
       const int wm = wave >> 1, wn = wave & 1;
       const int li = lane & 31, half = lane >> 5;
-      const bool vec4 = (dim % 4 == 0) &&
-                        ((reinterpret_cast<uintptr_t>(A) |
-                          reinterpret_cast<uintptr_t>(B)) % 16 == 0);
       f32x16 acc00 = {}, acc01 = {}, acc10 = {}, acc11 = {};
 
-      for (int k0 = 0; k0 < dim; k0 += kChunk)
+      for (int k0 = 0; k0 < dimp; k0 += kChunk)
       {
         if (k0 > 0)
           __syncthreads();  // the previous chunk's panels have been consumed
-        // ---- stage the two panels of this chunk (zero-padded) ----------------
-        if (vec4)
+        // ---- stage the four panels of this chunk: 128 rows x 8 pieces of 16
+        // bytes each, 4 pieces per thread and panel, every load in flight
+        // before the first LDS write (rows past the end: zeros)
+        uint4 v[16];
+        const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
         {
-          // 16 float4 per row and panel, 8 per thread: every load is in flight
-          // before the first LDS write
-          float4 va[8], vb[8];
-#pragma unroll
-          for (int it = 0; it < 8; ++it)
-          {
-            const int idx = tid + it * 256, r = idx >> 4, c = idx & 15;
-            const int k = k0 + 4 * c;
-            va[it] = (row0 + r < n1 && k < dim)
-                         ? *reinterpret_cast<const float4*>(A + size_t(row0 + r) * dim + k)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-#pragma unroll
-          for (int it = 0; it < 8; ++it)
-          {
-            const int idx = tid + it * 256, r = idx >> 4, c = idx & 15;
-            const int k = k0 + 4 * c;
-            vb[it] = (col0 + r < n2 && k < dim)
-                         ? *reinterpret_cast<const float4*>(B + size_t(col0 + r) * dim + k)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-#pragma unroll
-          for (int it = 0; it < 8; ++it)
-          {
-            const int idx = tid + it * 256, r = idx >> 4, c = idx & 15;
-            // k = 4 c .. 4 c + 3 -> even ones at 2 c, 2 c + 1, odd ones 32 further
-            float* pa = sA + r * kPanelStride + 2 * c;
-            *reinterpret_cast<float2*>(pa) = make_float2(va[it].x, va[it].z);
-            *reinterpret_cast<float2*>(pa + 32) = make_float2(va[it].y, va[it].w);
-            float* pb = sB + r * kPanelStride + 2 * c;
-            *reinterpret_cast<float2*>(pb) = make_float2(vb[it].x, vb[it].z);
-            *reinterpret_cast<float2*>(pb + 32) = make_float2(vb[it].y, vb[it].w);
-          }
+          const int idx = tid + it * 256, r = idx >> 3, c = idx & 7;
+          const size_t oa = size_t(row0 + r) * dimp + k0 + 8 * c;
+          const size_t ob = size_t(col0 + r) * dimp + k0 + 8 * c;
+          const bool ra = row0 + r < n1, rb = col0 + r < n2;
+          v[it] = ra ? *reinterpret_cast<const uint4*>(Ah + oa) : zero;
+          v[4 + it] = ra ? *reinterpret_cast<const uint4*>(Al + oa) : zero;
+          v[8 + it] = rb ? *reinterpret_cast<const uint4*>(Bh + ob) : zero;
+          v[12 + it] = rb ? *reinterpret_cast<const uint4*>(Bl + ob) : zero;
         }
-        else
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
         {
-          for (int idx = tid; idx < kTile * kChunk; idx += 256)
-          {
-            const int r = idx / kChunk, kl = idx - r * kChunk;
-            const int k = k0 + kl, pos = (kl >> 1) + 32 * (kl & 1);
-            sA[r * kPanelStride + pos] =
-                (row0 + r < n1 && k < dim) ? A[size_t(row0 + r) * dim + k] : 0.f;
-            sB[r * kPanelStride + pos] =
-                (col0 + r < n2 && k < dim) ? B[size_t(col0 + r) * dim + k] : 0.f;
-          }
+          const int idx = tid + it * 256, r = idx >> 3, c = idx & 7;
+          const int o = r * kPanelBytes + 16 * c;
+          *reinterpret_cast<uint4*>(sAh + o) = v[it];
+          *reinterpret_cast<uint4*>(sAl + o) = v[4 + it];
+          *reinterpret_cast<uint4*>(sBh + o) = v[8 + it];
+          *reinterpret_cast<uint4*>(sBl + o) = v[12 + it];
         }
         __syncthreads();
 
-        // ---- the contraction over this chunk: 32 steps of two k -----------------
-        const float4* qa0 = reinterpret_cast<const float4*>(
-            sA + (wm * 64 + li) * kPanelStride + 32 * half);
-        const float4* qa1 = reinterpret_cast<const float4*>(
-            sA + (wm * 64 + 32 + li) * kPanelStride + 32 * half);
-        const float4* qb0 = reinterpret_cast<const float4*>(
-            sB + (wn * 64 + li) * kPanelStride + 32 * half);
-        const float4* qb1 = reinterpret_cast<const float4*>(
-            sB + (wn * 64 + 32 + li) * kPanelStride + 32 * half);
-        float4 a0 = qa0[0], a1 = qa1[0], b0 = qb0[0], b1 = qb1[0];
+        // ---- the contraction over this chunk: 4 steps of 16 k, three products
+        // each (hi hi, hi lo, lo hi).  A lane supplies row / column (lane & 31)
+        // and the 8 k of its half of the step; A and B use the same k, which
+        // is all a dot product needs.
+        const int ra0 = (wm * 64 + li) * kPanelBytes, ra1 = ra0 + 32 * kPanelBytes;
+        const int rb0 = (wn * 64 + li) * kPanelBytes, rb1 = rb0 + 32 * kPanelBytes;
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < 4; ++t)
         {
-          // operands of the next four steps are requested before this group's
-          // sixteen instructions go to the matrix cores
-          const int tn = t < 7 ? t + 1 : 7;
-          const float4 na0 = qa0[tn], na1 = qa1[tn], nb0 = qb0[tn], nb1 = qb1[tn];
-#define SARA_MFMA_STEP(c)                                                      \
-  acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b0.c, acc00, 0, 0, 0);     \
-  acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b1.c, acc01, 0, 0, 0);     \
-  acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b0.c, acc10, 0, 0, 0);     \
-  acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b1.c, acc11, 0, 0, 0);
-          SARA_MFMA_STEP(x)
-          SARA_MFMA_STEP(y)
-          SARA_MFMA_STEP(z)
-          SARA_MFMA_STEP(w)
-#undef SARA_MFMA_STEP
-          a0 = na0;
-          a1 = na1;
-          b0 = nb0;
-          b1 = nb1;
+          const int ko = 2 * (16 * t + 8 * half);
+          const bf16x8 a0h = *reinterpret_cast<const bf16x8*>(sAh + ra0 + ko);
+          const bf16x8 a1h = *reinterpret_cast<const bf16x8*>(sAh + ra1 + ko);
+          const bf16x8 a0l = *reinterpret_cast<const bf16x8*>(sAl + ra0 + ko);
+          const bf16x8 a1l = *reinterpret_cast<const bf16x8*>(sAl + ra1 + ko);
+          const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(sBh + rb0 + ko);
+          const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(sBh + rb1 + ko);
+          const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(sBl + rb0 + ko);
+          const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(sBl + rb1 + ko);
+#define SARA_MFMA_BF16(x, y)                                                   \
+  acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0##x, b0##y, acc00, 0, 0, 0); \
+  acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0##x, b1##y, acc01, 0, 0, 0); \
+  acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1##x, b0##y, acc10, 0, 0, 0); \
+  acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1##x, b1##y, acc11, 0, 0, 0);
+          SARA_MFMA_BF16(h, h)
+          SARA_MFMA_BF16(h, l)
+          SARA_MFMA_BF16(l, h)
+#undef SARA_MFMA_BF16
         }
       }
       __syncthreads();  // the panels are dead: their LDS is reused below
@@ -545,8 +562,7 @@ namespace sara_hip {
         min3_update(p[1], m1, m2, m3);
         min3_update(p[2], m1, m2, m3);
       }
-      const float e = kGuard * float(2 * dim + 8) * kUnit *
-                      (norms[i] + __uint_as_float(*other_max_bits));
+      const float e = guard_coeff(dim) * (norms[i] + __uint_as_float(*other_max_bits));
       // fewer than three candidates: everything passes
       float t = m3 >= FLT_MAX ? FLT_MAX : m3 + fabsf(m3) * 1e-4f + 2.01f * e;
       if (squared_ratio_thres > 1.f && t < FLT_MAX)
@@ -607,8 +623,7 @@ namespace sara_hip {
       }
       if (!live)
         return;
-      const float e = kGuard * float(2 * dim + 8) * kUnit *
-                      (norms[i] + __uint_as_float(*other_max_bits));
+      const float e = guard_coeff(dim) * (norms[i] + __uint_as_float(*other_max_bits));
       int tau_key = kNoKey - 1;  // fewer than three candidates: everything passes
       if (m3 != INT_MAX)
       {
@@ -938,7 +953,8 @@ namespace sara_hip {
     const size_t tm = (size_t(n1) + kTile - 1) / kTile, tn = (size_t(n2) + kTile - 1) / kTile;
     // norms (n1 + n2 + 2), tau (n1 + n2), row minima [tn][n1][3], column minima [tm][n2][3]
     return 2 * (size_t(n1) + n2) + 16 + 4 * (tn * n1 + tm * n2) + 8 +
-           2 * size_t(kFallbackSlots) * size_t(std::max(n1, n2));  // staged distances
+           2 * size_t(kFallbackSlots) * size_t(std::max(n1, n2)) +  // staged distances
+           8 + (size_t(n1) + n2) * kMaxDimPadded;  // hi / lo bf16 rows (2 x 2 bytes per k)
   }
 
   size_t match_mfma_scratch_ints(int n1, int n2, int cap)
@@ -972,6 +988,12 @@ namespace sara_hip {
     rowmin += (4 - ((rowmin - fscratch) & 3)) & 3;
     float* colmin = rowmin + 4 * size_t(tn) * n1;
     float* staged = colmin + 4 * size_t(tm) * n2;  // [kFallbackSlots][max(n1, n2)]
+    // the keys as bf16 hi / lo rows, zero-padded to dimp: [hi n x dimp][lo n x dimp]
+    const int dimp = (dim + kChunk - 1) / kChunk * kChunk;
+    float* split_f = staged + 2 * size_t(kFallbackSlots) * size_t(std::max(n1, n2));
+    split_f += (4 - ((split_f - fscratch) & 3)) & 3;  // 16-byte aligned
+    unsigned short* split1 = reinterpret_cast<unsigned short*>(split_f);
+    unsigned short* split2 = split1 + 2 * size_t(n1) * dimp;
     int* cnt_r = iscratch;
     int* cnt_c = cnt_r + n1;
     int* scal = cnt_c + n2;  // [0] flagged rows, [1] flagged columns
@@ -1006,14 +1028,14 @@ namespace sara_hip {
       launch_zero_ranges(z, stream);
     }
     hipLaunchKernelGGL(row_norms_kernel, dim3((n1 + n2 + 63) / 64), dim3(1024), 0,
-                       stream, d1, n1, d2, n2, dim, na, nb, maxbits);
+                       stream, d1, n1, d2, n2, dim, na, nb, maxbits, split1, split2, dimp);
     // panels of one chunk, or the distance tile + norms / thresholds (minima),
     // or the hit queue in front of the norms / thresholds (emit: the queue must
     // end before the norm arrays start at kTile * kDStride floats)
     static_assert(1 + kQueue <= kTile * kDStride, "the queue overlaps the norms");
     tick();  // 1: memsets + norms
-    const size_t lds = sizeof(float) * std::max(2 * kTile * kPanelStride,
-                                                kTile * kDStride + 4 * kTile);
+    const size_t lds = std::max(size_t(4) * kTile * kPanelBytes,
+                                sizeof(float) * (kTile * kDStride + 4 * kTile));
     allow_big_lds<kMinima>(mfma_tiles_kernel<kMinima>);
     allow_big_lds<kEmit>(mfma_tiles_kernel<kEmit>);
     const dim3 grid(tn, tm);
@@ -1033,8 +1055,8 @@ namespace sara_hip {
     if (one_pass)
     {
       allow_big_lds<kPacked>(mfma_tiles_kernel<kPacked>);
-      hipLaunchKernelGGL(mfma_tiles_kernel<kPacked>, grid, dim3(256), lds, stream, d1,
-                         n1, d2, n2, dim, na, nb, rowmin, colmin, nullptr, nullptr,
+      hipLaunchKernelGGL(mfma_tiles_kernel<kPacked>, grid, dim3(256), lds, stream, split1,
+                         n1, split2, n2, dimp, na, nb, rowmin, colmin, nullptr, nullptr,
                          nullptr, nullptr, nullptr, nullptr, cap, cols_arg);
       tick();  // 2: minima
       hipLaunchKernelGGL(select_packed_kernel, dim3((n1 + 15) / 16), dim3(256), 0,
@@ -1049,8 +1071,8 @@ namespace sara_hip {
     }
     else
     {
-    hipLaunchKernelGGL(mfma_tiles_kernel<kMinima>, grid, dim3(256), lds, stream, d1,
-                       n1, d2, n2, dim, na, nb, rowmin, colmin, nullptr, nullptr,
+    hipLaunchKernelGGL(mfma_tiles_kernel<kMinima>, grid, dim3(256), lds, stream, split1,
+                       n1, split2, n2, dimp, na, nb, rowmin, colmin, nullptr, nullptr,
                        nullptr, nullptr, nullptr, nullptr, cap, cols_arg);
     tick();  // 2: minima
     {
@@ -1062,8 +1084,8 @@ namespace sara_hip {
                          dim3(256), 0, stream, ta, dim, squared_ratio_thres, top1);
     }
     tick();  // 3: thresholds
-    hipLaunchKernelGGL(mfma_tiles_kernel<kEmit>, grid, dim3(256), lds, stream, d1, n1,
-                       d2, n2, dim, na, nb, nullptr, nullptr, tau_r, tau_c, cand_r,
+    hipLaunchKernelGGL(mfma_tiles_kernel<kEmit>, grid, dim3(256), lds, stream, split1, n1,
+                       split2, n2, dimp, na, nb, nullptr, nullptr, tau_r, tau_c, cand_r,
                        cnt_r, cand_c, cnt_c, cap, cols_arg);
     tick();  // 4: emit
     }
