@@ -425,21 +425,23 @@ def match_config(torch, dev):
     # exact arithmetic of the exhaustive search: n1*n2*128 (sub, mul, add) per
     # direction; the prefilter path does one n1*n2*128 f32 MFMA contraction
     out["pair_distance_terms"] = 2 * n1 * n2 * 128
-    # one pass over the n1 x n2 tiles = 2 n1 n2 128 flop on the matrix cores
-    # (ratios <= 1: one pass; the radius search of ratios > 1: two), against the
-    # f32 MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md (157.3 TF)
-    flop = 2.0 * n1 * n2 * 128
+    # one pass over the n1 x n2 tiles = three bf16 products per pair of keys
+    # (hi hi + hi lo + lo hi of the split rows) = 3 * 2 n1 n2 128 flop on the
+    # matrix cores (ratios <= 1: one pass; the radius search of ratios > 1: two),
+    # against the dense bf16 MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md
+    flop = 3 * 2.0 * n1 * n2 * 128
     out["mfma_flop_per_pass"] = flop
     out["mfma_passes"] = {"ratio_0.6": 1, "ratio_1.2_default": 2}
     out["default_ratio_tail"] = ("ranks, scores, (x, y) duplicates of the two "
                                  "directions and the final order on the device; one "
                                  "read-back of the finished list")
-    out["mfma_time_at_peak_us_per_pass"] = flop / 157.3e12 * 1e6
-    out["producer"] = ("MFMA prefilter (v_mfma_f32_32x32x2_f32, both directions from "
-                       "one contraction, rigorous error guard; tile minima carry "
-                       "their position, so ratios <= 1 need one pass) + exact "
-                       "FLANN-order re-ranking; identical lists to the exhaustive "
-                       "search")
+    out["mfma_time_at_peak_us_per_pass"] = flop / 2.5e15 * 1e6
+    out["producer"] = ("MFMA prefilter (v_mfma_f32_32x32x16_bf16 on a hi / lo bf16 "
+                       "split of the rows, both directions from one contraction, "
+                       "rigorous error guard; tile minima carry their position, so "
+                       "ratios <= 1 need one pass; a pass is staging- and "
+                       "epilogue-bound, not MFMA-bound) + exact FLANN-order "
+                       "re-ranking; identical lists to the exhaustive search")
     return out
 
 
