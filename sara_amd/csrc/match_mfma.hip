@@ -85,11 +85,15 @@ namespace sara_hip {
       return kGuard * ((4.1f * float(dim) + 8.f) * kUnit + 3.03f / 65536.f);
     }
     using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-    //! Round to nearest even; finite inputs.
+    //! Round to nearest even; a finite input that would round up to infinity
+    //! takes the largest finite bf16 instead (|v - hi| <= 2^-8 |v| still holds).
     __device__ inline unsigned short to_bf16(float v)
     {
       const unsigned u = __float_as_uint(v);
-      return (unsigned short) ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+      unsigned short h = (unsigned short) ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+      if ((h & 0x7fffu) == 0x7f80u && (u & 0x7fffffffu) < 0x7f800000u)
+        h = (unsigned short) (h - 1u);
+      return h;
     }
     __device__ inline float from_bf16(unsigned short h)
     {
