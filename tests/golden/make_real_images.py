@@ -10,6 +10,9 @@ tests/golden/real/, so that the GPU box depends on no TIFF / JPEG decoder:
   sift_edge.jpg                a 319 x 67 strip of straight edges (on_edge, plateaus)
   ksmall.jpg, dog.jpg          JPEG photographs (8 x 8 block structure, saturation)
   stinkbug.png                 a PNG photograph with a flat saturated background
+  image-pinhole.png, image-omni.png
+                               two real 1920 x 1080 camera frames (pinhole and
+                               fisheye): the benchmark's frame size on real input
 
 Expected outputs come from the CPU oracle (oracle/sift_ref.hpp, pinned by the
 reference's unit tests) with two parameter sets:
@@ -45,7 +48,7 @@ import refbind as rb  # noqa: E402
 
 DATA = "/root/reference/data"
 IMAGES = ("All.tif", "GuardOnBlonde.tif", "sift_edge.jpg", "ksmall.jpg",
-          "dog.jpg", "stinkbug.png")
+          "dog.jpg", "stinkbug.png", "image-pinhole.png", "image-omni.png")
 PAIR = ("All", "GuardOnBlonde")
 RATIOS = (0.6, 1.0, 1.2)
 

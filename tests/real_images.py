@@ -7,7 +7,8 @@ import numpy as np
 
 from common import GOLDEN
 
-NAMES = ("All", "GuardOnBlonde", "sift_edge", "ksmall", "dog", "stinkbug")
+NAMES = ("All", "GuardOnBlonde", "sift_edge", "ksmall", "dog", "stinkbug",
+         "image-pinhole", "image-omni")
 TAGS = ("default", "bench")
 PAIR = ("All", "GuardOnBlonde")
 RATIOS = (0.6, 1.0, 1.2)
