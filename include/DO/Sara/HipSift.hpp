@@ -320,25 +320,42 @@ namespace DO::Sara {
   // matrix ROW-major - the reference's own transposition quirk, harmless for
   // the symmetric matrices it stores.
   namespace hip_detail {
+    //! Eigen's operator<< with the default IOFormat (Eigen/src/Core/IO.h):
+    //! ONE width for the whole expression = the widest coefficient as the
+    //! stream would print it, every coefficient right-aligned to it, " "
+    //! between columns, "\n" between rows.  `v` is column-major (Eigen's
+    //! default storage).  The reference's own examples/Sara/Features/
+    //! test.dogkey holds 578 such 2 x 2 blocks (tests/test_keypoint_text_pins.py).
     template <typename T>
-    inline void print_eigen_row(std::ostream& os, const T* v, int n)
+    inline void print_eigen_block(std::ostream& os, const T* v, int rows,
+                                  int cols)
     {
       std::size_t width = 0;
-      for (int i = 0; i < n; ++i)
+      for (int i = 0; i < rows * cols; ++i)
       {
         std::stringstream sstr;
         sstr.copyfmt(os);
         sstr << v[i];
         width = std::max(width, sstr.str().length());
       }
-      for (int i = 0; i < n; ++i)
+      for (int r = 0; r < rows; ++r)
       {
-        if (i)
-          os << " ";
-        if (width)
-          os.width(std::streamsize(width));
-        os << v[i];
+        if (r)
+          os << "\n";
+        for (int c = 0; c < cols; ++c)
+        {
+          if (c)
+            os << " ";
+          if (width)
+            os.width(std::streamsize(width));
+          os << v[c * rows + r];
+        }
       }
+    }
+    template <typename T>
+    inline void print_eigen_row(std::ostream& os, const T* v, int n)
+    {
+      print_eigen_block(os, v, 1, n);
     }
   }  // namespace hip_detail
 

@@ -889,12 +889,23 @@ def _ostream_float(v):
     return "%g" % float(np.float32(v))
 
 
-def _eigen_row(values):
-    """Eigen's operator<< for a row expression (Eigen/src/Core/IO.h, default
-    IOFormat): every coefficient right-aligned to the widest one."""
+def _eigen_block(values, rows, cols):
+    """Eigen's operator<< with the default IOFormat (Eigen/src/Core/IO.h): one
+    width for the whole expression = the widest coefficient, every coefficient
+    right-aligned to it, " " between columns, newline between rows.  ``values``
+    in column-major (storage) order.  Pinned on the 578 2 x 2 blocks of the
+    reference's examples/Sara/Features/test.dogkey
+    (tests/test_keypoint_text_pins.py)."""
     txt = [_ostream_float(v) for v in values]
     width = max((len(t) for t in txt), default=0)
-    return " ".join(t.rjust(width) for t in txt)
+    return "\n".join(" ".join(txt[c * rows + r].rjust(width)
+                              for c in range(cols)) for r in range(rows))
+
+
+def _eigen_row(values):
+    """A row expression through Eigen's operator<<."""
+    values = list(values)
+    return _eigen_block(values, 1, len(values))
 
 
 class H5File:
