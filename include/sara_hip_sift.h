@@ -153,6 +153,43 @@ SARA_HIP_API sara_hip_status sara_hip_pyramid_octave_info(
 SARA_HIP_API int sara_hip_make_gaussian_kernel(float sigma, float gauss_truncate,
                                               float* taps, int capacity);
 
+/* The same under a named arithmetic for the two operations of that function    */
+/* which are not single IEEE operations - Eigen's array exp() and sum()          */
+/* (LinearFiltering.hpp:196-200).  Which one the reference evaluates depends on  */
+/* how it was built; tests/golden/sensitivity.json holds what the choice does    */
+/* to the keypoints (about 3 in 10 000 change).             */
+enum
+{
+  SARA_HIP_TAPS_LIBM_SERIAL = 0, /* expf() per tap, left-to-right sum: a scalar  */
+                                 /* (EIGEN_DONT_VECTORIZE / non-SSE) build; the   */
+                                 /* default of every context                      */
+  SARA_HIP_TAPS_EIGEN34_SSE2 = 1,/* Eigen 3.4, x86-64 baseline (the reference's   */
+                                 /* Release flags): the first 4*(n/4) taps through*/
+                                 /* pexp<Packet4f> (Cephes reduction, degree-5    */
+                                 /* polynomial, no FMA), the n%4 trailing ones    */
+                                 /* through expf; sum() = two Packet4f            */
+                                 /* accumulators, (a0+a2)+(a1+a3), scalar tail    */
+  SARA_HIP_TAPS_EIGEN33_SSE2 = 2 /* the same with Eigen 3.3's Horner-form pexp    */
+};
+/* Values of SARA_HIP_OPT_KERNEL_SELECTION. */
+enum
+{
+  SARA_HIP_SELECT_ENVIRONMENT = 0, /* what the SARA_HIP_* variables of the       */
+                                   /* process ask for;    */
+                                   /* none set = SHIPPED.  Default of a context  */
+  SARA_HIP_SELECT_SHIPPED = 1,     /* the production thresholds, whatever the    */
+                                   /* environment says                           */
+  SARA_HIP_SELECT_FORCED_MARCH = 2,/* marching kernels + 8-strip groups at every */
+                                   /* launch size (small test images then run    */
+                                   /* the kernels big batches run)               */
+  SARA_HIP_SELECT_TILED = 3,       /* LDS-tiled blur, pixel-parallel gradient /  */
+                                   /* scan everywhere                            */
+  SARA_HIP_SELECT_TILED_BLUR = 4   /* LDS-tiled blur only                        */
+};
+SARA_HIP_API int sara_hip_make_gaussian_kernel_with(int arithmetic, float sigma,
+                                                   float gauss_truncate,
+                                                   float* taps, int capacity);
+
 /* -------------------------------------------------------------------------- */
 /* Whole-pipeline context == compute_sift_keypoints over a batch of frames.    */
 /* All device buffers are owned by the context and sized at creation.          */
@@ -370,6 +407,24 @@ enum
                                         /* of the Gaussian-pyramid stage, read by  */
                                         /* sara_hip_sift_pyramid_launches();       */
                                         /* ignored under HIP-graph replay          */
+  SARA_HIP_OPT_KERNEL_SELECTION = 10,   /* SARA_HIP_SELECT_*: which kernels the  */
+                                        /* context's launches take.  Results do */
+                                        /* not depend on it (every selection is */
+                                        /* bit-identical: tests); speed does    */
+  SARA_HIP_OPT_TILE_GEOMETRY = 11,      /* LDS tile of the tiled blur kernel:    */
+                                        /* 0 by tile count (default), 1 = 64x32 */
+                                        /* / 512 threads, 2 = 64x16 / 256,       */
+                                        /* 3 = 32x16 / 128 (BASELINE config 5's  */
+                                        /* tile-size sweep, bench.py)            */
+  SARA_HIP_OPT_MARCH_WAVES = 12,        /* target waves per marching blur launch */
+                                        /* (0 = shipped: 4096 / 2048); the other */
+                                        /* axis of that sweep                    */
+  SARA_HIP_OPT_TAP_ARITHMETIC = 9,      /* SARA_HIP_TAPS_*: the arithmetic of    */
+                                        /* make_gaussian_kernel's exp() / sum()  */
+                                        /* (default SARA_HIP_TAPS_LIBM_SERIAL).  */
+                                        /* Kernels with unequal mirrored taps    */
+                                        /* (the Eigen models give some) run on   */
+                                        /* the general marching kernel           */
   SARA_HIP_OPT_FMA_BLUR = 6             /* 1: the Gaussian blurs fuse multiply   */
                                         /* and add (v_fma_f32): half the         */
                                         /* arithmetic, pyramids within 3e-7 of   */

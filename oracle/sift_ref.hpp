@@ -25,8 +25,11 @@
 //     both are compared with round 1's stand-ins (Sylvester minors in double,
 //     left-to-right sum) site by site / row by row, see DESIGN.md section 2.
 //     Still at the last-ulp level only: make_gaussian_kernel's packet exp()
-//     and sum() (restated with libm expf and a left-to-right sum; the
-//     reference's own test accepts 1e-5 there).
+//     and sum().  Round 6: the arithmetic is a selectable variant
+//     (tap_variant(): expf + serial sum, the Eigen 3.4 / 3.3 SSE2 models,
+//     one-ulp perturbations) and tests/golden/sensitivity.json holds what each
+//     variant does to the keypoints of the real-image pack and of 64 synthetic
+//     1080p frames (the reference's own test accepts 1e-5 on the taps).
 // ========================================================================== //
 #pragma once
 
@@ -256,12 +259,158 @@ namespace sara_ref {
     }
   }
 
-  //! ImageProcessing/LinearFiltering.hpp:171-203.  Eigen's packet exp() and
-  //! vectorised sum() are restated with expf and a left-to-right sum
-  //! (last-ulp "parity unpinned", see header).
+  // ------------------------------------------------------------------------ //
+  // make_gaussian_kernel and the arithmetic the reference's build gives it.
+  //
+  // ImageProcessing/LinearFiltering.hpp:171-203 is three Eigen expressions:
+  //   kernel = LinSpaced(n, 0, n - 1);                    (exact integers)
+  //   kernel.array() = (-(kernel.array() - c).square() / (2 sigma^2)).exp();
+  //   kernel /= kernel.sum();
+  // Everything but exp() and sum() is a correctly rounded IEEE operation on the
+  // same operands whatever the evaluation path.  exp() and sum() are not: in
+  // the reference's Release build (x86-64 baseline => SSE2, Packet4f; Eigen
+  // 3.4.0 on the CI image) the dense assignment loop
+  // (AssignEvaluator.h, LinearVectorizedTraversal) sends the first 4*(n/4) taps
+  // through pexp<Packet4f> = pexp_float (GenericPacketMathFunctions.h: the
+  // Cephes range reduction with a degree-5 polynomial) and the n % 4 trailing
+  // ones through the scalar functor, i.e. libm's expf; sum() goes through
+  // redux_impl<LinearVectorizedTraversal, NoUnrolling> (Redux.h): two Packet4f
+  // accumulators over even / odd packets, acc0 + acc1, one more packet when
+  // their number is odd, predux = (a0 + a2) + (a1 + a3), then the scalar tail.
+  //
+  // No Eigen on this image => none of this can be compiled against the real
+  // thing: PARITY UNPINNED.  The oracle therefore offers the arithmetic as a
+  // selectable VARIANT and tests/golden/make_sensitivity.py measures what each
+  // choice does to the keypoints (tests/golden/sensitivity.json, DESIGN.md
+  // section 5): the distance oracle -> reference gets a number instead of an
+  // assumption.
+  //   kTapsExpfSerial   expf + left-to-right sum (rounds 1-5; the default the
+  //                     product's host code shares)
+  //   kTapsEigen34Sse   the model above, Eigen 3.4.0's pexp_float written from
+  //                     the published algorithm
+  //   kTapsEigen33Sse   the same with Eigen 3.3's pexp (plain Horner form)
+  //   kTapsUlp*         the default taps moved by one ulp each: seeded random
+  //                     signs (-1 / 0 / +1), all up, all down, alternating,
+  //                     centre up + tails down ("narrow") and its opposite -
+  //                     envelopes of what ANY exp()/sum() within 1 ulp per tap
+  //                     could do.
+  // ------------------------------------------------------------------------ //
+  enum
+  {
+    kTapsExpfSerial = 0,
+    kTapsEigen34Sse = 1,
+    kTapsEigen33Sse = 2,
+    kTapsUlpRandom = 3,
+    kTapsUlpPlus = 4,
+    kTapsUlpMinus = 5,
+    kTapsUlpAlternate = 6,
+    kTapsUlpNarrow = 7,
+    kTapsUlpWide = 8,
+    kTapsVariantCount = 9
+  };
+  struct TapVariant
+  {
+    int kind = kTapsExpfSerial;
+    std::uint32_t seed = 0;
+  };
+  inline TapVariant& tap_variant()
+  {
+    static TapVariant v;
+    return v;
+  }
+
+  //! Eigen 3.4.0 pexp_float (GenericPacketMathFunctions.h), one lane of it,
+  //! without FMA (pmadd = multiply, round, add, round on SSE2).  pldexp_generic
+  //! multiplies by exact powers of two: exact for the normal results here.
+  inline float eigen34_pexp_lane(float x0)
+  {
+    const float x = std::max(std::min(x0, 88.723f), -88.723f);
+    const float m = std::floor(x * 1.44269504088896341f + 0.5f);
+    float r = m * -0.693359375f + x;
+    r = m * 2.12194440e-4f + r;
+    const float r2 = r * r;
+    const float r3 = r2 * r;
+    float y = 1.9875691500E-4f * r + 1.3981999507E-3f;
+    float y1 = 4.1665795894E-2f * r + 1.6666665459E-1f;
+    const float y2 = r + 1.0f;
+    y = y * r + 8.3334519073E-3f;
+    y1 = y1 * r + 5.0000001201E-1f;
+    y = y * r3 + y1;
+    y = y * r2 + y2;
+    return std::max(std::ldexp(y, int(m)), x0);
+  }
+
+  //! Eigen 3.3 pexp<Packet4f> (arch/SSE/MathFunctions.h): same reduction,
+  //! Horner evaluation, y = (P(r) r^2 + r) + 1.
+  inline float eigen33_pexp_lane(float x0)
+  {
+    float x = std::max(std::min(x0, 88.3762626647950f), -88.3762626647949f);
+    const float fx = std::floor(x * 1.44269504088896341f + 0.5f);
+    const float tmp = fx * 0.693359375f;
+    float z = fx * -2.12194440e-4f;
+    x = x - tmp;
+    x = x - z;
+    z = x * x;
+    float y = 1.9875691500E-4f;
+    y = y * x + 1.3981999507E-3f;
+    y = y * x + 8.3334519073E-3f;
+    y = y * x + 4.1665795894E-2f;
+    y = y * x + 1.6666665459E-1f;
+    y = y * x + 5.0000001201E-1f;
+    y = y * z + x;
+    y = y + 1.0f;
+    return std::max(std::ldexp(y, int(fx)), x0);
+  }
+
+  //! VectorXf::sum() through redux_impl<LinearVectorizedTraversal,
+  //! NoUnrolling> with Packet4f (Redux.h; the data of a dynamic vector is
+  //! 16-byte aligned, so the packets start at coefficient 0).
+  inline float eigen_sum_sse(const float* v, int n)
+  {
+    const int aligned = (n / 4) * 4, aligned2 = (n / 8) * 8;
+    if (aligned == 0)
+    {
+      float res = v[0];
+      for (int i = 1; i < n; ++i)
+        res = res + v[i];
+      return res;
+    }
+    float a0[4] = {v[0], v[1], v[2], v[3]};
+    if (aligned > 4)
+    {
+      float a1[4] = {v[4], v[5], v[6], v[7]};
+      for (int i = 8; i < aligned2; i += 8)
+        for (int j = 0; j < 4; ++j)
+        {
+          a0[j] = a0[j] + v[i + j];
+          a1[j] = a1[j] + v[i + 4 + j];
+        }
+      for (int j = 0; j < 4; ++j)
+        a0[j] = a0[j] + a1[j];
+      if (aligned > aligned2)
+        for (int j = 0; j < 4; ++j)
+          a0[j] = a0[j] + v[aligned2 + j];
+    }
+    float res = (a0[0] + a0[2]) + (a0[1] + a0[3]);
+    for (int i = aligned; i < n; ++i)
+      res = res + v[i];
+    return res;
+  }
+
+  //! One ulp up (+1) or down (-1) of a positive finite float.
+  inline float step_ulp(float v, int dir)
+  {
+    if (dir == 0)
+      return v;
+    return std::nextafter(v, dir > 0 ? std::numeric_limits<float>::infinity()
+                                     : -std::numeric_limits<float>::infinity());
+  }
+
+  //! ImageProcessing/LinearFiltering.hpp:171-203 under tap_variant().
   inline std::vector<float> make_gaussian_kernel(float sigma,
                                                  float gauss_truncate = 4.f)
   {
+    const TapVariant variant = tap_variant();
     int kernel_size = int(2 * gauss_truncate * sigma + 1);
     kernel_size = std::max(3, kernel_size);
     if (kernel_size % 2 == 0)
@@ -269,16 +418,59 @@ namespace sara_ref {
     const int c = kernel_size / 2;
     std::vector<float> kernel(kernel_size);
     const float denom = 2 * (sigma * sigma);
+    const bool eigen = variant.kind == kTapsEigen34Sse ||
+                       variant.kind == kTapsEigen33Sse;
+    const int packets_end = eigen ? (kernel_size / 4) * 4 : 0;
     for (int i = 0; i < kernel_size; ++i)
     {
       const float d = float(i) - float(c);
-      kernel[i] = std::exp(-(d * d) / denom);
+      const float x = -(d * d) / denom;
+      if (i < packets_end)
+        kernel[i] = variant.kind == kTapsEigen34Sse ? eigen34_pexp_lane(x)
+                                                    : eigen33_pexp_lane(x);
+      else
+        kernel[i] = std::exp(x);
     }
     float sum = 0.f;
-    for (int i = 0; i < kernel_size; ++i)
-      sum += kernel[i];
+    if (eigen)
+      sum = eigen_sum_sse(kernel.data(), kernel_size);
+    else
+      for (int i = 0; i < kernel_size; ++i)
+        sum += kernel[i];
     for (int i = 0; i < kernel_size; ++i)
       kernel[i] /= sum;
+
+    if (variant.kind >= kTapsUlpRandom && variant.kind <= kTapsUlpWide)
+    {
+      std::uint32_t sigma_bits;
+      std::memcpy(&sigma_bits, &sigma, sizeof(sigma_bits));
+      for (int i = 0; i < kernel_size; ++i)
+      {
+        int dir = 0;
+        switch (variant.kind)
+        {
+        case kTapsUlpRandom:
+        {
+          // SplitMix64 of (seed, sigma, tap): the same sigma gets the same
+          // taps in every octave, as any deterministic exp() would give
+          std::uint64_t z = (std::uint64_t(variant.seed) << 32 | sigma_bits) +
+                            0x9E3779B97F4A7C15ull * std::uint64_t(i + 1);
+          z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+          z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+          z ^= z >> 31;
+          dir = int(z % 3) - 1;
+          break;
+        }
+        case kTapsUlpPlus: dir = 1; break;
+        case kTapsUlpMinus: dir = -1; break;
+        case kTapsUlpAlternate: dir = (i & 1) ? 1 : -1; break;
+        case kTapsUlpNarrow: dir = (i == c) ? 1 : -1; break;
+        case kTapsUlpWide: dir = (i == c) ? -1 : 1; break;
+        default: break;
+        }
+        kernel[i] = step_ulp(kernel[i], dir);
+      }
+    }
     return kernel;
   }
 

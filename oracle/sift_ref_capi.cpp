@@ -72,6 +72,23 @@ void ref_convolve_array(float* signal, const float* kernel, int signal_size,
   convolve_array(signal, kernel, signal_size, kernel_size);
 }
 
+//! Arithmetic variant of make_gaussian_kernel (sift_ref.hpp: kTaps*), applied
+//! by every later call of this library; returns the previous kind.
+int ref_set_tap_variant(int kind, unsigned seed)
+{
+  const int before = tap_variant().kind;
+  if (kind >= 0 && kind < kTapsVariantCount)
+  {
+    tap_variant().kind = kind;
+    tap_variant().seed = seed;
+  }
+  return before;
+}
+
+float ref_eigen34_pexp(float x) { return eigen34_pexp_lane(x); }
+float ref_eigen33_pexp(float x) { return eigen33_pexp_lane(x); }
+float ref_eigen_sum_sse(const float* v, int n) { return eigen_sum_sse(v, n); }
+
 int ref_make_gaussian_kernel(float sigma, float gauss_truncate, float* out,
                              int capacity)
 {

@@ -136,6 +136,28 @@ def descriptors(keys):
     return keys.descriptor_matrix
 
 
+#: Options (capi.OPT_* -> value) every NEW SiftContext gets right after it is
+#: created - also the contexts the free functions and ComputeDoGExtrema build
+#: and cache (the cache key includes them).  E.g. the parity tests run the
+#: real-image pack under {capi.OPT_KERNEL_SELECTION: capi.SELECT_SHIPPED} and
+#: ..._FORCED_MARCH in one process.  ``with sara_amd.default_options({...})``.
+DEFAULT_OPTIONS = {}
+
+
+class default_options:
+    def __init__(self, options):
+        self.options = dict(options)
+
+    def __enter__(self):
+        self.before = dict(DEFAULT_OPTIONS)
+        DEFAULT_OPTIONS.update(self.options)
+        return self
+
+    def __exit__(self, *exc):
+        DEFAULT_OPTIONS.clear()
+        DEFAULT_OPTIONS.update(self.before)
+
+
 class SiftContext:
     """Batched compute_sift_keypoints with all stages resident in HBM.
 
@@ -170,6 +192,8 @@ class SiftContext:
         self.max_batch = max_batch
         self.batch = 0
         self._keepalive = None
+        for option, value in sorted(DEFAULT_OPTIONS.items()):
+            self.set_option(option, value)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -633,7 +657,8 @@ def _cached_context(w, h, params, gauss_truncate, extremum_thres,
            s.scale_count_per_octave, s.scale_geometric_factor,
            s.image_padding_size, s.scale_camera, s.scale_initial,
            s.num_octaves_max, float(gauss_truncate), float(extremum_thres),
-           float(edge_ratio_thres), int(extremum_refinement_iter))
+           float(edge_ratio_thres), int(extremum_refinement_iter),
+           tuple(sorted(DEFAULT_OPTIONS.items())))
     cache = _CONTEXTS.entries
     for i, (k, ctx) in enumerate(cache):
         if k == key:
@@ -670,17 +695,26 @@ class ComputeDoGExtrema:
         self._args = (gauss_truncate, extremum_thres, edge_ratio_thres,
                       img_padding_sz, extremum_refinement_iter, device)
         self._ctx = None
+        self._ctx_key = None
 
     def __call__(self, image):
         """-> (regions, scale_octave pairs [N,2])."""
         img = np.ascontiguousarray(image, dtype=np.float32)
         h, w = img.shape
         gt, et, er, pad, it, dev = self._args
-        if self._ctx is None or (self._ctx.max_width, self._ctx.max_height) != (w, h):
+        # the reference builds its pyramids from the functor's members on every
+        # call (DoG.cpp:23-45): a params member changed between two calls counts
+        s = self.params._s
+        key = (w, h, s.first_octave_index, s.scale_count_per_octave,
+               s.scale_geometric_factor, s.image_padding_size, s.scale_camera,
+               s.scale_initial, s.num_octaves_max,
+               tuple(sorted(DEFAULT_OPTIONS.items())))
+        if self._ctx is None or self._ctx_key != key:
             if self._ctx is not None:
                 self._ctx.close()
             self._ctx = SiftContext(w, h, 1, self.params, gt, et, er,
                                     dog_args=(pad, it), device=dev)
+            self._ctx_key = key
         # no capacity in the reference (RefineExtremum.cpp:496-514): grow and
         # run again when a frame overflows the lists
         for _ in range(_MAX_GROWTH_STEPS):
@@ -711,11 +745,15 @@ def _f32(a):
     return a, a.ctypes.data_as(C.POINTER(C.c_float))
 
 
-def make_gaussian_kernel(sigma, gauss_truncate=4.0):
-    """LinearFiltering.hpp:171-203 (host arithmetic, no GPU needed)."""
+def make_gaussian_kernel(sigma, gauss_truncate=4.0,
+                         arithmetic=capi.TAPS_LIBM_SERIAL):
+    """LinearFiltering.hpp:171-203 (host arithmetic, no GPU needed).
+    ``arithmetic``: capi.TAPS_* - how exp() and sum() are evaluated (a scalar
+    build of the reference, or the Eigen 3.4 / 3.3 SSE2 packet paths)."""
     out = np.zeros(1024, np.float32)
-    n = capi.load().sara_hip_make_gaussian_kernel(
-        sigma, gauss_truncate, out.ctypes.data_as(C.POINTER(C.c_float)), 1024)
+    n = capi.load().sara_hip_make_gaussian_kernel_with(
+        arithmetic, sigma, gauss_truncate,
+        out.ctypes.data_as(C.POINTER(C.c_float)), 1024)
     if n <= 0:
         raise ValueError("kernel too large")
     return out[:n].copy()

@@ -33,6 +33,20 @@ OPT_DOWNSCALE_AT_DOUBLE_SIGMA = 5
 OPT_FMA_BLUR = 6
 OPT_SINGLE_STREAM = 7
 OPT_LAUNCH_TIMERS = 8
+OPT_TAP_ARITHMETIC = 9
+OPT_KERNEL_SELECTION = 10
+OPT_TILE_GEOMETRY = 11
+OPT_MARCH_WAVES = 12
+# values of OPT_KERNEL_SELECTION (sara_hip_sift.h SARA_HIP_SELECT_*)
+SELECT_ENVIRONMENT = 0
+SELECT_SHIPPED = 1
+SELECT_FORCED_MARCH = 2
+SELECT_TILED = 3
+SELECT_TILED_BLUR = 4
+# values of OPT_TAP_ARITHMETIC (sara_hip_sift.h SARA_HIP_TAPS_*)
+TAPS_LIBM_SERIAL = 0
+TAPS_EIGEN34_SSE2 = 1
+TAPS_EIGEN33_SSE2 = 2
 
 LAUNCH_TIME_DTYPE = np.dtype([("octave", "<i4"), ("scale", "<i4"), ("taps", "<i4"),
                               ("_pad", "<i4"), ("pixels", "<i8"), ("ms", "<f4"),
@@ -79,7 +93,8 @@ EXPORTS = [
     "sara_hip_last_error", "sara_hip_version", "sara_hip_device_count",
     "sara_hip_default_pyramid_params", "sara_hip_default_sift_params",
     "sara_hip_pyramid_octave_count", "sara_hip_pyramid_octave_info",
-    "sara_hip_make_gaussian_kernel", "sara_hip_sift_create",
+    "sara_hip_make_gaussian_kernel", "sara_hip_make_gaussian_kernel_with",
+    "sara_hip_sift_create",
     "sara_hip_sift_create_dog", "sara_hip_sift_destroy", "sara_hip_sift_detect",
     "sara_hip_sift_synchronize", "sara_hip_sift_counts", "sara_hip_sift_fetch",
     "sara_hip_sift_device_results", "sara_hip_sift_octave_count",
@@ -139,6 +154,8 @@ def _declare(lib):
                                                  C.POINTER(C.c_int), _f32p]
     lib.sara_hip_make_gaussian_kernel.argtypes = [C.c_float, C.c_float, _f32p,
                                                   C.c_int]
+    lib.sara_hip_make_gaussian_kernel_with.argtypes = [C.c_int, C.c_float,
+                                                       C.c_float, _f32p, C.c_int]
     lib.sara_hip_sift_create.argtypes = [C.POINTER(SiftParamsStruct), C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(_vp)]

@@ -494,10 +494,6 @@ namespace sara_hip {
     }
   }
 
-  static const bool g_use_march = [] {
-    const char* e = getenv("SARA_HIP_FEATURES");
-    return !(e && std::string(e) == "tile");
-  }();
   //! Segments of the marching gradient kernel made of whole 16-row bands (one
   //! writer per entry of the coarse magnitude map, no memset) for small
   //! batches, where the saved memset launches count (one 1080p frame: -20 us);
@@ -510,15 +506,11 @@ namespace sara_hip {
   constexpr int g_grad_waves = 18432;
   constexpr int g_extrema_waves = 4096;
 
-  //! Planes below this many pixels per launch (w x h x batch) go to the
-  //! pixel-parallel gradient kernel (SARA_HIP_GRAD_TILE_PIXELS; 0 = never).
-  static const long long g_grad_tile_pixels = [] {
-    const char* e = getenv("SARA_HIP_GRAD_TILE_PIXELS");
-    return e ? atoll(e) : (long long) 4 << 20;
-  }();
+  //! Planes below KernelSelection::grad_tile_pixels per launch (w x h x batch)
+  //! go to the pixel-parallel gradient kernel (0 = never).
   static inline bool grad_small_launch(int w, int h, int batch)
   {
-    return w >= 2 && h >= 2 && (long long) w * h * batch < g_grad_tile_pixels;
+    return w >= 2 && h >= 2 && (long long) w * h * batch < selection().grad_tile_pixels;
   }
 
   bool gradient_polar_needs_zeroed_cmax(const float* src, size_t src_stride,
@@ -530,7 +522,7 @@ namespace sara_hip {
     if (grad_small_launch(w, h, batch))
       return false;  // gradient_polar_tile_kernel: one writer per entry
     // the generic kernel and the free split of big batches use atomicMax
-    return !(aligned4 && g_use_march && grad_bands(batch));
+    return !(aligned4 && selection().feature_march && grad_bands(batch));
   }
 
   void launch_gradient_polar(const float* src, size_t src_stride, float* dst,
@@ -548,7 +540,7 @@ namespace sara_hip {
                          cmax_stride);
       return;
     }
-    if (aligned4 && g_use_march)
+    if (aligned4 && selection().feature_march)
     {
       const int nstrips = (w + 255) / 256;
       const int planes = batch * nscales;
@@ -1461,7 +1453,7 @@ namespace sara_hip {
     const bool wide_enough = gauss.w >= 4;
     // the Halide-branch classifier (signed_type) also classifies the border
     // pixels: it runs on the general path
-    if (wide_enough && g_use_march && gauss.scales == 6 && !p.signed_type)
+    if (wide_enough && selection().feature_march && gauss.scales == 6 && !p.signed_type)
     {
       const int nstrips = (gauss.w - 2 + 125) / 126;
       int nseg = (g_extrema_waves + nstrips * batch - 1) / (nstrips * batch);

@@ -37,52 +37,26 @@ namespace sara_hip {
   constexpr int TY = 32;
   constexpr int NT = 256;
 
-  //! Debug/A-B switch (SARA_HIP_BLUR=tile forces the tiled kernel).
-  static const bool g_use_march = [] {
-    const char* e = getenv("SARA_HIP_BLUR");
-    return !(e && std::string(e) == "tile");
-  }();
   //! Marching segments are at least max(32, 4 R) rows tall: every segment
   //! re-filters 2R halo rows.
   constexpr int g_march_minrows = 4;
-  //! Target number of waves per marching launch (tuning knobs; the launch
-  //! rounds up to whole segments).  4-column kernel (R <= 6, latency-bound:
-  //! VALU pipe 26-34 % busy): 4 per SIMD - 1080p x 64: 116 -> 111 us (R = 5),
-  //! 135 -> 128 (R = 6), 287 -> 235 (first blur) against 2 per SIMD, neutral
-  //! on 720p and 4K.  2-column kernel (R >= 8): 2048 -> 2880 waves on
-  //! 1080p x 64; 3072 is 10 % faster launch by launch on one stream but not
-  //! with the per-octave streams, which fill the same gaps.
-  static const int g_march_waves = [] {
-    const char* e = getenv("SARA_HIP_MARCH_WAVES");
-    return e ? std::max(64, atoi(e)) : 4096;
-  }();
-  static const int g_march2_waves = [] {
-    const char* e = getenv("SARA_HIP_MARCH2_WAVES");
-    return e ? std::max(64, atoi(e)) : 2048;
-  }();
-  //! Below this many pixels per launch (width x height x batch) the marching
-  //! kernels cannot fill the chip - a wave is a serial chain of row steps - and
-  //! the tiled kernel is used instead (240x135 x 64 frames: 12-20 us per blur
-  //! against 23-59 us).
-  static const size_t g_march_min_pixels = [] {
-    const char* e = getenv("SARA_HIP_MARCH_MIN_PIXELS");
-    return e ? size_t(atoll(e)) : size_t(4) << 20;
-  }();
-  size_t march_min_pixels() { return g_march_min_pixels; }
-  //! SARA_HIP_STRIP_GROUP (tests only): 0 / unset = the production rule -
-  //! strip-group workgroups (NW = 8 / 4) only for launches of >= 4096 / 2048
-  //! waves; 1, 4, 8 = the largest group taken at EVERY launch size, so that
-  //! the parity tests, whose images are small, run the grouped kernels.
-  static const int g_strip_group = [] {
-    const char* e = getenv("SARA_HIP_STRIP_GROUP");
-    return e ? atoi(e) : 0;
-  }();
-  int strip_group_limit(int waves)
-  {
-    if (g_strip_group > 0)
-      return g_strip_group;
-    return waves >= 4096 ? 8 : (waves >= 2048 ? 4 : 1);
-  }
+  // KernelSelection (sift_kernels.hpp) holds what used to be process-wide
+  // switches here; the measurements behind its defaults:
+  //  * march_waves / march2_waves - target number of waves per marching launch
+  //    (the launch rounds up to whole segments).  4-column kernel (R <= 6,
+  //    latency-bound: VALU pipe 26-34 % busy): 4 per SIMD - 1080p x 64: 116 ->
+  //    111 us (R = 5), 135 -> 128 (R = 6), 287 -> 235 (first blur) against 2
+  //    per SIMD, neutral on 720p and 4K.  2-column kernel (R >= 8): 2048 ->
+  //    2880 waves on 1080p x 64; 3072 is 10 % faster launch by launch on one
+  //    stream but not with the per-octave streams, which fill the same gaps.
+  //  * march_min_pixels - below this many pixels per launch (width x height x
+  //    batch) the marching kernels cannot fill the chip - a wave is a serial
+  //    chain of row steps - and the tiled kernel is used instead (240x135 x 64
+  //    frames: 12-20 us per blur against 23-59 us).
+  //  * strip_group (tests only): 0 = the production rule - strip-group
+  //    workgroups (NW = 8 / 4) only for launches of >= 4096 / 2048 waves; 1, 4,
+  //    8 = the largest group taken at EVERY launch size, so that the parity
+  //    tests, whose images are small, run the grouped kernels.
 
   // Round 3: the tile geometry is a template parameter and the window is staged
   // with 16-byte loads.  One frame per call is a chain of dependent launches of
@@ -519,7 +493,7 @@ namespace sara_hip {
     // enough waves to fill 256 CUs x 3-4 waves/SIMD, segments >= 32 rows
     // segments: enough waves to fill the chip, but every segment re-filters
     // 2R halo rows, so keep them at least g_march_minrows * R rows tall
-    int nseg = (g_march_waves + nstrips * batch - 1) / (nstrips * batch);
+    int nseg = (selection().march_waves + nstrips * batch - 1) / (nstrips * batch);
     const int min_rows = std::max(32, g_march_minrows * R);
     nseg = std::max(1, std::min(nseg, (h + min_rows - 1) / min_rows));
     const int seg_rows = (h + nseg - 1) / nseg;
@@ -921,7 +895,7 @@ namespace sara_hip {
     constexpr int W = 128;
     constexpr int PF = 4;
     const int nstrips = (w + W - 1) / W;
-    int nseg = (g_march2_waves + nstrips * batch - 1) / (nstrips * batch);
+    int nseg = (selection().march2_waves + nstrips * batch - 1) / (nstrips * batch);
     const int min_rows = std::max(32, g_march_minrows * R);
     nseg = std::max(1, std::min(nseg, (h + min_rows - 1) / min_rows));
     const int seg_rows = (h + nseg - 1) / nseg;
@@ -962,7 +936,10 @@ namespace sara_hip {
     // measurements behind the thresholds)
     const long long tiles6432 =
         (long long) ((w + 63) / 64) * ((h + 31) / 32) * batch;
-    const int geom = tiles6432 >= 200 ? 0 : (tiles6432 >= 48 ? 1 : 2);
+    const int forced = selection().tile_geometry;  // config 5's tile-shape sweep
+    const int geom = forced >= 1 && forced <= 3
+                         ? forced - 1
+                         : (tiles6432 >= 200 ? 0 : (tiles6432 >= 48 ? 1 : 2));
     if (geom == 0)
       launch_blur_geom<R, 64, 32, 512>(src, src_stride, dst, dst_stride, dog,
                                        dog_stride, w, h, batch, taps, stream, dec,
@@ -982,10 +959,10 @@ namespace sara_hip {
                                   int batch, const Taps& taps, hipStream_t stream)
   {
     const int R = taps.size / 2;
-    const bool big_enough = size_t(w) * h * batch >= g_march_min_pixels;
+    const bool big_enough = size_t(w) * h * batch >= selection().march_min_pixels;
     // any width from one full strip up (element-aligned vector accesses), or
     // a multiple of 4
-    const bool ok = big_enough && g_use_march &&
+    const bool ok = big_enough && selection().blur_march &&
                     ((w % 4 == 0 && w >= 4) || w >= 256);
     if (!ok)
       return false;
@@ -1020,7 +997,7 @@ namespace sara_hip {
     // 16-byte global accesses there at 96-100 % of the aligned rate
     // (tools/ubench/unaligned_check.hip).  Round 2 sent these widths to the
     // tiled kernel: 64 x 1366 x 768 ran the pyramid 1.9x slower than 1368.
-    const bool big_enough = size_t(w) * h * batch >= g_march_min_pixels;
+    const bool big_enough = size_t(w) * h * batch >= selection().march_min_pixels;
     const bool base_ok = big_enough && dog == nullptr;
     const bool march4_ok = base_ok && ((w % 4 == 0 && w >= 4) || w >= 256);
     const bool march2_ok = base_ok && ((w % 4 == 0 && w >= 4) || w >= 128);
@@ -1028,7 +1005,7 @@ namespace sara_hip {
     bool symmetric = true;
     for (int j = 0; j < R; ++j)
       symmetric &= std::memcmp(&taps.k[j], &taps.k[2 * R - j], sizeof(float)) == 0;
-    if (march2_ok && g_use_march && dec == nullptr && symmetric)
+    if (march2_ok && selection().blur_march && dec == nullptr && symmetric)
     {
       switch (R)
       {
@@ -1048,7 +1025,7 @@ namespace sara_hip {
         break;
       }
     }
-    if (march4_ok && g_use_march)
+    if (march4_ok && selection().blur_march)
     {
 #define SARA_MARCH_CASE(r)                                                     \
   case r:                                                                      \

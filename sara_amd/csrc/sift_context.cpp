@@ -287,10 +287,142 @@ namespace {
                                               hipGetErrorString(e_));          \
   } while (0)
 
+  // ---- kernel selection (sift_kernels.hpp) ---------------------------------
+  thread_local const KernelSelection* t_selection = nullptr;
+}  // namespace
+
+namespace sara_hip {
+  const KernelSelection& environment_selection()
+  {
+    static const KernelSelection env = [] {
+      KernelSelection k;
+      auto is = [](const char* name, const char* value) {
+        const char* e = getenv(name);
+        return e && std::string(e) == value;
+      };
+      k.blur_march = !is("SARA_HIP_BLUR", "tile");
+      k.feature_march = !is("SARA_HIP_FEATURES", "tile");
+      if (const char* e = getenv("SARA_HIP_MARCH_WAVES"))
+        k.march_waves = std::max(64, atoi(e));
+      if (const char* e = getenv("SARA_HIP_MARCH2_WAVES"))
+        k.march2_waves = std::max(64, atoi(e));
+      if (const char* e = getenv("SARA_HIP_MARCH_MIN_PIXELS"))
+        k.march_min_pixels = size_t(atoll(e));
+      if (const char* e = getenv("SARA_HIP_STRIP_GROUP"))
+        k.strip_group = atoi(e);
+      if (const char* e = getenv("SARA_HIP_GRAD_TILE_PIXELS"))
+        k.grad_tile_pixels = atoll(e);
+      if (const char* e = getenv("SARA_HIP_TILE_GEOMETRY"))
+        k.tile_geometry = atoi(e);
+      k.xcd_map = !is("SARA_HIP_XCD_MAP", "0");
+      return k;
+    }();
+    return env;
+  }
+  const KernelSelection& selection()
+  {
+    return t_selection ? *t_selection : environment_selection();
+  }
+  ScopedSelection::ScopedSelection(const KernelSelection* s)
+    : before{t_selection}
+  {
+    t_selection = s;
+  }
+  ScopedSelection::~ScopedSelection() { t_selection = before; }
+}  // namespace sara_hip
+
+namespace {
   // ---- host restatement of the parameter schedule --------------------------
 
+  // make_gaussian_kernel, ImageProcessing/LinearFiltering.hpp:171-203, is three
+  // Eigen expressions; exp() and sum() are the two operations in them that are
+  // not one correctly rounded IEEE operation, so their result depends on the
+  // path Eigen takes in the reference's build (SARA_HIP_TAPS_*):
+  //  * a scalar build: expf per tap, left-to-right sum;
+  //  * the Release build (x86-64 baseline = SSE2, Packet4f): the dense
+  //    assignment loop sends taps [0, 4*(n/4)) through pexp<Packet4f> and the
+  //    rest through the scalar functor (expf); sum() keeps two packet
+  //    accumulators over even / odd packets, adds them, adds the odd packet out,
+  //    reduces as (a0 + a2) + (a1 + a3) and finishes with the scalar tail.
+  // pexp is written from the published algorithm (Cephes: m = floor(x log2 e +
+  // 1/2), r = x - m ln 2 in two parts, degree-5 polynomial, times 2^m); on SSE2
+  // pmadd is a multiply and an add, each rounded (this file is compiled with
+  // -ffp-contract=off).
+
+  //! Eigen 3.4 pexp_float, one lane.
+  float pexp_eigen34(float x0)
+  {
+    const float x = std::max(std::min(x0, 88.723f), -88.723f);
+    const float m = std::floor(x * 1.44269504088896341f + 0.5f);
+    float r = m * -0.693359375f + x;
+    r = m * 2.12194440e-4f + r;
+    const float r2 = r * r, r3 = r2 * r;
+    float y = 1.9875691500E-4f * r + 1.3981999507E-3f;
+    float y1 = 4.1665795894E-2f * r + 1.6666665459E-1f;
+    const float y2 = r + 1.0f;
+    y = y * r + 8.3334519073E-3f;
+    y1 = y1 * r + 5.0000001201E-1f;
+    y = y * r3 + y1;
+    y = y * r2 + y2;
+    return std::max(std::ldexp(y, int(m)), x0);
+  }
+
+  //! Eigen 3.3 pexp<Packet4f>, one lane: Horner form, (P(r) r^2 + r) + 1.
+  float pexp_eigen33(float x0)
+  {
+    float x = std::max(std::min(x0, 88.3762626647950f), -88.3762626647949f);
+    const float fx = std::floor(x * 1.44269504088896341f + 0.5f);
+    const float hi = fx * 0.693359375f;
+    float z = fx * -2.12194440e-4f;
+    x = x - hi;
+    x = x - z;
+    z = x * x;
+    float y = 1.9875691500E-4f;
+    const float p[5] = {1.3981999507E-3f, 8.3334519073E-3f, 4.1665795894E-2f,
+                        1.6666665459E-1f, 5.0000001201E-1f};
+    for (float pi : p)
+      y = y * x + pi;
+    y = y * z + x;
+    y = y + 1.0f;
+    return std::max(std::ldexp(y, int(fx)), x0);
+  }
+
+  //! VectorXf::sum() on SSE2 (Redux.h, LinearVectorizedTraversal).
+  float sum_eigen_sse2(const float* v, int n)
+  {
+    const int n4 = (n / 4) * 4, n8 = (n / 8) * 8;
+    if (n4 == 0)
+    {
+      float res = v[0];
+      for (int i = 1; i < n; ++i)
+        res = res + v[i];
+      return res;
+    }
+    float a[4] = {v[0], v[1], v[2], v[3]};
+    if (n4 > 4)
+    {
+      float b[4] = {v[4], v[5], v[6], v[7]};
+      for (int i = 8; i < n8; i += 8)
+        for (int j = 0; j < 4; ++j)
+        {
+          a[j] = a[j] + v[i + j];
+          b[j] = b[j] + v[i + 4 + j];
+        }
+      for (int j = 0; j < 4; ++j)
+        a[j] = a[j] + b[j];
+      if (n4 > n8)
+        for (int j = 0; j < 4; ++j)
+          a[j] = a[j] + v[n8 + j];
+    }
+    float res = (a[0] + a[2]) + (a[1] + a[3]);
+    for (int i = n4; i < n; ++i)
+      res = res + v[i];
+    return res;
+  }
+
   //! make_gaussian_kernel, ImageProcessing/LinearFiltering.hpp:171-203.
-  std::vector<float> gaussian_taps(float sigma, float gauss_truncate)
+  std::vector<float> gaussian_taps(float sigma, float gauss_truncate,
+                                   int arithmetic = SARA_HIP_TAPS_LIBM_SERIAL)
   {
     int size = int(2 * gauss_truncate * sigma + 1);
     size = std::max(3, size);
@@ -299,14 +431,24 @@ namespace {
     const int c = size / 2;
     std::vector<float> k(size);
     const float denom = 2 * (sigma * sigma);
+    const bool packets = arithmetic != SARA_HIP_TAPS_LIBM_SERIAL;
+    const int packets_end = packets ? (size / 4) * 4 : 0;
     for (int i = 0; i < size; ++i)
     {
       const float d = float(i) - float(c);
-      k[i] = std::exp(-(d * d) / denom);
+      const float x = -(d * d) / denom;
+      if (i >= packets_end)
+        k[i] = std::exp(x);
+      else
+        k[i] = arithmetic == SARA_HIP_TAPS_EIGEN34_SSE2 ? pexp_eigen34(x)
+                                                        : pexp_eigen33(x);
     }
     float sum = 0.f;
-    for (int i = 0; i < size; ++i)
-      sum += k[i];
+    if (packets)
+      sum = sum_eigen_sse2(k.data(), size);
+    else
+      for (int i = 0; i < size; ++i)
+        sum += k[i];
     for (int i = 0; i < size; ++i)
       k[i] /= sum;
     return k;
@@ -519,6 +661,10 @@ struct sara_hip_sift
   bool signed_type = false;
   bool downscale_at_double_sigma = false;
   bool fma_blur = false;
+  int tap_arithmetic = SARA_HIP_TAPS_LIBM_SERIAL;  // SARA_HIP_OPT_TAP_ARITHMETIC
+  //! which kernels this context's launches take (SARA_HIP_OPT_KERNEL_SELECTION,
+  //! _TILE_GEOMETRY, _MARCH_WAVES); a new context starts from the environment's
+  KernelSelection sel = environment_selection();
   bool timers = true;
 
   // pyramids, one allocation per octave (sized for max dims / max batch).
@@ -752,6 +898,34 @@ namespace {
     drop(c->d_ex_xyso);
   }
 
+  //! Taps of the initial blur and of the S - 1 incremental blurs under the
+  //! context's tap arithmetic; nullptr or what is wrong.
+  const char* compute_taps(sara_hip_sift* c)
+  {
+    const sara_pyramid_params& pyr = c->pyr;
+    const float k = pyr.scale_geometric_factor;
+    if (c->max_sched.init_blur)
+    {
+      const float trunc = pyr.first_octave_index > 0 ? c->gauss_truncate : 4.f;
+      if (!to_taps(gaussian_taps(c->max_sched.init_sigma, trunc, c->tap_arithmetic),
+                   c->init_taps))
+        return "initial Gaussian needs more than 113 taps";
+      c->have_init_taps = true;
+    }
+    c->taps.resize(c->S);
+    float sigma_s_1 = pyr.scale_initial;
+    for (int s = 1; s < c->S; ++s)
+    {
+      const float ks = k * sigma_s_1;
+      const double sigma = std::sqrt(double(ks * ks - sigma_s_1 * sigma_s_1));
+      if (!to_taps(gaussian_taps(static_cast<float>(sigma), 4.f, c->tap_arithmetic),
+                   c->taps[s]))
+        return "a pyramid Gaussian needs more than 113 taps";
+      sigma_s_1 *= k;
+    }
+    return nullptr;
+  }
+
   sara_hip_status create_impl(const sara_pyramid_params& pyr, float gauss_truncate,
                               float extremum_thres, float edge_ratio_thres,
                               int img_padding_sz, int refine_iters, int max_w,
@@ -862,27 +1036,8 @@ namespace {
 
     // ---- taps and tables (host arithmetic as in GaussianPyramid.hpp:106-121)
     const float k = pyr.scale_geometric_factor;
-    if (c->max_sched.init_blur)
-    {
-      const float trunc = pyr.first_octave_index > 0 ? gauss_truncate : 4.f;
-      if (!to_taps(gaussian_taps(c->max_sched.init_sigma, trunc), c->init_taps))
-        return cleanup(fail(SARA_HIP_INVALID_PARAMS,
-                            "initial Gaussian needs more than 113 taps"));
-      c->have_init_taps = true;
-    }
-    c->taps.resize(c->S);
-    {
-      float sigma_s_1 = pyr.scale_initial;
-      for (int s = 1; s < c->S; ++s)
-      {
-        const float ks = k * sigma_s_1;
-        const double sigma = std::sqrt(double(ks * ks - sigma_s_1 * sigma_s_1));
-        if (!to_taps(gaussian_taps(static_cast<float>(sigma), 4.f), c->taps[s]))
-          return cleanup(fail(SARA_HIP_INVALID_PARAMS,
-                              "a pyramid Gaussian needs more than 113 taps"));
-        sigma_s_1 *= k;
-      }
-    }
+    if (const char* msg = compute_taps(c))
+      return cleanup(fail(SARA_HIP_INVALID_PARAMS, msg));
     std::vector<double> oriw;
     for (int s = 0; s < c->S; ++s)
     {
@@ -1127,6 +1282,19 @@ int sara_hip_make_gaussian_kernel(float sigma, float gauss_truncate, float* taps
   return int(k.size());
 }
 
+int sara_hip_make_gaussian_kernel_with(int arithmetic, float sigma,
+                                       float gauss_truncate, float* taps,
+                                       int capacity)
+{
+  if (arithmetic < SARA_HIP_TAPS_LIBM_SERIAL || arithmetic > SARA_HIP_TAPS_EIGEN33_SSE2)
+    return 0;
+  const auto k = gaussian_taps(sigma, gauss_truncate, arithmetic);
+  if (int(k.size()) > capacity || !taps)
+    return -int(k.size());
+  std::memcpy(taps, k.data(), sizeof(float) * k.size());
+  return int(k.size());
+}
+
 sara_hip_status sara_hip_sift_create(const sara_sift_params* params, int max_width,
                                      int max_height, int max_batch,
                                      int max_keypoints, int device,
@@ -1303,6 +1471,58 @@ sara_hip_status sara_hip_sift_set_option(sara_hip_sift* c, int option, int value
     c->fma_blur = value != 0;
     c->graph_stage_s[0] = c->graph_stage_s[1] = -1;
     return SARA_HIP_OK;
+  case SARA_HIP_OPT_KERNEL_SELECTION:
+  {
+    KernelSelection k;  // the shipped defaults
+    switch (value)
+    {
+    case SARA_HIP_SELECT_ENVIRONMENT: k = environment_selection(); break;
+    case SARA_HIP_SELECT_SHIPPED: break;
+    case SARA_HIP_SELECT_FORCED_MARCH:
+      k.march_min_pixels = 0;
+      k.strip_group = 8;
+      break;
+    case SARA_HIP_SELECT_TILED:
+      k.blur_march = false;
+      k.feature_march = false;
+      break;
+    case SARA_HIP_SELECT_TILED_BLUR: k.blur_march = false; break;
+    default: return fail(SARA_HIP_INVALID_PARAMS, "unknown kernel selection");
+    }
+    c->sel = k;
+    c->graph_stage_s[0] = c->graph_stage_s[1] = -1;  // launches are captured
+    return SARA_HIP_OK;
+  }
+  case SARA_HIP_OPT_TILE_GEOMETRY:
+    if (value < 0 || value > 3)
+      return fail(SARA_HIP_INVALID_PARAMS, "tile geometry is 0 (auto) .. 3");
+    c->sel.tile_geometry = value;
+    c->graph_stage_s[0] = c->graph_stage_s[1] = -1;
+    return SARA_HIP_OK;
+  case SARA_HIP_OPT_MARCH_WAVES:
+    if (value != 0 && value < 64)
+      return fail(SARA_HIP_INVALID_PARAMS, "waves per marching launch >= 64");
+    c->sel.march_waves = value ? value : KernelSelection{}.march_waves;
+    c->sel.march2_waves = value ? value : KernelSelection{}.march2_waves;
+    c->graph_stage_s[0] = c->graph_stage_s[1] = -1;
+    return SARA_HIP_OK;
+  case SARA_HIP_OPT_TAP_ARITHMETIC:
+  {
+    if (value < SARA_HIP_TAPS_LIBM_SERIAL || value > SARA_HIP_TAPS_EIGEN33_SSE2)
+      return fail(SARA_HIP_INVALID_PARAMS, "unknown tap arithmetic");
+    if (c->last_stream)
+      HIP_TRY(hipStreamSynchronize(c->last_stream));
+    const int before = c->tap_arithmetic;
+    c->tap_arithmetic = value;
+    if (const char* msg = compute_taps(c))
+    {
+      c->tap_arithmetic = before;
+      (void) compute_taps(c);
+      return fail(SARA_HIP_INVALID_PARAMS, msg);
+    }
+    c->graph_stage_s[0] = c->graph_stage_s[1] = -1;  // taps are kernel arguments
+    return SARA_HIP_OK;
+  }
   case SARA_HIP_OPT_DOWNSCALE_AT_DOUBLE_SIGMA:
   {
     const bool on = value != 0;
@@ -1403,6 +1623,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
 {
   if (!c || !images)
     return fail(SARA_HIP_INVALID_PARAMS, "null context or images");
+  const ScopedSelection selection_of_this_context(&c->sel);
   if (batch < 1 || batch > c->max_batch)
     return fail(SARA_HIP_CAPACITY_EXCEEDED, "batch exceeds max_batch");
   if (width < 2 || height < 2)
@@ -1594,6 +1815,8 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   };
 
   auto enqueue = [&]() -> sara_hip_status {
+  // also on the launcher thread, where a graph capture runs this lambda
+  const ScopedSelection selection_of_this_context(&c->sel);
 
   const bool want_gradients = last_stage >= SARA_HIP_STAGE_GRADIENT;
   const bool side = side_gradient && want_gradients && !debug_sync;

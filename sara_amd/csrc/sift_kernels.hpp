@@ -277,12 +277,49 @@ namespace sara_hip {
     size_t cmax_frame_stride[16];  // in uint32
   };
 
-  //! SARA_HIP_MARCH_MIN_PIXELS (pyramid_kernels.hip): launches below it are small.
-  size_t march_min_pixels();
+  //! Which kernel a launch takes and how it is cut (round 6).  One value per
+  //! context (sara_hip_sift_set_option: SARA_HIP_OPT_KERNEL_SELECTION,
+  //! _TILE_GEOMETRY) instead of process-wide switches read once from the
+  //! environment: the parity tests run the forced AND the shipped selection in
+  //! one process, bench.py sweeps config 5's decompositions in one run.  The
+  //! environment still provides the DEFAULT of a new context
+  //! (environment_selection()), so tools/test_modes.sh works as before.
+  struct KernelSelection
+  {
+    bool blur_march = true;      //!< false: tiled blur everywhere (SARA_HIP_BLUR=tile)
+    bool feature_march = true;   //!< false: pixel-parallel gradient / scan (SARA_HIP_FEATURES=tile)
+    int march_waves = 4096;      //!< target waves per launch, 4-column blur (SARA_HIP_MARCH_WAVES)
+    int march2_waves = 2048;     //!< the same, 2-column blur (SARA_HIP_MARCH2_WAVES)
+    size_t march_min_pixels = size_t(4) << 20;  //!< smaller launches take the tiled blur
+    int strip_group = 0;         //!< 0: production rule; 1 / 4 / 8 forced (SARA_HIP_STRIP_GROUP)
+    long long grad_tile_pixels = (long long) 4 << 20;  //!< smaller planes: pixel-parallel gradient
+    int tile_geometry = 0;       //!< tiled blur: 0 by tile count, 1 = 64x32, 2 = 64x16, 3 = 32x16
+    bool xcd_map = true;         //!< XCD-aware placement of marching workgroups (SARA_HIP_XCD_MAP)
+  };
+  //! What the process environment asks for (read once); without any variable
+  //! set it equals KernelSelection{} = the shipped selection.
+  const KernelSelection& environment_selection();
+  //! The selection of the calling thread: the one installed by the innermost
+  //! ScopedSelection, else environment_selection() (operator-level seams).
+  const KernelSelection& selection();
+  struct ScopedSelection
+  {
+    explicit ScopedSelection(const KernelSelection* s);
+    ~ScopedSelection();
+    ScopedSelection(const ScopedSelection&) = delete;
+    ScopedSelection& operator=(const ScopedSelection&) = delete;
+    const KernelSelection* before;
+  };
   //! Largest strip-group workgroup (1, 4 or 8 waves) a marching launch of
   //! `waves` waves may use: 8 from 4096 waves, 4 from 2048 (the launch fills the
-  //! chip anyway), else 1; SARA_HIP_STRIP_GROUP overrides it for tests.
-  int strip_group_limit(int waves);
+  //! chip anyway), else 1; KernelSelection::strip_group overrides it for tests.
+  inline int strip_group_limit(int waves)
+  {
+    const int forced = selection().strip_group;
+    if (forced > 0)
+      return forced;
+    return waves >= 4096 ? 8 : (waves >= 2048 ? 4 : 1);
+  }
 
   //! grad / tab are device pointers (indexed per wave, so they live in HBM
   //! rather than in the kernel argument segment).
@@ -462,14 +499,7 @@ namespace sara_hip {
 #endif
 
   //! XCD-aware placement of the marching workgroups (march_work_item);
-  //! SARA_HIP_XCD_MAP=0 restores the plain launch order.
-  inline bool xcd_map_enabled()
-  {
-    static const bool on = [] {
-      const char* e = std::getenv("SARA_HIP_XCD_MAP");
-      return !(e && e[0] == '0' && e[1] == 0);
-    }();
-    return on;
-  }
+  //! KernelSelection::xcd_map = false restores the plain launch order.
+  inline bool xcd_map_enabled() { return selection().xcd_map; }
 
 }  // namespace sara_hip

@@ -47,3 +47,19 @@ def oracle():
     refbind.build()
     refbind.lib().ref_omp_set_threads(_usable_cpus())
     return refbind
+
+
+@pytest.fixture(params=["forced", "shipped"])
+def kernel_selection(request):
+    """Round 6: the same test under the kernel selection the environment above
+    forces (marching kernels and 8-strip groups at every launch size) AND under
+    the one the library ships (thresholds as bench.py and every user run them),
+    in one process: SARA_HIP_OPT_KERNEL_SELECTION is a context option, applied
+    to every context the test creates - the cached ones of the free functions
+    included (sara_amd.DEFAULT_OPTIONS)."""
+    import sara_amd
+    from sara_amd import capi
+    value = (capi.SELECT_FORCED_MARCH if request.param == "forced"
+             else capi.SELECT_SHIPPED)
+    with sara_amd.default_options({capi.OPT_KERNEL_SELECTION: value}):
+        yield request.param

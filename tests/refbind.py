@@ -201,6 +201,32 @@ def convolve_array(signal, kernel, signal_size):
     return s
 
 
+TAP_VARIANTS = {"expf_serial": 0, "eigen34_sse": 1, "eigen33_sse": 2,
+                "ulp_random": 3, "ulp_plus": 4, "ulp_minus": 5,
+                "ulp_alternate": 6, "ulp_narrow": 7, "ulp_wide": 8}
+
+
+def set_tap_variant(kind, seed=0):
+    """Arithmetic of make_gaussian_kernel for every later oracle call
+    (sift_ref.hpp kTaps*); returns the previous kind.  Process-wide: restore
+    it (``with tap_variant(...)``)."""
+    kind = TAP_VARIANTS.get(kind, kind)
+    lib().ref_set_tap_variant.argtypes = [C.c_int, C.c_uint]
+    lib().ref_set_tap_variant.restype = C.c_int
+    return lib().ref_set_tap_variant(int(kind), int(seed))
+
+
+class tap_variant:
+    def __init__(self, kind, seed=0):
+        self.kind, self.seed = kind, seed
+
+    def __enter__(self):
+        self.before = set_tap_variant(self.kind, self.seed)
+
+    def __exit__(self, *exc):
+        set_tap_variant(self.before, 0)
+
+
 def make_gaussian_kernel(sigma, gauss_truncate=4.0):
     out = np.zeros(1024, dtype=np.float32)
     n = lib().ref_make_gaussian_kernel(C.c_float(sigma), C.c_float(gauss_truncate),

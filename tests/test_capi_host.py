@@ -95,6 +95,32 @@ def test_gaussian_taps_match_oracle(lib, oracle, sigma, trunc):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("name,arith", [("eigen34_sse", capi.TAPS_EIGEN34_SSE2),
+                                        ("eigen33_sse", capi.TAPS_EIGEN33_SSE2),
+                                        ("expf_serial", capi.TAPS_LIBM_SERIAL)])
+def test_gaussian_taps_match_oracle_under_each_arithmetic(lib, oracle, name, arith):
+    """SARA_HIP_OPT_TAP_ARITHMETIC: the product's host code and the oracle's
+    tap variants (oracle/sift_ref.hpp kTaps*) are the same floats."""
+    sigmas = [1.51986849, 1.22627354, 1.54500782, 1.94658804, 2.45254707,
+              3.09001565, 1.24899971, 0.3, 0.8, 5.3, 11.0]
+    differs = asym = 0
+    for sigma in sigmas:
+        a = sara_amd.make_gaussian_kernel(sigma, 4.0, arith)
+        with oracle.tap_variant(name):
+            b = oracle.make_gaussian_kernel(sigma, 4.0)
+        assert np.array_equal(a.view(np.int32), b.view(np.int32)), sigma
+        base = sara_amd.make_gaussian_kernel(sigma, 4.0)
+        differs += not np.array_equal(a, base)
+        asym += not np.array_equal(a, a[::-1])
+        # the reference's own acceptance (test_imageprocessing_linear_filtering
+        # .cpp:136-187): 1e-5 in L2 - every arithmetic is far inside it
+        assert np.linalg.norm(a.astype(np.float64) - base) < 1e-6
+    if arith != capi.TAPS_LIBM_SERIAL:
+        assert differs >= 4      # the choice is visible in the last ulp ...
+    if arith == capi.TAPS_EIGEN34_SSE2:
+        assert asym >= 2         # ... and the packet / scalar split breaks symmetry
+
+
 def test_no_gpu_fails_loudly(lib):
     if lib.sara_hip_device_count() > 0:
         pytest.skip("a GPU is visible")

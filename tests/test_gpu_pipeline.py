@@ -485,7 +485,7 @@ def _fuzz_cases(n, seed):
 
 @pytest.mark.parametrize("case", _fuzz_cases(16, 20260929),
                          ids=lambda c: "fuzz%d_%dx%d" % (c[0], c[1], c[2]))
-def test_fuzz_parity(oracle, case):
+def test_fuzz_parity(oracle, case, kernel_selection):
     """Random image sizes and detector parameters: every plane, site, keypoint
     and descriptor against the oracle, same bars as everywhere else."""
     i, w, h, first, scales, kfac, cam, noct, thres, edge, iters = case
@@ -887,3 +887,76 @@ def test_context_churn_from_several_threads_next_to_a_replaying_thread():
                        timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout[-400:], r.stderr[-400:])
     assert "errors: []" in r.stdout, r.stdout[-400:]
+
+
+@pytest.mark.parametrize("name,arith", [("eigen34_sse", "TAPS_EIGEN34_SSE2"),
+                                        ("eigen33_sse", "TAPS_EIGEN33_SSE2")])
+@pytest.mark.parametrize("w,h,batch", [(640, 480, 1), (1920, 1080, 2)])
+def test_tap_arithmetic_option_matches_the_oracle_variant(oracle, name, arith,
+                                                          w, h, batch):
+    """SARA_HIP_OPT_TAP_ARITHMETIC (round 6): with the Eigen SSE2 model of
+    make_gaussian_kernel's exp() / sum() the pipeline equals the oracle run
+    under the same tap variant at the usual bars (planes bit-exact); the
+    unequal mirrored taps some of these kernels have (sigma 1.545, 3.09) run on
+    the general marching kernel.  Switching back restores the default."""
+    from sara_amd import capi
+    imgs = np.stack([synth(w, h, 1234 + i) for i in range(batch)])
+    with oracle.tap_variant(name):
+        refs = [oracle.RefSift(imgs[i], ref_params(oracle, 0, 4), parallel=True)
+                for i in range(batch)]
+    base = oracle.RefSift(imgs[0], ref_params(oracle, 0, 4), parallel=True)
+    with sara_amd.SiftContext(w, h, batch, hip_params(0, 4)) as ctx:
+        ctx.set_option(capi.OPT_TAP_ARITHMETIC, getattr(capi, arith))
+        ctx.detect(imgs)
+        lists = run_lists(ctx)
+        for i in range(batch):
+            compare_full(ctx, refs[i], frame=i, check_planes=(i == 0))
+            compare_lists(lists, refs[i], i)
+        # the variant is visible: the last Gaussian plane differs from the default's
+        assert not np.array_equal(ctx.gaussian(5, 0, 0), base.gaussian(5, 0))
+        ctx.set_option(capi.OPT_TAP_ARITHMETIC, capi.TAPS_LIBM_SERIAL)
+        ctx.detect(imgs)
+        compare_full(ctx, base, frame=0)
+        compare_lists(run_lists(ctx), base, 0)
+        with pytest.raises(sara_amd.SaraHipError):
+            ctx.set_option(capi.OPT_TAP_ARITHMETIC, 17)
+
+
+def test_kernel_selection_options_do_not_change_a_byte():
+    """SARA_HIP_OPT_KERNEL_SELECTION / _TILE_GEOMETRY / _MARCH_WAVES (round 6)
+    choose kernels and launch geometry per context: every combination bench.py
+    sweeps for config 5 returns the same bytes, on a batch large enough for the
+    shipped thresholds to pick the marching kernels (8 x 960x540 > 4 Mpx)."""
+    from sara_amd import capi
+    w, h, b = 960, 540, 8
+    imgs = synth_batch(w, h, b, unique=2)
+    combos = [
+        {capi.OPT_KERNEL_SELECTION: capi.SELECT_SHIPPED},
+        {capi.OPT_KERNEL_SELECTION: capi.SELECT_FORCED_MARCH},
+        {capi.OPT_KERNEL_SELECTION: capi.SELECT_TILED},
+        {capi.OPT_KERNEL_SELECTION: capi.SELECT_TILED_BLUR, capi.OPT_TILE_GEOMETRY: 1},
+        {capi.OPT_KERNEL_SELECTION: capi.SELECT_TILED_BLUR, capi.OPT_TILE_GEOMETRY: 2},
+        {capi.OPT_KERNEL_SELECTION: capi.SELECT_TILED_BLUR, capi.OPT_TILE_GEOMETRY: 3},
+        {capi.OPT_KERNEL_SELECTION: capi.SELECT_SHIPPED, capi.OPT_MARCH_WAVES: 1024},
+        {capi.OPT_KERNEL_SELECTION: capi.SELECT_SHIPPED, capi.OPT_MARCH_WAVES: 8192},
+        {capi.OPT_KERNEL_SELECTION: capi.SELECT_ENVIRONMENT},
+    ]
+    want = None
+    with sara_amd.SiftContext(w, h, b, hip_params(0, 4)) as ctx:
+        for combo in combos:
+            ctx.set_option(capi.OPT_TILE_GEOMETRY, 0)
+            ctx.set_option(capi.OPT_MARCH_WAVES, 0)
+            for opt in sorted(combo, reverse=True):   # selection first
+                ctx.set_option(opt, combo[opt])
+            ctx.detect(imgs)
+            got = [a.tobytes() for a in ctx.fetch()]
+            got.append(ctx.gaussian(5, 0, b - 1).tobytes())
+            got.append(ctx.gradient(2, 1, 0).tobytes())
+            if want is None:
+                want = got
+                assert len(got[1]) > 48 * 1000
+            assert got == want, combo
+        for opt, bad in ((capi.OPT_KERNEL_SELECTION, 9), (capi.OPT_TILE_GEOMETRY, 4),
+                         (capi.OPT_MARCH_WAVES, 7)):
+            with pytest.raises(sara_amd.SaraHipError):
+                ctx.set_option(opt, bad)

@@ -38,7 +38,7 @@ def assert_keys_equal_pack(keys, name, tag):
 
 @pytest.mark.parametrize("name", ri.NAMES)
 @pytest.mark.parametrize("tag", ri.TAGS)
-def test_float_frames_through_the_free_function(oracle, name, tag):
+def test_float_frames_through_the_free_function(oracle, name, tag, kernel_selection):
     """image.convert<float>() -> compute_sift_keypoints(), as the example."""
     gray = ri.gray(oracle, name)
     keys = sara_amd.compute_sift_keypoints(gray, ri.hip_params(tag))
@@ -48,7 +48,7 @@ def test_float_frames_through_the_free_function(oracle, name, tag):
 
 @pytest.mark.parametrize("name", ri.NAMES)
 @pytest.mark.parametrize("tag", ri.TAGS)
-def test_extrema_through_compute_dog_extrema(name, tag):
+def test_extrema_through_compute_dog_extrema(name, tag, kernel_selection):
     import refbind as rb
     g = ri.pack()
     k = "%s_%s_" % (name, tag)
@@ -64,7 +64,7 @@ def test_extrema_through_compute_dog_extrema(name, tag):
 
 
 @pytest.mark.parametrize("name", ri.NAMES)
-def test_rgb8_frames_converted_on_the_device(oracle, name):
+def test_rgb8_frames_converted_on_the_device(oracle, name, kernel_selection):
     """The f1 upload path: interleaved RGB8 in, converted by the device with
     the reference's arithmetic - byte-identical to the float path."""
     rgb = ri.rgb(name)
