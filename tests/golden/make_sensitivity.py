@@ -278,9 +278,13 @@ def main():
     if args.quick:
         print(json.dumps(groups, indent=1))
         return
+    # one line per (workload, variant) row, the rest indented
+    rows = doc.pop("rows")
+    head = json.dumps(doc, indent=1, sort_keys=True)
+    body = ",\n".join("  " + json.dumps(r, sort_keys=True, separators=(",", ":"))
+                      for r in rows)
     with open(args.out, "w") as f:
-        json.dump(doc, f, indent=1, sort_keys=True)
-        f.write("\n")
+        f.write(head[:-2] + ',\n "rows": [\n' + body + "\n ]\n}\n")
     for name, g in groups.items():
         k, e = g["all"]["keypoints"], g["all"]["extrema"]
         print("%-14s extrema lost %d gained %d of %d | keypoints lost %d gained "
