@@ -407,6 +407,10 @@ enum
                                         /* of the Gaussian-pyramid stage, read by  */
                                         /* sara_hip_sift_pyramid_launches();       */
                                         /* ignored under HIP-graph replay          */
+  SARA_HIP_OPT_GRAPH_REPLAY = 13,       /* 0: batches <= 8 run plain launches    */
+                                        /* instead of replaying a captured HIP   */
+                                        /* graph (default 1; the process-wide    */
+                                        /* switch is SARA_HIP_GRAPH=0)           */
   SARA_HIP_OPT_KERNEL_SELECTION = 10,   /* SARA_HIP_SELECT_*: which kernels the  */
                                         /* context's launches take.  Results do */
                                         /* not depend on it (every selection is */

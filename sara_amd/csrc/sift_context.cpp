@@ -261,6 +261,32 @@ namespace {
     }();
     return old_runtime;
   }
+  //! Second rule for those runtimes (round 6).  One thread is not enough: a
+  //! single thread that keeps creating contexts, capturing and destroying
+  //! graphs dies in the same place (hipGraphLaunch -> hip::Graph::UpdateStreams,
+  //! rocgdb backtrace on the launcher thread) once enough graphs have come and
+  //! gone in the process - the full GPU test suite did, deterministically, after
+  //! 215 instantiations when round 6 added 60 contexts to it, after about 290
+  //! with other tests left out, and earlier still when destroyed executables
+  //! were kept alive instead (so it is not the destruction).  A process on such
+  //! a runtime therefore instantiates at most kOldRuntimeGraphBudget graphs
+  //! (SARA_HIP_GRAPH_MAX_INSTANTIATIONS overrides); contexts that need a new
+  //! graph after that run plain launches (+ 0.15 ms of host time per 1080p
+  //! frame), contexts that have theirs keep replaying it.  A video pipeline
+  //! uses one or two graphs; the budget only matters to processes that see
+  //! hundreds of frame sizes or parameter sets.  ROCm >= 7.2: no limit.
+  constexpr int kOldRuntimeGraphBudget = 128;
+  std::atomic<int> g_graph_instantiations{0};
+  bool graph_budget_left()
+  {
+    if (!graphs_need_one_thread())
+      return true;
+    static const int limit = [] {
+      const char* e = getenv("SARA_HIP_GRAPH_MAX_INSTANTIATIONS");
+      return e ? atoi(e) : kOldRuntimeGraphBudget;
+    }();
+    return g_graph_instantiations.load(std::memory_order_relaxed) < limit;
+  }
   bool first_graph_thread()
   {
     static std::atomic<std::thread::id> first{std::thread::id()};
@@ -1471,6 +1497,10 @@ sara_hip_status sara_hip_sift_set_option(sara_hip_sift* c, int option, int value
     c->fma_blur = value != 0;
     c->graph_stage_s[0] = c->graph_stage_s[1] = -1;
     return SARA_HIP_OK;
+  case SARA_HIP_OPT_GRAPH_REPLAY:
+    c->use_graph = value != 0;
+    c->graph_stage_s[0] = c->graph_stage_s[1] = -1;
+    return SARA_HIP_OK;
   case SARA_HIP_OPT_KERNEL_SELECTION:
   {
     KernelSelection k;  // the shipped defaults
@@ -2250,6 +2280,17 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       (void) hipGraphDestroy(graph);
     graph_exec = nullptr;
     graph = nullptr;
+    if (!graph_budget_left())
+    {
+      // see kOldRuntimeGraphBudget: plain launches from now on
+      c->graph_broken = true;
+      const sara_hip_status est = enqueue();
+      if (est != SARA_HIP_OK)
+        return est;
+      c->has_result = true;
+      return SARA_HIP_OK;
+    }
+    g_graph_instantiations.fetch_add(1, std::memory_order_relaxed);
     bool ok = hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed) ==
               hipSuccess;
     if (ok)

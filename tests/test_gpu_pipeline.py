@@ -906,6 +906,8 @@ def test_tap_arithmetic_option_matches_the_oracle_variant(oracle, name, arith,
                 for i in range(batch)]
     base = oracle.RefSift(imgs[0], ref_params(oracle, 0, 4), parallel=True)
     with sara_amd.SiftContext(w, h, batch, hip_params(0, 4)) as ctx:
+        if batch > 1:
+            ctx.set_option(capi.OPT_GRAPH_REPLAY, 0)
         ctx.set_option(capi.OPT_TAP_ARITHMETIC, getattr(capi, arith))
         ctx.detect(imgs)
         lists = run_lists(ctx)
@@ -943,6 +945,9 @@ def test_kernel_selection_options_do_not_change_a_byte():
     ]
     want = None
     with sara_amd.SiftContext(w, h, b, hip_params(0, 4)) as ctx:
+        # nine captures of an 80-node graph would be this test's share of the
+        # process's graph budget on old runtimes: plain launches
+        ctx.set_option(capi.OPT_GRAPH_REPLAY, 0)
         for combo in combos:
             ctx.set_option(capi.OPT_TILE_GEOMETRY, 0)
             ctx.set_option(capi.OPT_MARCH_WAVES, 0)
