@@ -592,7 +592,7 @@ def secondary_configs(args, torch, dev):
         for label, combo in combos:
             c4.set_option(capi.OPT_TILE_GEOMETRY, 0)
             c4.set_option(capi.OPT_MARCH_WAVES, 0)
-            for opt in sorted(combo, reverse=True):
+            for opt in sorted(combo):  # the selection (10) first: it resets 11, 12
                 c4.set_option(opt, combo[opt])
             ms, _, _ = stage_ms(8, stage=1)
             sweep.append({"decomposition": label, "pyramid_ms": round(ms, 3),

@@ -951,7 +951,7 @@ def test_kernel_selection_options_do_not_change_a_byte():
         for combo in combos:
             ctx.set_option(capi.OPT_TILE_GEOMETRY, 0)
             ctx.set_option(capi.OPT_MARCH_WAVES, 0)
-            for opt in sorted(combo, reverse=True):   # selection first
+            for opt in sorted(combo):   # OPT_KERNEL_SELECTION (10) first: it resets the others
                 ctx.set_option(opt, combo[opt])
             ctx.detect(imgs)
             got = [a.tobytes() for a in ctx.fetch()]

@@ -20,8 +20,8 @@ for _ in range(3):
     ctx.detect(frames); ctx.counts()
 lib.sara_hip_debug_desc_prof(out, 0)
 v = np.array(list(out), dtype=np.float64) / 3
-names = ["-", "gather+bin+weight", "sort machinery", "replay loop", "smooth+peaks+write", "-", "-", "item total"]
+names = ["-", "gather+bin+weight", "sort machinery", "replay loop", "smooth+peaks+write", "placement (whole-patch kernel)", "-", "item total"]
 for n, x in zip(names, v):
     if n != "-":
         print("%-20s %14.0f  %5.1f %%" % (n, x, 100 * x / v[7]))
-print("setup + rest        %14.0f  %5.1f %%" % (v[7] - v[1:5].sum(), 100 * (v[7] - v[1:5].sum()) / v[7]))
+print("setup + rest        %14.0f  %5.1f %%" % (v[7] - v[1:6].sum(), 100 * (v[7] - v[1:6].sum()) / v[7]))
