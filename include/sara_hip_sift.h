@@ -559,6 +559,29 @@ SARA_HIP_API sara_hip_status sara_hip_match_descriptors(
     float sift_ratio_thres, int on_device, sara_match* matches, int capacity,
     int* count, int device);
 
+/* The same for a STREAM of independent pairs in one call - the consumer matches */
+/* consecutive frames, pair after pair (SfM/Helpers/KeypointMatching.cpp:19-25   */
+/* in the loops of SfM/BuildingBlocks): pair p is (desc1, n1) x (desc2, n2) of   */
+/* pairs[p], all with the same `dim`, ratio and on_device.  For ratios <= 1      */
+/* (the consumer's: match(keys1, keys2, 0.6f)) four searches are kept in flight  */
+/* on private streams - the host enqueues pair p + 1.. while the device works on */
+/* pair p, the small kernels of one search run beside the tile pass of another,  */
+/* and nothing waits for a read-back but the pair it belongs to; ratios > 1 run  */
+/* pair by pair.  Lists are byte-identical to n_pairs single calls: `matches`    */
+/* receives them back to back, pair p's at [offsets[p], offsets[p + 1])          */
+/* (offsets: n_pairs + 1 ints).  SARA_HIP_CAPACITY_EXCEEDED: offsets[n_pairs]    */
+/* holds the total needed.  One empty key set fails the whole call               */
+/* (SARA_HIP_RUNTIME_ERROR) before anything runs.                                */
+typedef struct sara_match_pair
+{
+  const float* desc1;
+  const float* desc2;
+  int32_t n1, n2;
+} sara_match_pair;
+SARA_HIP_API sara_hip_status sara_hip_match_descriptors_batch(
+    const sara_match_pair* pairs, int n_pairs, int dim, float sift_ratio_thres,
+    int on_device, sara_match* matches, int capacity, int* offsets, int device);
+
 /* AnnMatcher{keys, ratio, min_max_metric_dist_thres, pixel_dist_thres}         */
 /* .compute_matches() - the self-matching constructor (AnnMatcher.hpp:42-46,    */
 /* .cpp:199-215): one key set matched against itself.  Rank 0 of every search   */

@@ -26,7 +26,7 @@ __all__ = [
     "apply_gaussian_filter", "gaussian", "scale", "downscale", "enlarge",
     "gradient_polar_coordinates", "scale_space_dog_extremum_map",
     "from_rgb8_to_gray32f", "from_gray8_to_gray32f", "AnnMatcher", "match",
-    "MATCH_DTYPE", "write_keypoints", "read_keypoints", "root_sift", "H5File",
+    "MATCH_DTYPE", "match_pairs", "write_keypoints", "read_keypoints", "root_sift", "H5File",
     "make_gaussian_kernel", "SaraHipError", "OEREGION_DTYPE", "DeviceArray",
     "pinned_empty",
 ]
@@ -467,6 +467,21 @@ class SiftContext:
             capi.check(st)
             break
         return out[:count.value]
+
+    def match_frame_pairs(self, frame_pairs, lowe_ratio):
+        """match_frames() for several (i, j) pairs of the last detect() in one
+        call (sara_hip_match_descriptors_batch): e.g. consecutive frames of a
+        batch, [(0, 1), (1, 2), ...].  Returns one match array per pair."""
+        counts, _ = self.counts()
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        _, d_desc, _, _ = self.device_results()
+        pairs = [(d_desc + int(off[i]) * 512, int(counts[i]),
+                  d_desc + int(off[j]) * 512, int(counts[j]))
+                 for i, j in frame_pairs]
+        if not pairs:
+            return []
+        cap = sum(2 * (n1 + n2) + 16 for _, n1, _, n2 in pairs)
+        return _match_batch(pairs, 128, lowe_ratio, 1, self.device, cap)
 
     def keypoint_lists(self, with_descriptors=True):
         c, regions, desc, so = self.fetch(with_descriptors)
@@ -920,6 +935,46 @@ class AnnMatcher:
 def match(keys1, keys2, lowe_ratio, device=0):
     """SfM/Helpers/KeypointMatching.cpp:19-25."""
     return AnnMatcher(keys1, keys2, lowe_ratio, device=device).compute_matches()
+
+
+def _match_batch(pairs, dim, lowe_ratio, on_device, device, cap):
+    lib = capi.load()
+    arr = (capi.MatchPairStruct * max(len(pairs), 1))()
+    for k, (p1, n1, p2, n2) in enumerate(pairs):
+        arr[k] = capi.MatchPairStruct(p1, p2, n1, n2)
+    offsets = (C.c_int * (len(pairs) + 1))()
+    for _ in range(2):
+        out = np.zeros(max(cap, 1), MATCH_DTYPE)
+        st = lib.sara_hip_match_descriptors_batch(
+            arr, len(pairs), dim, float(lowe_ratio), int(on_device),
+            out.ctypes.data, cap, offsets, device)
+        if st == capi.CAPACITY_EXCEEDED and offsets[len(pairs)] > cap:
+            cap = offsets[len(pairs)]
+            continue
+        capi.check(st)
+        break
+    off = list(offsets)
+    return [out[off[k]:off[k + 1]] for k in range(len(pairs))]
+
+
+def match_pairs(key_pairs, lowe_ratio, device=0):
+    """match() for a stream of independent pairs in ONE call
+    (sara_hip_match_descriptors_batch): ``key_pairs`` = [(keys1, keys2), ...],
+    KeypointLists or N x dim matrices; returns the list of match arrays, each
+    byte-identical to ``match(keys1, keys2, lowe_ratio)``.  For ratios <= 1
+    four searches are kept in flight on the device."""
+    mats, pairs, dim = [], [], None
+    for k1, k2 in key_pairs:
+        d1, d2 = AnnMatcher._descriptors(k1), AnnMatcher._descriptors(k2)
+        if d1.shape[1] != d2.shape[1] or (dim is not None and d1.shape[1] != dim):
+            raise ValueError("descriptor dimensions differ")
+        dim = d1.shape[1]
+        mats.append((d1, d2))   # keep the arrays alive
+        pairs.append((d1.ctypes.data, d1.shape[0], d2.ctypes.data, d2.shape[0]))
+    if not pairs:
+        return []
+    cap = sum(2 * (n1 + n2) + 16 for _, n1, _, n2 in pairs)
+    return _match_batch(pairs, dim, lowe_ratio, 0, device, cap)
 
 
 def _ostream_float(v):

@@ -54,6 +54,12 @@ LAUNCH_TIME_DTYPE = np.dtype([("octave", "<i4"), ("scale", "<i4"), ("taps", "<i4
                               ("_pad2", "<f4")])
 
 #: numpy view of sara_oeregion (48 bytes, Features/Feature.hpp:155-177).
+class MatchPairStruct(C.Structure):
+    """sara_match_pair: one pair of sara_hip_match_descriptors_batch."""
+    _fields_ = [("desc1", C.c_void_p), ("desc2", C.c_void_p),
+                ("n1", C.c_int32), ("n2", C.c_int32)]
+
+
 MATCH_DTYPE = np.dtype([("x_index", "<i4"), ("y_index", "<i4"), ("score", "<f4"),
                         ("rank", "<i4"), ("direction", "<i4")])
 OEREGION_DTYPE = np.dtype(
@@ -108,6 +114,7 @@ EXPORTS = [
     "sara_hip_scale_space_dog_extremum_map", "sara_hip_selfcheck_atan2f",
     "sara_hip_sift_detect_u8", "sara_hip_from_rgb8_to_gray32f",
     "sara_hip_from_gray8_to_gray32f", "sara_hip_match_descriptors",
+    "sara_hip_match_descriptors_batch",
     "sara_hip_sift_stage", "sara_hip_sift_detect_staged", "sara_hip_root_sift",
     "sara_hip_selfcheck_device_math", "sara_hip_selfcheck_sincos",
     "sara_hip_selfcheck_definiteness", "sara_hip_selfcheck_orientation_bins",
@@ -214,6 +221,9 @@ def _declare(lib):
     lib.sara_hip_match_descriptors.argtypes = [
         _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, C.c_int,
         C.POINTER(C.c_int), C.c_int]
+    lib.sara_hip_match_descriptors_batch.argtypes = [
+        C.POINTER(MatchPairStruct), C.c_int, C.c_int, C.c_float, C.c_int, _vp,
+        C.c_int, C.POINTER(C.c_int), C.c_int]
     lib.sara_hip_self_match_descriptors.argtypes = [
         _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, _vp,
         C.c_int, C.POINTER(C.c_int), C.c_int]

@@ -12,6 +12,7 @@
 #include "sift_kernels.hpp"
 
 #include <algorithm>
+#include <climits>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -158,6 +159,24 @@ namespace {
         ;
       return e;
     }
+    //! mark(): an event behind what `stream` holds now; wait_mark() polls it.
+    hipError_t mark(hipStream_t stream)
+    {
+      if (!done)
+      {
+        const hipError_t e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+        if (e != hipSuccess)
+          return e;
+      }
+      return hipEventRecord(done, stream);
+    }
+    hipError_t wait_mark()
+    {
+      hipError_t e;
+      while ((e = hipEventQuery(done)) == hipErrorNotReady)
+        ;
+      return e;
+    }
     hipError_t host(size_t bytes, void*& p)
     {
       if (bytes > pinned_bytes)
@@ -188,6 +207,22 @@ namespace {
   Workspace& workspace(int device)
   {
     Workspace& w = workspaces()[device];
+    w.device = device;
+    return w;
+  }
+
+  //! The batched entry point keeps kBatchLanes searches in flight: one more
+  //! set of workspaces per (thread, device), each with its own stream, scratch
+  //! and pinned read-back buffer.
+  constexpr int kBatchLanes = 4;
+  std::map<int, Workspace>& lane_workspaces()
+  {
+    thread_local std::map<int, Workspace> ws;  // key: device * kBatchLanes + lane
+    return ws;
+  }
+  Workspace& lane_workspace(int device, int lane)
+  {
+    Workspace& w = lane_workspaces()[device * kBatchLanes + lane];
     w.device = device;
     return w;
   }
@@ -651,6 +686,90 @@ namespace {
     return SARA_HIP_OK;
   }
 
+  // ---- ratios <= 1, in two halves ----------------------------------------
+  // Only the best neighbour can pass (K = 1, AnnMatcher.cpp:131): the ratio
+  // test of both directions, the removal of (x, y) duplicates and the sort by
+  // score all run on the device; one copy brings the finished list back.  The
+  // tail's buffers exist before the search, so that ONE launch clears the
+  // counters of both.  Nothing in this path waits for the device before the
+  // final copy, so it splits into an asynchronous half - everything enqueued on
+  // the workspace's stream, the read-back into its pinned buffer included - and
+  // a half that waits and hands the list over: the batched entry point keeps
+  // several workspaces between the two.
+  struct BestMatchHeader
+  {
+    int count, pad[3];
+  };
+
+  sara_hip_status enqueue_best_match_search(Workspace& ws, const float* d1, int n1,
+                                            const float* d2, int n2, int dim,
+                                            float thres2)
+  {
+    using Header = BestMatchHeader;
+    const int cap_dev = n1 + n2;
+    unsigned char *d_out = nullptr, *d_tmp = nullptr;
+    const size_t list_bytes = sizeof(sara_match) * size_t(cap_dev);
+    const size_t out_bytes = sizeof(Header) + list_bytes;
+    ZeroRanges tail;
+    HIPM_TRY(ws.get(Workspace::kOut, out_bytes, d_out));
+    HIPM_TRY(ws.get(Workspace::kAux3, list_bytes + sizeof(int) * size_t(cap_dev), d_tmp));
+    tail.add(d_out, sizeof(Header) / sizeof(int));
+    tail.add(d_tmp + list_bytes, size_t(cap_dev));
+    DeviceSearch ds;
+    const sara_hip_status ss = device_search(ws, d1, n1, d2, n2, dim, thres2, 0, false,
+                                             &ds, false, 0, &tail);
+    if (ss != SARA_HIP_OK)
+      return ss;
+    launch_finish_matches(ds.top_d[0], ds.top_i[0], n1, ds.top_d[1], ds.top_i[1], n2,
+                          ds.have[0] ? 1 : 0, ds.have[1] ? 1 : 0, thres2,
+                          reinterpret_cast<sara_match*>(d_tmp),
+                          reinterpret_cast<int*>(d_tmp + list_bytes),
+                          reinterpret_cast<int*>(d_out),
+                          reinterpret_cast<sara_match*>(d_out + sizeof(Header)),
+                          ws.stream, true);
+    HIPM_TRY(hipGetLastError());
+    void* h = nullptr;
+    HIPM_TRY(ws.host(out_bytes, h));
+    HIPM_TRY(hipMemcpyAsync(h, d_out, out_bytes, hipMemcpyDeviceToHost, ws.stream));
+    HIPM_TRY(ws.mark(ws.stream));
+    return SARA_HIP_OK;
+  }
+
+  //! Waits for the search enqueue_best_match_search() left in `ws`;
+  //! *count = matches found, copied to `matches` when they fit.
+  sara_hip_status collect_best_match_search(Workspace& ws, int n1, int n2,
+                                            sara_match* matches, int capacity,
+                                            int* count)
+  {
+    using Header = BestMatchHeader;
+    HIPM_TRY(ws.wait_mark());
+    const unsigned char* h = static_cast<const unsigned char*>(ws.pinned);
+    const int found = std::min(reinterpret_cast<const Header*>(h)->count, n1 + n2);
+    *count = found;
+    if (found > capacity)
+      return set_error(SARA_HIP_CAPACITY_EXCEEDED,
+                       "more matches than `capacity` (*count holds the number "
+                       "needed)");
+    std::memcpy(matches, h + sizeof(Header), sizeof(sara_match) * size_t(found));
+    return SARA_HIP_OK;
+  }
+
+  //! Host descriptors -> the workspace's device buffers (asynchronous).
+  sara_hip_status upload_pair(Workspace& ws, const float*& d1, int n1,
+                              const float*& d2, int n2, int dim)
+  {
+    float *a = nullptr, *b = nullptr;
+    HIPM_TRY(ws.get(Workspace::kDescA, size_t(n1) * dim, a));
+    HIPM_TRY(ws.get(Workspace::kDescB, size_t(n2) * dim, b));
+    HIPM_TRY(hipMemcpyAsync(a, d1, size_t(n1) * dim * sizeof(float),
+                            hipMemcpyHostToDevice, ws.stream));
+    HIPM_TRY(hipMemcpyAsync(b, d2, size_t(n2) * dim * sizeof(float),
+                            hipMemcpyHostToDevice, ws.stream));
+    d1 = a;
+    d2 = b;
+    return SARA_HIP_OK;
+  }
+
 }  // namespace
 
 extern "C" {
@@ -793,82 +912,24 @@ sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,
     // both attempts overflowed (more than half a million radius members per
     // direction): the host path below sizes the lists exactly
   }
-  // Ratios <= 1: only the best neighbour can pass (K = 1, AnnMatcher.cpp:131):
-  // the ratio test of both directions, the removal of (x, y) duplicates and the
-  // sort by score all run on the device; one copy brings the finished list
-  // back.  The tail's buffers exist before the search, so that ONE launch
-  // clears the counters of both.
-  struct Header1
-  {
-    int count, pad[3];
-  };
-  const int cap_dev = n1 + n2;
-  unsigned char *d_out1 = nullptr, *d_tmp1 = nullptr;
-  const size_t list_bytes1 = sizeof(sara_match) * size_t(cap_dev);
-  const size_t out_bytes1 = sizeof(Header1) + list_bytes1;
-  ZeroRanges tail1;
+  // Ratios <= 1: enqueue_best_match_search / collect_best_match_search above.
   if (!(thres2 > 1.f))
   {
-    HIPM_TRY(ws.get(Workspace::kOut, out_bytes1, d_out1));
-    HIPM_TRY(ws.get(Workspace::kAux3, list_bytes1 + sizeof(int) * size_t(cap_dev), d_tmp1));
-    tail1.add(d_out1, sizeof(Header1) / sizeof(int));
-    tail1.add(d_tmp1 + list_bytes1, size_t(cap_dev));
+    const sara_hip_status es =
+        enqueue_best_match_search(ws, d1, n1, d2, n2, dim, thres2);
+    if (es != SARA_HIP_OK)
+      return es;
+    lap("enqueue");
+    const sara_hip_status cs = collect_best_match_search(ws, n1, n2, matches, capacity,
+                                                         count);
+    lap("collect");
+    return cs;
   }
   const sara_hip_status ss = device_search(ws, d1, n1, d2, n2, dim, thres2, 0, false,
-                                           &ds, false, 0, &tail1);
+                                           &ds, false, 0, nullptr);
   if (ss != SARA_HIP_OK)
     return ss;
   lap("search");
-  if (!(thres2 > 1.f))
-  {
-    using Header = Header1;
-    unsigned char *d_out = d_out1, *d_tmp = d_tmp1;
-    const size_t list_bytes = list_bytes1;
-    const size_t out_bytes = out_bytes1;
-    launch_finish_matches(ds.top_d[0], ds.top_i[0], n1, ds.top_d[1], ds.top_i[1], n2,
-                          ds.have[0] ? 1 : 0, ds.have[1] ? 1 : 0, thres2,
-                          reinterpret_cast<sara_match*>(d_tmp),
-                          reinterpret_cast<int*>(d_tmp + list_bytes),
-                          reinterpret_cast<int*>(d_out),
-                          reinterpret_cast<sara_match*>(d_out + sizeof(Header)),
-                          ws.stream, true);
-    HIPM_TRY(hipGetLastError());
-    void* h = nullptr;
-    HIPM_TRY(ws.host(out_bytes, h));
-    static hipEvent_t pe2 = nullptr;
-    if (prof)
-    {
-      if (!pe2)
-        (void) hipEventCreate(&pe2);
-      (void) hipEventRecord(pe2, ws.stream);
-    }
-    lap("finish");
-    HIPM_TRY(hipMemcpyAsync(h, d_out, out_bytes, hipMemcpyDeviceToHost, ws.stream));
-    lap("copy");
-    if (prof)
-      (void) hipEventRecord(pe1, ws.stream);
-    HIPM_TRY(ws.wait(ws.stream));
-    lap("wait");
-    if (prof)
-    {
-      float ms = 0.f;
-      (void) hipEventElapsedTime(&ms, pe0, pe1);
-      std::fprintf(stderr, "[match prof] gpu span   %8.1f us\n", 1e3 * ms);
-      (void) hipEventElapsedTime(&ms, pe2, pe1);
-      std::fprintf(stderr, "[match prof] d2h copy   %8.1f us (%zu bytes)\n", 1e3 * ms,
-                   out_bytes);
-    }
-    const int found = std::min(static_cast<Header*>(h)->count, cap_dev);
-    *count = found;
-    if (found > capacity)
-      return set_error(SARA_HIP_CAPACITY_EXCEEDED,
-                       "more matches than `capacity` (*count holds the number "
-                       "needed)");
-    std::memcpy(matches, static_cast<unsigned char*>(h) + sizeof(Header),
-                sizeof(sara_match) * size_t(found));
-    return SARA_HIP_OK;
-  }
-  else
   {
     const KeyProximity unused{0.f, 0.f};
     Neighbours nb[2];
@@ -883,6 +944,119 @@ sara_hip_status sara_hip_match_descriptors(const float* desc1, int n1,
   finish_matches(m, nullptr, nullptr);
   lap("finish");
   return deliver(m, matches, capacity, count);
+}
+
+sara_hip_status sara_hip_match_descriptors_batch(
+    const sara_match_pair* pairs, int n_pairs, int dim, float sift_ratio_thres,
+    int on_device, sara_match* matches, int capacity, int* offsets, int device)
+{
+  if (!pairs || n_pairs < 0 || !matches || !offsets || capacity < 0)
+    return set_error(SARA_HIP_INVALID_PARAMS, "null pointer or negative size");
+  for (int p = 0; p <= n_pairs; ++p)
+    offsets[p] = 0;
+  if (dim < 1 || dim > 128)
+    return set_error(SARA_HIP_INVALID_PARAMS,
+                     "descriptor dimension must be in 1..128");
+  if (sift_ratio_thres != sift_ratio_thres)
+    return set_error(SARA_HIP_INVALID_PARAMS, "the ratio threshold is NaN");
+  for (int p = 0; p < n_pairs; ++p)
+  {
+    if (!pairs[p].desc1 || !pairs[p].desc2 || pairs[p].n1 < 0 || pairs[p].n2 < 0)
+      return set_error(SARA_HIP_INVALID_PARAMS, "null pointer or negative size");
+    if (pairs[p].n1 == 0 || pairs[p].n2 == 0)
+      return set_error(SARA_HIP_RUNTIME_ERROR,
+                       "Error: the list of key-points is empty!");
+  }
+  const float thres2 = sift_ratio_thres * sift_ratio_thres;
+  int at = 0;         // records written so far
+  long long need = 0; // records all pairs hold (reported on overflow)
+  bool overflow = false;
+  if (thres2 > 1.f)
+  {
+    // The adaptive radius search sizes its lists from what it finds (and
+    // repeats itself when they overflow): pair by pair.
+    for (int p = 0; p < n_pairs; ++p)
+    {
+      int found = 0;
+      const sara_hip_status st = sara_hip_match_descriptors(
+          pairs[p].desc1, pairs[p].n1, pairs[p].desc2, pairs[p].n2, dim,
+          sift_ratio_thres, on_device, matches + at, overflow ? 0 : capacity - at,
+          &found, device);
+      if (st == SARA_HIP_CAPACITY_EXCEEDED)
+        overflow = true;
+      else if (st != SARA_HIP_OK)
+        return st;
+      need += found;
+      if (!overflow)
+        at += found;
+      offsets[p + 1] = int(std::min<long long>(need, INT_MAX));
+    }
+    if (overflow)
+      return set_error(SARA_HIP_CAPACITY_EXCEEDED,
+                       "more matches than `capacity` (offsets[n_pairs] holds the "
+                       "number needed)");
+    return SARA_HIP_OK;
+  }
+  const sara_hip_status st = use_device(device);
+  if (st != SARA_HIP_OK)
+    return st;
+  // kBatchLanes searches in flight: while the device works on pair p the host
+  // enqueues pairs p + 1 .. p + 3 on the other lanes' streams - the small
+  // kernels of one search (norms, selection, re-ranking, the tail) run beside
+  // the tile pass of another, and no pair waits for a read-back but its own.
+  // Results are collected in pair order, so the concatenated list is the one
+  // n_pairs single calls would have produced.
+  auto collect = [&](int p) -> sara_hip_status {
+    Workspace& ws = lane_workspace(device, p % kBatchLanes);
+    int found = 0;
+    const sara_hip_status cs = collect_best_match_search(
+        ws, pairs[p].n1, pairs[p].n2, matches + at, overflow ? 0 : capacity - at,
+        &found);
+    if (cs == SARA_HIP_CAPACITY_EXCEEDED)
+      overflow = true;
+    else if (cs != SARA_HIP_OK)
+      return cs;
+    need += found;
+    if (!overflow)
+      at += found;
+    offsets[p + 1] = int(std::min<long long>(need, INT_MAX));
+    return SARA_HIP_OK;
+  };
+  sara_hip_status result = SARA_HIP_OK;
+  int enqueued = 0, collected = 0;
+  for (; enqueued < n_pairs && result == SARA_HIP_OK; ++enqueued)
+  {
+    if (enqueued - collected == kBatchLanes)  // the lane is still busy
+      result = collect(collected++);
+    if (result != SARA_HIP_OK)
+      break;
+    const int p = enqueued;
+    Workspace& ws = lane_workspace(device, p % kBatchLanes);
+    HIPM_TRY(ws.ensure_stream());
+    const float *d1 = pairs[p].desc1, *d2 = pairs[p].desc2;
+    if (!on_device)
+      result = upload_pair(ws, d1, pairs[p].n1, d2, pairs[p].n2, dim);
+    if (result == SARA_HIP_OK)
+      result = enqueue_best_match_search(ws, d1, pairs[p].n1, d2, pairs[p].n2, dim,
+                                         thres2);
+    if (result != SARA_HIP_OK)
+      break;
+  }
+  // drain (also after an error: nothing of this call stays in flight)
+  for (; collected < enqueued; ++collected)
+  {
+    if (result == SARA_HIP_OK)
+      result = collect(collected);
+    else
+      (void) lane_workspace(device, collected % kBatchLanes).wait_mark();
+  }
+  if (result != SARA_HIP_OK)
+    return result;
+  if (overflow)
+    return set_error(SARA_HIP_CAPACITY_EXCEEDED,
+                     "more matches than `capacity` (offsets[n_pairs] holds the "
+                     "number needed)");
+  return SARA_HIP_OK;
 }
 
 sara_hip_status sara_hip_self_match_descriptors(
@@ -949,6 +1123,13 @@ sara_hip_status sara_hip_match_release_workspace(int device)
   const auto it = all.find(device);
   if (it != all.end())
     all.erase(it);  // ~Workspace() frees on its device, restores the current one
+  auto& lanes = lane_workspaces();
+  for (int lane = 0; lane < kBatchLanes; ++lane)
+  {
+    const auto lt = lanes.find(device * kBatchLanes + lane);
+    if (lt != lanes.end())
+      lanes.erase(lt);
+  }
   return SARA_HIP_OK;
 }
 

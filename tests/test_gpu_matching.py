@@ -355,3 +355,72 @@ def test_gpu_self_matcher_equals_annmatcher_on_flann_linear(flann_pins):
     want = flann_pins["linear_self_matches_crop"]
     assert len(got) == len(want) > 10000
     assert got.tobytes() == want.tobytes()
+
+
+# ---- batched entry point (round 6) -------------------------------------------
+@pytest.mark.parametrize("ratio", [0.6, 0.8, 1.0, 1.2])
+def test_batched_matcher_equals_single_calls_on_the_flann_pair(flann_pair, flann_pins,
+                                                               ratio):
+    """sara_hip_match_descriptors_batch: a stream of pairs in one call, four
+    searches in flight (ratios <= 1).  Every list is byte-identical to the
+    single call's - and so to the reference's FLANN (tests/golden/flann_pins.npz).
+    Ten pairs over four lanes: the same pair several times, the swapped pair,
+    sub-sets of different sizes (the lanes' workspaces are re-used with growing
+    and shrinking scratch)."""
+    d1, d2 = flann_pair
+    pairs = [(d1, d2), (d2, d1), (d1[:1000], d2[:3000]), (d1, d2), (d1[:70], d2[:50]),
+             (d1[2000:], d2), (d1, d2), (d2[:129], d2[:129]), (d1, d2[::2]), (d1, d2)]
+    got = sara_amd.match_pairs(pairs, ratio)
+    assert len(got) == len(pairs)
+    want = flann_pins["linear_matches_%.1f" % ratio]
+    for k in (0, 3, 6, 9):
+        assert got[k].tobytes() == want.tobytes(), k
+    for k, (a, b) in enumerate(pairs):
+        single = sara_amd.AnnMatcher(a, b, ratio).compute_matches()
+        assert got[k].tobytes() == single.tobytes(), k
+    assert sum(len(g) for g in got) > 20000
+
+
+def test_batched_matcher_capacity_and_errors(flann_pair):
+    from sara_amd import capi
+    import ctypes as C
+    d1, d2 = flann_pair
+    lib = capi.load()
+    arr = (capi.MatchPairStruct * 3)()
+    for k in range(3):
+        arr[k] = capi.MatchPairStruct(d1.ctypes.data, d2.ctypes.data, len(d1), len(d2))
+    offsets = (C.c_int * 4)()
+    out = np.zeros(100, sara_amd.MATCH_DTYPE)
+    st = lib.sara_hip_match_descriptors_batch(arr, 3, 128, 0.6, 0, out.ctypes.data,
+                                              100, offsets, 0)
+    assert st == capi.CAPACITY_EXCEEDED
+    single = sara_amd.match(d1, d2, 0.6)
+    assert offsets[3] == 3 * len(single)          # the total needed
+    # an empty key set fails the whole call before anything runs
+    empty = np.zeros((0, 128), np.float32)
+    with pytest.raises(sara_amd.SaraHipError):
+        sara_amd.match_pairs([(d1, d2), (empty, d2)], 0.6)
+    assert sara_amd.match_pairs([], 0.6) == []
+    # and the next call is unaffected
+    again = sara_amd.match_pairs([(d1, d2)], 0.6)
+    assert again[0].tobytes() == single.tobytes()
+
+
+def test_batched_match_of_consecutive_frames_on_device(oracle):
+    """The consumer's loop (SfM: frame i against frame i + 1) on descriptors
+    that never leave HBM."""
+    img = synth(420, 300, 23)
+    frames = np.stack([np.ascontiguousarray(img[:280, 6 * k:6 * k + 320])
+                       for k in range(6)])
+    p = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=3)
+    with sara_amd.SiftContext(320, 280, 6, p) as ctx:
+        ctx.detect(frames)
+        kl = ctx.keypoint_lists()
+        pairs = [(k, k + 1) for k in range(5)] + [(5, 0)]
+        got = ctx.match_frame_pairs(pairs, 0.6)
+        for (i, j), g in zip(pairs, got):
+            want = oracle.compute_matches(kl[i].descriptor_matrix,
+                                          kl[j].descriptor_matrix, 0.6)
+            assert_same(g, want)
+            assert g.tobytes() == ctx.match_frames(i, j, 0.6).tobytes()
+        assert min(len(g) for g in got[:5]) > 50

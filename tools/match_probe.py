@@ -45,6 +45,28 @@ for ratio in (0.6, 1.2):
         dt = (time.perf_counter() - t0) / reps
         print(f"[{mode}] ratio {ratio} {name}: {n1} x {n2}, {cnt.value} matches, "
               f"{dt*1e3:.3f} ms per call", flush=True)
+# the batched entry point: P pairs per call (descriptors in HBM), per-pair time and
+# the share of the bf16 MFMA peak the three products of every pair amount to
+if "SARA_HIP_MATCH" not in os.environ:
+    flop = 3 * 2.0 * n1 * n2 * 128          # hi*hi + hi*lo + lo*hi
+    for P in (1, 2, 4, 8, 16, 32):
+        arr = (capi.MatchPairStruct * P)()
+        for k in range(P):
+            arr[k] = capi.MatchPairStruct(t1.data_ptr(), t2.data_ptr(), n1, n2)
+        offs = (C.c_int * (P + 1))()
+        bout = np.zeros(P * (n1 + n2), capi.MATCH_DTYPE)
+        for _ in range(3):
+            capi.check(lib.sara_hip_match_descriptors_batch(
+                arr, P, 128, 0.6, 1, bout.ctypes.data, len(bout), offs, 0))
+        reps = max(4, 64 // P)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            capi.check(lib.sara_hip_match_descriptors_batch(
+                arr, P, 128, 0.6, 1, bout.ctypes.data, len(bout), offs, 0))
+        dt = (time.perf_counter() - t0) / reps / P
+        print(f"[batch] ratio 0.6 device pointers, P = {P:2d}: {dt*1e3:.3f} ms per pair, "
+              f"{flop / dt / 1e12:.0f} TFLOP/s = {flop / dt / 2.5e15:.3f} of the bf16 "
+              f"MFMA peak ({offs[P] // P} matches per pair)", flush=True)
 if "SARA_HIP_MATCH" not in os.environ and "--no-child" not in sys.argv:
     subprocess.run([sys.executable, __file__, "--no-child"],
                    env=dict(os.environ, SARA_HIP_MATCH="exhaustive"))
