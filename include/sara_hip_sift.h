@@ -423,6 +423,8 @@ enum
   SARA_HIP_OPT_MARCH_WAVES = 12,        /* target waves per marching blur launch */
                                         /* (0 = shipped: 4096 / 2048); the other */
                                         /* axis of that sweep                    */
+  SARA_HIP_OPT_MARCH2_WAVES = 14,       /* the same for the R >= 8 blurs only    */
+                                        /* (set after _MARCH_WAVES)              */
   SARA_HIP_OPT_TAP_ARITHMETIC = 9,      /* SARA_HIP_TAPS_*: the arithmetic of    */
                                         /* make_gaussian_kernel's exp() / sum()  */
                                         /* (default SARA_HIP_TAPS_LIBM_SERIAL).  */

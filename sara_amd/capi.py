@@ -38,6 +38,7 @@ OPT_KERNEL_SELECTION = 10
 OPT_TILE_GEOMETRY = 11
 OPT_MARCH_WAVES = 12
 OPT_GRAPH_REPLAY = 13
+OPT_MARCH2_WAVES = 14
 # values of OPT_KERNEL_SELECTION (sara_hip_sift.h SARA_HIP_SELECT_*)
 SELECT_ENVIRONMENT = 0
 SELECT_SHIPPED = 1

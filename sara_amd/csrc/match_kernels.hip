@@ -364,7 +364,7 @@ namespace sara_hip {
       out[rank[e]] = in[e];
   }
 
-  __global__ __launch_bounds__(256) void zero_ranges_kernel(ZeroRanges r)
+  __global__ __launch_bounds__(256) void zero_ranges_kernel(ZeroRangesArg r)
   {
     int* p = r.p[blockIdx.y];
     const unsigned n = r.n[blockIdx.y];
@@ -372,16 +372,31 @@ namespace sara_hip {
       p[i] = 0;
   }
 
-  void launch_zero_ranges(const ZeroRanges& r, hipStream_t stream)
+  bool launch_zero_ranges(const ZeroRanges& r, hipStream_t stream)
   {
-    if (r.count == 0)
-      return;
-    unsigned longest = 0;
-    for (int k = 0; k < r.count; ++k)
-      longest = std::max(longest, r.n[k]);
-    const unsigned blocks = std::min(512u, (longest + 1023) / 1024);
-    hipLaunchKernelGGL(zero_ranges_kernel, dim3(std::max(blocks, 1u), r.count), dim3(256),
-                       0, stream, r);
+    if (r.overflow)
+    {
+      // a range was not registered: whoever relies on it would read stale
+      // counters - poison the stream's error state instead of running on
+      (void) hipMemsetAsync(nullptr, 0, 1, stream);  // -> hipErrorInvalidValue
+      return false;
+    }
+    for (int first = 0; first < r.count; first += kZeroRangesPerLaunch)
+    {
+      const int m = std::min(kZeroRangesPerLaunch, r.count - first);
+      ZeroRangesArg a;
+      unsigned longest = 0;
+      for (int k = 0; k < m; ++k)
+      {
+        a.p[k] = r.p[first + k];
+        a.n[k] = r.n[first + k];
+        longest = std::max(longest, a.n[k]);
+      }
+      const unsigned blocks = std::min(512u, (longest + 1023) / 1024);
+      hipLaunchKernelGGL(zero_ranges_kernel, dim3(std::max(blocks, 1u), m), dim3(256), 0,
+                         stream, a);
+    }
+    return true;
   }
 
   void launch_finish_matches(const float* top_d0, const int* top_i0, int n1,

@@ -46,9 +46,18 @@ namespace sara_hip {
   //    (the launch rounds up to whole segments).  4-column kernel (R <= 6,
   //    latency-bound: VALU pipe 26-34 % busy): 4 per SIMD - 1080p x 64: 116 ->
   //    111 us (R = 5), 135 -> 128 (R = 6), 287 -> 235 (first blur) against 2
-  //    per SIMD, neutral on 720p and 4K.  2-column kernel (R >= 8): 2048 ->
-  //    2880 waves on 1080p x 64; 3072 is 10 % faster launch by launch on one
-  //    stream but not with the per-octave streams, which fill the same gaps.
+  //    per SIMD, neutral on 720p and 4K.  2-column kernel (R >= 8, 86 / 100 /
+  //    114 VGPRs: 5 / 4 / 4 waves per SIMD fit): 3072 -> 3840 waves on 1080p x
+  //    64, one round of resident waves.  Round 6, tools/march2_waves_probe.py
+  //    (64 x 1080p, octave 0, single stream): 2048 / 2560 / 3072 / 3584 / 4096
+  //    / 5120 -> R = 8: 295 / 276 / 231 / 234 / 229 / 261 us, R = 10: 295 / 277
+  //    / 262 / 267 / 299 / 269, R = 12: 335 / 307 / 301 / 307 / 330 / 299 (a
+  //    launch of more waves than fit runs a second, short round); the whole
+  //    stage on one stream 2.34 -> 2.11 ms.  With the per-octave streams the
+  //    stage does not move (1.934 / 1.938 / 1.944 / 1.948 / 1.967 / 1.975 ms):
+  //    the other octaves' launches fill the same wave slots - round 4 saw the
+  //    same and kept 2048; 3072 is kept now because a single stream (and every
+  //    per-kernel figure) gains 10 % and the overlapped stage loses nothing.
   //  * march_min_pixels - below this many pixels per launch (width x height x
   //    batch) the marching kernels cannot fill the chip - a wave is a serial
   //    chain of row steps - and the tiled kernel is used instead (240x135 x 64
@@ -1199,16 +1208,36 @@ namespace sara_hip {
       out[i] = a[i] - b[i];
   }
 
-  __global__ void zero_counters_kernel(int4* p)
+  //! Clears the per-step counters and STAMPS the step: the thread that owns
+  //! the int4 holding counters[stamp] bumps the context's persistent step
+  //! counter *epoch (outside the cleared block; this thread is its only
+  //! writer) and stores the new value there.  The host counts the steps it
+  //! enqueued; a read-back whose stamp is not that number did not go through
+  //! this kernel - its counters are the previous step's (sift_context.cpp,
+  //! counters_corrupt).
+  __global__ void zero_counters_kernel(int4* p, unsigned* epoch, int stamp)
   {
-    p[blockIdx.x * 16 + threadIdx.x] = make_int4(0, 0, 0, 0);
+    const int i = blockIdx.x * 16 + threadIdx.x;
+    int4 v = make_int4(0, 0, 0, 0);
+    if (i == (stamp >> 2))
+    {
+      const unsigned e = *epoch + 1u;
+      *epoch = e;
+      const int lane = stamp & 3;
+      v.x = lane == 0 ? int(e) : 0;
+      v.y = lane == 1 ? int(e) : 0;
+      v.z = lane == 2 ? int(e) : 0;
+      v.w = lane == 3 ? int(e) : 0;
+    }
+    p[i] = v;
   }
 
-  void launch_zero_counters(int* counters, size_t count, hipStream_t stream)
+  void launch_zero_counters(int* counters, size_t count, unsigned* epoch, int stamp,
+                            hipStream_t stream)
   {
     // whole 256-byte blocks (counters_padded): 16 lanes x 16 bytes each
     hipLaunchKernelGGL(zero_counters_kernel, dim3(unsigned(count / 64)), dim3(16), 0,
-                       stream, reinterpret_cast<int4*>(counters));
+                       stream, reinterpret_cast<int4*>(counters), epoch, stamp);
   }
 
   void launch_subtract(const float* a, const float* b, float* out, size_t count,

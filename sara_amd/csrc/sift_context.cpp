@@ -194,7 +194,11 @@ namespace {
       {
         if (ready())
           return true;
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        asm volatile("yield" ::: "memory");
+#endif
       }
       while (!ready())
       {
@@ -231,6 +235,9 @@ namespace {
       // fork(): the child inherits the launcher's state (started, perhaps a
       // locked mutex) but not its thread - the first run() would wait for
       // ever.  The child gets a fresh launcher; the old one is abandoned.
+      // This only keeps a forked child from HANGING inside the library: the
+      // HIP runtime itself does not survive fork(), GPU work in the child is
+      // not supported (spawn, or fork before the first call).
       pthread_atfork(nullptr, nullptr, [] {
         g_launcher.store(new GraphLauncher, std::memory_order_release);
       });
@@ -620,8 +627,9 @@ static void orientation_bin_thresholds(float thr_out[40])
   }
 }
 
-//! Ints in d_counters (4 * max_batch + 3 used: the per-frame counters, the
-//! frame offsets, the peak scan's arrival counter, the error flag), in whole
+//! Ints in d_counters (4 * max_batch + 4 used: the per-frame counters, the
+//! frame offsets, the peak scan's arrival counter, the error flag, the step
+//! stamp), in whole
 //! 256-byte blocks; the last three ints are the graph's filler targets.
 static inline size_t counters_padded(int max_batch)
 {
@@ -629,6 +637,11 @@ static inline size_t counters_padded(int max_batch)
 }
 //! Ints of d_counters that travel to the host with a batch's counts.
 static inline size_t counters_read(int max_batch)
+{
+  return 4 * size_t(max_batch) + 4;
+}
+//! The step stamp zero_counters_kernel leaves (the context's step number).
+static inline size_t step_stamp_index(int max_batch)
 {
   return 4 * size_t(max_batch) + 3;
 }
@@ -717,6 +730,11 @@ struct sara_hip_sift
   Taps init_taps{};
   std::vector<Taps> taps;  // per scale s = 1..S-1
   int* d_counters = nullptr;  // cand.count | sites.count | ori.kp_count | ori.frame_offset
+  //! steps this context has run: bumped by zero_counters_kernel on the device
+  //! (d_epoch, behind the cleared block) and by detect() on the host
+  unsigned* d_epoch = nullptr;
+  unsigned epoch_host = 0;
+  bool epoch_synced = false;  // false: adopt the device's number at the next read-back
   ScaleTable h_tab{};
   ScaleTable* d_tab = nullptr;
   double* d_oriw = nullptr;
@@ -751,6 +769,7 @@ struct sara_hip_sift
     sara_hip_stage stage = SARA_HIP_STAGE_DESCRIPTOR;  // last_stage of the submit()
     hipEvent_t done = nullptr;   // counters of the batch are in h_counters
     int* h_counters = nullptr;   // pinned copy of d_counters (counters_read())
+    unsigned step = 0;           // the context's step number of this batch
     sara_oeregion* h_feat = nullptr;  // pinned result arrays, grown on demand
     float* h_desc = nullptr;
     int32_t* h_so = nullptr;
@@ -1123,7 +1142,9 @@ namespace {
     // + 1 for frame_offset[batch], + 1 arrival counter of the peak scan
     // padded to whole 256-byte blocks: the runtime then zeroes it with one
     // fill kernel instead of an aligned part and a tail
-    TRY_ST(c->alloc(c->d_counters, counters_padded(max_batch)));
+    TRY_ST(c->alloc(c->d_counters, counters_padded(max_batch) + 64));
+    TRY_HIP(hipMemset(c->d_counters, 0, sizeof(int) * (counters_padded(max_batch) + 64)));
+    c->d_epoch = reinterpret_cast<unsigned*>(c->d_counters + counters_padded(max_batch));
     c->cand.count = c->d_counters;
     c->sites.count = c->d_counters + max_batch;
     c->ori.kp_count = c->d_counters + 2 * size_t(max_batch);
@@ -1163,7 +1184,8 @@ namespace {
   //! cleared by a kernel of the library): a kernel met a negative counter and
   //! raised the flag, or a counter is negative now.  The lists of such a step
   //! are incomplete - the call fails instead of returning them.
-  bool counters_corrupt(const int* h, int mb, int batch, int lists)
+  bool counters_corrupt(sara_hip_sift* c, const int* h, int mb, int batch, int lists,
+                        unsigned expected_step)
   {
     if (h[error_flag_index(mb)] != 0)
       return true;
@@ -1171,13 +1193,26 @@ namespace {
       for (int b = 0; b < batch; ++b)
         if (h[size_t(l) * mb + b] < 0)
           return true;
-    return false;
+    // a counter that was not cleared holds the previous step's
+    // POSITIVE count and passes the test above.  The clearing kernel stamps the
+    // block with the number of the step; the host knows which step it is
+    // reading (after a failed enqueue it does not: the next read-back adopts the
+    // device's number).
+    const unsigned stamp = unsigned(h[step_stamp_index(mb)]);
+    if (!c->epoch_synced)
+    {
+      c->epoch_host += stamp - expected_step;
+      c->epoch_synced = true;
+      return false;
+    }
+    return stamp != expected_step;
   }
   sara_hip_status corrupt_counters_error()
   {
     return fail(SARA_HIP_RUNTIME_ERROR,
-                "a keypoint-list counter was not cleared before this batch ran "
-                "(negative counter): the lists are incomplete");
+                "the keypoint-list counters were not cleared before this batch "
+                "ran (negative counter or a stale step stamp): the lists are "
+                "incomplete");
   }
 
   //! Remembers what list capacity a batch asked for: per frame the largest of
@@ -1533,6 +1568,12 @@ sara_hip_status sara_hip_sift_set_option(sara_hip_sift* c, int option, int value
     if (value != 0 && value < 64)
       return fail(SARA_HIP_INVALID_PARAMS, "waves per marching launch >= 64");
     c->sel.march_waves = value ? value : KernelSelection{}.march_waves;
+    c->sel.march2_waves = value ? value : KernelSelection{}.march2_waves;
+    c->graph_stage_s[0] = c->graph_stage_s[1] = -1;
+    return SARA_HIP_OK;
+  case SARA_HIP_OPT_MARCH2_WAVES:
+    if (value != 0 && value < 64)
+      return fail(SARA_HIP_INVALID_PARAMS, "waves per marching launch >= 64");
     c->sel.march2_waves = value ? value : KernelSelection{}.march2_waves;
     c->graph_stage_s[0] = c->graph_stage_s[1] = -1;
     return SARA_HIP_OK;
@@ -1896,7 +1937,8 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     return SARA_HIP_OK;
   };
   if (pipe)  // the scans start before the pyramid is complete
-    launch_zero_counters(c->d_counters, counters_padded(c->max_batch), tail);
+    launch_zero_counters(c->d_counters, counters_padded(c->max_batch), c->d_epoch,
+                         int(step_stamp_index(c->max_batch)), tail);
 
   // ---- Gaussian pyramid + fused DoG ---------------------------------------
   if (sc.num_octaves > 0)
@@ -2150,7 +2192,8 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
 
   // ---- extrema ------------------------------------------------------------
   if (!pipe)
-    launch_zero_counters(c->d_counters, counters_padded(c->max_batch), stream);
+    launch_zero_counters(c->d_counters, counters_padded(c->max_batch), c->d_epoch,
+                         int(step_stamp_index(c->max_batch)), stream);
   if (last_stage >= SARA_HIP_STAGE_EXTREMA)
   {
     if (!pipe)
@@ -2221,7 +2264,11 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   {
     const sara_hip_status est = enqueue();
     if (est != SARA_HIP_OK)
+    {
+      c->epoch_synced = false;  // some of the step's launches may have run
       return est;
+    }
+    ++c->epoch_host;
     c->has_result = true;
     return SARA_HIP_OK;
   }
@@ -2286,7 +2333,11 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       c->graph_broken = true;
       const sara_hip_status est = enqueue();
       if (est != SARA_HIP_OK)
+      {
+        c->epoch_synced = false;
         return est;
+      }
+      ++c->epoch_host;
       c->has_result = true;
       return SARA_HIP_OK;
     }
@@ -2313,7 +2364,11 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       c->graph_broken = true;
       const sara_hip_status est = enqueue();
       if (est != SARA_HIP_OK)
+      {
+        c->epoch_synced = false;
         return est;
+      }
+      ++c->epoch_host;
       c->has_result = true;
       return SARA_HIP_OK;
     }
@@ -2352,7 +2407,16 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
         c->graph_inplace = false;
     }
   }
-  HIP_TRY(hipGraphLaunch(graph_exec, stream));
+  {
+    const hipError_t ge = hipGraphLaunch(graph_exec, stream);
+    if (ge != hipSuccess)
+    {
+      c->epoch_synced = false;
+      return fail(SARA_HIP_RUNTIME_ERROR,
+                  std::string("hipGraphLaunch: ") + hipGetErrorString(ge));
+    }
+    ++c->epoch_host;
+  }
   if (c->timers)
   {
     c->ev_recorded[SARA_HIP_TIME_TOTAL] = true;
@@ -2691,6 +2755,7 @@ sara_hip_status submit_impl(sara_hip_sift* c, const void* images,
                          hipMemcpyDeviceToHost, c->last_stream));
   HIP_TRY(hipEventRecord(r.done, c->last_stream));
   r.ticket = c->next_ticket;
+  r.step = c->epoch_host;
   r.pending = true;
   r.batch = batch;
   r.stage = last_stage;
@@ -2723,7 +2788,7 @@ sara_hip_status sara_hip_sift_collect(sara_hip_sift* c, int ticket,
                 "descriptors requested, but the ticket was submitted with "
                 "last_stage < DESCRIPTOR (collect it with descriptors = NULL)");
   sara_hip_status status = SARA_HIP_OK;
-  if (counters_corrupt(r.h_counters, mb, r.batch, 3))
+  if (counters_corrupt(c, r.h_counters, mb, r.batch, 3, r.step))
   {
     r.pending = false;
     return corrupt_counters_error();
@@ -2856,7 +2921,7 @@ namespace sara_hip {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(r.done));
     const int mb = c->max_batch;
-    if (counters_corrupt(r.h_counters, mb, r.batch, 3))
+    if (counters_corrupt(c, r.h_counters, mb, r.batch, 3, r.step))
     {
       r.pending = false;
       return corrupt_counters_error();
@@ -2911,7 +2976,8 @@ sara_hip_status sara_hip_sift_counts(sara_hip_sift* c, int* per_frame, int* tota
     return st;
   HIP_TRY(hipSetDevice(c->device));
   // cand.count | sites.count | ori.kp_count are contiguous in d_counters: one
-  // round trip brings all three (h_counts holds 3 * max_batch + 2 ints)
+  // round trip brings all three (h_counts holds counters_read(max_batch) ints: the three per-frame
+  // lists, the frame offsets and the error flag)
   int* h_ex = c->h_counts;
   int* h_sites = c->h_counts + c->max_batch;
   int* h_kp = c->h_counts + 2 * size_t(c->max_batch);
@@ -2919,7 +2985,7 @@ sara_hip_status sara_hip_sift_counts(sara_hip_sift* c, int* per_frame, int* tota
                          sizeof(int) * counters_read(c->max_batch),
                          hipMemcpyDeviceToHost, c->last_stream));
   HIP_TRY(hipStreamSynchronize(c->last_stream));
-  if (counters_corrupt(c->h_counts, c->max_batch, c->cur_batch, 3))
+  if (counters_corrupt(c, c->h_counts, c->max_batch, c->cur_batch, 3, c->epoch_host))
     return corrupt_counters_error();
   note_required(c, h_ex, h_sites, h_kp, c->cur_batch);
   int sum = 0;
@@ -3103,7 +3169,7 @@ sara_hip_status sara_hip_sift_extrema_counts(sara_hip_sift* c, int* per_frame,
                          sizeof(int) * counters_read(c->max_batch),
                          hipMemcpyDeviceToHost, c->last_stream));
   HIP_TRY(hipStreamSynchronize(c->last_stream));
-  if (counters_corrupt(c->h_counts, c->max_batch, c->cur_batch, 2))
+  if (counters_corrupt(c, c->h_counts, c->max_batch, c->cur_batch, 2, c->epoch_host))
     return corrupt_counters_error();
   note_required(c, h_ex, h_sites, nullptr, c->cur_batch);
   int sum = 0;

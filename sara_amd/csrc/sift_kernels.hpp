@@ -207,7 +207,8 @@ namespace sara_hip {
   //! its memset node had not cleared yet (round 4; the lists then came back
   //! truncated with status OK).  A kernel node is ordered like every other
   //! kernel of the chain.
-  void launch_zero_counters(int* counters, size_t count, hipStream_t stream);
+  void launch_zero_counters(int* counters, size_t count, unsigned* epoch, int stamp,
+                            hipStream_t stream);
   void launch_subtract(const float* a, const float* b, float* out, size_t count,
                        hipStream_t stream);
 
@@ -289,7 +290,7 @@ namespace sara_hip {
     bool blur_march = true;      //!< false: tiled blur everywhere (SARA_HIP_BLUR=tile)
     bool feature_march = true;   //!< false: pixel-parallel gradient / scan (SARA_HIP_FEATURES=tile)
     int march_waves = 4096;      //!< target waves per launch, 4-column blur (SARA_HIP_MARCH_WAVES)
-    int march2_waves = 2048;     //!< the same, 2-column blur (SARA_HIP_MARCH2_WAVES)
+    int march2_waves = 3072;     //!< the same, 2-column blur (SARA_HIP_MARCH2_WAVES)
     size_t march_min_pixels = size_t(4) << 20;  //!< smaller launches take the tiled blur
     int strip_group = 0;         //!< 0: production rule; 1 / 4 / 8 forced (SARA_HIP_STRIP_GROUP)
     long long grad_tile_pixels = (long long) 4 << 20;  //!< smaller planes: pixel-parallel gradient
@@ -368,22 +369,40 @@ namespace sara_hip {
   //! matcher's counters, flags and rank arrays of a call.  Round 4 cleared them
   //! with a hipMemsetAsync each, which the runtime turns into up to three fill
   //! kernels per call site - 17 fills per match call, a fifth of its GPU time.
+  //! Integer ranges one launch clears.  kZeroRangesPerLaunch of them ride in the
+  //! kernel's argument; a caller that registers more gets further launches
+  //! (launch_zero_ranges) - a range is never dropped: callers tell their tails
+  //! "your scratch is cleared" on the strength of having added it here.
+  constexpr int kZeroRangesPerLaunch = 6;
+  struct ZeroRangesArg
+  {
+    int* p[kZeroRangesPerLaunch] = {};
+    unsigned n[kZeroRangesPerLaunch] = {};  // ints
+  };
   struct ZeroRanges
   {
-    int* p[6] = {};
-    unsigned n[6] = {};  // ints
+    static constexpr int kMax = 4 * kZeroRangesPerLaunch;
+    int* p[kMax] = {};
+    unsigned n[kMax] = {};  // ints
     int count = 0;
+    bool overflow = false;  // more than kMax ranges: launch_zero_ranges fails loudly
     void add(void* ptr, size_t ints)
     {
-      if (ptr && ints && count < 6)
+      if (!ptr || !ints)
+        return;
+      if (count == kMax)
       {
-        p[count] = static_cast<int*>(ptr);
-        n[count] = unsigned(ints);
-        ++count;
+        overflow = true;
+        return;
       }
+      p[count] = static_cast<int*>(ptr);
+      n[count] = unsigned(ints);
+      ++count;
     }
   };
-  void launch_zero_ranges(const ZeroRanges& r, hipStream_t stream);
+  //! false (nothing launched, the thread's error text set by the caller's
+  //! HIPM_TRY through hipErrorInvalidValue) when ranges were lost.
+  bool launch_zero_ranges(const ZeroRanges& r, hipStream_t stream);
 
   //! (query block, candidate chunk) decomposition of an exhaustive search.
   void match_chunking(int nq, int nt, int* chunk, int* nchunks);

@@ -49,7 +49,8 @@ def test_random_descriptors_match_oracle(oracle, n1, n2, dim):
             assert (got["rank"] > 1).any()
 
 
-@pytest.mark.parametrize("case", ["random", "clusters", "big_norms", "odd_dim"])
+@pytest.mark.parametrize("case", ["random", "clusters", "big_norms", "odd_dim",
+                                  "near_ties", "tiny", "mixed_magnitude", "dim65"])
 def test_mfma_prefilter_equals_exhaustive_and_oracle(oracle, case, tmp_path):
     """Key sets large enough (>= 256) for the default producer, the MFMA
     prefilter with exact re-ranking (match_mfma.hip): the match lists must be
@@ -57,7 +58,15 @@ def test_mfma_prefilter_equals_exhaustive_and_oracle(oracle, case, tmp_path):
     SARA_HIP_MATCH=exhaustive must return the same bytes.  Adversarial inputs:
     `clusters` puts hundreds of keys inside the prefilter's error guard of each
     other (slot overflow -> exhaustive fallback per query), `big_norms` has
-    components up to 1e4 (large guard), `odd_dim` is not a multiple of four."""
+    components up to 1e4 (large guard), `odd_dim` is not a multiple of four.
+    Round 6 (the bf16 hi / lo bound assumes round-to-nearest f32
+    accumulation in the matrix cores and no flushing of tiny lo halves):
+    `near_ties` - every query has its 2nd..5th neighbours within a few ulp of
+    each other (the order of near-tied 3rd / 4th neighbours decides the list);
+    `tiny` - components around 1e-19, where x - hi underflows towards the
+    subnormals; `mixed_magnitude` - rows of norm 1e4 next to rows of norm 1e-2
+    in one tile (the bound scales with max |b|^2); `dim65` - one chunk of 64
+    plus a single column."""
     import os
     import subprocess
     import sys
@@ -78,6 +87,38 @@ def test_mfma_prefilter_equals_exhaustive_and_oracle(oracle, case, tmp_path):
         d1 = (rng.random((700, dim), dtype=np.float32) * 1e4).astype(np.float32)
         d2 = d1[::-1][:650] + rng.normal(0, 5.0, (650, dim)).astype(np.float32)
         d2 = d2.astype(np.float32)
+    elif case == "near_ties":
+        base = (rng.random((300, dim), dtype=np.float32) * 255).astype(np.float32)
+        d1 = base.copy()
+        # five copies of every key, each moved by about one ulp of its largest
+        # components in a few places: distances to them differ in the last bits
+        reps = []
+        for k in range(5):
+            c = base.copy()
+            cols = rng.integers(0, dim, (300, 3))
+            for j in range(3):
+                c[np.arange(300), cols[:, j]] = np.nextafter(
+                    c[np.arange(300), cols[:, j]], np.float32(1e9))
+            reps.append(c)
+        d2 = np.concatenate(reps).astype(np.float32)
+        d2 = d2[rng.permutation(len(d2))]
+    elif case == "tiny":
+        d1 = (rng.random((500, dim), dtype=np.float32) * 1e-19).astype(np.float32)
+        d2 = (d1[::-1][:450] * np.float32(1.001)).astype(np.float32)
+        d2[:50] = (rng.random((50, dim), dtype=np.float32) * 1e-19).astype(np.float32)
+    elif case == "mixed_magnitude":
+        big = (rng.random((300, dim), dtype=np.float32) * 1e3).astype(np.float32)
+        small = (rng.random((300, dim), dtype=np.float32) * 1e-3).astype(np.float32)
+        d1 = np.concatenate([big, small])[rng.permutation(600)]
+        d2 = np.concatenate([big[:250] + rng.normal(0, 0.5, (250, dim)).astype(np.float32),
+                             small[:250] * np.float32(1.01),
+                             small[250:] + np.float32(1e-6)]).astype(np.float32)
+        d2 = d2[rng.permutation(len(d2))]
+    elif case == "dim65":
+        dim = 65
+        d1 = (rng.random((450, dim), dtype=np.float32) * 255).astype(np.float32)
+        d2 = (rng.random((380, dim), dtype=np.float32) * 255).astype(np.float32)
+        d2[:200] = d1[100:300] + rng.normal(0, 1.0, (200, dim)).astype(np.float32)
     else:
         dim = 57
         d1 = rng.random((400, dim), dtype=np.float32)
@@ -89,7 +130,7 @@ def test_mfma_prefilter_equals_exhaustive_and_oracle(oracle, case, tmp_path):
     got = {r: sara_amd.match(d1, d2, r) for r in ratios}
     for r in ratios:
         assert_same(got[r], oracle.compute_matches(d1, d2, r))
-    assert len(got[0.8]) > 0 or case == "clusters"
+    assert len(got[0.8]) > 0 or case in ("clusters", "near_ties")
     script = (
         "import sys, numpy as np\n"
         "sys.path.insert(0, %r)\n"
