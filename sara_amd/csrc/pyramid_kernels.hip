@@ -1213,7 +1213,7 @@ namespace sara_hip {
   //! counter *epoch (outside the cleared block; this thread is its only
   //! writer) and stores the new value there.  The host counts the steps it
   //! enqueued; a read-back whose stamp is not that number did not go through
-  //! this kernel - its counters are the previous step's (sift_context.cpp,
+  //! this kernel - its counters are the previous step's (sift_context.cpp:
   //! counters_corrupt).
   __global__ void zero_counters_kernel(int4* p, unsigned* epoch, int stamp)
   {

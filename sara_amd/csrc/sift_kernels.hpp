@@ -1,4 +1,4 @@
-// Launch interface between the context (sift_context.cpp) and the gfx950
+// Launch interface between the host side (sift_host.hpp: context, detect()) and the gfx950
 // kernels (sift_kernels.hip).  Internal header, not part of the C-ABI.
 #pragma once
 
@@ -480,7 +480,7 @@ namespace sara_hip {
   sara_hip_status ticket_results(sara_hip_sift* ctx, int ticket, TicketResults* out);
   void ticket_release(sara_hip_sift* ctx, int ticket);
   //! Process-wide lock around graph capture / launch and the creation /
-  //! destruction of contexts, streams and graphs (sift_context.cpp says why).
+  //! destruction of contexts, streams and graphs (graph_launcher.cpp says why).
   std::recursive_mutex& runtime_mutex();
   //! Records the error message sara_hip_last_error() returns on this thread.
   sara_hip_status set_error(sara_hip_status code, const char* msg);

@@ -63,7 +63,7 @@ def kernel_selection(request):
     # how they are submitted, graph replay of the shipped selection has its own
     # fresh-process tests (test_gpu_full_size.py), and the ROCm 7.0 runtime that
     # `import torch` loads does not survive many more graph captures per process
-    # than round 5's suite already made (sift_context.cpp: kOldRuntimeGraphBudget).
+    # than round 5's suite already made (graph_launcher.cpp: kOldRuntimeGraphBudget).
     options = ({capi.OPT_KERNEL_SELECTION: capi.SELECT_FORCED_MARCH}
                if request.param == "forced" else
                {capi.OPT_KERNEL_SELECTION: capi.SELECT_SHIPPED,

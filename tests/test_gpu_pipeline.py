@@ -877,7 +877,7 @@ def test_context_churn_from_several_threads_next_to_a_replaying_thread():
     replaying its graph.  That runtime crashed in hip::Graph::UpdateStreams
     when several threads replayed graphs (3 of 3 runs of this script); the
     library now keeps graph replay with one thread there
-    (sift_context.cpp: graphs_need_one_thread)."""
+    (graph_launcher.cpp: graphs_need_one_thread)."""
     import os
     import subprocess
     import sys

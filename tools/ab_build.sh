@@ -9,11 +9,11 @@ set -e
 cd "$(dirname "$0")/../sara_amd/csrc"
 name=$1; extra=$2; shift; shift
 files="$*"
-[ -z "$files" ] && files="pyramid_kernels.hip feature_kernels.hip keypoint_kernels.hip match_kernels.hip sift_context.cpp"
+[ -z "$files" ] && files="pyramid_kernels.hip feature_kernels.hip keypoint_kernels.hip match_kernels.hip sift_context.cpp sift_detect.cpp"
 flags="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -fvisibility=hidden $extra"
 mkdir -p ../lib/ab /tmp/ab_$name
 objs=""
-for f in pyramid_kernels.hip feature_kernels.hip keypoint_kernels.hip match_kernels.hip match_mfma.hip sift_context.cpp sift_comm.cpp sift_match.cpp; do
+for f in pyramid_kernels.hip feature_kernels.hip keypoint_kernels.hip match_kernels.hip match_mfma.hip graph_launcher.cpp sift_schedule.cpp sift_context.cpp sift_detect.cpp sift_results.cpp sift_operators.cpp sift_comm.cpp sift_match.cpp; do
   o=${f%.*}.o
   if echo " $files " | grep -q " $f "; then
     x=""; { [ "$f" = match_kernels.hip ] || [ "$f" = feature_kernels.hip ] || [ "$f" = pyramid_kernels.hip ]; } && x="-fno-slp-vectorize"
