@@ -249,6 +249,20 @@ namespace sara_hip {
     }
   }
 
+  //! A pointer every lane holds alike (it came out of the pair table at
+  //! blockIdx), pinned into scalar registers: the compiler then combines the
+  //! wave's atomicAdd(count, 1) into one atomic per wave, as it does for a
+  //! kernel argument - 4 140 same-address atomics took 45 us instead of 5.
+  template <typename T>
+  __device__ __forceinline__ T* wave_uniform(T* p)
+  {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(v));
+    const unsigned hi = __builtin_amdgcn_readfirstlane(unsigned(v >> 32));
+    using G = __attribute__((address_space(1))) T*;
+    return (T*) (G) ((static_cast<unsigned long long>(hi) << 32) | lo);
+  }
+
   // ---- the whole tail of compute_matches on the device (squared ratio <= 1) ---
   //! AnnMatcher.cpp:126-147 for both directions plus the sort by (x, y, score)
   //! and the std::unique of :239-254: thread q < n1 is key q of the first set
@@ -257,15 +271,30 @@ namespace sara_hip {
   //! (direction 0 on equal scores - the order the restated sort leaves).
   //! have0 / have1: the direction has >= 2 candidates (a single candidate
   //! scores 1 and never passes a squared ratio <= 1, :87-101).
-  __global__ void mutual_filter_kernel(const float* __restrict__ top_d0,
-                                       const int* __restrict__ top_i0, int n1,
-                                       const float* __restrict__ top_d1,
-                                       const int* __restrict__ top_i1, int n2,
+  template <bool BATCH>
+  __global__ void mutual_filter_kernel(const float* __restrict__ top_d0_,
+                                       const int* __restrict__ top_i0_, int n1_,
+                                       const float* __restrict__ top_d1_,
+                                       const int* __restrict__ top_i1_, int n2_,
                                        int have0, int have1,
                                        float squared_ratio_thres,
-                                       sara_match* __restrict__ out,
-                                       int* __restrict__ count)
+                                       sara_match* __restrict__ out_,
+                                       int* __restrict__ count_,
+                                       const MatchBatchPair* __restrict__ batch)
   {
+    // pair blockIdx.y of a batch (both directions have >= 2 keys), or the
+    // kernel's own arguments
+    const MatchBatchPair* b = BATCH ? batch + blockIdx.y : nullptr;
+    const int n1 = BATCH ? b->n1 : n1_;
+    const int n2 = BATCH ? b->n2 : n2_;
+    const float* __restrict__ top_d0 = BATCH ? b->top_d : top_d0_;
+    const int* __restrict__ top_i0 = BATCH ? b->top_i : top_i0_;
+    const float* __restrict__ top_d1 = BATCH ? b->top_d + 3 * size_t(n1) : top_d1_;
+    const int* __restrict__ top_i1 = BATCH ? b->top_i + 3 * size_t(n1) : top_i1_;
+    sara_match* __restrict__ out = BATCH ? wave_uniform(b->tmp) : out_;
+    int* __restrict__ count = BATCH ? wave_uniform(b->header) : count_;
+    if (BATCH)
+      have0 = have1 = 1;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n1 + n2)
       return;
@@ -314,12 +343,17 @@ namespace sara_hip {
     k2 = m.y_index;
   }
 
+  template <bool BATCH>
   __global__ __launch_bounds__(256) void rank_count_kernel(
-      const sara_match* __restrict__ in, const int* __restrict__ count,
-      int* __restrict__ rank)
+      const sara_match* __restrict__ in_, const int* __restrict__ count_,
+      int* __restrict__ rank_, const MatchBatchPair* __restrict__ batch)
   {
     __shared__ unsigned long long s_k1[256];
     __shared__ int s_k2[256];
+    const MatchBatchPair* b = BATCH ? batch + blockIdx.z : nullptr;  // pair blockIdx.z
+    const sara_match* __restrict__ in = BATCH ? wave_uniform(b->tmp) : in_;
+    const int* __restrict__ count = BATCH ? wave_uniform(b->header) : count_;
+    int* __restrict__ rank = BATCH ? wave_uniform(b->rank) : rank_;
     const int n = *count;
     // (the grid may be smaller than the list: tiles are walked with its stride)
     for (int tx = blockIdx.x; tx * 256 < n; tx += gridDim.x)
@@ -354,11 +388,18 @@ namespace sara_hip {
       }
   }
 
-  __global__ void rank_scatter_kernel(const sara_match* __restrict__ in,
-                                      const int* __restrict__ count,
-                                      const int* __restrict__ rank,
-                                      sara_match* __restrict__ out)
+  template <bool BATCH>
+  __global__ void rank_scatter_kernel(const sara_match* __restrict__ in_,
+                                      const int* __restrict__ count_,
+                                      const int* __restrict__ rank_,
+                                      sara_match* __restrict__ out_,
+                                      const MatchBatchPair* __restrict__ batch)
   {
+    const MatchBatchPair* b = BATCH ? batch + blockIdx.y : nullptr;  // pair blockIdx.y
+    const sara_match* __restrict__ in = BATCH ? wave_uniform(b->tmp) : in_;
+    const int* __restrict__ count = BATCH ? wave_uniform(b->header) : count_;
+    const int* __restrict__ rank = BATCH ? wave_uniform(b->rank) : rank_;
+    sara_match* __restrict__ out = BATCH ? wave_uniform(b->out) : out_;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < *count;
          e += gridDim.x * blockDim.x)
       out[rank[e]] = in[e];
@@ -413,13 +454,64 @@ namespace sara_hip {
       z.add(rank_scratch, size_t(n));
       launch_zero_ranges(z, stream);
     }
-    hipLaunchKernelGGL(mutual_filter_kernel, dim3(tiles), dim3(256), 0, stream,
+    hipLaunchKernelGGL(mutual_filter_kernel<false>, dim3(tiles), dim3(256), 0, stream,
                        top_d0, top_i0, n1, top_d1, top_i1, n2, have0, have1,
-                       squared_ratio_thres, scratch, count);
-    hipLaunchKernelGGL(rank_count_kernel, dim3(tiles, tiles), dim3(256), 0, stream,
-                       scratch, count, rank_scratch);
-    hipLaunchKernelGGL(rank_scatter_kernel, dim3(tiles), dim3(256), 0, stream,
-                       scratch, count, rank_scratch, out);
+                       squared_ratio_thres, scratch, count, nullptr);
+    hipLaunchKernelGGL(rank_count_kernel<false>, dim3(tiles, tiles), dim3(256), 0, stream,
+                       scratch, count, rank_scratch, nullptr);
+    hipLaunchKernelGGL(rank_scatter_kernel<false>, dim3(tiles), dim3(256), 0, stream,
+                       scratch, count, rank_scratch, out, nullptr);
+  }
+
+  //! The sorted lists of a batch back to back in `dense`, pair p's at
+  //! [heads[p], heads[p + 1]) - what travels to the host is the matches that
+  //! exist, not every pair's capacity (n1 + n2 records each).
+  __global__ __launch_bounds__(256) void compact_lists_kernel(
+      const MatchBatchPair* __restrict__ batch, int n_pairs,
+      sara_match* __restrict__ dense, int* __restrict__ heads)
+  {
+    const int pair = blockIdx.y;
+    int offset = 0;
+    for (int q = 0; q < pair; ++q)
+      offset += min(batch[q].header[0], batch[q].n1 + batch[q].n2);
+    const MatchBatchPair& b = batch[pair];
+    const int count = min(b.header[0], b.n1 + b.n2);
+    const sara_match* __restrict__ in = wave_uniform(b.out);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < count;
+         e += gridDim.x * blockDim.x)
+      dense[offset + e] = in[e];
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+      heads[pair] = offset;
+      if (pair == n_pairs - 1)
+        heads[n_pairs] = offset + count;
+    }
+  }
+
+  void launch_compact_lists(const MatchBatchPair* table, int n_pairs, int n_max,
+                            sara_match* dense, int* heads, hipStream_t stream)
+  {
+    const int tiles = std::min((n_max + 255) / 256, 16);
+    hipLaunchKernelGGL(compact_lists_kernel, dim3(tiles, n_pairs), dim3(256), 0, stream,
+                       table, n_pairs, dense, heads);
+  }
+
+  void launch_finish_matches_batch(const MatchBatchPair* table, int n_pairs,
+                                   int n_max, float squared_ratio_thres,
+                                   hipStream_t stream)
+  {
+    // n_max = largest n1 + n2 of the batch; a pair's list is at most that long.
+    // The rank sort walks its tiles with the grid's stride: a grid of 16 x 16
+    // tiles per pair covers lists of any length.
+    const int tiles = (n_max + 255) / 256;
+    const int rt = std::min(tiles, 16);
+    hipLaunchKernelGGL(mutual_filter_kernel<true>, dim3(tiles, n_pairs), dim3(256), 0, stream,
+                       nullptr, nullptr, 0, nullptr, nullptr, 0, 1, 1,
+                       squared_ratio_thres, nullptr, nullptr, table);
+    hipLaunchKernelGGL(rank_count_kernel<true>, dim3(rt, rt, n_pairs), dim3(256), 0, stream,
+                       nullptr, nullptr, nullptr, table);
+    hipLaunchKernelGGL(rank_scatter_kernel<true>, dim3(rt, n_pairs), dim3(256), 0, stream,
+                       nullptr, nullptr, nullptr, nullptr, table);
   }
 
   // ------------------------------------------------------------------------ //
@@ -625,10 +717,10 @@ namespace sara_hip {
                        scratch, int(n), header, header + 1);
     const int mtiles = std::max(1, std::min(int((n + 255) / 256),
                                             (4 * std::max(n1, n2) + 255) / 256));
-    hipLaunchKernelGGL(rank_count_kernel, dim3(mtiles, mtiles), dim3(256), 0, stream,
-                       scratch, header, mrank);
-    hipLaunchKernelGGL(rank_scatter_kernel, dim3(mtiles), dim3(256), 0, stream, scratch,
-                       header, mrank, out);
+    hipLaunchKernelGGL(rank_count_kernel<false>, dim3(mtiles, mtiles), dim3(256), 0, stream,
+                       scratch, header, mrank, nullptr);
+    hipLaunchKernelGGL(rank_scatter_kernel<false>, dim3(mtiles), dim3(256), 0, stream, scratch,
+                       header, mrank, out, nullptr);
   }
 
   void match_chunking(int nq, int nt, int* chunk, int* nchunks)

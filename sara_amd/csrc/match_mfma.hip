@@ -142,15 +142,45 @@ namespace sara_hip {
       m1 = fminf(m1, v);
     }
 
+    //! A value every lane of the wave holds alike (read through a table entry
+    //! indexed by blockIdx): pinned into SGPRs, or the compiler keeps a copy
+    //! per lane and the tile kernel spills.
+    __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+    //! Pointers read from the pair table are pointers into HBM: said so (a
+    //! pointer that comes out of a load is generic to the compiler, and the tile
+    //! kernel - global loads into LDS, accumulator arrays it wants in registers -
+    //! spilled 72 dwords per lane on generic ones).
+    template <typename T>
+    __device__ __forceinline__ T* uni(T* p)
+    {
+      using G = __attribute__((address_space(1))) T*;
+      return (T*) (G) p;
+    }
+
     //! |x_i|^2 of every row of both key sets and the maximum over each set
     //! (norms are >= 0, so their bit patterns order like unsigned integers).
     //! 16 lanes per row, 4 rows per wave; any summation order fits the bound.
+    template <bool BATCH = false>
     __global__ __launch_bounds__(1024) void row_norms_kernel(
         const float* __restrict__ x1, int n1, const float* __restrict__ x2, int n2,
         int dim, float* __restrict__ norms1, float* __restrict__ norms2,
         unsigned* __restrict__ max_bits, unsigned short* __restrict__ split1,
-        unsigned short* __restrict__ split2, int dimp)
+        unsigned short* __restrict__ split2, int dimp,
+        const MatchBatchPair* __restrict__ batch)
     {
+      if constexpr (BATCH)  // pair blockIdx.y of a batch
+      {
+        const MatchBatchPair& b = batch[blockIdx.y];
+        x1 = uni(b.d1);
+        n1 = uni(b.n1);
+        x2 = uni(b.d2);
+        n2 = uni(b.n2);
+        norms1 = uni(b.na);
+        norms2 = uni(b.nb);
+        max_bits = uni(b.maxbits);
+        split1 = uni(b.split1);
+        split2 = uni(b.split2);
+      }
       const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;  // row of both
       const int sub = threadIdx.x & 15;
       const bool second = g >= n1;
@@ -246,8 +276,11 @@ namespace sara_hip {
     //! co-resident workgroups fall into step, so the phases add up).  The bf16
     //! contraction is 12 MFMA per 16 k and quadrant at 16 x the f32 rate: what
     //! is left is staging and the epilogue.
+    //! The tile at (tile_x, tile_y) by the 256 threads of the workgroup: the body
+    //! of mfma_tiles_kernel (single pair: the arguments are the kernel's) and of
+    //! mfma_tiles_batch_kernel (the arguments come out of the pair table).
     template <int MODE>
-    __global__ __launch_bounds__(256, 2) void mfma_tiles_kernel(
+    __device__ __forceinline__ void mfma_tile(
         const unsigned short* __restrict__ Ah, int n1,
         const unsigned short* __restrict__ Bh, int n2, int dimp,
         const float* __restrict__ na, const float* __restrict__ nb,
@@ -257,7 +290,7 @@ namespace sara_hip {
         const float* __restrict__ tau_row, const float* __restrict__ tau_col,
         int* __restrict__ cand_row, int* __restrict__ cnt_row,
         int* __restrict__ cand_col, int* __restrict__ cnt_col, int cap,
-        int with_cols_and_debug)
+        int with_cols_and_debug, const int tile_x, const int tile_y)
     {
       extern __shared__ __attribute__((aligned(16))) float lds[];
       const int with_cols = with_cols_and_debug & 1;
@@ -269,7 +302,7 @@ namespace sara_hip {
       const unsigned short* Al = Ah + size_t(n1) * dimp;
       const unsigned short* Bl = Bh + size_t(n2) * dimp;
       const int tid = threadIdx.x;
-      const int row0 = blockIdx.y * kTile, col0 = blockIdx.x * kTile;
+      const int row0 = tile_y * kTile, col0 = tile_x * kTile;
       const int lane = tid & 63, wave = tid >> 6;
       const int wm = wave >> 1, wn = wave & 1;
       const int li = lane & 31, half = lane >> 5;
@@ -291,10 +324,20 @@ namespace sara_hip {
           const size_t oa = size_t(row0 + r) * dimp + k0 + 8 * c;
           const size_t ob = size_t(col0 + r) * dimp + k0 + 8 * c;
           const bool ra = row0 + r < n1, rb = col0 + r < n2;
-          v[it] = ra ? *reinterpret_cast<const uint4*>(Ah + oa) : zero;
-          v[4 + it] = ra ? *reinterpret_cast<const uint4*>(Al + oa) : zero;
-          v[8 + it] = rb ? *reinterpret_cast<const uint4*>(Bh + ob) : zero;
-          v[12 + it] = rb ? *reinterpret_cast<const uint4*>(Bl + ob) : zero;
+          // explicitly global-memory loads: through a generic pointer (the
+          // batched kernel's come out of an argument array) they are flat
+          // loads that may address LDS as far as the compiler knows, and it
+          // then orders every one of them behind the LDS writes of the
+          // previous chunk instead of keeping all sixteen in flight
+          auto gload = [](const unsigned short* p) -> uint4 {
+            using G = const __attribute__((address_space(1))) unsigned*;
+            const G g = (G) p;
+            return make_uint4(g[0], g[1], g[2], g[3]);
+          };
+          v[it] = ra ? gload(Ah + oa) : zero;
+          v[4 + it] = ra ? gload(Al + oa) : zero;
+          v[8 + it] = rb ? gload(Bh + ob) : zero;
+          v[12 + it] = rb ? gload(Bl + ob) : zero;
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it)
@@ -400,7 +443,7 @@ namespace sara_hip {
           for (int c = 0; c < kTile; ++c)
             min4_update((ordered_bits(p[c]) & ~127) | c, k1, k2, k3, k4);
           if (row0 + tid < n1)
-            reinterpret_cast<int4*>(rowmin)[size_t(blockIdx.x) * n1 + row0 + tid] =
+            reinterpret_cast<int4*>(rowmin)[size_t(tile_x) * n1 + row0 + tid] =
                 make_int4(k1, k2, k3, k4);
         }
         else if (with_cols)
@@ -411,7 +454,7 @@ namespace sara_hip {
           for (int r = 0; r < kTile; ++r)
             min4_update((ordered_bits(p[r * kDStride]) & ~127) | r, k1, k2, k3, k4);
           if (col0 + c < n2)
-            reinterpret_cast<int4*>(colmin)[size_t(blockIdx.y) * n2 + col0 + c] =
+            reinterpret_cast<int4*>(colmin)[size_t(tile_y) * n2 + col0 + c] =
                 make_int4(k1, k2, k3, k4);
         }
       }
@@ -438,7 +481,7 @@ namespace sara_hip {
             min3_update(p[c], m1, m2, m3);
           if (row0 + tid < n1)
           {
-            float* o = rowmin + (size_t(blockIdx.x) * n1 + row0 + tid) * 3;
+            float* o = rowmin + (size_t(tile_x) * n1 + row0 + tid) * 3;
             o[0] = m1;
             o[1] = m2;
             o[2] = m3;
@@ -453,7 +496,7 @@ namespace sara_hip {
             min3_update(p[r * kDStride], m1, m2, m3);
           if (col0 + c < n2)
           {
-            float* o = colmin + (size_t(blockIdx.y) * n2 + col0 + c) * 3;
+            float* o = colmin + (size_t(tile_y) * n2 + col0 + c) * 3;
             o[0] = m1;
             o[1] = m2;
             o[2] = m3;
@@ -532,6 +575,51 @@ namespace sara_hip {
     //! Global three smallest approximations of every query -> its threshold.
     //! top1: rank of the best real neighbour (1 when a set is matched against
     //! itself: rank 0 is the query).
+    template <int MODE>
+    __global__ __launch_bounds__(256, 2) void mfma_tiles_kernel(
+        const unsigned short* __restrict__ Ah, int n1,
+        const unsigned short* __restrict__ Bh, int n2, int dimp,
+        const float* __restrict__ na, const float* __restrict__ nb,
+        float* __restrict__ rowmin, float* __restrict__ colmin,
+        const float* __restrict__ tau_row, const float* __restrict__ tau_col,
+        int* __restrict__ cand_row, int* __restrict__ cnt_row,
+        int* __restrict__ cand_col, int* __restrict__ cnt_col, int cap,
+        int with_cols_and_debug)
+    {
+      mfma_tile<MODE>(Ah, n1, Bh, n2, dimp, na, nb, rowmin, colmin, tau_row, tau_col,
+                      cand_row, cnt_row, cand_col, cnt_col, cap, with_cols_and_debug,
+                      blockIdx.x, blockIdx.y);
+    }
+
+    //! ONE tile grid over a batch of pairs: blockIdx.z = pair; the grid covers
+    //! the largest pair, the surplus workgroups of the others leave.  The pairs'
+    //! pointers travel in the kernel's argument segment (scalar loads, like the
+    //! single kernel's own arguments), at most kTileBatchPairs per launch.
+    constexpr int kTileBatchPairs = 32;
+    struct TileBatchArgs
+    {
+      const unsigned short* Ah[kTileBatchPairs];
+      const unsigned short* Bh[kTileBatchPairs];
+      const float* na[kTileBatchPairs];
+      const float* nb[kTileBatchPairs];
+      float* rowmin[kTileBatchPairs];
+      float* colmin[kTileBatchPairs];
+      int n1[kTileBatchPairs];
+      int n2[kTileBatchPairs];
+    };
+    template <int MODE>
+    __global__ __launch_bounds__(256, 2) void mfma_tiles_batch_kernel(TileBatchArgs a,
+                                                                     int dimp, int cap)
+    {
+      const int z = blockIdx.z;
+      const int n1 = a.n1[z], n2 = a.n2[z];
+      if (int(blockIdx.y) * kTile >= n1 || int(blockIdx.x) * kTile >= n2)
+        return;  // the whole workgroup
+      mfma_tile<MODE>(a.Ah[z], n1, a.Bh[z], n2, dimp, a.na[z], a.nb[z], a.rowmin[z],
+                      a.colmin[z], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                      cap, 1, blockIdx.x, blockIdx.y);
+    }
+
     //! blockIdx.y = direction (rows / columns of the tiles): one launch.
     struct ThresholdDir
     {
@@ -592,11 +680,25 @@ namespace sara_hip {
     //! are merged across the 16 lanes by xor shuffles, every lane then emits
     //! the passing keys of its own tiles (slots claimed with atomicAdd on the
     //! query's counter, which the launch zeroes).
+    template <bool BATCH = false>
     __global__ __launch_bounds__(256) void select_packed_kernel(
         const int4* __restrict__ partial, int ntiles, int n,
         const float* __restrict__ norms, const unsigned* __restrict__ other_max_bits,
-        int dim, int cap, int* __restrict__ cand, int* __restrict__ cnt)
+        int dim, int cap, int* __restrict__ cand, int* __restrict__ cnt,
+        const MatchBatchPair* __restrict__ batch)
     {
+      if constexpr (BATCH)  // blockIdx.y = 2 * pair + direction
+      {
+        const MatchBatchPair& b = batch[blockIdx.y >> 1];
+        const bool cols = (blockIdx.y & 1) != 0;
+        partial = reinterpret_cast<const int4*>(uni(cols ? b.colmin : b.rowmin));
+        ntiles = (uni(cols ? b.n1 : b.n2) + kTile - 1) / kTile;
+        n = uni(cols ? b.n2 : b.n1);
+        norms = uni(cols ? b.nb : b.na);
+        other_max_bits = uni(cols ? b.maxbits : b.maxbits + 1);
+        cand = uni(cols ? b.cand_c : b.cand_r);
+        cnt = uni(cols ? b.cnt_c : b.cnt_r);
+      }
       const int gid = blockIdx.x * blockDim.x + threadIdx.x;
       const int i = gid >> 4, sub = gid & 15;
       const bool live = i < n;
@@ -684,24 +786,57 @@ namespace sara_hip {
     {
       RerankDir d[2];
     };
-    template <int CAP>
-    __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs args, int dim,
-                                                         float squared_ratio_thres,
-                                                         int top1)
+    template <int CAP, bool BATCH = false>
+    __global__ __launch_bounds__(256) void rerank_kernel(
+        RerankArgs args, int dim, float squared_ratio_thres, int top1,
+        const MatchBatchPair* __restrict__ batch)
     {
-      const RerankDir& a = args.d[blockIdx.y];
-      const float* __restrict__ q = a.q;
-      const int nq = a.nq;
-      const float* __restrict__ t = a.t;
-      const int* __restrict__ cand = a.cand;
-      const int* __restrict__ cnt = a.cnt;
-      float* __restrict__ top_d = a.top_d;
-      int* __restrict__ top_i = a.top_i;
-      MatchNeighbour* __restrict__ radius_out = a.radius_out;
-      const int radius_cap = a.radius_cap;
-      int* __restrict__ radius_count = a.radius_count;
-      int* __restrict__ flagged = a.flagged;
-      int* __restrict__ flagged_count = a.flagged_count;
+      const float* __restrict__ q;
+      int nq;
+      const float* __restrict__ t;
+      const int* __restrict__ cand;
+      const int* __restrict__ cnt;
+      float* __restrict__ top_d;
+      int* __restrict__ top_i;
+      MatchNeighbour* __restrict__ radius_out;
+      int radius_cap;
+      int* __restrict__ radius_count;
+      int* __restrict__ flagged;
+      int* __restrict__ flagged_count;
+      if constexpr (BATCH)  // pair blockIdx.z, direction blockIdx.y
+      {
+        const MatchBatchPair& b = batch[blockIdx.z];
+        const bool cols = blockIdx.y != 0;
+        const int n1 = uni(b.n1);
+        q = uni(cols ? b.d2 : b.d1);
+        nq = cols ? uni(b.n2) : n1;
+        t = uni(cols ? b.d1 : b.d2);
+        cand = uni(cols ? b.cand_c : b.cand_r);
+        cnt = uni(cols ? b.cnt_c : b.cnt_r);
+        top_d = uni(b.top_d) + (cols ? 3 * size_t(n1) : 0);
+        top_i = uni(b.top_i) + (cols ? 3 * size_t(n1) : 0);
+        radius_out = nullptr;
+        radius_cap = 0;
+        radius_count = nullptr;
+        flagged = uni(cols ? b.flag_c : b.flag_r);
+        flagged_count = uni(b.scal) + (cols ? 1 : 0);
+      }
+      else
+      {
+        const RerankDir& a = args.d[blockIdx.y];
+        q = a.q;
+        nq = a.nq;
+        t = a.t;
+        cand = a.cand;
+        cnt = a.cnt;
+        top_d = a.top_d;
+        top_i = a.top_i;
+        radius_out = a.radius_out;
+        radius_cap = a.radius_cap;
+        radius_count = a.radius_count;
+        flagged = a.flagged;
+        flagged_count = a.flagged_count;
+      }
       const int gid = blockIdx.x * blockDim.x + threadIdx.x;
       const int qi = gid / CAP, slot = gid % CAP;
       const int lane = threadIdx.x & 63;
@@ -837,27 +972,62 @@ namespace sara_hip {
     //! Queries whose candidate slots overflowed: exhaustive search, one
     //! 1024-thread workgroup per query (a single wave per query spent 0.3 ms on
     //! its 67 dependent row reads per lane).
-    __global__ __launch_bounds__(1024) void fallback_kernel(FallbackArgs args, int dim,
-                                                            float squared_ratio_thres,
-                                                            int top1)
+    template <bool BATCH = false>
+    __global__ __launch_bounds__(1024) void fallback_kernel(
+        FallbackArgs args, int dim, float squared_ratio_thres, int top1,
+        const MatchBatchPair* __restrict__ batch)
     {
-      const FallbackDir& a = args.d[blockIdx.z];
-      const float* __restrict__ q = a.q;
-      const int nq = a.nq;
-      const float* __restrict__ t = a.t;
-      const int nt = a.nt;
-      const int* __restrict__ flagged = a.flagged;
-      float* __restrict__ top_d = a.top_d;
-      int* __restrict__ top_i = a.top_i;
-      MatchNeighbour* __restrict__ radius_out = a.radius_out;
-      const int radius_cap = a.radius_cap;
-      int* __restrict__ radius_count = a.radius_count;
-      const float* __restrict__ staged = a.staged;
+      const float* __restrict__ q;
+      int nq;
+      const float* __restrict__ t;
+      int nt;
+      const int* __restrict__ flagged;
+      const int* __restrict__ flagged_count;
+      float* __restrict__ top_d;
+      int* __restrict__ top_i;
+      MatchNeighbour* __restrict__ radius_out;
+      int radius_cap;
+      int* __restrict__ radius_count;
+      const float* __restrict__ staged;
+      if constexpr (BATCH)  // pair blockIdx.y, direction blockIdx.z
+      {
+        const MatchBatchPair& b = batch[blockIdx.y];
+        const bool cols = blockIdx.z != 0;
+        const int n1 = uni(b.n1), n2 = uni(b.n2);
+        q = uni(cols ? b.d2 : b.d1);
+        nq = cols ? n2 : n1;
+        t = uni(cols ? b.d1 : b.d2);
+        nt = cols ? n1 : n2;
+        flagged = uni(cols ? b.flag_c : b.flag_r);
+        flagged_count = uni(b.scal) + (cols ? 1 : 0);
+        top_d = uni(b.top_d) + (cols ? 3 * size_t(n1) : 0);
+        top_i = uni(b.top_i) + (cols ? 3 * size_t(n1) : 0);
+        radius_out = nullptr;
+        radius_cap = 0;
+        radius_count = nullptr;
+        staged = nullptr;
+      }
+      else
+      {
+        const FallbackDir& a = args.d[blockIdx.z];
+        q = a.q;
+        nq = a.nq;
+        t = a.t;
+        nt = a.nt;
+        flagged = a.flagged;
+        flagged_count = a.flagged_count;
+        top_d = a.top_d;
+        top_i = a.top_i;
+        radius_out = a.radius_out;
+        radius_cap = a.radius_cap;
+        radius_count = a.radius_count;
+        staged = a.staged;
+      }
       __shared__ float s_d[1024 * 3];
       __shared__ int s_i[1024 * 3];
       __shared__ float s_radius;
       const int tid = threadIdx.x;
-      const int n = *a.flagged_count;
+      const int n = *flagged_count;
       for (int k = blockIdx.x; k < n; k += gridDim.x)
       {
         const int qi = flagged[k];
@@ -1031,8 +1201,8 @@ namespace sara_hip {
       z.add(cnt_r, size_t(n1) + n2 + 16);
       launch_zero_ranges(z, stream);
     }
-    hipLaunchKernelGGL(row_norms_kernel, dim3((n1 + n2 + 63) / 64), dim3(1024), 0,
-                       stream, d1, n1, d2, n2, dim, na, nb, maxbits, split1, split2, dimp);
+    hipLaunchKernelGGL(row_norms_kernel<false>, dim3((n1 + n2 + 63) / 64), dim3(1024), 0,
+                       stream, d1, n1, d2, n2, dim, na, nb, maxbits, split1, split2, dimp, nullptr);
     // panels of one chunk, or the distance tile + norms / thresholds (minima),
     // or the hit queue in front of the norms / thresholds (emit: the queue must
     // end before the norm arrays start at kTile * kDStride floats)
@@ -1063,13 +1233,13 @@ namespace sara_hip {
                          n1, split2, n2, dimp, na, nb, rowmin, colmin, nullptr, nullptr,
                          nullptr, nullptr, nullptr, nullptr, cap, cols_arg);
       tick();  // 2: minima
-      hipLaunchKernelGGL(select_packed_kernel, dim3((n1 + 15) / 16), dim3(256), 0,
+      hipLaunchKernelGGL(select_packed_kernel<false>, dim3((n1 + 15) / 16), dim3(256), 0,
                          stream, reinterpret_cast<const int4*>(rowmin), tn, n1, na,
-                         maxbits + 1, dim, cap, cand_r, cnt_r);
+                         maxbits + 1, dim, cap, cand_r, cnt_r, nullptr);
       if (with_dir1)
-        hipLaunchKernelGGL(select_packed_kernel, dim3((n2 + 15) / 16), dim3(256), 0,
+        hipLaunchKernelGGL(select_packed_kernel<false>, dim3((n2 + 15) / 16), dim3(256), 0,
                            stream, reinterpret_cast<const int4*>(colmin), tm, n2, nb,
-                           maxbits, dim, cap, cand_c, cnt_c);
+                           maxbits, dim, cap, cand_c, cnt_c, nullptr);
       tick();  // 3: thresholds
       tick();  // 4: emit (none)
     }
@@ -1103,13 +1273,13 @@ namespace sara_hip {
       const dim3 g(unsigned((threads + 255) / 256), with_dir1 ? 2 : 1);
       if (cap == 8)
         hipLaunchKernelGGL(rerank_kernel<8>, g, dim3(256), 0, stream, ra, dim,
-                           squared_ratio_thres, top1);
+                           squared_ratio_thres, top1, nullptr);
       else if (cap == 64)
         hipLaunchKernelGGL(rerank_kernel<64>, g, dim3(256), 0, stream, ra, dim,
-                           squared_ratio_thres, top1);
+                           squared_ratio_thres, top1, nullptr);
       else
         hipLaunchKernelGGL(rerank_kernel<32>, g, dim3(256), 0, stream, ra, dim,
-                           squared_ratio_thres, top1);
+                           squared_ratio_thres, top1, nullptr);
     }
     {
       // Queries whose candidate slots overflowed.  Their distances are staged
@@ -1130,8 +1300,9 @@ namespace sara_hip {
         hipLaunchKernelGGL(fallback_distances_kernel,
                            dim3(kFallbackParts, std::min(nq_max, kFallbackSlots), ndir),
                            dim3(256), 0, stream, fa, dim);
-      hipLaunchKernelGGL(fallback_kernel, dim3(std::min(nq_max, 256), 1, ndir),
-                         dim3(1024), 0, stream, fa, dim, squared_ratio_thres, top1);
+      hipLaunchKernelGGL(fallback_kernel<false>, dim3(std::min(nq_max, 256), 1, ndir),
+                         dim3(1024), 0, stream, fa, dim, squared_ratio_thres, top1,
+                         nullptr);
     }
     tick();  // 5: rerank + fallback
     if (prof)
@@ -1145,6 +1316,138 @@ namespace sara_hip {
         std::fprintf(stderr, "[match prof]   %-10s %8.1f us\n", names[k], 1e3 * ms);
       }
     }
+  }
+
+
+  // ---- a batch of pairs in one set of launches (round 6) -----------------------
+  namespace {
+    template <typename T>
+    T* carve(unsigned char* base, size_t& at, size_t count)
+    {
+      at = (at + 15) & ~size_t(15);
+      T* p = base ? reinterpret_cast<T*>(base + at) : nullptr;
+      at += count * sizeof(T);
+      return p;
+    }
+  }  // namespace
+
+  void match_batch_carve(int n1, int n2, int dim, unsigned char* zero_base,
+                         unsigned char* work_base, unsigned char* out_base,
+                         MatchBatchLayout* at, MatchBatchPair* pair)
+  {
+    const int tm = (n1 + kTile - 1) / kTile, tn = (n2 + kTile - 1) / kTile;
+    const int dimp = (dim + kChunk - 1) / kChunk * kChunk;
+    const size_t n = size_t(n1) + n2;
+    MatchBatchPair p{};
+    p.n1 = n1;
+    p.n2 = n2;
+    // cleared at the head of the batch: maxima, candidate counters, flag
+    // counters, the list header and the rank sort's counters
+    p.maxbits = carve<unsigned>(zero_base, at->zero_bytes, 16);
+    p.cnt_r = carve<int>(zero_base, at->zero_bytes, n + 16);
+    p.cnt_c = p.cnt_r ? p.cnt_r + n1 : nullptr;
+    p.scal = p.cnt_r ? p.cnt_r + n : nullptr;
+    p.rank = carve<int>(zero_base, at->zero_bytes, n);
+    // work
+    p.na = carve<float>(work_base, at->work_bytes, n);
+    p.nb = p.na ? p.na + n1 : nullptr;
+    p.rowmin = carve<float>(work_base, at->work_bytes, 4 * size_t(tn) * n1);
+    p.colmin = carve<float>(work_base, at->work_bytes, 4 * size_t(tm) * n2);
+    p.split1 = carve<unsigned short>(work_base, at->work_bytes, 2 * size_t(n1) * dimp);
+    p.split2 = carve<unsigned short>(work_base, at->work_bytes, 2 * size_t(n2) * dimp);
+    p.flag_r = carve<int>(work_base, at->work_bytes, n);
+    p.flag_c = p.flag_r ? p.flag_r + n1 : nullptr;
+    p.cand_r = carve<int>(work_base, at->work_bytes, n * kMatchBatchCap);
+    p.cand_c = p.cand_r ? p.cand_r + size_t(n1) * kMatchBatchCap : nullptr;
+    p.top_d = carve<float>(work_base, at->work_bytes, 3 * n);
+    p.top_i = carve<int>(work_base, at->work_bytes, 3 * n);
+    p.tmp = carve<sara_match>(work_base, at->work_bytes, n);
+    // read back: header (cleared by its own tiny range: it sits in the out
+    // arena so that ONE copy brings every list home) + sorted list
+    p.header = carve<int>(out_base, at->out_bytes, 4);
+    p.out = carve<sara_match>(out_base, at->out_bytes, n);
+    if (pair)
+    {
+      p.d1 = pair->d1;
+      p.d2 = pair->d2;
+      *pair = p;
+    }
+  }
+
+  __global__ void zero_headers_kernel(const MatchBatchPair* __restrict__ batch)
+  {
+    if (threadIdx.x < 4)
+      batch[blockIdx.x].header[threadIdx.x] = 0;
+  }
+
+  void launch_match_batch(const MatchBatchPair* table, const MatchBatchPair* host_table,
+                          int n_pairs, int n1_max, int n2_max, int dim,
+                          float squared_ratio_thres, void* zero, size_t zero_bytes,
+                          hipStream_t stream)
+  {
+    const int dimp = (dim + kChunk - 1) / kChunk * kChunk;
+    const int tm = (n1_max + kTile - 1) / kTile, tn = (n2_max + kTile - 1) / kTile;
+    const int cap = kMatchBatchCap;
+    {
+      ZeroRanges z;
+      z.add(zero, zero_bytes / sizeof(int));
+      launch_zero_ranges(z, stream);
+      hipLaunchKernelGGL(zero_headers_kernel, dim3(n_pairs), dim3(64), 0, stream, table);
+    }
+    hipLaunchKernelGGL(row_norms_kernel<true>, dim3((n1_max + n2_max + 63) / 64, n_pairs),
+                       dim3(1024), 0, stream, nullptr, 0, nullptr, 0, dim, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, dimp, table);
+    const size_t lds = std::max(size_t(4) * kTile * kPanelBytes,
+                                sizeof(float) * (kTile * kDStride + 4 * kTile));
+    {
+      static std::atomic<bool> allowed[64];
+      int dev = 0;
+      (void) hipGetDevice(&dev);
+      if (!allowed[dev & 63].load(std::memory_order_acquire))
+      {
+        (void) hipFuncSetAttribute(
+            reinterpret_cast<const void*>(mfma_tiles_batch_kernel<kPacked>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        allowed[dev & 63].store(true, std::memory_order_release);
+      }
+    }
+    // ONE tile grid over all pairs: blockIdx.z = pair
+    for (int first = 0; first < n_pairs; first += kTileBatchPairs)
+    {
+      const int m = std::min(kTileBatchPairs, n_pairs - first);
+      TileBatchArgs a{};
+      for (int k = 0; k < m; ++k)
+      {
+        const MatchBatchPair& b = host_table[first + k];
+        a.Ah[k] = b.split1;
+        a.Bh[k] = b.split2;
+        a.na[k] = b.na;
+        a.nb[k] = b.nb;
+        a.rowmin[k] = b.rowmin;
+        a.colmin[k] = b.colmin;
+        a.n1[k] = b.n1;
+        a.n2[k] = b.n2;
+      }
+      hipLaunchKernelGGL(mfma_tiles_batch_kernel<kPacked>, dim3(tn, tm, m), dim3(256), lds,
+                         stream, a, dimp, cap);
+    }
+    const int nmax = std::max(n1_max, n2_max);
+    hipLaunchKernelGGL(select_packed_kernel<true>, dim3((nmax + 15) / 16, 2 * n_pairs),
+                       dim3(256), 0, stream, nullptr, 0, 0, nullptr, nullptr, dim, cap,
+                       nullptr, nullptr, table);
+    {
+      const size_t threads = size_t(nmax) * cap;
+      const dim3 g(unsigned((threads + 255) / 256), 2, n_pairs);
+      static_assert(kMatchBatchCap == 8, "rerank_kernel<8>");
+      hipLaunchKernelGGL((rerank_kernel<8, true>), g, dim3(256), 0, stream, RerankArgs{}, dim,
+                         squared_ratio_thres, 0, table);
+    }
+    // queries whose candidate slots overflowed (none on ordinary pairs: the
+    // workgroups find a zero count and leave)
+    hipLaunchKernelGGL(fallback_kernel<true>, dim3(std::min(nmax, 64), n_pairs, 2), dim3(1024),
+                       0, stream, FallbackArgs{}, dim, squared_ratio_thres, 0, table);
+    launch_finish_matches_batch(table, n_pairs, n1_max + n2_max, squared_ratio_thres,
+                                stream);
   }
 
 }  // namespace sara_hip

@@ -404,6 +404,68 @@ namespace sara_hip {
   //! HIPM_TRY through hipErrorInvalidValue) when ranges were lost.
   bool launch_zero_ranges(const ZeroRanges& r, hipStream_t stream);
 
+  // ---- a batch of independent pairs in ONE set of launches (round 6) ---------
+  //! Everything the kernels of the best-match search (squared ratio <= 1) need
+  //! to know about one pair: a table of these lives in HBM and the pair is a
+  //! grid dimension of every launch.  Scratch pointers address the batch's
+  //! arenas (match_batch_layout).
+  struct MatchBatchPair
+  {
+    const float* d1;
+    const float* d2;
+    int n1, n2;
+    float* na;             // |row|^2 of the first set
+    float* nb;             // ... of the second
+    unsigned* maxbits;     // [0] max of na, [1] max of nb (bit patterns)
+    unsigned short* split1;  // hi | lo bf16 rows of the first set
+    unsigned short* split2;
+    float* rowmin;         // packed minima [tiles along B][n1] int4
+    float* colmin;         // ... [tiles along A][n2]
+    int* cnt_r;            // candidates claimed per query, then cnt_c, then scal[16]
+    int* cnt_c;
+    int* scal;             // [0] flagged rows, [1] flagged columns
+    int* flag_r;
+    int* flag_c;
+    int* cand_r;           // [n1][cap]
+    int* cand_c;           // [n2][cap]
+    float* top_d;          // [3][n1] then [3][n2]
+    int* top_i;
+    sara_match* tmp;       // unsorted list (n1 + n2 records)
+    int* rank;             // (n1 + n2)
+    int* header;           // [0] = matches found (4 ints)
+    sara_match* out;       // sorted list, right behind the header
+  };
+  //! Bytes of the three arenas of a batch: `zero` (cleared by one launch at the
+  //! head of the batch), `work`, and `out` (headers + lists, read back in one
+  //! copy); the table itself is P * sizeof(MatchBatchPair) more.
+  struct MatchBatchLayout
+  {
+    size_t zero_bytes = 0, work_bytes = 0, out_bytes = 0;
+  };
+  //! Candidate slots per query of the batched search (ratios <= 1).
+  constexpr int kMatchBatchCap = 8;
+  //! Carves pair p of the batch out of the arenas (pass nullptr bases to get
+  //! the sizes only); the arenas grow by this pair's share.
+  void match_batch_carve(int n1, int n2, int dim, unsigned char* zero_base,
+                         unsigned char* work_base, unsigned char* out_base,
+                         MatchBatchLayout* at, MatchBatchPair* pair);
+  //! The whole search + tail for `n_pairs` pairs: `table` is the DEVICE copy of
+  //! the carved pairs (`host_table` the host's: the tile kernel takes its pointers
+  //! as kernel arguments), n1_max / n2_max the largest set sizes, `zero` the zero
+  //! arena (cleared here).  AnnMatcher::compute_matches for squared ratios <= 1.
+  void launch_match_batch(const MatchBatchPair* table, const MatchBatchPair* host_table,
+                          int n_pairs, int n1_max, int n2_max, int dim,
+                          float squared_ratio_thres, void* zero, size_t zero_bytes,
+                          hipStream_t stream);
+  //! The batch's sorted lists back to back in `dense` (room for every pair's
+  //! n1 + n2 records), heads[p] = where pair p's starts, heads[n_pairs] = total.
+  void launch_compact_lists(const MatchBatchPair* table, int n_pairs, int n_max,
+                            sara_match* dense, int* heads, hipStream_t stream);
+  //! mutual filter + rank sort of every pair (match_kernels.hip).
+  void launch_finish_matches_batch(const MatchBatchPair* table, int n_pairs,
+                                   int n_max, float squared_ratio_thres,
+                                   hipStream_t stream);
+
   //! (query block, candidate chunk) decomposition of an exhaustive search.
   void match_chunking(int nq, int nt, int* chunk, int* nchunks);
   //! knnSearch(3) of every row of `q` in `t` (exhaustive, FLANN's squared L2,

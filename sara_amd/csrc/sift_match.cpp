@@ -66,6 +66,11 @@ namespace {
       kAux2,
       kAux3,
       kFinish,
+      kBatchZero,   // the arenas and the pair table of a batched search
+      kBatchWork,
+      kBatchOut,
+      kBatchTable,
+      kBatchDense,  // the batch's lists back to back + their offsets
       kSlots
     };
     int device = -1;
@@ -770,6 +775,120 @@ namespace {
     return SARA_HIP_OK;
   }
 
+  // ---- a batch in ONE set of launches (squared ratio <= 1) -------------------
+  // Every kernel of the search takes the pair as a grid dimension and reads the
+  // pair's pointers from a table in HBM (MatchBatchPair, match_mfma.hip): the
+  // tile grid of a batch of 16 pairs of 4.3 k keys is 18 496 workgroups instead
+  // of 16 grids of 1 156 that fill the 512 workgroup slots 2.26 times each, the
+  // small kernels (norms, selection, re-ranking, tail) are launched once per
+  // batch instead of once per pair, and ONE copy brings every list home.
+  constexpr int kTrueBatchMax = 32;                   // pairs per set of launches
+  constexpr size_t kTrueBatchBytes = size_t(3) << 30;  // scratch of one set
+
+  //! Pairs [first, last) (all eligible: both sets >= 256 keys) -> their lists
+  //! appended at `at`; counts[] per pair.
+  sara_hip_status true_batch(Workspace& ws, const sara_match_pair* pairs, int first,
+                             int last, int dim, float thres2, bool on_device,
+                             sara_match* matches, int capacity, int* at,
+                             long long* need, bool* overflow, int* offsets)
+  {
+    const int P = last - first;
+    MatchBatchLayout lay;
+    size_t desc_floats = 0;
+    int n1_max = 0, n2_max = 0;
+    for (int p = first; p < last; ++p)
+    {
+      match_batch_carve(pairs[p].n1, pairs[p].n2, dim, nullptr, nullptr, nullptr, &lay,
+                        nullptr);
+      desc_floats += (size_t(pairs[p].n1) + pairs[p].n2) * dim;
+      n1_max = std::max(n1_max, pairs[p].n1);
+      n2_max = std::max(n2_max, pairs[p].n2);
+    }
+    unsigned char *d_zero = nullptr, *d_work = nullptr, *d_out = nullptr;
+    MatchBatchPair* d_table = nullptr;
+    float* d_desc = nullptr;
+    HIPM_TRY(ws.get(Workspace::kBatchZero, lay.zero_bytes + 64, d_zero));
+    HIPM_TRY(ws.get(Workspace::kBatchWork, lay.work_bytes + 64, d_work));
+    HIPM_TRY(ws.get(Workspace::kBatchOut, lay.out_bytes + 64, d_out));
+    HIPM_TRY(ws.get(Workspace::kBatchTable, size_t(P), d_table));
+    if (!on_device)
+      HIPM_TRY(ws.get(Workspace::kDescA, desc_floats, d_desc));
+    // dense copy of the lists (what travels home) behind their P + 1 offsets
+    size_t records = 0;
+    for (int p = first; p < last; ++p)
+      records += size_t(pairs[p].n1) + pairs[p].n2;
+    const size_t heads_bytes = (sizeof(int) * size_t(P + 1) + 63) & ~size_t(63);
+    unsigned char* d_dense = nullptr;
+    HIPM_TRY(ws.get(Workspace::kBatchDense, heads_bytes + sizeof(sara_match) * records,
+                    d_dense));
+    int* d_heads = reinterpret_cast<int*>(d_dense);
+    sara_match* d_lists = reinterpret_cast<sara_match*>(d_dense + heads_bytes);
+    // pinned: the table on its way up, offsets and lists on their way down
+    const size_t table_bytes = (sizeof(MatchBatchPair) * size_t(P) + 63) & ~size_t(63);
+    void* h = nullptr;
+    HIPM_TRY(ws.host(table_bytes + heads_bytes + sizeof(sara_match) * records + 64, h));
+    MatchBatchPair* h_table = static_cast<MatchBatchPair*>(h);
+    int* h_heads = reinterpret_cast<int*>(static_cast<unsigned char*>(h) + table_bytes);
+    sara_match* h_lists = reinterpret_cast<sara_match*>(
+        static_cast<unsigned char*>(h) + table_bytes + heads_bytes);
+    MatchBatchLayout run;
+    size_t desc_at = 0;
+    for (int p = first; p < last; ++p)
+    {
+      MatchBatchPair& e = h_table[p - first];
+      e = MatchBatchPair{};
+      e.d1 = pairs[p].desc1;
+      e.d2 = pairs[p].desc2;
+      if (!on_device)
+      {
+        float* a = d_desc + desc_at;
+        float* b = a + size_t(pairs[p].n1) * dim;
+        desc_at += (size_t(pairs[p].n1) + pairs[p].n2) * dim;
+        HIPM_TRY(hipMemcpyAsync(a, pairs[p].desc1, size_t(pairs[p].n1) * dim * sizeof(float),
+                                hipMemcpyHostToDevice, ws.stream));
+        HIPM_TRY(hipMemcpyAsync(b, pairs[p].desc2, size_t(pairs[p].n2) * dim * sizeof(float),
+                                hipMemcpyHostToDevice, ws.stream));
+        e.d1 = a;
+        e.d2 = b;
+      }
+      match_batch_carve(pairs[p].n1, pairs[p].n2, dim, d_zero, d_work, d_out, &run, &e);
+    }
+    HIPM_TRY(hipMemcpyAsync(d_table, h_table, sizeof(MatchBatchPair) * size_t(P),
+                            hipMemcpyHostToDevice, ws.stream));
+    launch_match_batch(d_table, h_table, P, n1_max, n2_max, dim, thres2, d_zero,
+                       run.zero_bytes, ws.stream);
+    launch_compact_lists(d_table, P, n1_max + n2_max, d_lists, d_heads, ws.stream);
+    HIPM_TRY(hipGetLastError());
+    // the offsets first (their last entry is the number of records), then
+    // exactly the records there are
+    HIPM_TRY(hipMemcpyAsync(h_heads, d_heads, sizeof(int) * size_t(P + 1),
+                            hipMemcpyDeviceToHost, ws.stream));
+    HIPM_TRY(ws.wait(ws.stream));
+    const size_t total = size_t(std::max(h_heads[P], 0));
+    if (total > records)
+      return set_error(SARA_HIP_RUNTIME_ERROR, "batched matcher: list offsets out of range");
+    if (total)
+    {
+      HIPM_TRY(hipMemcpyAsync(h_lists, d_lists, sizeof(sara_match) * total,
+                              hipMemcpyDeviceToHost, ws.stream));
+      HIPM_TRY(ws.wait(ws.stream));
+    }
+    for (int p = first; p < last; ++p)
+    {
+      const int begin = h_heads[p - first], found = h_heads[p - first + 1] - begin;
+      *need += found;
+      if (!*overflow && found > capacity - *at)
+        *overflow = true;
+      if (!*overflow)
+      {
+        std::memcpy(matches + *at, h_lists + begin, sizeof(sara_match) * size_t(found));
+        *at += found;
+      }
+      offsets[p + 1] = int(std::min<long long>(*need, INT_MAX));
+    }
+    return SARA_HIP_OK;
+  }
+
 }  // namespace
 
 extern "C" {
@@ -1000,7 +1119,51 @@ sara_hip_status sara_hip_match_descriptors_batch(
   const sara_hip_status st = use_device(device);
   if (st != SARA_HIP_OK)
     return st;
-  // kBatchLanes searches in flight: while the device works on pair p the host
+  // Eligible for ONE set of launches: every pair large enough for the MFMA
+  // prefilter (the producer a single call would pick).  Groups of at most
+  // kTrueBatchMax pairs / kTrueBatchBytes of scratch.
+  {
+    bool eligible = n_pairs >= 2;
+    for (int p = 0; p < n_pairs && eligible; ++p)
+      eligible = pairs[p].n1 >= 2 && pairs[p].n2 >= 2 &&
+                 use_mfma(pairs[p].n1, pairs[p].n2);
+    static const bool lanes_only = getenv("SARA_HIP_MATCH_BATCH") &&
+                                   std::string(getenv("SARA_HIP_MATCH_BATCH")) == "lanes";
+    if (eligible && !lanes_only)
+    {
+      Workspace& ws = workspace(device);
+      HIPM_TRY(ws.ensure_stream());
+      int first = 0;
+      while (first < n_pairs)
+      {
+        MatchBatchLayout lay;
+        int last = first;
+        while (last < n_pairs && last - first < kTrueBatchMax)
+        {
+          MatchBatchLayout next = lay;
+          match_batch_carve(pairs[last].n1, pairs[last].n2, dim, nullptr, nullptr,
+                            nullptr, &next, nullptr);
+          if (last > first &&
+              next.zero_bytes + next.work_bytes + next.out_bytes > kTrueBatchBytes)
+            break;
+          lay = next;
+          ++last;
+        }
+        const sara_hip_status bs = true_batch(ws, pairs, first, last, dim, thres2,
+                                              on_device != 0, matches, capacity, &at,
+                                              &need, &overflow, offsets);
+        if (bs != SARA_HIP_OK)
+          return bs;
+        first = last;
+      }
+      if (overflow)
+        return set_error(SARA_HIP_CAPACITY_EXCEEDED,
+                         "more matches than `capacity` (offsets[n_pairs] holds the "
+                         "number needed)");
+      return SARA_HIP_OK;
+    }
+  }
+  // Otherwise kBatchLanes searches in flight: while the device works on pair p the host
   // enqueues pairs p + 1 .. p + 3 on the other lanes' streams - the small
   // kernels of one search (norms, selection, re-ranking, the tail) run beside
   // the tile pass of another, and no pair waits for a read-back but its own.

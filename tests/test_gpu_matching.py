@@ -465,3 +465,33 @@ def test_batched_match_of_consecutive_frames_on_device(oracle):
             assert_same(g, want)
             assert g.tobytes() == ctx.match_frames(i, j, 0.6).tobytes()
         assert min(len(g) for g in got[:5]) > 50
+
+
+@pytest.mark.parametrize("ratio", [0.6, 0.8, 1.0])
+def test_one_set_of_launches_for_a_batch_of_large_pairs(flann_pair, flann_pins, ratio):
+    """Pairs whose sets all have >= 256 keys take the batched kernels: the pair
+    is a grid dimension of every launch (one tile grid over all pairs, one
+    read-back).  Different sizes in one batch (the grid covers the largest
+    pair, the others' surplus workgroups leave), 40 pairs (two sets of
+    launches), host and device descriptors."""
+    d1, d2 = flann_pair
+    pairs = [(d1, d2), (d2, d1), (d1[:1000], d2[:3000]), (d1[2000:], d2),
+             (d2[:300], d1[:257]), (d1, d2[::2]), (d1[:256], d2[:256])]
+    pairs = pairs + pairs[::-1] + pairs * 3 + pairs[:5]
+    assert len(pairs) == 40
+    got = sara_amd.match_pairs(pairs, ratio)
+    want = flann_pins["linear_matches_%.1f" % ratio]
+    assert got[0].tobytes() == want.tobytes()
+    singles = {}
+    for k, (a, b) in enumerate(pairs):
+        key = (a.ctypes.data, b.ctypes.data, len(a), len(b))
+        if key not in singles:
+            singles[key] = sara_amd.AnnMatcher(a, b, ratio).compute_matches()
+        assert got[k].tobytes() == singles[key].tobytes(), k
+    # the same from descriptors that are already in HBM
+    with sara_amd.DeviceArray(d1) as t1, sara_amd.DeviceArray(d2) as t2:
+        raw = [(t1.ptr, len(d1), t2.ptr, len(d2)), (t2.ptr, len(d2), t1.ptr, len(d1)),
+               (t1.ptr, 1000, t2.ptr, 3000)]
+        dev = sara_amd._match_batch(raw, 128, ratio, 1, 0, 3 * (len(d1) + len(d2)))
+    for k in range(3):
+        assert dev[k].tobytes() == got[k].tobytes(), k
