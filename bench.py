@@ -415,6 +415,32 @@ def match_config(torch, dev):
             call(ratio)
             t = timed(lambda: call(ratio), 50, 5)
             out[name] = {"ms_per_pair": 1e3 * t, "matches": int(cnt.value)}
+        # A stream of pairs in ONE call (sara_hip_match_descriptors_batch): the
+        # same pair 16 times - the pair is a grid dimension of every kernel, one
+        # tile grid over all pairs, one dense read-back.
+        P = 16
+        pairs = (capi.MatchPairStruct * P)()
+        for k in range(P):
+            pairs[k] = capi.MatchPairStruct(d_desc + int(off[0]) * 512,
+                                            d_desc + int(off[1]) * 512, n1, n2)
+        offs = (C.c_int * (P + 1))()
+        bbuf = np.zeros(P * (n1 + n2), capi.MATCH_DTYPE)
+
+        def batch():
+            capi.check(lib.sara_hip_match_descriptors_batch(
+                pairs, P, 128, 0.6, 1, bbuf.ctypes.data, len(bbuf), offs,
+                dev.index or 0))
+
+        batch()
+        tb = timed(batch, 10, 2) / P
+        same = all(bbuf[offs[k]:offs[k + 1]].tobytes() == bbuf[:offs[1]].tobytes()
+                   for k in range(P))
+        call(0.6)
+        same = same and bbuf[:offs[1]].tobytes() == buf[:cnt.value].tobytes()
+        out["batch_16_pairs_ratio_0.6"] = {
+            "ms_per_pair": 1e3 * tb, "matches_per_pair": int(offs[1]),
+            "identical_to_single_calls": bool(same),
+            "frac_of_bf16_mfma_peak": 3 * 2.0 * n1 * n2 * 128 / tb / 2.5e15}
         # The consumer's unit of work (SfM/Helpers/KeypointMatching.cpp:19-25 after
         # OdometryPipeline::detect_keypoints): detect two frames, match them.  The
         # frames are resident in HBM, the keypoints never leave the device between
