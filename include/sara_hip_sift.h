@@ -414,7 +414,10 @@ enum
   SARA_HIP_OPT_KERNEL_SELECTION = 10,   /* SARA_HIP_SELECT_*: which kernels the  */
                                         /* context's launches take.  Results do */
                                         /* not depend on it (every selection is */
-                                        /* bit-identical: tests); speed does    */
+                                        /* bit-identical: tests); speed does.   */
+                                        /* Setting it also puts _TILE_GEOMETRY  */
+                                        /* and _MARCH(2)_WAVES back to their    */
+                                        /* defaults: set those after it         */
   SARA_HIP_OPT_TILE_GEOMETRY = 11,      /* LDS tile of the tiled blur kernel:    */
                                         /* 0 by tile count (default), 1 = 64x32 */
                                         /* / 512 threads, 2 = 64x16 / 256,       */
