@@ -1190,24 +1190,20 @@ namespace sara_hip {
   //! and fetched those lines twice (FETCH_SIZE 4.77 GB per 64 x 1080p step for
   //! 4.23 GB of planes; launched together but unsynchronised: no change; with
   //! the barrier 4.38 GB, the kernel 1 % faster).
+  //! The scan of one (strip, segment, frame) by one wave: the body of
+  //! extrema_march_kernel (one octave per launch) and of
+  //! extrema_march_multi_kernel (every octave of a frame in one launch).
   template <int ND, int PF, int NW>
-  __global__ __launch_bounds__(64 * NW, kExtremaWavesPerEu) void extrema_march_kernel(
-      OctaveView gauss, int octave, ExtremaParams p, SiteLists sites,
-      int seg_rows, int nstrips, int nseg, int xcd_total)
+  __device__ __forceinline__ void extrema_march_body(
+      const OctaveView& gauss, const int octave, const ExtremaParams& p,
+      const SiteLists& sites, const int seg_rows, const int strip, const int seg,
+      const int b, unsigned* s_queue)
   {
     static_assert(PF == 3, "the row loop is unrolled 3x");
-    __shared__ unsigned s_queue_all[NW][kSiteQueueCap * kSiteQueueWords];
-    unsigned* s_queue = s_queue_all[threadIdx.x >> 6];
     int qn = 0;  // wave-uniform fill of the queue
     constexpr int NG = ND + 1;
     constexpr int STRIDE = 126;
     const int lane = threadIdx.x & 63;
-    int strip, seg;
-    size_t bb;
-    if (!march_work_item(nstrips / NW, nseg, xcd_total, strip, seg, bb))
-      return;
-    strip = strip * NW + int(threadIdx.x >> 6);
-    const int b = int(bb);
     const int w = gauss.w, h = gauss.h;
     const int pad = p.img_padding_sz;
     const float* g = gauss.base + size_t(b) * gauss.frame_stride;
@@ -1399,6 +1395,51 @@ namespace sara_hip {
       flush_sites(s_queue, qn, lane, b, sites);
   }
 
+  template <int ND, int PF, int NW>
+  __global__ __launch_bounds__(64 * NW, kExtremaWavesPerEu) void extrema_march_kernel(
+      OctaveView gauss, int octave, ExtremaParams p, SiteLists sites,
+      int seg_rows, int nstrips, int nseg, int xcd_total)
+  {
+    __shared__ unsigned s_queue_all[NW][kSiteQueueCap * kSiteQueueWords];
+    int strip, seg;
+    size_t bb;
+    if (!march_work_item(nstrips / NW, nseg, xcd_total, strip, seg, bb))
+      return;
+    extrema_march_body<ND, PF, NW>(gauss, octave, p, sites, seg_rows,
+                                   strip * NW + int(threadIdx.x >> 6), seg, int(bb),
+                                   s_queue_all[threadIdx.x >> 6]);
+  }
+
+  //! One frame per call (round 6): the scans of ALL octaves in one launch.  The
+  //! octaves' (strip, segment) lists lie back to back in the grid; single-wave
+  //! workgroups as in the small launches of extrema_march_kernel.
+  struct ScanMultiArgs
+  {
+    OctaveView gauss[kScanMultiMax];
+    int octave[kScanMultiMax];
+    int seg_rows[kScanMultiMax];
+    int nstrips[kScanMultiMax];
+    int first_block[kScanMultiMax];
+    int n;
+  };
+  template <int ND, int PF>
+  __global__ __launch_bounds__(64, kExtremaWavesPerEu) void extrema_march_multi_kernel(
+      ScanMultiArgs a, ExtremaParams p, SiteLists sites)
+  {
+    __shared__ unsigned s_queue[kSiteQueueCap * kSiteQueueWords];
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < kScanMultiMax; ++i)
+      if (i < a.n && int(blockIdx.x) >= a.first_block[i])
+        k = i;
+    const int local = int(blockIdx.x) - a.first_block[k];
+    const int nstrips = a.nstrips[k];
+    const int seg = local / nstrips;
+    extrema_march_body<ND, PF, 1>(a.gauss[k], a.octave[k], p, sites, a.seg_rows[k],
+                                  local - seg * nstrips, seg, int(blockIdx.y), s_queue);
+  }
+
+
   //! Second half of the fast path: one thread per classified site.
   __global__ __launch_bounds__(256) void finish_sites_kernel(
       OctavePyramidView pyr, ExtremaParams p,
@@ -1488,6 +1529,39 @@ namespace sara_hip {
     const dim3 grid((gauss.w + 63) / 64, (gauss.h + 3) / 4, batch * nscan);
     hipLaunchKernelGGL(extrema_scan_kernel, grid, block, 0, stream, gauss, octave,
                        nscan, p, tab, cand);
+  }
+
+  bool launch_extrema_scan_multi(const OctaveView* gauss, const int* octaves, int n,
+                                 int batch, const ExtremaParams& p,
+                                 const SiteLists& sites, hipStream_t stream)
+  {
+    if (n < 1 || n > kScanMultiMax || p.signed_type || !selection().feature_march)
+      return false;
+    ScanMultiArgs a{};
+    a.n = n;
+    int blocks = 0;
+    for (int k = 0; k < n; ++k)
+    {
+      const OctaveView& g = gauss[k];
+      if (g.scales != 6 || g.w < 4)
+        return false;
+      // the geometry launch_extrema_scan gives a launch of this size
+      const int nstrips = (g.w - 2 + 125) / 126;
+      int nseg = (g_extrema_waves + nstrips * batch - 1) / (nstrips * batch);
+      constexpr int min_rows = 16;
+      nseg = std::max(1, std::min(nseg, (g.h + min_rows - 1) / min_rows));
+      const int seg_rows = (g.h + nseg - 1) / nseg;
+      nseg = (g.h + seg_rows - 1) / seg_rows;
+      a.gauss[k] = g;
+      a.octave[k] = octaves[k];
+      a.seg_rows[k] = seg_rows;
+      a.nstrips[k] = nstrips;
+      a.first_block[k] = blocks;
+      blocks += nstrips * nseg;
+    }
+    hipLaunchKernelGGL((extrema_march_multi_kernel<5, 3>), dim3(blocks, batch), dim3(64), 0,
+                       stream, a, p, sites);
+    return true;
   }
 
   __global__ void extremum_map_kernel(const float* __restrict__ a,

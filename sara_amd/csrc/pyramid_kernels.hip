@@ -80,31 +80,40 @@ namespace sara_hip {
   // more, smaller tiles (a 240 x 135 plane is 20 tiles of 64 x 32 on 256 CUs):
   // 64 x 16 / 256 threads 4.1 us at 480x270, 32 x 16 / 128 threads 3.7 us at
   // 240x135.  launch_blur_r picks the geometry from the number of tiles.
-  template <int R, int TX_, int TY_, int NT_>
-  __global__ __launch_bounds__(NT_) void gaussian_blur_kernel(
-      const float* __restrict__ src, size_t src_stride,
-      float* __restrict__ dst, size_t dst_stride, float* __restrict__ dog,
-      size_t dog_stride, int w, int h, Taps taps, float* __restrict__ dec,
-      size_t dec_stride)
+  //! LDS floats the tile body needs: staged window, row-filtered window.
+  template <int R, int TX_, int TY_>
+  struct BlurTileLds
   {
+    static constexpr int RP = ((R + 3) / 4) * 4;     // left halo rounded up to 16 bytes
+    static constexpr int IW4 = (RP + TX_ + RP) / 4;  // float4 per staged row
+    static constexpr int IP = IW4 * 4 + 4;           // row pitch, over-read safe
+    static constexpr int IH = TY_ + 2 * R;
+    static constexpr int in_floats = IH * IP;
+    static constexpr int tmp_floats = IH * TX_;
+  };
+
+  //! One TX_ x TY_ output tile at (x0, y0) of one frame, by the NT_ threads of
+  //! the workgroup (two workgroup barriers; threads outside the image return
+  //! after the second).  src / dst / dog / dec address the frame.
+  template <int R, int TX_, int TY_, int NT_, typename TapsT>
+  __device__ __forceinline__ void blur_tile(
+      const float* __restrict__ src, float* __restrict__ dst,
+      float* __restrict__ dog, int w, int h, const TapsT& taps,
+      float* __restrict__ dec, int x0, int y0, float* __restrict__ s_in,
+      float* __restrict__ s_tmp)
+  {
+    using L = BlurTileLds<R, TX_, TY_>;
     constexpr int K = 2 * R + 1;
-    constexpr int RP = ((R + 3) / 4) * 4;     // left halo rounded up to 16 bytes
+    constexpr int RP = L::RP;
     constexpr int D = RP - R;
-    constexpr int IW4 = (RP + TX_ + RP) / 4;  // float4 per staged row
-    constexpr int IP = IW4 * 4 + 4;           // row pitch, over-read safe
-    constexpr int IH = TY_ + 2 * R;
+    constexpr int IW4 = L::IW4;
+    constexpr int IP = L::IP;
+    constexpr int IH = L::IH;
     constexpr int NQ = (D + 4 + 2 * R + 3) / 4;  // b128 reads per 4 outputs
     constexpr int CR = TX_ * TY_ / NT_;       // rows per thread, column pass
     static_assert(TX_ % 4 == 0 && (TX_ * TY_) % NT_ == 0 && NT_ % TX_ == 0, "geometry");
-    __shared__ __attribute__((aligned(16))) float s_in[IH * IP];
-    __shared__ __attribute__((aligned(16))) float s_tmp[IH * TX_];
 
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * TX_;
-    const int y0 = blockIdx.y * TY_;
-    const size_t b = blockIdx.z;
-    src += b * src_stride;
-    dst += b * dst_stride;
 
     // Stage the clamped source window, columns x0 - RP .. x0 + TX + RP - 1.
     const bool inside = x0 - RP >= 0 && x0 + TX_ + RP <= w;  // block-uniform
@@ -172,8 +181,6 @@ namespace sara_hip {
     const int gx = x0 + tx;
     if (gx >= w)
       return;
-    if (dog)
-      dog += b * dog_stride;
 #pragma unroll
     for (int i = 0; i < CR; ++i)
     {
@@ -191,9 +198,179 @@ namespace sara_hip {
         // octave (Resize.cpp:45-84: int(x * (w / (w/2))) == 2x), see the
         // marching kernel's DEC
         if (dec && ((gx | gy) & 1) == 0 && (gx >> 1) < (w >> 1) && (gy >> 1) < (h >> 1))
-          dec[b * dec_stride + size_t(gy >> 1) * (w >> 1) + (gx >> 1)] = sum;
+          dec[size_t(gy >> 1) * (w >> 1) + (gx >> 1)] = sum;
       }
     }
+  }
+
+  template <int R, int TX_, int TY_, int NT_>
+  __global__ __launch_bounds__(NT_) void gaussian_blur_kernel(
+      const float* __restrict__ src, size_t src_stride,
+      float* __restrict__ dst, size_t dst_stride, float* __restrict__ dog,
+      size_t dog_stride, int w, int h, Taps taps, float* __restrict__ dec,
+      size_t dec_stride)
+  {
+    using L = BlurTileLds<R, TX_, TY_>;
+    __shared__ __attribute__((aligned(16))) float s_in[L::in_floats];
+    __shared__ __attribute__((aligned(16))) float s_tmp[L::tmp_floats];
+    const size_t b = blockIdx.z;
+    blur_tile<R, TX_, TY_, NT_>(src + b * src_stride, dst + b * dst_stride,
+                                dog ? dog + b * dog_stride : nullptr, w, h, taps,
+                                dec ? dec + b * dec_stride : nullptr,
+                                blockIdx.x * TX_, blockIdx.y * TY_, s_in, s_tmp);
+  }
+
+  // ------------------------------------------------------------------------ //
+  // One frame per call (round 6): the blurs of DIFFERENT octaves that sit at
+  // the same depth of the pyramid's dependency graph in ONE launch.
+  //
+  // compute_sift_keypoints once per video frame (SfM/Odometry/OdometryPipeline
+  // .cpp:82-90) replays a HIP graph; the host hands the graph's ~40 kernel
+  // nodes to the queues at ~3.3 us each, which is what bounded the call (a
+  // context with ONE octave - the critical chain alone - takes 0.127 / 0.209
+  // ms for pyramid + extrema / full SIFT, four octaves 0.193 / 0.270 although
+  // octaves 1-3 could hide under octave 0's chain: tools/b1_floor.py).
+  // Octave o + 1 starts from G(downscale_index, o), so blur s of octave o and
+  // blur s - downscale_index of octave o + 1 are independent: they form one
+  // LEVEL.  A level is one kernel node whose workgroups are dealt to the
+  // level's members (tile lists back to back); dependencies stay at kernel
+  // boundaries - no grid barrier, no cooperative launch (round 5's cooperative
+  // kernel paid a kernel boundary per phase and more).  24 blur nodes become
+  // 11 for the default schedule.  Every member runs the tile body above
+  // unchanged (64 x 32 tiles, 512 threads): bit-identical planes.
+  // ------------------------------------------------------------------------ //
+  constexpr int kLevelMaxRadius = 12;
+  struct LevelTaps
+  {
+    int size;
+    float k[2 * kLevelMaxRadius + 1];
+  };
+  struct BlurLevelMember
+  {
+    const float* src;
+    float* dst;
+    float* dec;  // G(0, o + 1) when this blur produces G(downscale_index, o)
+    unsigned long long src_stride, dst_stride, dec_stride;  // per frame, floats
+    int w, h, tiles_x, first_block;
+    LevelTaps taps;
+  };
+  struct BlurLevelArgs
+  {
+    int n;
+    int pad;
+    BlurLevelMember m[kBlurLevelMaxMembers];
+  };
+
+  //! Bit of a radius in a level's radius set (0: not compiled for levels).
+  __host__ __device__ constexpr unsigned level_radius_bit(int R)
+  {
+    return R == 5 ? 1u : R == 6 ? 2u : R == 8 ? 4u : R == 10 ? 8u : R == 12 ? 16u : 0u;
+  }
+  //! Largest radius of a radius set (LDS and registers follow it: a level of
+  //! small blurs keeps the footprint - workgroups per CU - of the plain kernels).
+  __host__ __device__ constexpr int level_max_radius(unsigned mask)
+  {
+    return (mask & 16u) ? 12 : (mask & 8u) ? 10 : (mask & 4u) ? 8 : (mask & 2u) ? 6 : 5;
+  }
+
+  //! RMASK: the radii of the level's members (level_radius_bit); only those
+  //! tile bodies are compiled into the instance.
+  template <unsigned RMASK>
+  __global__ __launch_bounds__(512) void gaussian_blur_level_kernel(BlurLevelArgs a)
+  {
+    using L = BlurTileLds<level_max_radius(RMASK), 64, 32>;
+    __shared__ __attribute__((aligned(16))) float s_in[L::in_floats];
+    __shared__ __attribute__((aligned(16))) float s_tmp[L::tmp_floats];
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < kBlurLevelMaxMembers; ++i)
+      if (i < a.n && int(blockIdx.x) >= a.m[i].first_block)
+        k = i;
+    const BlurLevelMember& m = a.m[k];  // workgroup-uniform
+    const int local = int(blockIdx.x) - m.first_block;
+    const int ty = local / m.tiles_x;
+    const int x0 = (local - ty * m.tiles_x) * 64, y0 = ty * 32;
+    const size_t b = blockIdx.y;
+    const float* src = m.src + b * m.src_stride;
+    float* dst = m.dst + b * m.dst_stride;
+    float* dec = m.dec ? m.dec + b * m.dec_stride : nullptr;
+    const int R = m.taps.size / 2;
+#define SARA_LEVEL_CASE(r)                                                     \
+  if constexpr ((RMASK & level_radius_bit(r)) != 0)                            \
+  {                                                                            \
+    if (RMASK == level_radius_bit(r) || R == r)                                \
+    {                                                                          \
+      blur_tile<r, 64, 32, 512>(src, dst, nullptr, m.w, m.h, m.taps, dec, x0,  \
+                                y0, s_in, s_tmp);                              \
+      return;                                                                  \
+    }                                                                          \
+  }
+    SARA_LEVEL_CASE(5)
+    SARA_LEVEL_CASE(6)
+    SARA_LEVEL_CASE(8)
+    SARA_LEVEL_CASE(10)
+    SARA_LEVEL_CASE(12)
+#undef SARA_LEVEL_CASE
+  }
+
+  bool blur_level_radius_ok(int taps_size)
+  {
+    const int R = taps_size / 2;
+    return taps_size == 2 * R + 1 && (R == 5 || R == 6 || R == 8 || R == 10 || R == 12);
+  }
+
+  bool launch_blur_level(const BlurLevelBlur* blurs, int n, int batch,
+                         hipStream_t stream)
+  {
+    if (n < 1 || n > kBlurLevelMaxMembers)
+      return false;
+    BlurLevelArgs a{};
+    a.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i)
+    {
+      const BlurLevelBlur& bl = blurs[i];
+      if (!blur_level_radius_ok(bl.taps->size))
+        return false;
+      BlurLevelMember& m = a.m[i];
+      m.src = bl.src;
+      m.dst = bl.dst;
+      m.dec = bl.dec;
+      m.src_stride = bl.src_stride;
+      m.dst_stride = bl.dst_stride;
+      m.dec_stride = bl.dec_stride;
+      m.w = bl.w;
+      m.h = bl.h;
+      m.tiles_x = (bl.w + 63) / 64;
+      m.first_block = blocks;
+      m.taps.size = bl.taps->size;
+      for (int j = 0; j < bl.taps->size; ++j)
+        m.taps.k[j] = bl.taps->k[j];
+      blocks += m.tiles_x * ((bl.h + 31) / 32);
+    }
+    unsigned mask = 0;
+    for (int i = 0; i < n; ++i)
+      mask |= level_radius_bit(a.m[i].taps.size / 2);
+    const dim3 grid(blocks, batch);
+    switch (mask)
+    {
+#define SARA_LEVEL_MASK(mk)                                                    \
+  case mk:                                                                     \
+    hipLaunchKernelGGL(gaussian_blur_level_kernel<mk>, grid, dim3(512), 0, stream, a); \
+    break;
+      SARA_LEVEL_MASK(1) SARA_LEVEL_MASK(2) SARA_LEVEL_MASK(3) SARA_LEVEL_MASK(4)
+      SARA_LEVEL_MASK(5) SARA_LEVEL_MASK(6) SARA_LEVEL_MASK(7) SARA_LEVEL_MASK(8)
+      SARA_LEVEL_MASK(9) SARA_LEVEL_MASK(10) SARA_LEVEL_MASK(11) SARA_LEVEL_MASK(12)
+      SARA_LEVEL_MASK(13) SARA_LEVEL_MASK(14) SARA_LEVEL_MASK(15) SARA_LEVEL_MASK(16)
+      SARA_LEVEL_MASK(17) SARA_LEVEL_MASK(18) SARA_LEVEL_MASK(19) SARA_LEVEL_MASK(20)
+      SARA_LEVEL_MASK(21) SARA_LEVEL_MASK(22) SARA_LEVEL_MASK(23) SARA_LEVEL_MASK(24)
+      SARA_LEVEL_MASK(25) SARA_LEVEL_MASK(26) SARA_LEVEL_MASK(27) SARA_LEVEL_MASK(28)
+      SARA_LEVEL_MASK(29) SARA_LEVEL_MASK(30) SARA_LEVEL_MASK(31)
+#undef SARA_LEVEL_MASK
+    default:
+      return false;
+    }
+    return true;
   }
 
   //! Any radius up to kMaxRadius: same structure, runtime loops, dynamic LDS.

@@ -264,6 +264,7 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
     launch_zero_counters(c->d_counters, counters_padded(c->max_batch), c->d_epoch,
                          int(step_stamp_index(c->max_batch)), tail);
 
+  bool linear = false;  // the fork-free schedule of one-frame calls ran (below)
   // ---- Gaussian pyramid + fused DoG ---------------------------------------
   if (sc.num_octaves > 0)
   {
@@ -366,7 +367,91 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
       for (int s = s_lo; s <= s_hi; ++s)
         enqueue_blur(o, s, st);
     };
-    if (pipe)
+    // One frame per call that stops at the keypoint sites (the reference's
+    // own call pattern, SfM/Odometry/OdometryPipeline.cpp:82-90): the
+    // fork-free schedule (round 6).  The graph runtime starts a node whose
+    // predecessor sits on another hardware queue only when that queue has
+    // drained what the graph put there before it (measured on four forked
+    // layouts, docs/experiments.md): every fork of the spine layout below
+    // costs tens of microseconds.  This schedule has none: same-depth blurs of
+    // different octaves are ONE launch (gaussian_blur_level_kernel: 24 blur
+    // nodes -> S - 1 + (octaves - 1) dsi), then the scans of all octaves in
+    // one launch - one chain on one queue (0.186 ms against 0.193 ms for one
+    // 1080p frame).  With gradients and the per-keypoint stages behind it the
+    // forked layout wins (0.261 against 0.281 ms: the gradients of octave 0
+    // overlap the later octaves' blurs there), so those calls keep it.
+    // Conditions: every blur is tiled-kernel sized and has one of the level
+    // kernel's radii, no level has more members than a launch takes, default
+    // scan kernels.
+    bool levels = pipe && graph_mode && selection().level_merge && !want_gradients &&
+                  dsi >= 1 && last >= 1 && last < kScanMultiMax && !c->fma_blur && S == 6 &&
+                  !c->signed_type && selection().feature_march &&
+                  (S - 1 + dsi - 1) / dsi <= kBlurLevelMaxMembers &&
+                  (!selection().blur_march ||
+                   size_t(sc.oct[0].w) * sc.oct[0].h * batch <
+                       selection().march_min_pixels);
+    for (int s = 1; s < S && levels; ++s)
+      levels = blur_level_radius_ok(c->taps[s].size);
+    for (int o = 0; o <= last && levels; ++o)
+      levels = sc.oct[o].w >= 4 && sc.oct[o].h >= 2;
+    if (levels)
+    {
+      linear = true;
+      // blur s of octave o runs at level o * dsi + s: the level that writes
+      // G(dsi, o) also writes its half, G(0, o + 1)
+      const int n_levels = last * dsi + S - 1;
+      for (int L = 1; L <= n_levels; ++L)
+      {
+        BlurLevelBlur mem[kBlurLevelMaxMembers];
+        int n = 0;
+        for (int o = 0; o <= last; ++o)
+        {
+          const int s = L - o * dsi;
+          if (s < 1 || s > S - 1)
+            continue;
+          const int w = sc.oct[o].w, h = sc.oct[o].h;
+          const size_t pl = size_t(w) * h;
+          BlurLevelBlur& m = mem[n++];
+          m.src = c->G[o] + pl * (s - 1);
+          m.dst = c->G[o] + pl * s;
+          m.src_stride = m.dst_stride = pl * S;
+          m.dec = nullptr;
+          m.dec_stride = 0;
+          if (o < last && s == dsi)
+          {
+            m.dec = c->G[o + 1];
+            m.dec_stride = size_t(sc.oct[o + 1].w) * sc.oct[o + 1].h * S;
+          }
+          m.w = w;
+          m.h = h;
+          m.taps = &c->taps[s];
+        }
+        if (!launch_blur_level(mem, n, batch, tail))
+          return fail(SARA_HIP_RUNTIME_ERROR, "level blur refused its members");
+      }
+      OctaveView views[kScanMultiMax];
+      int octs[kScanMultiMax];
+      int n_scan = 0;
+      for (int o = 0; o <= last && last_stage >= SARA_HIP_STAGE_EXTREMA; ++o)
+      {
+        OctaveView dv;
+        dv.base = c->G[o];
+        dv.w = sc.oct[o].w;
+        dv.h = sc.oct[o].h;
+        dv.scales = S;
+        dv.plane = size_t(dv.w) * dv.h;
+        dv.frame_stride = dv.plane * S;
+        if (dv.w > 2 * c->img_padding && dv.h > 2 * c->img_padding)
+        {
+          views[n_scan] = dv;
+          octs[n_scan++] = o;
+        }
+      }
+      if (n_scan > 0 &&
+          !launch_extrema_scan_multi(views, octs, n_scan, batch, ep, c->sites, tail))
+        return fail(SARA_HIP_RUNTIME_ERROR, "multi-octave scan refused an octave");
+    }
+    else if (pipe)
     {
       // Small batches are bound by the chain of dependent launches, and a
       // dependency that crosses hardware queues costs ~12 us against ~0 on
@@ -548,7 +633,11 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   HIP_TRY(mark(3));
 
   // ---- polar gradients ----------------------------------------------------
-  if (pipe)
+  if (pipe && linear)
+  {
+    // one chain: nothing to join
+  }
+  else if (pipe)
   {
     // join the side chains (their gradients follow their scans)
     for (int o = 0; o + 1 < sc.num_octaves; ++o)

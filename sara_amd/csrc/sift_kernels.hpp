@@ -179,6 +179,24 @@ namespace sara_hip {
                             hipStream_t stream, float* dec = nullptr,
                             size_t dec_stride = 0, bool fma = false);
 
+  //! One frame per call: several independent tiled blurs (different octaves,
+  //! same depth of the dependency graph) as ONE kernel node
+  //! (gaussian_blur_level_kernel, pyramid_kernels.hip).  false = nothing
+  //! launched (a radius outside {5, 6, 8, 10, 12} or too many members).
+  constexpr int kBlurLevelMaxMembers = 4;
+  struct BlurLevelBlur
+  {
+    const float* src;
+    float* dst;
+    float* dec;  // also write the half-size plane here (nullptr: no)
+    size_t src_stride, dst_stride, dec_stride;  // per frame, in floats
+    int w, h;
+    const Taps* taps;
+  };
+  bool blur_level_radius_ok(int taps_size);
+  bool launch_blur_level(const BlurLevelBlur* blurs, int n, int batch,
+                         hipStream_t stream);
+
   //! The same blur reading 8-bit gray frames (src_stride in bytes), converted
   //! on the fly as float(v) / 255.f.  Returns false (nothing launched) when the
   //! marching kernel cannot take the shape / radius: the caller then converts
@@ -235,6 +253,9 @@ namespace sara_hip {
                              int batch, hipStream_t stream,
                              unsigned* cmax = nullptr, size_t cmax_stride = 0);
 
+  //! Octaves one multi-octave scan launch takes.
+  constexpr int kScanMultiMax = 8;
+
   // ---- extrema -------------------------------------------------------------
   //! Scans DoG scales 1..S-3 of one Gaussian octave.  The fast path only
   //! classifies and appends to `sites` (finish with launch_finish_sites once
@@ -244,6 +265,12 @@ namespace sara_hip {
                            const ExtremaParams& p, const ScaleTable* tab,
                            const CandidateLists& cand, const SiteLists& sites,
                            hipStream_t stream);
+  //! One frame per call: the scans of up to kScanMultiMax octaves in ONE launch
+  //! (extrema_march_multi_kernel).  false = nothing launched (signed-type mode,
+  //! a scale count other than 6, the general kernels selected).
+  bool launch_extrema_scan_multi(const OctaveView* gauss, const int* octaves, int n,
+                                 int batch, const ExtremaParams& p,
+                                 const SiteLists& sites, hipStream_t stream);
 
   //! Edge test + refinement + contrast test of the classified sites.
   void launch_finish_sites(const OctavePyramidView& pyr, int batch,
@@ -296,6 +323,7 @@ namespace sara_hip {
     long long grad_tile_pixels = (long long) 4 << 20;  //!< smaller planes: pixel-parallel gradient
     int tile_geometry = 0;       //!< tiled blur: 0 by tile count, 1 = 64x32, 2 = 64x16, 3 = 32x16
     bool xcd_map = true;         //!< XCD-aware placement of marching workgroups (SARA_HIP_XCD_MAP)
+    bool level_merge = true;     //!< one frame per call: same-depth blurs of different octaves in one launch (SARA_HIP_LEVELS=0: off)
   };
   //! What the process environment asks for (read once); without any variable
   //! set it equals KernelSelection{} = the shipped selection.

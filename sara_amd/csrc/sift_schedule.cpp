@@ -45,6 +45,7 @@ namespace sara_hip {
       if (const char* e = getenv("SARA_HIP_TILE_GEOMETRY"))
         k.tile_geometry = atoi(e);
       k.xcd_map = !is("SARA_HIP_XCD_MAP", "0");
+      k.level_merge = !is("SARA_HIP_LEVELS", "0");
       return k;
     }();
     return env;
