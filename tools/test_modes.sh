@@ -7,7 +7,7 @@ for mode in "A=1" "SARA_HIP_GRAPH=0" "SARA_HIP_STREAMS=1" "SARA_HIP_BLUR=tile" \
             "SARA_HIP_OCTAVE_PIPELINE=0" "SARA_HIP_OCTAVE_PIPELINE=1" \
             "SARA_HIP_GRAPH=0 SARA_HIP_OCTAVE_PIPELINE=1" \
             "SARA_HIP_GRAD_TILE_PIXELS=0" "SARA_HIP_GRAD_TILE_PIXELS=100000000000" \
-            "SARA_HIP_STREAMS=1 SARA_HIP_SIDE_GRADIENT=0"; do
+            "SARA_HIP_STREAMS=1 SARA_HIP_SIDE_GRADIENT=0" "SARA_HIP_LEVELS=0"; do
   echo "== $mode"
   env $mode python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_operators.py tests/test_gpu_full_size.py -m gpu -x -q 2>&1 | tail -1
 done
