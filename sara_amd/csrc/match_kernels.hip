@@ -343,13 +343,17 @@ namespace sara_hip {
     k2 = m.y_index;
   }
 
+  //! keys per tile of predecessors: short tiles = many workgroups with a short
+  //! loop each (a single 4.3 k x 4.3 k search, 4 140 matches: 256-key tiles
+  //! 21.6 us - 289 workgroups of 256 dependent LDS reads - against 64-key tiles)
+  constexpr int kRankKeys = 64;
   template <bool BATCH>
   __global__ __launch_bounds__(256) void rank_count_kernel(
       const sara_match* __restrict__ in_, const int* __restrict__ count_,
       int* __restrict__ rank_, const MatchBatchPair* __restrict__ batch)
   {
-    __shared__ unsigned long long s_k1[256];
-    __shared__ int s_k2[256];
+    __shared__ unsigned long long s_k1[kRankKeys];
+    __shared__ int s_k2[kRankKeys];
     const MatchBatchPair* b = BATCH ? batch + blockIdx.z : nullptr;  // pair blockIdx.z
     const sara_match* __restrict__ in = BATCH ? wave_uniform(b->tmp) : in_;
     const int* __restrict__ count = BATCH ? wave_uniform(b->header) : count_;
@@ -357,35 +361,38 @@ namespace sara_hip {
     const int n = *count;
     // (the grid may be smaller than the list: tiles are walked with its stride)
     for (int tx = blockIdx.x; tx * 256 < n; tx += gridDim.x)
-      for (int ty = blockIdx.y; ty * 256 < n; ty += gridDim.y)
-      {
-        const int e = tx * 256 + threadIdx.x;
-        const int base = ty * 256;
-        const int f = base + threadIdx.x;
-        unsigned long long o1 = ~0ull;
-        int o2 = 0x7fffffff;
-        if (f < n)
-          match_key(in[f], o1, o2);
-        __syncthreads();  // the previous tile has been consumed
-        s_k1[threadIdx.x] = o1;
-        s_k2[threadIdx.x] = o2;
-        __syncthreads();
-        if (e >= n)
-          continue;
-        unsigned long long k1;
-        int k2;
+    {
+      const int e = tx * 256 + threadIdx.x;
+      unsigned long long k1 = 0ull;
+      int k2 = 0;
+      if (e < n)
         match_key(in[e], k1, k2);
-        int before = 0;
-        const int m = min(256, n - base);
+      int before = 0;
+      for (int ty = blockIdx.y; ty * kRankKeys < n; ty += gridDim.y)
+      {
+        const int base = ty * kRankKeys;
+        __syncthreads();  // the previous tile has been consumed
+        if (threadIdx.x < kRankKeys)
+        {
+          unsigned long long o1 = ~0ull;
+          int o2 = 0x7fffffff;
+          if (base + int(threadIdx.x) < n)
+            match_key(in[base + threadIdx.x], o1, o2);
+          s_k1[threadIdx.x] = o1;
+          s_k2[threadIdx.x] = o2;
+        }
+        __syncthreads();
+        // (keys behind the list are the largest key: they precede nothing)
 #pragma unroll 8
-        for (int k = 0; k < m; ++k)
+        for (int k = 0; k < kRankKeys; ++k)
         {
           const unsigned long long p1 = s_k1[k];
           before += (p1 < k1 || (p1 == k1 && s_k2[k] < k2)) ? 1 : 0;
         }
-        if (before)
-          atomicAdd(rank + e, before);
       }
+      if (e < n && before)
+        atomicAdd(rank + e, before);
+    }
   }
 
   template <bool BATCH>
@@ -457,7 +464,8 @@ namespace sara_hip {
     hipLaunchKernelGGL(mutual_filter_kernel<false>, dim3(tiles), dim3(256), 0, stream,
                        top_d0, top_i0, n1, top_d1, top_i1, n2, have0, have1,
                        squared_ratio_thres, scratch, count, nullptr);
-    hipLaunchKernelGGL(rank_count_kernel<false>, dim3(tiles, tiles), dim3(256), 0, stream,
+    hipLaunchKernelGGL(rank_count_kernel<false>,
+                       dim3(tiles, (n + kRankKeys - 1) / kRankKeys), dim3(256), 0, stream,
                        scratch, count, rank_scratch, nullptr);
     hipLaunchKernelGGL(rank_scatter_kernel<false>, dim3(tiles), dim3(256), 0, stream,
                        scratch, count, rank_scratch, out, nullptr);
@@ -508,8 +516,9 @@ namespace sara_hip {
     hipLaunchKernelGGL(mutual_filter_kernel<true>, dim3(tiles, n_pairs), dim3(256), 0, stream,
                        nullptr, nullptr, 0, nullptr, nullptr, 0, 1, 1,
                        squared_ratio_thres, nullptr, nullptr, table);
-    hipLaunchKernelGGL(rank_count_kernel<true>, dim3(rt, rt, n_pairs), dim3(256), 0, stream,
-                       nullptr, nullptr, nullptr, table);
+    hipLaunchKernelGGL(rank_count_kernel<true>,
+                       dim3(rt, std::min((n_max + kRankKeys - 1) / kRankKeys, 64), n_pairs),
+                       dim3(256), 0, stream, nullptr, nullptr, nullptr, table);
     hipLaunchKernelGGL(rank_scatter_kernel<true>, dim3(rt, n_pairs), dim3(256), 0, stream,
                        nullptr, nullptr, nullptr, nullptr, table);
   }
