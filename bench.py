@@ -588,6 +588,7 @@ def secondary_configs(args, torch, dev):
                     tot.append(st["total"])
             return float(np.mean(pyr)), float(np.mean(tot)), kp
         c4.set_option(capi.OPT_KERNEL_SELECTION, capi.SELECT_SHIPPED)
+        c4.set_option(capi.OPT_GRAPH_REPLAY, 0)  # per-stage timers: plain launches
         pyr_ms, tot_ms, kp = stage_ms()
         # BASELINE.json words config 5 as an LDS tile-size sweep.  Measured IN
         # THIS RUN (round 6: the kernel selection is a context option): the

@@ -101,8 +101,13 @@ sara_hip_status sara_hip_sift_detect(sara_hip_sift* c, const float* images,
   const size_t in_plane = size_t(width) * height;
 
   // Graph replay: own stream, small batch, no stage timers inside a capture.
+  // (up to 8 frames of any size; 9 .. graph_max_batch frames while the call
+  // stays in the launch-bound regime - 16 x 1080p - where the replay still wins)
+  const bool graph_sized =
+      batch <= std::min(c->graph_max_batch, 8) ||
+      (batch <= c->graph_max_batch && size_t(width) * height * batch <= (size_t(40) << 20));
   const bool graph_mode = c->use_graph && !c->graph_broken && !hip_stream &&
-                          batch <= c->graph_max_batch && !debug_sync &&
+                          graph_sized && !debug_sync &&
                           (!graphs_need_one_thread() || first_graph_thread());
   const bool multi_stream = c->multi_stream;
   const bool side_gradient = c->side_gradient;

@@ -442,7 +442,7 @@ def test_gray8_read_by_the_first_blur(oracle, w, h, cam):
     256-column strip up: byte-aligned 4-byte loads), one it does not (162), and
     a camera scale without an initial blur; also through stage() /
     detect_staged()."""
-    batch = 10  # > SARA_HIP_GRAPH_MAX_BATCH
+    batch = 18  # > SARA_HIP_GRAPH_MAX_BATCH (16)
     u8 = (synth_batch(w, h, batch) * 255).astype(np.uint8)
     f32 = u8.astype(np.float32) / np.float32(255)
     with sara_amd.SiftContext(w, h, batch, hip_params(0, 3, cam=cam)) as ctx:
