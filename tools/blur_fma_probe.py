@@ -15,12 +15,13 @@ import sara_amd  # noqa: E402
 from sara_amd import capi  # noqa: E402
 from sara_amd.synth import synth_batch  # noqa: E402
 
-B, W, H = 64, 1920, 1080
-frames = torch.from_numpy(synth_batch(W, H, B, unique=8)).to("cuda:0")
+B, W, H = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), 1920, 1080
+frames = torch.from_numpy(synth_batch(W, H, B, unique=min(B, 8))).to("cuda:0")
 params = sara_amd.ImagePyramidParams(0, 6, num_octaves_max=4)
 res = {}
 with sara_amd.SiftContext(W, H, B, params) as c:
     c.set_option(capi.OPT_SINGLE_STREAM, 1)
+    c.set_option(capi.OPT_GRAPH_REPLAY, 0)
     c.set_option(capi.OPT_LAUNCH_TIMERS, 1)
     for name, fma in (("exact", 0), ("fma", 1)):
         c.set_option(capi.OPT_FMA_BLUR, fma)
