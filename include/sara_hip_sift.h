@@ -350,8 +350,9 @@ SARA_HIP_API sara_hip_status sara_hip_sift_fetch_extrema(sara_hip_sift* ctx,
                                                         int32_t* xyso_type);
 
 /* Device time of each stage of the last detect() in milliseconds (hipEvent),  */
-/* indexed by SARA_HIP_TIME_*.  Synchronises.  Batches of up to 8 frames on the */
-/* context's own stream replay a captured HIP graph (launch-bound regime); then */
+/* indexed by SARA_HIP_TIME_*.  Synchronises.  Batches of up to 16 frames (up  */
+/* to 8 when they hold more pixels than 16 x 1080p) on the context's own        */
+/* stream replay a captured HIP graph (launch-bound regime); then               */
 /* only SARA_HIP_TIME_TOTAL is measured and the per-stage entries are 0         */
 /* (environment SARA_HIP_GRAPH=0 restores plain launches and stage times).      */
 SARA_HIP_API sara_hip_status sara_hip_sift_stage_times(sara_hip_sift* ctx,
@@ -407,7 +408,7 @@ enum
                                         /* of the Gaussian-pyramid stage, read by  */
                                         /* sara_hip_sift_pyramid_launches();       */
                                         /* ignored under HIP-graph replay          */
-  SARA_HIP_OPT_GRAPH_REPLAY = 13,       /* 0: batches <= 8 run plain launches    */
+  SARA_HIP_OPT_GRAPH_REPLAY = 13,       /* 0: small batches run plain launches   */
                                         /* instead of replaying a captured HIP   */
                                         /* graph (default 1; the process-wide    */
                                         /* switch is SARA_HIP_GRAPH=0)           */
@@ -719,7 +720,7 @@ SARA_HIP_API sara_hip_status sara_hip_copy_to_host(void* dst,
 
 /* The other direction, and HBM buffers, for the same kind of caller: frames    */
 /* that several calls reuse (images_on_device = 1) are uploaded once.  A context */
-/* replaying its HIP graph (batches <= 8) reads such frames IN PLACE; they must  */
+/* replaying its HIP graph (batches <= 16) reads such frames IN PLACE; they must */
 /* stay unmodified until the results of the call have been fetched / collected. */
 SARA_HIP_API sara_hip_status sara_hip_copy_to_device(void* dst_device,
                                                     const void* src, size_t bytes,
