@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("w,h,first,noct,b", [
     (200, 150, 0, 4, 1), (257, 131, 0, 5, 1), (640, 480, 0, 4, 1),
     (97, 203, -1, 4, 1), (1920, 1080, 0, 4, 1), (333, 222, 0, 3, 3),
-    (64, 48, 0, 2, 8), (150, 200, -1, 3, 2)])
+    (64, 48, 0, 2, 8), (150, 200, -1, 3, 2), (96, 80, 0, 3, 12), (120, 64, 0, 2, 16)])
 def test_site_only_calls_take_the_level_schedule(oracle, w, h, first, noct, b):
     """A call of up to 8 frames that stops at the Gaussian planes or at the
     extremum sites replays the fork-free schedule (same-depth blurs of all
