@@ -6,10 +6,11 @@ contexts run plain launches and would not reach this schedule."""
 import numpy as np
 import pytest
 
+import common
 import sara_amd
 from sara_amd.synth import synth, synth_batch
-from test_gpu_pipeline import (compare_full, compare_lists, hip_params, ref_params,
-                               run_lists)
+from test_gpu_pipeline import (SHAPE_RTOL, compare_full, compare_lists, hip_params,
+                               ref_params, run_lists)
 
 pytestmark = pytest.mark.gpu
 
@@ -54,3 +55,50 @@ def test_site_only_calls_take_the_level_schedule(oracle, w, h, first, noct, b):
         for f, ref in enumerate(refs):
             compare_full(ctx, ref, f, check_planes=False)
             compare_lists(lists, ref, f)
+
+
+def _site_only_fuzz_cases(n, seed):
+    """Random sizes and parameters inside the level schedule's conditions: six
+    scales per octave, at least two octaves."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(n):
+        w = int(rng.integers(12, 120)) * 4 if i % 2 == 0 else int(rng.integers(40, 480))
+        h = int(rng.integers(33, 400))
+        first = int(rng.choice([0, 0, 0, -1])) if max(w, h) <= 200 else 0
+        cam = float(rng.choice([0.5, 0.5, 1.0, 0.8]))
+        noct = int(rng.integers(2, 7))
+        thres = float(rng.choice([0.01, 0.01, 0.02, 0.005]))
+        edge = float(rng.choice([10.0, 10.0, 6.0, 20.0]))
+        iters = int(rng.choice([5, 5, 2, 3]))
+        b = int(rng.choice([1, 1, 1, 2, 5]))
+        cases.append((i, w, h, first, cam, noct, thres, edge, iters, b))
+    return cases
+
+
+@pytest.mark.parametrize("case", _site_only_fuzz_cases(16, 20260930),
+                         ids=lambda c: "sites%d_%dx%dx%d" % (c[0], c[1], c[2], c[9]))
+def test_fuzz_site_only_calls(oracle, case):
+    i, w, h, first, cam, noct, thres, edge, iters, b = case
+    imgs = np.stack([synth(w, h, 7000 + 16 * i + f) for f in range(b)])
+    refs = [oracle.RefSift(im, ref_params(oracle, first, noct, cam),
+                           extremum_thres=thres, edge_ratio_thres=edge,
+                           extremum_refinement_iter=iters) for im in imgs]
+    S = refs[0].params.scale_count_per_octave
+    with sara_amd.SiftContext(w, h, b, hip_params(first, noct, cam),
+                              extremum_thres=thres, edge_ratio_thres=edge,
+                              extremum_refinement_iter=iters) as ctx:
+        ctx.detect(imgs, last_stage=sara_amd.STAGE_EXTREMA)
+        ec, ereg, exyso = ctx.extrema()
+        want = [r.extrema() for r in refs]
+        assert [int(n) for n in ec[:b]] == [len(x[1]) for x in want]
+        assert np.array_equal(exyso, np.concatenate([x[1] for x in want]))
+        e0 = 0
+        for f, ref in enumerate(refs):
+            common.assert_regions_equal(ereg[e0:e0 + len(want[f][0])], want[f][0],
+                                        rtol_shape=SHAPE_RTOL)
+            e0 += len(want[f][0])
+            for o in range(ref.octave_count):
+                for s in range(S):
+                    assert np.array_equal(ctx.gaussian(s, o, f), ref.gaussian(s, o)), \
+                        ("G", s, o, f)
