@@ -1403,11 +1403,13 @@ namespace sara_hip {
     __shared__ unsigned s_queue_all[NW][kSiteQueueCap * kSiteQueueWords];
     int strip, seg;
     size_t bb;
-    if (!march_work_item(nstrips / NW, nseg, xcd_total, strip, seg, bb))
+    if (!march_work_item((nstrips + NW - 1) / NW, nseg, xcd_total, strip, seg, bb))
       return;
-    extrema_march_body<ND, PF, NW>(gauss, octave, p, sites, seg_rows,
-                                   strip * NW + int(threadIdx.x >> 6), seg, int(bb),
-                                   s_queue_all[threadIdx.x >> 6]);
+    strip = strip * NW + int(threadIdx.x >> 6);
+    if (NW > 1 && strip >= nstrips)
+      return;  // surplus wave of the row's last group (strip_group_size)
+    extrema_march_body<ND, PF, NW>(gauss, octave, p, sites, seg_rows, strip, seg,
+                                   int(bb), s_queue_all[threadIdx.x >> 6]);
   }
 
   //! One frame per call (round 6): the scans of ALL octaves in one launch.  The
@@ -1507,9 +1509,8 @@ namespace sara_hip {
       // frame per call) keeps single-wave workgroups, which spread over all CUs
       // (SARA_HIP_STRIP_GROUP forces the groups for the parity tests)
       const int limit = strip_group_limit(nstrips * nseg * batch);
-      const int NW = (nstrips % 8 == 0 && limit >= 8) ? 8
-                     : ((nstrips % 4 == 0 && limit >= 4) ? 4 : 1);
-      const int gstrips = nstrips / NW;
+      const int NW = strip_group_size(nstrips, limit);
+      const int gstrips = (nstrips + NW - 1) / NW;
       const int total = xcd_map_enabled() ? gstrips * nseg * batch : 0;
       const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(gstrips * nseg, batch);
 #define SARA_SCAN(NW_)                                                         \

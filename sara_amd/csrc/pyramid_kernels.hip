@@ -489,9 +489,11 @@ namespace sara_hip {
     const int lane = threadIdx.x & 63;
     int strip, seg;
     size_t b;
-    if (!march_work_item(nstrips / NW, nseg, xcd_total, strip, seg, b))
+    if (!march_work_item((nstrips + NW - 1) / NW, nseg, xcd_total, strip, seg, b))
       return;
     strip = strip * NW + int(threadIdx.x >> 6);
+    if (NW > 1 && strip >= nstrips)
+      return;  // surplus wave of the row's last group (strip_group_size)
     const unsigned char* src8 =
         reinterpret_cast<const unsigned char*>(src) + b * src_stride;
     src += b * src_stride;
@@ -693,9 +695,8 @@ namespace sara_hip {
     // (the wave counts keep the groups to launches that fill the chip;
     // SARA_HIP_STRIP_GROUP forces them for the parity tests)
     const int limit = (src_is_u8 || fma) ? 1 : strip_group_limit(nstrips * nseg * batch);
-    const int NW = (nstrips % 8 == 0 && limit >= 8) ? 8
-                   : ((nstrips % 4 == 0 && limit >= 4) ? 4 : 1);
-    const int gstrips = nstrips / NW;
+    const int NW = strip_group_size(nstrips, limit);
+    const int gstrips = (nstrips + NW - 1) / NW;
     const int total = xcd_map_enabled() ? gstrips * nseg * batch : 0;
     const dim3 grid = total ? dim3(8 * ((total + 7) / 8)) : dim3(gstrips * nseg, batch);
     if (NW == 8 || NW == 4)

@@ -350,6 +350,20 @@ namespace sara_hip {
     return waves >= 4096 ? 8 : (waves >= 2048 ? 4 : 1);
   }
 
+  //! Waves per strip-group workgroup for a row of `nstrips` strips: 8 or 4 when
+  //! the strips fill whole groups or leave at most a quarter of the last group
+  //! idle (its surplus waves leave at once; the barrier counts live waves) -
+  //! 3840 columns are 15 blur strips and 31 scan strips, which a whole-groups
+  //! rule left to single-wave workgroups (16 x 4K, same box: 6.46 / 6.55 against
+  //! 6.51 / 6.60 ms per step).
+  inline int strip_group_size(int nstrips, int limit)
+  {
+    auto fits = [&](int g) {
+      return nstrips >= g && 4 * ((g - nstrips % g) % g) <= g;
+    };
+    return (limit >= 8 && fits(8)) ? 8 : ((limit >= 4 && fits(4)) ? 4 : 1);
+  }
+
   //! grad / tab are device pointers (indexed per wave, so they live in HBM
   //! rather than in the kernel argument segment).
   void launch_orientations(const GradPyramidView* grad, const ScaleTable* tab,
