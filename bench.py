@@ -995,6 +995,7 @@ def main():
 
     comm = None
     count_group = None
+    native_failed = False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if gather_mode == "rccl":
@@ -1021,18 +1022,39 @@ def main():
                     comm.close()
                 comm = None
                 if world <= ndev:
-                    # a node with a device per rank on which RCCL cannot form the
-                    # communicator is a failure, not something to paper over
-                    raise SystemExit(
-                        "rank %d: the RCCL communicator could not be created "
-                        "although the box has %d devices for %d ranks" %
-                        (rank, ndev, world))
-                gather_mode, backend = "torch", "gloo"
-                if rank == 0:
-                    print("bench: %d ranks on %d device(s): ranks share devices, "
-                          "RCCL refuses that - the gather runs over "
-                          "torch.distributed/GLOO (said so in the line)" %
-                          (world, ndev), file=sys.stderr)
+                    # A node with a device per rank on which the library cannot
+                    # form its communicator: measure with torch.distributed's
+                    # RCCL instead of returning nothing, and say so - loudly on
+                    # stderr, and in the line (config.parallelism names the
+                    # transport, config.native_rccl_gather is false).
+                    if os.environ.get("SARA_BENCH_STRICT_RCCL"):
+                        raise SystemExit(
+                            "rank %d: the RCCL communicator could not be created "
+                            "although the box has %d devices for %d ranks" %
+                            (rank, ndev, world))
+                    native_failed = True
+                    dist.destroy_process_group()
+                    gather_mode, backend = "torch", "nccl"
+                    dist.init_process_group("nccl", rank=rank, world_size=world,
+                                            device_id=dev)
+                    try:
+                        count_group = dist.new_group(backend="gloo")
+                    except Exception:
+                        count_group = None
+                    dist.all_reduce(torch.zeros(1, device=dev))
+                    torch.cuda.synchronize()
+                    if rank == 0:
+                        print("bench: THE LIBRARY'S RCCL COMMUNICATOR COULD NOT BE "
+                              "CREATED on a box with %d devices for %d ranks - the "
+                              "gather runs over torch.distributed/NCCL (said so in "
+                              "the line)" % (ndev, world), file=sys.stderr)
+                else:
+                    gather_mode, backend = "torch", "gloo"
+                    if rank == 0:
+                        print("bench: %d ranks on %d device(s): ranks share devices, "
+                              "RCCL refuses that - the gather runs over "
+                              "torch.distributed/GLOO (said so in the line)" %
+                              (world, ndev), file=sys.stderr)
         elif backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=dev)
@@ -1247,6 +1269,8 @@ def main():
                                 "torch.distributed/" + backend))
                                if world > 1 else "single GPU",
                 "last_stage": args.stage,
+                "native_rccl_gather": (comm is not None) if world > 1 else None,
+                "native_rccl_gather_failed": bool(native_failed),
             },
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {

@@ -26,6 +26,7 @@ N=${1:-8}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 export HSA_ENABLE_IPC_MODE_LEGACY=0   # dmabuf IPC only on this driver; RCCL needs it
+export SARA_BENCH_STRICT_RCCL=1       # a communicator that cannot be formed stops the run here (bench.py alone falls back to torch.distributed and says so)
 OUT=$R/gpurun_out/first_contact
 mkdir -p "$OUT"
 die() { echo "FIRST CONTACT FAILED at step $1: $2" | tee -a "$OUT/summary.txt"; exit 1; }
