@@ -87,6 +87,26 @@ namespace sara_hip { namespace host {
   //! hundreds of frame sizes or parameter sets.  ROCm >= 7.2: no limit.
   constexpr int kOldRuntimeGraphBudget = 128;
   std::atomic<int> g_graph_instantiations{0};
+  namespace {
+    // SARA_HIP_DEBUG_COUNTS=1: what the process asked of the runtime, at exit
+    std::atomic<int> g_streams_created{0}, g_streams_reused{0};
+    struct CountsAtExit
+    {
+      ~CountsAtExit()
+      {
+        if (getenv("SARA_HIP_DEBUG_COUNTS"))
+        {
+          int version = 0;
+          (void) hipRuntimeGetVersion(&version);
+          std::fprintf(stderr,
+                       "[sara_hip] HIP runtime %d: graphs instantiated %d, streams created "
+                       "%d, reused %d\n",
+                       version, g_graph_instantiations.load(), g_streams_created.load(),
+                       g_streams_reused.load());
+        }
+      }
+    } g_counts_at_exit;
+  }
   bool graph_budget_left()
   {
     if (!graphs_need_one_thread())
@@ -96,6 +116,64 @@ namespace sara_hip { namespace host {
       return e ? atoi(e) : kOldRuntimeGraphBudget;
     }();
     return g_graph_instantiations.load(std::memory_order_relaxed) < limit;
+  }
+  namespace {
+    struct StreamPool
+    {
+      std::mutex m;
+      std::vector<hipStream_t> idle[64][2];  // [device][high priority]
+    };
+    StreamPool& stream_pool()
+    {
+      static StreamPool* p = new StreamPool;  // never destroyed: no teardown order to get wrong
+      return *p;
+    }
+    bool pool_streams()
+    {
+      static const bool on = [] {
+        const char* e = getenv("SARA_HIP_STREAM_POOL");
+        return !e || e[0] != '0';
+      }();
+      return on;
+    }
+  }
+  hipError_t pooled_stream_acquire(int device, bool high_priority, hipStream_t* out)
+  {
+    if (pool_streams())
+    {
+      StreamPool& p = stream_pool();
+      std::lock_guard<std::mutex> lock(p.m);
+      auto& idle = p.idle[device & 63][high_priority ? 1 : 0];
+      if (!idle.empty())
+      {
+        *out = idle.back();
+        idle.pop_back();
+        g_streams_reused.fetch_add(1, std::memory_order_relaxed);
+        return hipSuccess;
+      }
+    }
+    g_streams_created.fetch_add(1, std::memory_order_relaxed);
+    if (!high_priority)
+      return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    int lo = 0, hi = 0;
+    const hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (e != hipSuccess)
+      return e;
+    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, hi);
+  }
+  void pooled_stream_release(int device, bool high_priority, hipStream_t stream)
+  {
+    if (!stream)
+      return;
+    (void) hipStreamSynchronize(stream);
+    if (!pool_streams())
+    {
+      (void) hipStreamDestroy(stream);
+      return;
+    }
+    StreamPool& p = stream_pool();
+    std::lock_guard<std::mutex> lock(p.m);
+    p.idle[device & 63][high_priority ? 1 : 0].push_back(stream);
   }
   bool first_graph_thread()
   {

@@ -205,7 +205,7 @@ namespace sara_hip { namespace host {
   } while (0)
 
     auto make_stream = [&](hipStream_t* st) -> hipError_t {
-      return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+      return pooled_stream_acquire(c->device, false, st);
     };
     TRY_HIP(make_stream(&c->own_stream));
   for (auto& e : c->ev)
@@ -227,7 +227,7 @@ namespace sara_hip { namespace host {
     TRY_HIP(make_stream(&c->aux_stream));
     for (int k = 0; k < 3; ++k)
     {
-      TRY_HIP(hipStreamCreateWithFlags(&c->filler_stream[k], hipStreamNonBlocking));
+      TRY_HIP(make_stream(&c->filler_stream[k]));
       TRY_HIP(hipEventCreateWithFlags(&c->filler_done[k], hipEventDisableTiming));
     }
     TRY_HIP(hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
@@ -487,11 +487,7 @@ sara_hip_status sara_hip_sift_destroy(sara_hip_sift* c)
   }
   for (int o = 0; o < 16; ++o)
   {
-    if (c->oct_stream[o])
-    {
-      (void) hipStreamSynchronize(c->oct_stream[o]);
-      (void) hipStreamDestroy(c->oct_stream[o]);
-    }
+    pooled_stream_release(c->device, false, c->oct_stream[o]);
     if (c->oct_ready[o])
       (void) hipEventDestroy(c->oct_ready[o]);
     if (c->oct_done[o])
@@ -506,11 +502,7 @@ sara_hip_status sara_hip_sift_destroy(sara_hip_sift* c)
     if (c->stage_free[k])
       (void) hipEventDestroy(c->stage_free[k]);
   }
-  if (c->copy_stream)
-  {
-    (void) hipStreamSynchronize(c->copy_stream);
-    (void) hipStreamDestroy(c->copy_stream);
-  }
+  pooled_stream_release(c->device, false, c->copy_stream);
   for (int k = 0; k < 2; ++k)
   {
     sara_hip_sift::RingSlot& r = c->ring[k];
@@ -525,29 +517,19 @@ sara_hip_status sara_hip_sift_destroy(sara_hip_sift* c)
     if (r.h_so)
       (void) hipHostFree(r.h_so);
   }
-  if (c->d2h_stream)
-  {
-    (void) hipStreamSynchronize(c->d2h_stream);
-    (void) hipStreamDestroy(c->d2h_stream);
-  }
+  pooled_stream_release(c->device, true, c->d2h_stream);
   for (int k = 0; k < 3; ++k)
   {
-    if (c->filler_stream[k])
-      (void) hipStreamDestroy(c->filler_stream[k]);
+    pooled_stream_release(c->device, false, c->filler_stream[k]);
     if (c->filler_done[k])
       (void) hipEventDestroy(c->filler_done[k]);
   }
-  if (c->aux_stream)
-  {
-    (void) hipStreamSynchronize(c->aux_stream);
-    (void) hipStreamDestroy(c->aux_stream);
-  }
+  pooled_stream_release(c->device, false, c->aux_stream);
   if (c->aux_fork)
     (void) hipEventDestroy(c->aux_fork);
   if (c->aux_join)
     (void) hipEventDestroy(c->aux_join);
-  if (c->own_stream)
-    (void) hipStreamDestroy(c->own_stream);
+  pooled_stream_release(c->device, false, c->own_stream);
   delete c;
   return SARA_HIP_OK;
 }

@@ -219,6 +219,13 @@ namespace sara_hip { namespace host {
   bool graph_budget_left();
   extern std::atomic<int> g_graph_instantiations;
 
+  //! Streams of closed contexts are kept for the next context on the device
+  //! (graph_launcher.cpp): creating nine of them is the slowest part of opening
+  //! a context, and a process that keeps creating and destroying streams next
+  //! to graph launches is where the ROCm 7.0 runtime came apart.
+  hipError_t pooled_stream_acquire(int device, bool high_priority, hipStream_t* out);
+  void pooled_stream_release(int device, bool high_priority, hipStream_t stream);
+
   // ---- error text of the calling thread (sift_schedule.cpp) -----------------
   extern thread_local std::string g_error;
   sara_hip_status fail(sara_hip_status code, const std::string& msg);

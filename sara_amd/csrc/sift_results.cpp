@@ -16,10 +16,8 @@ namespace {
       return SARA_HIP_OK;
     // highest priority: the read-back kernel's few workgroups should not
     // queue behind the next batch's launches
-    int lo = 0, hi = 0;
     std::lock_guard<std::recursive_mutex> runtime_lock(runtime_mutex());
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIP_TRY(hipStreamCreateWithPriority(&c->d2h_stream, hipStreamNonBlocking, hi));
+    HIP_TRY(pooled_stream_acquire(c->device, true, &c->d2h_stream));
     return SARA_HIP_OK;
   }
 }  // namespace
@@ -55,7 +53,7 @@ sara_hip_status sara_hip_sift_stage(sara_hip_sift* c, const void* images,
     if (ds != SARA_HIP_OK)
       return ds;
     std::lock_guard<std::recursive_mutex> runtime_lock(runtime_mutex());
-    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(pooled_stream_acquire(c->device, false, &c->copy_stream));
     for (int k = 0; k < 2; ++k)
     {
       HIP_TRY(hipEventCreateWithFlags(&c->stage_ready[k], hipEventDisableTiming));

@@ -12,11 +12,19 @@ import os
 
 import numpy as np
 
-try:  # torch only serves the gloo / torch.distributed variant below
-    import torch
-    import torch.distributed as dist
-except ImportError:  # pragma: no cover
-    torch = dist = None
+# torch only serves the torch.distributed variant below and is imported when
+# that variant is first used: `import torch` makes the ROCm runtime it bundles
+# the process's HIP runtime, and a process that only drives the library (the
+# native communicator further down, the GPU tests) should keep the system's.
+torch = dist = None
+
+
+def _need_torch():
+    global torch, dist
+    if torch is None:
+        import torch as _torch
+        import torch.distributed as _dist
+        torch, dist = _torch, _dist
 
 from . import capi
 
@@ -47,6 +55,7 @@ def exchange_counts(n, group=None):
     """Every rank's keypoint count, exchanged through HOST tensors on `group`
     (a gloo group): unlike a device-side all_gather this neither waits for the
     kernels already enqueued on the GPU nor adds a device synchronisation."""
+    _need_torch()
     world = dist.get_world_size(group)
     n_t = torch.tensor([int(n)], dtype=torch.int64)
     all_n = [torch.zeros_like(n_t) for _ in range(world)]
@@ -62,6 +71,7 @@ def gatherv_to_root(arrays, root=0, group=None, async_op=False, counts=None):
     transfers are only posted and a PendingGather is returned, so the next
     batch's kernels overlap the exchange.  `counts` (from exchange_counts)
     skips the all_gather of the counts on the arrays' device."""
+    _need_torch()
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)   # group-local; `root` is group-local as well
     n = int(arrays[0].shape[0])

@@ -8,12 +8,14 @@ import socket
 
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 from sara_amd.distributed import (exchange_counts, gatherv_to_root,
                                   shard_range)
+
+# torch is imported where it is used, not when pytest collects this module: the
+# same pytest process runs the GPU tests (-m gpu), and `import torch` would make
+# the ROCm runtime torch bundles that process's HIP runtime (sara_amd.distributed
+# imports it lazily for the same reason).
 
 
 def test_shard_range_partitions():
@@ -36,6 +38,8 @@ def _free_port():
 
 def _worker(rank, world, port, n_frames, tmpdir):
     import sys
+    import torch
+    import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import refbind as rb
     from sara_amd.synth import synth
@@ -92,6 +96,7 @@ def _worker(rank, world, port, n_frames, tmpdir):
 @pytest.mark.parametrize("world,n_frames", [(2, 5), (2, 1)])
 def test_gatherv_over_gloo(oracle, tmp_path, world, n_frames):
     port = _free_port()
+    import torch.multiprocessing as mp
     mp.start_processes(_worker, args=(world, port, n_frames, str(tmp_path)),
                        nprocs=world, join=True, start_method="spawn")
     got = np.load(tmp_path / "root.npz")
@@ -113,6 +118,8 @@ def test_gatherv_over_gloo(oracle, tmp_path, world, n_frames):
 
 
 def _subgroup_worker(rank, world, port):
+    import torch
+    import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -138,5 +145,6 @@ def _subgroup_worker(rank, world, port):
 def test_gatherv_in_a_subgroup():
     """Peers of P2POp are GLOBAL ranks: a gather inside a subgroup whose ranks
     are not 0..n-1 must translate its group-local ranks."""
+    import torch.multiprocessing as mp
     mp.start_processes(_subgroup_worker, args=(3, _free_port()), nprocs=3,
                        join=True, start_method="spawn")
